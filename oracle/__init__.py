@@ -1,0 +1,25 @@
+"""CPU oracle (fp64, numpy) for the AcinoSet triangulation + FTE hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``acinoset_amd/`` imports this package;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may use it, and only as the checker / the timed CPU baseline.
+
+Each function cites the reference file:line it restates (paths relative to the
+upstream AcinoSet tree).  Pinning status:
+
+* ``loss.redescending_loss``, ``camera.pt3d_to_2d``, rotation helpers, cheetah FK
+  (positions AND Jacobian), adjacent-pair index path: pinned against vectors
+  generated from the reference's own Python (tests/golden/make_golden.py).
+* fisheye undistort / 2-view DLT / fisheye projection (OpenCV algorithms, cv2 is
+  an un-vendored, unpinned dependency of the reference): pinned jointly by KAT-1,
+  the residual statistics recorded in src/calib_with_gui.ipynb cell 29, on the
+  shipped sunday_amelia fixtures.
+* pinhole ``project_points`` / ``undistort_points`` / ``triangulate_points``
+  (cv2.projectPoints / cv2.undistortPoints): PARITY UNPINNED - no recorded
+  output in the reference exercises them; restated from OpenCV's documented model.
+* the FTE solve (Pyomo + IPOPT, absent): PARITY UNPINNED end to end - no cheetah
+  IPOPT trajectory is shipped.  Structure is pinned by KAT-4 (integration /
+  third-difference identities on the stored build.py runs) and the objective
+  pieces above; the LM solution is the tightly converged minimiser of the same
+  reduced problem.
+"""
