@@ -1,0 +1,171 @@
+"""ctypes binding of libacinoset_hip.so (the C ABI in include/acinoset_hip.h).
+
+The library is built in-tree by ``build()`` (hipcc, gfx950 only).  There is NO CPU fallback:
+``lib()`` raises if the shared object is missing or cannot be loaded, and every wrapper raises
+``RuntimeError`` carrying ``acino_last_error_string()`` on a non-zero status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip"]
+HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
+
+N_ACTIVE = 25
+N_STATES = 45
+N_MARKERS = 20
+CAM_STRIDE = 24
+PINHOLE_STRIDE = 32
+BS = 80
+SEP_DOUBLES = 2 * BS * BS + BS
+
+
+class FteParams(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("n_global", C.c_int64), ("n_offset", C.c_int64),
+                ("pin_left", C.c_int32), ("pin_right", C.c_int32), ("dlc_thresh", C.c_double),
+                ("inv_r_meas", C.c_double), ("redesc_a", C.c_double), ("redesc_b", C.c_double),
+                ("redesc_c", C.c_double), ("q_w", C.c_double * N_ACTIVE), ("lo", C.c_double * N_ACTIVE),
+                ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
+                ("gtol", C.c_double)]
+
+
+class FteState(C.Structure):
+    _fields_ = [("cost", C.c_double), ("cost_trial", C.c_double), ("lam", C.c_double), ("nu", C.c_double),
+                ("gain", C.c_double), ("pred", C.c_double), ("step_inf", C.c_double), ("gnorm_inf", C.c_double),
+                ("iter", C.c_int32), ("accepted", C.c_int32), ("status", C.c_int32), ("cur", C.c_int32),
+                ("n_behind", C.c_int32), ("last_accept", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32)]
+
+    def as_dict(self):
+        names = {0: "running", 1: "ftol", 2: "xtol", 3: "gtol", 4: "lambda_overflow", 5: "numeric"}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
+        d["status_name"] = names.get(self.status, "?")
+        return d
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_D = C.c_double
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/acinoset_hip.h declares
+SIGNATURES = {
+    "acino_last_error_string": (C.c_char_p, []),
+    "acino_abi_version": (_I, []),
+    "acino_device_count": (_I, []),
+    "acino_undistort_fisheye": (_I, [_P, _L, _P, _P, _I, _D, _P]),
+    "acino_triangulate_fisheye": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "acino_triangulate_pinhole": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "acino_project_fisheye": (_I, [_P, _L, _P, _P, _P]),
+    "acino_project_pinhole": (_I, [_P, _L, _P, _P, _P]),
+    "acino_triangulate_pairs": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "acino_reproject_residuals": (_I, [_P, _P, _L, _I, _I, _D, _P, _P, _P, _P]),
+    "acino_cheetah_fk": (_I, [_P, _L, _P, _P]),
+    "acino_fk_active": (_I, [_P, _L, _P, _P]),
+    "acino_fte_workspace_bytes": (_Z, [C.POINTER(FteParams)]),
+    "acino_fte_create": (_I, [C.POINTER(_P), C.POINTER(FteParams), _P, _P, _P, _Z, _P]),
+    "acino_fte_destroy": (_I, [_P]),
+    "acino_fte_set_x": (_I, [_P, _P, _P]),
+    "acino_fte_step": (_I, [_P, _P]),
+    "acino_fte_solve": (_I, [_P, _I, C.POINTER(FteState), _P]),
+    "acino_fte_get_state": (_I, [_P, C.POINTER(FteState), _P]),
+    "acino_fte_get_result": (_I, [_P, _D, _P, _P, _P, _P, _P]),
+    "acino_fte_cost": (_I, [_P, _P, _P, _P]),
+    "acino_fte_get_grad_hess": (_I, [_P, _P, _P, _P]),
+    "acino_fte_derivatives": (_I, [_P, _L, _D, _P, _P, _P]),
+    "acino_fte_load_x": (_I, [_P, _P, _P]),
+    "acino_fte_set_halo": (_I, [_P, _I, _P, _P, _P]),
+    "acino_fte_eval": (_I, [_P, _I, _P]),
+    "acino_fte_export_partials": (_I, [_P, _P, _P]),
+    "acino_fte_control": (_I, [_P, _P, _I, _P]),
+    "acino_fte_reduce_local": (_I, [_P, _P]),
+    "acino_fte_export_separators": (_I, [_P, _P, _I, _I, _P]),
+    "acino_sep_scratch_bytes": (_Z, [_I]),
+    "acino_solve_separators": (_I, [_P, _I, _P, _P, _Z, _P]),
+    "acino_fte_backsub_local": (_I, [_P, _P, _I, _I, _P]),
+    "acino_fte_trial": (_I, [_P, _P]),
+    "acino_fte_export_edges": (_I, [_P, _I, _P, _P]),
+    "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def _needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    so_m = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > so_m for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into acinoset_amd/libacinoset_hip.so (hipcc cross-compiles
+    without a GPU).  Raises on any compiler error."""
+    if not force and not _needs_build():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-DNDEBUG"]
+    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
+    cmd += ["-o", SO_PATH]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libacinoset_hip.so:\n" + res.stderr[-4000:])
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(acinoset_amd has no CPU fallback)")
+    try:
+        handle = C.CDLL(SO_PATH)
+    except OSError as exc:
+        raise RuntimeError(f"cannot load {SO_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)   # AttributeError = ABI mismatch, let it surface
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = lib().acino_last_error_string().decode("utf-8", "replace")
+        codes = {-1: ValueError}
+        raise codes.get(status, RuntimeError)(f"libacinoset_hip status {status}: {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("acinoset_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    lib()
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float64/uint8 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,476 @@
+// Block cyclic reduction (BCR) for the block-tridiagonal Gauss-Newton system of the FTE solve.
+//
+// Unknowns are grouped in super-blocks ("nodes") of 3 frames x 25 states = 75, padded to 80 = 5 tiles
+// of 16 with identity rows, so every block operation is a 5x5 grid of 16x16 fp64 tiles executed on
+// the matrix cores (v_mfma_f64_16x16x4_f64).  One level = two launches:
+//   elim   (one workgroup per eliminated node i with neighbours l, r):
+//            D_i = L L^T (blocked Cholesky in LDS, explicit inverses of the diagonal tiles),
+//            W_l = L^-1 A_il, W_r = L^-1 A_ir, y = L^-1 b_i                         -> HBM
+//   update (two workgroups per remaining node j):
+//            D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+),  b_j -= W^T y,
+//            new coupling block(j', j) = -W_r(i+)^T W_l(i+)
+// and back-substitution x_i = L^-T (y - W_l x_l - W_r x_r) walks the levels in reverse.
+// Level-0 couplings are the constant third-difference blocks and are generated in LDS, never stored.
+// LDS: three 80x81 fp64 matrices (155.5 KB of the 160 KB) - leading dimension 81 makes both the
+// row-pattern and the column-pattern MFMA operand reads bank-conflict free.
+#include "bcr.hpp"
+
+namespace acino {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int LD = 81;
+constexpr int MAT = BS * LD;
+constexpr int NT = 5;
+
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  long long b = __builtin_bit_cast(long long, x);
+  int lo = __builtin_amdgcn_readlane((int)b, lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// spare (strictly upper) tiles of the factor matrix hold the inverses of the diagonal tiles
+__device__ __forceinline__ int inv_tile_off(int kb) {
+  const int r[5] = {0, 0, 0, 0, 1}, c[5] = {1, 2, 3, 4, 2};
+  return (r[kb] * 16) * LD + c[kb] * 16;
+}
+__host__ __device__ inline int inv_tile_off_g(int kb) {  // same positions with leading dimension 80
+  const int r[5] = {0, 0, 0, 0, 1}, c[5] = {1, 2, 3, 4, 2};
+  return (r[kb] * 16) * BS + c[kb] * 16;
+}
+
+// One wave: Cholesky of the 16x16 tile T (LDS, leading dim LD) in registers (lane = row, cross-lane
+// broadcast by v_readlane), then its inverse (lane = column) into Tinv.
+__device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
+  const int r = lane & 15;
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[r * LD + c] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double ajj = readlane_d(a[j], j);
+    if (!(ajj > 0.0)) {
+      bad = true;
+      ajj = 1.0;
+    }
+    double d = sqrt(ajj), inv = 1.0 / d;
+    a[j] = (r == j) ? d : a[j] * inv;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) {
+      double lc = readlane_d(a[j], c);
+      a[c] = (r >= c) ? a[c] - a[j] * lc : a[c];
+    }
+  }
+  double x[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    double lrr = readlane_d(a[rr], rr);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < rr; ++k) {
+      double lrk = readlane_d(a[k], rr);
+      acc += lrk * x[k];
+    }
+    x[rr] = (rr == r) ? 1.0 / lrr : ((rr > r) ? -acc / lrr : 0.0);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) T[r * LD + c] = a[c];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) Tinv[rr * LD + r] = x[rr];
+    if (bad && err) atomicExch(err, 1);
+  }
+}
+
+// Blocked Cholesky of the 80x80 matrix in LDS (lower triangle in place, inverse diagonal tiles in the
+// spare upper tiles).  All 256 threads.
+__device__ void chol80(double* Lm, int tid, int* err) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  for (int kb = 0; kb < NT; ++kb) {
+    double* Tinv = Lm + inv_tile_off(kb);
+    if (wave == 0) chol16_inv(Lm + (kb * 16) * LD + kb * 16, Tinv, lane, err);
+    __syncthreads();
+    for (int ib = kb + 1 + wave; ib < NT; ib += 4) {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T
+      double* A = Lm + (ib * 16) * LD + kb * 16;
+      double av[4], bv[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        av[s] = A[li * LD + 4 * s + lk];
+        bv[s] = Tinv[li * LD + 4 * s + lk];
+      }
+      d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int ib = kb + 1; ib < NT; ++ib)
+      for (int jb = kb + 1; jb <= ib; ++jb) {
+        if ((cnt++ & 3) != wave) continue;
+        double* Cc = Lm + (ib * 16) * LD + jb * 16;
+        const double* A = Lm + (ib * 16) * LD + kb * 16;
+        const double* B = Lm + (jb * 16) * LD + kb * 16;
+        d4 acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(-A[li * LD + 4 * s + lk], B[li * LD + 4 * s + lk], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = acc[rr];
+      }
+    __syncthreads();
+  }
+}
+
+// W <- L^-1 W for the column tile starting at column cc of W (one wave; no workgroup barrier needed).
+__device__ __forceinline__ void trsm_coltile(const double* Lm, double* W, int cc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  for (int ib = 0; ib < NT; ++ib) {
+    d4 acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[rr] = W[(ib * 16 + lk + 4 * rr) * LD + cc + li];
+    for (int kb = 0; kb < ib; ++kb) {
+      const double* A = Lm + (ib * 16) * LD + kb * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma(-A[li * LD + 4 * s + lk], W[(kb * 16 + 4 * s + lk) * LD + cc + li], acc);
+    }
+    const double* Tinv = Lm + inv_tile_off(ib);
+    d4 out = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) out = mfma(Tinv[li * LD + 4 * s + lk], acc[s], out);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) W[(ib * 16 + lk + 4 * rr) * LD + cc + li] = out[rr];
+  }
+}
+
+__device__ __forceinline__ void load_mat(double* dst, const double* __restrict__ src, int tid) {
+  for (int e = tid; e < BS * BS; e += 256) dst[(e / BS) * LD + (e % BS)] = src[e];
+}
+__device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict__ src, int tid) {
+  for (int e = tid; e < BS * BS; e += 256) dst[(e % BS) * LD + (e / BS)] = src[e];
+}
+__device__ __forceinline__ void store_mat(double* __restrict__ dst, const double* src, int tid) {
+  for (int e = tid; e < BS * BS; e += 256) dst[e] = src[(e / BS) * LD + (e % BS)];
+}
+
+// Analytic level-0 coupling between node `i` (rows) and its chain neighbour (cols): third-difference blocks.
+__device__ void gen_coupling(double* W, const FteConst& K, int node_i, bool left, int tid) {
+  for (int e = tid; e < BS * LD; e += 256) W[e] = 0.0;
+  __syncthreads();
+  const int64_t f_i = K.n_offset + 3 * (int64_t)(node_i - K.pin_left);
+  for (int e = tid; e < 9 * NP; e += 256) {
+    int p = e % NP, pair = e / NP, ii = pair / 3, jj = pair % 3;
+    if (ii > jj) continue;
+    int k = 3 + ii - jj;
+    if (left) {   // rows (ii,p) of node i, cols (jj,p) of node i-1 ; column frame is the earlier one
+      double v = 2.0 * K.q_w[p] * band_coef(f_i - 3 + jj, k, K.n_global);
+      W[(ii * NP + p) * LD + jj * NP + p] = v;
+    } else {      // rows (jj,p) of node i, cols (ii,p) of node i+1 ; row frame is the earlier one
+      double v = 2.0 * K.q_w[p] * band_coef(f_i + jj, k, K.n_global);
+      W[(jj * NP + p) * LD + ii * NP + p] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst, int* numeric_err,
+           const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Lm = reinterpret_cast<double*>(smem_raw);
+  double* WL = Lm + MAT;
+  double* WR = WL + MAT;
+  double* yv = WR + MAT;       // [80] rhs, then y
+  double* sv = yv + BS;        // [80] scratch
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
+  const size_t MB = (size_t)BS * BS;
+  load_mat(Lm, ch.D + i * MB, tid);
+  if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
+  if (l >= 0) {
+    if (ch.implicit_couplings && l == i - 1) gen_coupling(WL, *cst, i, true, tid);
+    else load_mat(WL, ch.Cpl + l * MB, tid);           // block(i, l): rows i, cols l
+  }
+  if (r >= 0) {
+    if (ch.implicit_couplings && r == i + 1) gen_coupling(WR, *cst, i, false, tid);
+    else load_mat_t(WR, ch.Cpl + i * MB, tid);         // block(r, i)^T: rows i, cols r
+  }
+  __syncthreads();
+  chol80(Lm, tid, numeric_err);
+  // W_l, W_r: ten column tiles over four waves
+  for (int ct = wave; ct < 10; ct += 4) {
+    if (ct < 5) {
+      if (l >= 0) trsm_coltile(Lm, WL, ct * 16, lane);
+    } else {
+      if (r >= 0) trsm_coltile(Lm, WR, (ct - 5) * 16, lane);
+    }
+  }
+  // y = L^-1 b (blocked forward substitution, VALU)
+  for (int ib = 0; ib < NT; ++ib) {
+    if (tid < 16) {
+      const int row = ib * 16 + tid;
+      double s = yv[row];
+      for (int c = 0; c < ib * 16; ++c) s -= Lm[row * LD + c] * yv[c];
+      sv[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const double* Tinv = Lm + inv_tile_off(ib);
+      double s = 0;
+      for (int c = 0; c <= tid; ++c) s += Tinv[tid * LD + c] * sv[c];
+      yv[ib * 16 + tid] = s;
+    }
+    __syncthreads();
+  }
+  store_mat(ch.D + i * MB, Lm, tid);
+  if (l >= 0) store_mat(ch.Wl + i * MB, WL, tid);
+  if (r >= 0) store_mat(ch.Cpl + i * MB, WR, tid);
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = yv[tid];
+}
+
+// role 0: D_j / b_j update; role 1: new coupling block(jn, j)
+__global__ void __launch_bounds__(256)
+k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* WA = reinterpret_cast<double*>(smem_raw);
+  double* WB = WA + MAT;
+  double* ya = WB + MAT;
+  double* yb = ya + BS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ent = blockIdx.x >> 1, role = blockIdx.x & 1;
+  const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
+  const size_t MB = (size_t)BS * BS;
+  if (role == 0) {
+    if (im < 0 && ip < 0) return;
+    if (im >= 0) {
+      load_mat(WA, ch.Cpl + im * MB, tid);   // W_r of the eliminated left neighbour (cols = j)
+      if (tid < BS) ya[tid] = ch.b[(size_t)im * BS + tid];
+    }
+    if (ip >= 0) {
+      load_mat(WB, ch.Wl + ip * MB, tid);    // W_l of the eliminated right neighbour (cols = j)
+      if (tid < BS) yb[tid] = ch.b[(size_t)ip * BS + tid];
+    }
+    __syncthreads();
+    double* Dj = ch.D + j * MB;
+    int cnt = 0;
+    for (int ib = 0; ib < NT; ++ib)
+      for (int jb = 0; jb <= ib; ++jb) {
+        if ((cnt++ & 3) != wave) continue;
+        d4 acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+        if (im >= 0)
+          for (int s = 0; s < BS / 4; ++s)
+            acc = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WA[(4 * s + lk) * LD + jb * 16 + li], acc);
+        if (ip >= 0)
+          for (int s = 0; s < BS / 4; ++s)
+            acc = mfma(-WB[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
+          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[rr];
+        }
+      }
+    if (tid < BS) {
+      double s = ch.b[(size_t)j * BS + tid];
+      if (im >= 0)
+        for (int k = 0; k < BS; ++k) s -= WA[k * LD + tid] * ya[k];
+      if (ip >= 0)
+        for (int k = 0; k < BS; ++k) s -= WB[k * LD + tid] * yb[k];
+      ch.b[(size_t)j * BS + tid] = s;
+    }
+  } else {
+    if (ip < 0 || jn < 0) return;
+    load_mat(WA, ch.Cpl + ip * MB, tid);     // W_r(ip): cols = jn
+    load_mat(WB, ch.Wl + ip * MB, tid);      // W_l(ip): cols = j
+    __syncthreads();
+    double* Cj = ch.Cpl + j * MB;            // block(jn, j): rows jn, cols j
+    for (int t = wave; t < NT * NT; t += 4) {
+      const int ib = t / NT, jb = t % NT;
+      d4 acc = {0, 0, 0, 0};
+      for (int s = 0; s < BS / 4; ++s)
+        acc = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
+    }
+  }
+}
+
+// x_i = L^-T (y_i - W_l x_l - W_r x_r)
+__global__ void __launch_bounds__(256)
+k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Lm = reinterpret_cast<double*>(smem_raw);
+  double* xl = Lm + MAT;
+  double* xr = xl + BS;
+  double* tv = xr + BS;
+  double* part = tv + BS;      // [16][16] partial sums
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
+  const size_t MB = (size_t)BS * BS;
+  load_mat(Lm, ch.D + i * MB, tid);
+  if (tid < BS) {
+    xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
+    xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
+    tv[tid] = ch.b[(size_t)i * BS + tid];
+  }
+  __syncthreads();
+  // t = y - W_l x_l - W_r x_r : one wave per row, lanes along the (contiguous) columns
+  const double* Wl = ch.Wl + i * MB;
+  const double* Wr = ch.Cpl + i * MB;
+  for (int row = wave; row < BS; row += 4) {
+    double s = 0.0;
+    if (l >= 0) {
+      s += Wl[row * BS + lane] * xl[lane];
+      if (lane < BS - 64) s += Wl[row * BS + 64 + lane] * xl[64 + lane];
+    }
+    if (r >= 0) {
+      s += Wr[row * BS + lane] * xr[lane];
+      if (lane < BS - 64) s += Wr[row * BS + 64 + lane] * xr[64 + lane];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) tv[row] -= s;
+  }
+  __syncthreads();
+  // blocked backward substitution with L^T; x overwrites tv
+  for (int ib = NT - 1; ib >= 0; --ib) {
+    const int jc = tid & 15, grp = tid >> 4;   // 16 column lanes x 16 row groups
+    double s = 0.0;
+    for (int row = (ib + 1) * 16 + grp; row < BS; row += 16) s += Lm[row * LD + ib * 16 + jc] * tv[row];
+    part[grp * 16 + jc] = s;
+    __syncthreads();
+    if (tid < 16) {
+      double acc = tv[ib * 16 + tid];
+      for (int g = 0; g < 16; ++g) acc -= part[g * 16 + tid];
+      part[256 + tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const double* Tinv = Lm + inv_tile_off(ib);
+      double acc = 0.0;
+      for (int c = tid; c < 16; ++c) acc += Tinv[c * LD + tid] * part[256 + c];   // Linv^T
+      tv[ib * 16 + tid] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = tv[tid];
+}
+
+// ---- host side ------------------------------------------------------------------------------
+void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
+  levels.clear();
+  elim.clear();
+  remain.clear();
+  std::vector<int> act(n);
+  for (int i = 0; i < n; ++i) act[i] = i;
+  auto pinned = [&](int node) { return (pin_left && node == 0) || (pin_right && node == n - 1); };
+  while (true) {
+    const int R = (int)act.size();
+    std::vector<char> pick(R, 0);
+    int n_pick = 0;
+    for (int p = 0; p < R; ++p)
+      if (!pinned(act[p]) && (p == 0 || !pick[p - 1])) {
+        pick[p] = 1;
+        ++n_pick;
+      }
+    if (n_pick == 0) break;
+    BcrLevel lv;
+    lv.elim_off = (int)elim.size() / 3;
+    lv.remain_off = (int)remain.size() / 4;
+    lv.n_elim = n_pick;
+    std::vector<int> next;
+    for (int p = 0; p < R; ++p) {
+      if (pick[p]) {
+        elim.push_back(act[p]);
+        elim.push_back(p > 0 ? act[p - 1] : -1);
+        elim.push_back(p + 1 < R ? act[p + 1] : -1);
+      } else {
+        next.push_back(act[p]);
+      }
+    }
+    int n_rem = 0;
+    for (int p = 0; p < R; ++p) {
+      if (pick[p]) continue;
+      int im = (p > 0 && pick[p - 1]) ? act[p - 1] : -1;
+      int ip = (p + 1 < R && pick[p + 1]) ? act[p + 1] : -1;
+      int jn = (ip >= 0 && p + 2 < R) ? act[p + 2] : -1;
+      if (im < 0 && ip < 0) continue;
+      remain.push_back(act[p]);
+      remain.push_back(im);
+      remain.push_back(ip);
+      remain.push_back(jn);
+      ++n_rem;
+    }
+    lv.n_remain = n_rem;
+    levels.push_back(lv);
+    act.swap(next);
+    if (act.empty()) break;
+  }
+}
+
+static constexpr size_t kElimLds = (3 * MAT + 2 * BS) * sizeof(double);
+static constexpr size_t kUpdateLds = (2 * MAT + 2 * BS) * sizeof(double);
+static constexpr size_t kBacksubLds = (MAT + 3 * BS + 256 + 16) * sizeof(double);
+
+int bcr_set_func_attributes() {
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kElimLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
+  return ACINO_OK;
+}
+
+int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
+               const int* d_status, hipStream_t s) {
+  for (const BcrLevel& lv : sch.levels) {
+    hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off, d_c,
+                       d_numeric_err, d_status);
+    ACINO_LAUNCH_CHECK();
+    if (lv.n_remain > 0) {
+      hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
+                         ch.d_remain + 4 * lv.remain_off, d_status);
+      ACINO_LAUNCH_CHECK();
+    }
+  }
+  return ACINO_OK;
+}
+
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s) {
+  for (int k = (int)sch.levels.size() - 1; k >= 0; --k) {
+    const BcrLevel& lv = sch.levels[k];
+    hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
+                       ch.d_elim + 3 * lv.elim_off, d_status);
+    ACINO_LAUNCH_CHECK();
+  }
+  return ACINO_OK;
+}
+
+// ---- MFMA layout self-test: C[16][16] = A[16][K] * B[K][16] ---------------------------------
+__global__ void k_selftest_mfma(const double* a, const double* b, int k, double* c) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  d4 acc = {0, 0, 0, 0};
+  for (int s = 0; s < k / 4; ++s) acc = mfma(a[li * k + 4 * s + lk], b[(4 * s + lk) * 16 + li], acc);
+  for (int rr = 0; rr < 4; ++rr) c[(lk + 4 * rr) * 16 + li] = acc[rr];
+}
+
+}  // namespace acino
+
+extern "C" int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream) {
+  using namespace acino;
+  ACINO_REQUIRE(k > 0 && k % 4 == 0, "k must be a positive multiple of 4");
+  ACINO_REQUIRE(d_a && d_b && d_c, "null buffer");
+  hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, d_a, d_b, k, d_c);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}

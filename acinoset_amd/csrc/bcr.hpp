@@ -1,0 +1,39 @@
+// Block cyclic reduction on a block-tridiagonal SPD chain of 80x80 fp64 blocks (gfx950).
+#pragma once
+#include <vector>
+
+#include "fte_kernels.hpp"
+
+namespace acino {
+
+struct BcrLevel {
+  int n_elim, n_remain;
+  int elim_off, remain_off;  // offsets (in entries) into the device schedule arrays
+};
+
+// Host-side elimination schedule for a chain of n nodes; pinned ends are never eliminated.
+struct BcrSchedule {
+  std::vector<BcrLevel> levels;
+  std::vector<int> elim;    // 3 ints per entry: node, left, right        (-1 = none)
+  std::vector<int> remain;  // 4 ints per entry: node, elim-left, elim-right, new right neighbour
+  void build(int n, bool pin_left, bool pin_right);
+};
+
+// Device views of one chain.
+struct BcrChain {
+  int n_nodes;
+  double* D;     // [n][80][80] working diagonal blocks -> Cholesky factors (+ inverse diagonal tiles)
+  double* Cpl;   // [n][80][80] coupling block (right neighbour rows, own cols) -> W_r once eliminated
+  double* Wl;    // [n][80][80] W_l of eliminated nodes
+  double* b;     // [n][80] rhs -> y -> solution
+  const int* d_elim;
+  const int* d_remain;
+  int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
+};
+
+int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
+               const int* d_status, hipStream_t s);
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s);
+int bcr_set_func_attributes();
+
+}  // namespace acino

@@ -1,0 +1,376 @@
+// Point-wise camera model kernels and the dense adjacent-pair triangulation (gfx950, fp64).
+// Reference: src/calib/calib.py:52-66,121-136,394-423 (OpenCV algorithms restated in DESIGN.md).
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace acino {
+
+static thread_local char g_err[512] = "ok";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ---- pinhole (rational) model ----------------------------------------------------------------
+struct Pin {
+  double fx, fy, cx, cy;
+  double d[14];
+  double R[9];
+  double t[3];
+  double pad0, pad1;
+};
+static_assert(sizeof(Pin) == ACINO_PINHOLE_STRIDE * sizeof(double), "pinhole record layout");
+
+__device__ __forceinline__ void undistort_pinhole_pt(const Pin& c, double u, double v, double& x, double& y) {
+  const double* k = c.d;
+  double x0 = (u - c.cx) / c.fx, y0 = (v - c.cy) / c.fy;
+  x = x0;
+  y = y0;
+  for (int j = 0; j < 5; ++j) {  // OpenCV default criteria (MAX_ITER, 5, 0.01)
+    double r2 = x * x + y * y;
+    double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+    if (icdist < 0) {
+      x = x0;
+      y = y0;
+      break;
+    }
+    double dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+    double dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_undistort_fisheye(const double* __restrict__ pts, int64_t m, const double* __restrict__ cam,
+                                    double* __restrict__ out, int max_iter, double eps) {
+  __shared__ Cam c;
+  if (threadIdx.x < ACINO_CAM_STRIDE) reinterpret_cast<double*>(&c)[threadIdx.x] = cam[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 p = reinterpret_cast<const double2*>(pts)[i];
+    double x, y;
+    bool ok = undistort_fisheye_pt(c, p.x, p.y, max_iter, eps, x, y);
+    if (!ok) x = y = -1000000.0;
+    reinterpret_cast<double2*>(out)[i] = make_double2(x, y);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_triangulate_fisheye(const double* __restrict__ p1, const double* __restrict__ p2, int64_t m,
+                                      const double* __restrict__ cam_a, const double* __restrict__ cam_b,
+                                      double* __restrict__ out) {
+  __shared__ Cam c[2];
+  if (threadIdx.x < ACINO_CAM_STRIDE) {
+    reinterpret_cast<double*>(&c[0])[threadIdx.x] = cam_a[threadIdx.x];
+    reinterpret_cast<double*>(&c[1])[threadIdx.x] = cam_b[threadIdx.x];
+  }
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 a = reinterpret_cast<const double2*>(p1)[i];
+    double2 b = reinterpret_cast<const double2*>(p2)[i];
+    double x1, y1, x2, y2;
+    if (!undistort_fisheye_pt(c[0], a.x, a.y, 10, 1e-8, x1, y1)) x1 = y1 = -1000000.0;
+    if (!undistort_fisheye_pt(c[1], b.x, b.y, 10, 1e-8, x2, y2)) x2 = y2 = -1000000.0;
+    double X[3];
+    triangulate_two_view(c[0], c[1], x1, y1, x2, y2, X);
+    out[3 * i + 0] = X[0];
+    out[3 * i + 1] = X[1];
+    out[3 * i + 2] = X[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_triangulate_pinhole(const double* __restrict__ p1, const double* __restrict__ p2, int64_t m,
+                                      const double* __restrict__ cam_a, const double* __restrict__ cam_b,
+                                      double* __restrict__ out) {
+  __shared__ Pin c[2];
+  if (threadIdx.x < ACINO_PINHOLE_STRIDE) {
+    reinterpret_cast<double*>(&c[0])[threadIdx.x] = cam_a[threadIdx.x];
+    reinterpret_cast<double*>(&c[1])[threadIdx.x] = cam_b[threadIdx.x];
+  }
+  __syncthreads();
+  Cam ea, eb;  // only R, t are read by the DLT
+  for (int j = 0; j < 9; ++j) {
+    ea.R[j] = c[0].R[j];
+    eb.R[j] = c[1].R[j];
+  }
+  for (int j = 0; j < 3; ++j) {
+    ea.t[j] = c[0].t[j];
+    eb.t[j] = c[1].t[j];
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 a = reinterpret_cast<const double2*>(p1)[i];
+    double2 b = reinterpret_cast<const double2*>(p2)[i];
+    double x1, y1, x2, y2;
+    undistort_pinhole_pt(c[0], a.x, a.y, x1, y1);
+    undistort_pinhole_pt(c[1], b.x, b.y, x2, y2);
+    double X[3];
+    triangulate_two_view(ea, eb, x1, y1, x2, y2, X);
+    out[3 * i + 0] = X[0];
+    out[3 * i + 1] = X[1];
+    out[3 * i + 2] = X[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_project_fisheye(const double* __restrict__ obj, int64_t m, const double* __restrict__ cam,
+                                  double* __restrict__ out) {
+  __shared__ Cam c;
+  if (threadIdx.x < ACINO_CAM_STRIDE) reinterpret_cast<double*>(&c)[threadIdx.x] = cam[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    double u, v;
+    project_fisheye_pt(c, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u, v);
+    reinterpret_cast<double2*>(out)[i] = make_double2(u, v);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_project_pinhole(const double* __restrict__ obj, int64_t m, const double* __restrict__ cam,
+                                  double* __restrict__ out) {
+  __shared__ Pin c;
+  if (threadIdx.x < ACINO_PINHOLE_STRIDE) reinterpret_cast<double*>(&c)[threadIdx.x] = cam[threadIdx.x];
+  __syncthreads();
+  const double* k = c.d;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+    double xc = c.R[0] * X + c.R[1] * Y + c.R[2] * Z + c.t[0];
+    double yc = c.R[3] * X + c.R[4] * Y + c.R[5] * Z + c.t[1];
+    double zc = c.R[6] * X + c.R[7] * Y + c.R[8] * Z + c.t[2];
+    double x = xc / zc, y = yc / zc;
+    double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    double icdist2 = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+    double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4;
+    double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4;
+    reinterpret_cast<double2*>(out)[i] = make_double2(xd * c.fx + c.cx, yd * c.fy + c.cy);
+  }
+}
+
+// ---- dense adjacent-pair triangulation ------------------------------------------------------
+// One thread per (frame, marker).  Camera records are staged in LDS once per workgroup; detections
+// are read as 24-byte (x, y, likelihood) records, consecutive lanes = consecutive markers, so a wave
+// reads one contiguous 1.5 KB span per camera.  Undistortion of camera c is reused for pairs (c-1,c)
+// and (c,c+1).  Mean = Kahan sum in pair order / count (pandas group_mean), NaN when no pair.
+__global__ void __launch_bounds__(256)
+k_triangulate_pairs(const double* __restrict__ det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                    const double* __restrict__ cams, double* __restrict__ tri, uint8_t* __restrict__ npairs,
+                    uint8_t* __restrict__ pairmask) {
+  __shared__ Cam c[ACINO_MAX_CAMS];
+  for (int i = threadIdx.x; i < n_cams * ACINO_CAM_STRIDE; i += blockDim.x)
+    reinterpret_cast<double*>(c)[i] = cams[i];
+  __syncthreads();
+  const int64_t total = n_frames * n_markers;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / n_markers;
+    const int l = (int)(idx - n * n_markers);
+    const double* base = det + ((n * n_cams) * n_markers + l) * 3;
+    double sum[3] = {0, 0, 0}, comp[3] = {0, 0, 0};
+    int cnt = 0;
+    unsigned mask = 0;
+    bool pv = false;
+    double px = 0, py = 0;
+    for (int ci = 0; ci < n_cams; ++ci) {
+      const double* d = base + (int64_t)ci * n_markers * 3;
+      double u = d[0], v = d[1], lik = d[2];
+      bool valid = lik > thresh;
+      double x = 0, y = 0;
+      if (valid) {
+        if (!undistort_fisheye_pt(c[ci], u, v, 10, 1e-8, x, y)) x = y = -1000000.0;
+      }
+      if (valid && pv) {
+        double X[3];
+        triangulate_two_view(c[ci - 1], c[ci], px, py, x, y, X);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // Kahan step
+          double yk = X[k] - comp[k];
+          double t = sum[k] + yk;
+          comp[k] = (t - sum[k]) - yk;
+          sum[k] = t;
+        }
+        ++cnt;
+        mask |= 1u << (ci - 1);
+      }
+      pv = valid;
+      px = x;
+      py = y;
+    }
+    double* o = tri + idx * 3;
+    if (cnt > 0) {
+      o[0] = sum[0] / cnt;
+      o[1] = sum[1] / cnt;
+      o[2] = sum[2] / cnt;
+    } else {
+      o[0] = o[1] = o[2] = __builtin_nan("");
+    }
+    if (npairs) npairs[idx] = (uint8_t)cnt;
+    if (pairmask) pairmask[idx] = (uint8_t)mask;
+  }
+}
+
+// Reprojection residual of pts3[N][L][3] in every camera; one thread per (frame, marker).
+__global__ void __launch_bounds__(256)
+k_reproject_residuals(const double* __restrict__ pts3, const double* __restrict__ det, int64_t n_frames, int n_cams,
+                      int n_markers, double thresh, const double* __restrict__ cams, double* __restrict__ res,
+                      double* __restrict__ sums) {
+  __shared__ Cam c[ACINO_MAX_CAMS];
+  __shared__ double red[4][4];
+  for (int i = threadIdx.x; i < n_cams * ACINO_CAM_STRIDE; i += blockDim.x)
+    reinterpret_cast<double*>(c)[i] = cams[i];
+  __syncthreads();
+  double s_cnt = 0, s_r = 0, s_r2 = 0, s_c = 0;
+  const int64_t total = n_frames * n_markers;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / n_markers;
+    const int l = (int)(idx - n * n_markers);
+    double X = pts3[idx * 3], Y = pts3[idx * 3 + 1], Z = pts3[idx * 3 + 2];
+    bool fin = isfinite(X) && isfinite(Y) && isfinite(Z);
+    for (int ci = 0; ci < n_cams; ++ci) {
+      const int64_t o = ((n * n_cams + ci) * n_markers + l);
+      const double* d = det + o * 3;
+      double ru = __builtin_nan(""), rv = __builtin_nan("");
+      if (fin && d[2] > thresh) {
+        double u, v;
+        project_fisheye_pt(c[ci], X, Y, Z, u, v);
+        ru = u - d[0];
+        rv = v - d[1];
+        s_cnt += 2;
+        s_r += ru + rv;
+        s_r2 += ru * ru + rv * rv;
+        s_c += 0.5 * (log1p(ru * ru) + log1p(rv * rv));
+      }
+      reinterpret_cast<double2*>(res)[o] = make_double2(ru, rv);
+    }
+  }
+  if (sums) {
+    double v[4] = {s_cnt, s_r, s_r2, s_c};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+      for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
+      atomicAdd(&sums[threadIdx.x], t);
+    }
+  }
+}
+
+static inline int grid_for(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;  // 256 CUs x 8 blocks, grid-stride beyond
+  return (int)g;
+}
+
+}  // namespace acino
+
+using namespace acino;
+
+extern "C" {
+
+const char* acino_last_error_string(void) { return acino::last_error(); }
+int acino_abi_version(void) { return ACINO_ABI_VERSION; }
+int acino_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return ACINO_ERR_NO_DEVICE;
+  }
+  return n;
+}
+
+int acino_undistort_fisheye(const double* d_pts, int64_t m, const double* d_cam24, double* d_out, int max_iter,
+                            double eps, void* stream) {
+  ACINO_REQUIRE(m >= 0, "m");
+  ACINO_REQUIRE(d_cam24 != nullptr, "camera");
+  if (m == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_pts && d_out, "null buffer");
+  hipLaunchKernelGGL(k_undistort_fisheye, dim3(grid_for(m, 256)), dim3(256), 0, (hipStream_t)stream, d_pts, m,
+                     d_cam24, d_out, max_iter, eps);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_triangulate_fisheye(const double* d_pts1, const double* d_pts2, int64_t m, const double* d_cam_a24,
+                              const double* d_cam_b24, double* d_out, void* stream) {
+  ACINO_REQUIRE(m >= 0, "m");
+  ACINO_REQUIRE(d_cam_a24 && d_cam_b24, "camera");
+  if (m == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_pts1 && d_pts2 && d_out, "null buffer");
+  hipLaunchKernelGGL(k_triangulate_fisheye, dim3(grid_for(m, 256)), dim3(256), 0, (hipStream_t)stream, d_pts1,
+                     d_pts2, m, d_cam_a24, d_cam_b24, d_out);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_triangulate_pinhole(const double* d_pts1, const double* d_pts2, int64_t m, const double* d_cam_a32,
+                              const double* d_cam_b32, double* d_out, void* stream) {
+  ACINO_REQUIRE(m >= 0, "m");
+  ACINO_REQUIRE(d_cam_a32 && d_cam_b32, "camera");
+  if (m == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_pts1 && d_pts2 && d_out, "null buffer");
+  hipLaunchKernelGGL(k_triangulate_pinhole, dim3(grid_for(m, 256)), dim3(256), 0, (hipStream_t)stream, d_pts1,
+                     d_pts2, m, d_cam_a32, d_cam_b32, d_out);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_project_fisheye(const double* d_obj, int64_t m, const double* d_cam24, double* d_out, void* stream) {
+  ACINO_REQUIRE(m >= 0, "m");
+  ACINO_REQUIRE(d_cam24 != nullptr, "camera");
+  if (m == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_obj && d_out, "null buffer");
+  hipLaunchKernelGGL(k_project_fisheye, dim3(grid_for(m, 256)), dim3(256), 0, (hipStream_t)stream, d_obj, m,
+                     d_cam24, d_out);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32, double* d_out, void* stream) {
+  ACINO_REQUIRE(m >= 0, "m");
+  ACINO_REQUIRE(d_cam32 != nullptr, "camera");
+  if (m == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_obj && d_out, "null buffer");
+  hipLaunchKernelGGL(k_project_pinhole, dim3(grid_for(m, 256)), dim3(256), 0, (hipStream_t)stream, d_obj, m,
+                     d_cam32, d_out);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                            const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                            void* stream) {
+  ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= 8, "n_cams must be 1..8 (pair mask is one byte)");
+  if (n_frames == 0 || n_markers == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_det && d_cams24 && d_tri, "null buffer");
+  hipLaunchKernelGGL(k_triangulate_pairs, dim3(grid_for(n_frames * n_markers, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs,
+                     d_pairmask);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_reproject_residuals(const double* d_pts3, const double* d_det, int64_t n_frames, int n_cams,
+                              int n_markers, double thresh, const double* d_cams24, double* d_res, double* d_sums,
+                              void* stream) {
+  ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= ACINO_MAX_CAMS, "n_cams");
+  if (n_frames == 0 || n_markers == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_pts3 && d_det && d_cams24 && d_res, "null buffer");
+  hipLaunchKernelGGL(k_reproject_residuals, dim3(grid_for(n_frames * n_markers, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_pts3, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_res,
+                     d_sums);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+// Shared host/device helpers for libacinoset_hip (gfx950, fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/acinoset_hip.h"
+
+namespace acino {
+
+void set_error(const char* fmt, ...);
+
+#define ACINO_HIP_CHECK(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ::acino::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                         __LINE__);                                                        \
+      return ACINO_ERR_HIP;                                                                \
+    }                                                                                      \
+  } while (0)
+
+#define ACINO_REQUIRE(cond, msg)                                        \
+  do {                                                                  \
+    if (!(cond)) {                                                      \
+      ::acino::set_error("invalid argument: %s (%s)", msg, #cond);      \
+      return ACINO_ERR_INVALID_ARG;                                     \
+    }                                                                   \
+  } while (0)
+
+#define ACINO_LAUNCH_CHECK()                                                             \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess) {                                                              \
+      ::acino::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),      \
+                         __FILE__, __LINE__);                                            \
+      return ACINO_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+// ---- fisheye camera record (24 doubles, see acinoset_hip.h) -------------------------------
+struct Cam {
+  double fx, fy, cx, cy;
+  double k1, k2, k3, k4;
+  double R[9];
+  double t[3];
+  double alpha, pad0, pad1, pad2;
+};
+static_assert(sizeof(Cam) == ACINO_CAM_STRIDE * sizeof(double), "camera record layout");
+
+// Kannala-Brandt inverse (OpenCV fisheye::undistortPoints, no R/P).  Returns false when OpenCV would
+// flag the point (not converged / theta sign flipped) - caller writes -1e6.
+__device__ __forceinline__ bool undistort_fisheye_pt(const Cam& c, double u, double v, int max_iter, double eps,
+                                                    double& xn, double& yn) {
+  double pwy = (v - c.cy) / c.fy;
+  double pwx = (u - c.cx) / c.fx - c.alpha * pwy;
+  double theta_d = sqrt(pwx * pwx + pwy * pwy);
+  theta_d = fmin(fmax(-M_PI / 2.0, theta_d), M_PI / 2.0);
+  bool converged = false;
+  double theta = theta_d;
+  double scale = 0.0;
+  if (fabs(theta_d) > eps) {
+    for (int j = 0; j < max_iter; ++j) {
+      double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      double k0t2 = c.k1 * t2, k1t4 = c.k2 * t4, k2t6 = c.k3 * t6, k3t8 = c.k4 * t8;
+      double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) /
+                   (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+      theta = theta - fix;
+      if (fabs(fix) < eps) {
+        converged = true;
+        break;
+      }
+    }
+    scale = tan(theta) / theta_d;
+  } else {
+    converged = true;
+  }
+  bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+  xn = pwx * scale;
+  yn = pwy * scale;
+  return converged && !flipped;
+}
+
+// cv2.fisheye.projectPoints for one point (r > 1e-8 branch as OpenCV).
+__device__ __forceinline__ void project_fisheye_pt(const Cam& c, double X, double Y, double Z, double& u,
+                                                  double& v) {
+  double xc = c.R[0] * X + c.R[1] * Y + c.R[2] * Z + c.t[0];
+  double yc = c.R[3] * X + c.R[4] * Y + c.R[5] * Z + c.t[1];
+  double zc = c.R[6] * X + c.R[7] * Y + c.R[8] * Z + c.t[2];
+  double a = xc / zc, b = yc / zc;
+  double r = sqrt(a * a + b * b);
+  double th = atan(r);
+  double th2 = th * th;
+  double thd = th * (1 + th2 * (c.k1 + th2 * (c.k2 + th2 * (c.k3 + th2 * c.k4))));
+  double cdist = r > 1e-8 ? thd / r : 1.0;
+  double xd = a * cdist, yd = b * cdist;
+  u = (xd + c.alpha * yd) * c.fx + c.cx;
+  v = yd * c.fy + c.cy;
+}
+
+// Null vector of the 4x4 DLT matrix by one-sided Jacobi (Hestenes) on its columns: on exit the
+// columns of A*V are orthogonal; the right-singular vector of the smallest singular value is the
+// column of V whose A*V column has the smallest norm.  Returns X/W (dehomogenised).
+__device__ __forceinline__ void dlt_null_vector(double A[4][4], double out[3]) {
+  double V[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          al += A[i][p] * A[i][p];
+          be += A[i][q] * A[i][q];
+          ga += A[i][p] * A[i][q];
+        }
+        double lim = 1e-30 + 1e-32 * sqrt(al * be);
+        if (fabs(ga) > 1e-17 * sqrt(al * be) && fabs(ga) > lim) {
+          off = fmax(off, fabs(ga) / sqrt(al * be));
+          double zeta = (be - al) / (2.0 * ga);
+          double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            double ap = A[i][p], aq = A[i][q];
+            A[i][p] = cs * ap - sn * aq;
+            A[i][q] = sn * ap + cs * aq;
+            double vp = V[i][p], vq = V[i][q];
+            V[i][p] = cs * vp - sn * vq;
+            V[i][q] = sn * vp + cs * vq;
+          }
+        }
+      }
+    }
+    if (off < 1e-15) break;
+  }
+  double best = 1e300;
+  double x = 0, y = 0, z = 0, w = 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double nrm = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nrm += A[i][j] * A[i][j];
+    if (nrm < best) {
+      best = nrm;
+      x = V[0][j];
+      y = V[1][j];
+      z = V[2][j];
+      w = V[3][j];
+    }
+  }
+  out[0] = x / w;
+  out[1] = y / w;
+  out[2] = z / w;
+}
+
+// Two-view DLT from normalised image points (cv2.triangulatePoints + dehomogenise, calib.py:126-129).
+__device__ __forceinline__ void triangulate_two_view(const Cam& ca, const Cam& cb, double x1, double y1, double x2,
+                                                    double y2, double out[3]) {
+  double A[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double p1_0 = k < 3 ? ca.R[k] : ca.t[0], p1_1 = k < 3 ? ca.R[3 + k] : ca.t[1],
+           p1_2 = k < 3 ? ca.R[6 + k] : ca.t[2];
+    double p2_0 = k < 3 ? cb.R[k] : cb.t[0], p2_1 = k < 3 ? cb.R[3 + k] : cb.t[1],
+           p2_2 = k < 3 ? cb.R[6 + k] : cb.t[2];
+    A[0][k] = x1 * p1_2 - p1_0;
+    A[1][k] = y1 * p1_2 - p1_1;
+    A[2][k] = x2 * p2_2 - p2_0;
+    A[3][k] = y2 * p2_2 - p2_1;
+  }
+  dlt_null_vector(A, out);
+}
+
+// ---- redescending loss (build.py:382-395) ---------------------------------------------------
+struct LossC {
+  double a, b, c;
+  double ea, eb, ec;     // exp(a), exp(b), exp(c)
+  double d0;             // rho'(0+)
+  double t4;             // a*b - a^2/2 + a*(c-b)/2
+};
+
+__host__ __device__ inline double loss_step(double start, double x) { return 1.0 / (1.0 + exp(-(x - start))); }
+
+inline LossC make_loss(double a, double b, double c) {
+  LossC L;
+  L.a = a; L.b = b; L.c = c;
+  L.ea = exp(a); L.eb = exp(b); L.ec = exp(c);
+  double sa = loss_step(a, 0.0), sb = loss_step(b, 0.0), sc = loss_step(c, 0.0);
+  double dsa = sa * (1 - sa), dsb = sb * (1 - sb), dsc = sc * (1 - sc);
+  double cb = c - b;
+  double t2 = -a * a / 2;
+  double t3 = a * b - a * a / 2 + (a * cb / 2) * (1 - (c / cb) * (c / cb));
+  L.t4 = a * b - a * a / 2 + a * cb / 2;
+  L.d0 = (dsa - dsb) * t2 + (sa - sb) * a + (dsb - dsc) * t3 + (sb - sc) * (a * c / cb) + dsc * L.t4;
+  return L;
+}
+
+// rho(e), rho'(e) and the Gauss-Newton curvature weight h = clip((rho'(e) - rho'(0+))/e, 0, 1); e = |err|.
+template <bool DERIV>
+__device__ __forceinline__ void redescending(const LossC& L, double err, double& rho, double& drho, double& h) {
+  double e = fabs(err);
+  double u = exp(-e);                       // one exp: sigma(s, e) = 1 / (1 + exp(s) * exp(-e))
+  double sa = 1.0 / (1.0 + L.ea * u), sb = 1.0 / (1.0 + L.eb * u), sc = 1.0 / (1.0 + L.ec * u);
+  double cb = L.c - L.b;
+  double t2 = L.a * e - L.a * L.a / 2;
+  double ce = (L.c - e) / cb;
+  double t3 = L.a * L.b - L.a * L.a / 2 + (L.a * cb / 2) * (1 - ce * ce);
+  rho = (1 - sa) / 2 * e * e + (sa - sb) * t2 + (sb - sc) * t3 + sc * L.t4;
+  if (DERIV) {
+    double dsa = sa * (1 - sa), dsb = sb * (1 - sb), dsc = sc * (1 - sc);
+    drho = -dsa / 2 * e * e + (1 - sa) * e + (dsa - dsb) * t2 + (sa - sb) * L.a + (dsb - dsc) * t3 +
+           (sb - sc) * (L.a * (L.c - e) / cb) + dsc * L.t4;
+    double hh = e > 1e-12 ? (drho - L.d0) / e : 1.0;
+    h = fmin(fmax(hh, 0.0), 1.0);
+  }
+}
+
+}  // namespace acino

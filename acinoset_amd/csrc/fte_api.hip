@@ -1,0 +1,820 @@
+// FTE solve: context, Levenberg-Marquardt controller (device-resident) and the C ABI.
+// Reference: the Pyomo model + IPOPT solve of src/all_optimizations.py:283-556 in reduced form.
+#include <algorithm>
+#include <map>
+#include <new>
+
+#include "bcr.hpp"
+
+namespace acino {
+
+struct Buffers {
+  FteConst* cst;
+  acino_fte_state* state;
+  double* x[2];       // [(N+6)][25] with 3 halo frames each side
+  double* g[2];       // [N][25]
+  double* H[2];       // [N][25][25] Gauss-Newton blocks (measurement + smoothness diagonal)
+  double* cost_part;  // [nblk]
+  double* pred_part;  // [nblk_t]
+  double* step_part;  // [nblk_t]
+  double* gn_part;    // [n_nodes]
+  double* totals;     // [8]
+  int* nbehind;
+  int* numeric_err;
+  int* sched;         // elim (3/entry) then remain (4/entry)
+};
+
+}  // namespace acino
+
+struct acino_fte_ctx {
+  double lam0;
+  acino::FteConst h;
+  acino::Buffers b;
+  acino::BcrChain chain;
+  acino::BcrSchedule sched;
+  const double* d_det;
+  int n_blk_asm, n_blk_trial;
+  size_t ws_bytes;
+};
+
+namespace acino {
+
+static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+static int chain_nodes(const acino_fte_params* p) { return (p->n_frames + 2) / 3 + (p->pin_left ? 1 : 0); }
+
+struct Carver {
+  char* base;
+  size_t off;
+  template <class T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off = align_up(off + count * sizeof(T));
+    return p;
+  }
+};
+
+static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChain* ch, size_t sched_ints) {
+  Carver c{base, 0};
+  const size_t N = p->n_frames, T = chain_nodes(p);
+  Buffers b;
+  b.cst = c.take<FteConst>(1);
+  b.state = c.take<acino_fte_state>(1);
+  for (int k = 0; k < 2; ++k) b.x[k] = c.take<double>((N + 2 * HALO) * NP);
+  for (int k = 0; k < 2; ++k) b.g[k] = c.take<double>(N * NP);
+  for (int k = 0; k < 2; ++k) b.H[k] = c.take<double>(N * NP * NP);
+  b.cost_part = c.take<double>(n_assemble_blocks((int)N) + 1);
+  b.pred_part = c.take<double>((N * NP + 255) / 256 + 1);
+  b.step_part = c.take<double>((N * NP + 255) / 256 + 1);
+  b.gn_part = c.take<double>(T + 1);
+  b.totals = c.take<double>(8);
+  b.nbehind = c.take<int>(4);
+  b.numeric_err = b.nbehind + 1;
+  b.sched = c.take<int>(sched_ints + 4);
+  BcrChain chn;
+  chn.n_nodes = (int)T;
+  chn.D = c.take<double>(T * BS * BS);
+  chn.Cpl = c.take<double>(T * BS * BS);
+  chn.Wl = c.take<double>(T * BS * BS);
+  chn.b = c.take<double>(T * BS);
+  chn.d_elim = nullptr;
+  chn.d_remain = nullptr;
+  chn.implicit_couplings = 1;
+  if (out) *out = b;
+  if (ch) *ch = chn;
+  return c.off;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------
+// Working system of one LM step: D = H_gn + lam*diag(H_gn) (bound-active variables pinned by a 2^70
+// diagonal boost), b = -g.  One workgroup per chain node.
+__global__ void __launch_bounds__(256)
+k_setup(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, const double* __restrict__ x0,
+        const double* __restrict__ x1, const double* __restrict__ g0, const double* __restrict__ g1,
+        const double* __restrict__ H0, const double* __restrict__ H1, BcrChain ch, double* __restrict__ gn_part) {
+  if (st->status != 0) return;
+  const FteConst& K = *cst;
+  const int cur = st->cur;
+  const double* x = cur ? x1 : x0;
+  const double* g = cur ? g1 : g0;
+  const double* H = cur ? H1 : H0;
+  const double lam = st->lam;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double* D = ch.D + (size_t)t * BS * BS;
+  double* b = ch.b + (size_t)t * BS;
+  __shared__ double red[4];
+  double gmax = 0.0;
+  const bool sep_left = K.pin_left && t == 0;
+  const int fbase = 3 * (t - K.pin_left);   // local frame of sub-row 0
+  for (int e = tid; e < BS * BS; e += 256) {
+    const int r = e / BS, c = e % BS;
+    double v = 0.0;
+    if (sep_left) {
+      v = 0.0;
+    } else if (r >= 3 * NP || c >= 3 * NP) {
+      v = (r == c) ? 1.0 : 0.0;
+    } else {
+      const int ii = r / NP, p = r % NP, jj = c / NP, pc = c % NP;
+      const int nr = fbase + ii, nc = fbase + jj;
+      const bool er = nr < K.n_frames, ec = nc < K.n_frames;
+      if (!er || !ec) {
+        v = (r == c) ? 1.0 : 0.0;
+      } else if (ii == jj) {
+        v = H[((size_t)nr * NP + p) * NP + pc];
+        if (p == pc) {
+          const double xv = x[(size_t)(nr + HALO) * NP + p], gv = g[(size_t)nr * NP + p];
+          const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+          v = v + lam * v;
+          if (fixed) v *= FIX_SCALE;
+        }
+      } else if (p == pc) {
+        const int lo_f = ii < jj ? nr : nc, k = ii < jj ? jj - ii : ii - jj;
+        v = 2.0 * K.q_w[p] * band_coef(K.n_offset + lo_f, k, K.n_global);
+      }
+    }
+    D[e] = v;
+  }
+  if (tid < BS) {
+    double bv = 0.0;
+    if (!sep_left && tid < 3 * NP) {
+      const int ii = tid / NP, p = tid % NP, n = fbase + ii;
+      if (n < K.n_frames) {
+        const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
+        const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+        bv = fixed ? 0.0 : -gv;
+        gmax = fabs(bv);
+      }
+    }
+    b[tid] = bv;
+  }
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = gmax;
+  __syncthreads();
+  if (tid == 0) gn_part[t] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Trial iterate x_t = clip(x + delta) and the model quantities of the step.
+__global__ void __launch_bounds__(256)
+k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, double* __restrict__ x0,
+        double* __restrict__ x1, const double* __restrict__ g0, const double* __restrict__ g1,
+        const double* __restrict__ H0, const double* __restrict__ H1, const double* __restrict__ delta_nodes,
+        double* __restrict__ pred_part, double* __restrict__ step_part) {
+  if (st->status != 0) return;
+  const FteConst& K = *cst;
+  const int cur = st->cur;
+  const double* x = cur ? x1 : x0;
+  double* xt = cur ? x0 : x1;
+  const double* g = cur ? g1 : g0;
+  const double* H = cur ? H1 : H0;
+  const double lam = st->lam;
+  const int tid = threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+  double pred = 0.0, step = 0.0;
+  if (e < (int64_t)K.n_frames * NP) {
+    const int n = (int)(e / NP), p = (int)(e % NP);
+    const int node = n / 3 + K.pin_left, row = (n % 3) * NP + p;
+    const double d = delta_nodes[(size_t)node * BS + row];
+    const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[e];
+    const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+    const double pg = fixed ? 0.0 : gv;
+    const double d0 = H[((size_t)n * NP + p) * NP + p];
+    const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
+    xt[(size_t)(n + HALO) * NP + p] = xn;
+    pred = 0.5 * d * (lam * d0 * d - pg);
+    step = fabs(xn - xv);
+  }
+  __shared__ double rp[4], rs[4];
+  for (int off = 32; off > 0; off >>= 1) {
+    pred += __shfl_down(pred, off, 64);
+    step = fmax(step, __shfl_down(step, off, 64));
+  }
+  if ((tid & 63) == 0) {
+    rp[tid >> 6] = pred;
+    rs[tid >> 6] = step;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    pred_part[blockIdx.x] = (rp[0] + rp[1]) + (rp[2] + rp[3]);
+    step_part[blockIdx.x] = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+  }
+}
+
+__device__ double block_sum(const double* v, int n, double* sh) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+__device__ double block_max(const double* v, int n, double* sh) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s = fmax(s, v[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// totals = {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}   (fixed summation order)
+__global__ void __launch_bounds__(256)
+k_totals(const acino_fte_state* __restrict__ st, const double* cost_part, int n_cost, const double* pred_part,
+         const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
+         int with_step) {
+  if (st->status != 0) return;
+  __shared__ double sh[256];
+  double c = block_sum(cost_part, n_cost, sh);
+  double p = with_step ? block_sum(pred_part, n_trial, sh) : 0.0;
+  double s = with_step ? block_max(step_part, n_trial, sh) : 0.0;
+  double g = with_step ? block_max(gn_part, n_nodes, sh) : 0.0;
+  if (threadIdx.x == 0) {
+    totals[0] = c;
+    totals[1] = p;
+    totals[2] = s;
+    totals[3] = g;
+    totals[4] = (double)*nbehind;
+    totals[5] = totals[6] = totals[7] = 0.0;
+    *nbehind = 0;
+  }
+}
+
+// Accept / reject + Nielsen lambda update; mirrors oracle/fte.py:lm_solve step for step.
+__global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st, const double* __restrict__ totals,
+                          const int* __restrict__ numeric_err, int init) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->status != 0) return;
+  const FteConst& K = *cst;
+  if (init) {
+    st->cost = totals[0];
+    st->cost_trial = totals[0];
+    st->n_behind = (int)totals[4];
+    return;
+  }
+  const double F = st->cost, Ft = totals[0], pred = totals[1], step = totals[2], gnorm = totals[3];
+  st->cost_trial = Ft;
+  st->pred = pred;
+  st->step_inf = step;
+  st->gnorm_inf = gnorm;
+  st->iter += 1;
+  if (*numeric_err) {
+    st->status = 5;
+    return;
+  }
+  if (gnorm <= K.gtol) {   // the iterate the step started from was already stationary: keep it
+    st->status = 3;
+    st->last_accept = 0;
+    return;
+  }
+  const double gain = pred > 0.0 ? (F - Ft) / pred : -1.0;
+  st->gain = gain;
+  if (Ft < F) {
+    const double dF = F - Ft;
+    st->cur ^= 1;
+    st->cost = Ft;
+    st->accepted += 1;
+    st->last_accept = 1;
+    st->n_behind = (int)totals[4];
+    const double t = 2.0 * gain - 1.0;
+    st->lam = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+    st->nu = 2.0;
+    if (dF <= K.ftol * fabs(Ft)) st->status = 1;
+    else if (step <= K.xtol) st->status = 2;
+  } else {
+    st->last_accept = 0;
+    st->lam *= st->nu;
+    st->nu *= 2.0;
+    if (st->lam > 1e16) st->status = 4;
+  }
+}
+
+__global__ void k_copy_x_in(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
+                            const double* __restrict__ src, double* x0, double* x1) {
+  const FteConst& K = *cst;
+  double* dst = (st->cur ^ which) ? x1 : x0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < (int64_t)K.n_frames * NP) {
+    const int p = (int)(e % NP);
+    dst[e + HALO * NP] = fmin(fmax(src[e], K.lo[p]), K.hi[p]);
+  }
+}
+
+__global__ void k_set_halo(const acino_fte_state* __restrict__ st, int which, double* x0, double* x1, int n_frames,
+                           const double* __restrict__ hl, const double* __restrict__ hr) {
+  double* xbuf = (st->cur ^ which) ? x1 : x0;
+  const int t = threadIdx.x;
+  if (t < HALO * NP) {
+    xbuf[t] = hl ? hl[t] : 0.0;
+    xbuf[(size_t)(n_frames + HALO) * NP + t] = hr ? hr[t] : 0.0;
+  }
+}
+
+// dx_n = (x_n - x_{n-1})/Ts, ddx_n = (dx_n - dx_{n-1})/Ts (all_optimizations.py:369-383); the free first
+// rows take the values of the optimum: ddx_0 = ddx_1 = ddx_2, dx_0 = dx_1 - Ts ddx_1.
+__global__ void k_derivatives(const double* __restrict__ x, int64_t n, double ts, double* __restrict__ dx,
+                              double* __restrict__ ddx) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * NP) return;
+  const int64_t f = e / NP;
+  const int p = (int)(e % NP);
+  auto X = [&](int64_t k) { return x[k * NP + p]; };
+  auto DX = [&](int64_t k) { return (X(k) - X(k - 1)) / ts; };          // k >= 1
+  auto DDX = [&](int64_t k) { return (DX(k) - DX(k - 1)) / ts; };       // k >= 2
+  double v = 0.0, a = 0.0;
+  if (n >= 3) {
+    a = f >= 2 ? DDX(f) : DDX(2);
+    v = f >= 1 ? DX(f) : DX(1) - ts * DDX(2);
+  } else if (n == 2) {
+    v = DX(1);
+  }
+  if (dx) dx[e] = v;
+  if (ddx) ddx[e] = a;
+}
+
+__global__ void k_copy_x_out(const acino_fte_state* __restrict__ st, int which, const double* x0, const double* x1,
+                             int64_t n, double* __restrict__ dst) {
+  const double* xh = (st->cur ^ which) ? x1 : x0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * NP) dst[e] = xh[e + HALO * NP];
+}
+
+__global__ void k_export_HG(const acino_fte_state* __restrict__ st, const double* g0, const double* g1,
+                            const double* H0, const double* H1, int64_t n, double* __restrict__ dg,
+                            double* __restrict__ dh) {
+  const double* g = st->cur ? g1 : g0;
+  const double* H = st->cur ? H1 : H0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (dg && e < n * NP) dg[e] = g[e];
+  if (dh)
+    for (int64_t k = e; k < n * NP * NP; k += (int64_t)gridDim.x * 256) dh[k] = H[k];
+}
+
+__global__ void k_export_edges(const acino_fte_state* __restrict__ st, int which, const double* x0, const double* x1,
+                               int n_frames, double* __restrict__ edge) {
+  const double* xh = (st->cur ^ which) ? x1 : x0;
+  const int t = threadIdx.x;
+  if (t < HALO * NP) {
+    edge[t] = xh[HALO * NP + t];                                              // first 3 frames
+    edge[HALO * NP + t] = xh[(size_t)(n_frames + HALO - 3) * NP + t];         // last 3 frames
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_export_sep(BcrChain ch, int node_left, int node_right, double* __restrict__ rec_left, double* __restrict__ rec_right) {
+  // rec layout: D[6400] | C[6400] | b[80]
+  const size_t MB = (size_t)BS * BS;
+  for (int e = threadIdx.x + blockIdx.x * 256; e < (int)MB; e += gridDim.x * 256) {
+    if (rec_left) {   // this rank's pinned-left node: Schur update of separator (rank-1), plus coupling to the right separator
+      rec_left[e] = ch.D[(size_t)node_left * MB + e];
+    }
+    if (rec_right) {
+      rec_right[e] = ch.D[(size_t)node_right * MB + e];
+      if (rec_left) rec_left[MB + e] = ch.Cpl[(size_t)node_left * MB + e];    // block(right sep, left sep)
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < BS) {
+    if (rec_left) rec_left[2 * MB + threadIdx.x] = ch.b[(size_t)node_left * BS + threadIdx.x];
+    if (rec_right) rec_right[2 * MB + threadIdx.x] = ch.b[(size_t)node_right * BS + threadIdx.x];
+  }
+}
+
+__global__ void k_import_sep(const double* __restrict__ rec, int n_sep, BcrChain ch) {
+  const size_t MB = (size_t)BS * BS;
+  const int s = blockIdx.y;
+  const double* r = rec + (size_t)s * ACINO_SEP_DOUBLES;
+  for (int e = threadIdx.x + blockIdx.x * 256; e < (int)MB; e += gridDim.x * 256) {
+    ch.D[(size_t)s * MB + e] = r[e];
+    if (s + 1 < n_sep) ch.Cpl[(size_t)s * MB + e] = rec[(size_t)(s + 1) * ACINO_SEP_DOUBLES + MB + e];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < BS) ch.b[(size_t)s * BS + threadIdx.x] = r[2 * MB + threadIdx.x];
+}
+
+__global__ void k_set_node_x(BcrChain ch, int node, const double* __restrict__ xsep) {
+  if (threadIdx.x < BS) ch.b[(size_t)node * BS + threadIdx.x] = xsep[threadIdx.x];
+}
+
+__global__ void k_copy_vec(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst* c) {
+  memset(c, 0, sizeof(*c));
+  c->n_frames = p->n_frames;
+  c->n_cams = p->n_cams;
+  c->n_global = p->n_global;
+  c->n_offset = p->n_offset;
+  c->pin_left = p->pin_left ? 1 : 0;
+  c->pin_right = p->pin_right ? 1 : 0;
+  c->n_nodes = chain_nodes(p);
+  c->dlc_thresh = p->dlc_thresh;
+  c->inv_r = p->inv_r_meas;
+  c->loss = make_loss(p->redesc_a, p->redesc_b, p->redesc_c);
+  for (int i = 0; i < NP; ++i) {
+    c->q_w[i] = p->q_w[i];
+    c->lo[i] = p->lo[i];
+    c->hi[i] = p->hi[i];
+  }
+  c->ftol = p->ftol;
+  c->xtol = p->xtol;
+  c->gtol = p->gtol;
+  memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
+  return ACINO_OK;
+}
+
+static int validate(const acino_fte_params* p) {
+  ACINO_REQUIRE(p != nullptr, "params");
+  ACINO_REQUIRE(p->n_frames >= 1, "n_frames >= 1");
+  ACINO_REQUIRE(p->n_cams >= 1 && p->n_cams <= ACINO_MAX_CAMS, "n_cams in 1..16");
+  ACINO_REQUIRE(p->n_global >= p->n_frames && p->n_offset >= 0 && p->n_offset + p->n_frames <= p->n_global,
+                "shard range inside the sequence");
+  ACINO_REQUIRE(!p->pin_left || (p->n_offset >= 3 && p->n_offset % 3 == 0), "pinned-left shard must start at a multiple of 3");
+  ACINO_REQUIRE(!p->pin_right || (p->n_frames % 3 == 0), "pinned-right shard must hold a multiple of 3 frames");
+  ACINO_REQUIRE(!(p->pin_left || p->pin_right) || p->n_frames >= 6, "sharded ranks need >= 6 frames");
+  ACINO_REQUIRE(p->redesc_c > p->redesc_b && p->redesc_b > p->redesc_a && p->redesc_a > 0, "redescending a<b<c");
+  ACINO_REQUIRE(p->lam0 > 0, "lam0 > 0");
+  return ACINO_OK;
+}
+
+}  // namespace acino
+
+using namespace acino;
+
+static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_step, bool respect_status,
+                        hipStream_t s) {
+  const Buffers& b = ctx->b;
+  int rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.cost_part, b.nbehind,
+                           need_jac, respect_status, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
+                     b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
+                     with_step ? 1 : 0);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+extern "C" {
+
+size_t acino_fte_workspace_bytes(const acino_fte_params* p) {
+  if (!p || p->n_frames < 1) return 0;
+  BcrSchedule sch;
+  sch.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
+  return carve(p, nullptr, nullptr, nullptr, sch.elim.size() + sch.remain.size()) + 256;
+}
+
+int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det, const double* d_cams24,
+                     void* d_workspace, size_t workspace_bytes, void* stream) {
+  ACINO_REQUIRE(out != nullptr, "out");
+  *out = nullptr;
+  int rc = validate(p);
+  if (rc) return rc;
+  ACINO_REQUIRE(d_det && d_cams24 && d_workspace, "null buffer");
+  ACINO_REQUIRE(((uintptr_t)d_workspace & 255) == 0, "workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  acino_fte_ctx* ctx = new (std::nothrow) acino_fte_ctx();
+  if (!ctx) {
+    set_error("out of host memory");
+    return ACINO_ERR_INVALID_ARG;
+  }
+  ctx->lam0 = p->lam0;
+  ctx->sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
+  const size_t sched_ints = ctx->sched.elim.size() + ctx->sched.remain.size();
+  const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, sched_ints);
+  if (need > workspace_bytes) {
+    set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    delete ctx;
+    return ACINO_ERR_WORKSPACE;
+  }
+  ctx->ws_bytes = need;
+  ctx->d_det = d_det;
+  double h_cams[ACINO_MAX_CAMS * ACINO_CAM_STRIDE];
+  hipError_t e = hipMemcpyAsync(h_cams, d_cams24, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams,
+                                hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    set_error("reading camera records failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return ACINO_ERR_HIP;
+  }
+  fill_const(p, h_cams, &ctx->h);
+  acino_fte_state st;
+  memset(&st, 0, sizeof(st));
+  st.lam = p->lam0;
+  st.nu = 2.0;
+  e = hipMemcpyAsync(ctx->b.cst, &ctx->h, sizeof(FteConst), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(ctx->b.state, &st, sizeof(st), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.nbehind, 0, 4 * sizeof(int), s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.x[0], 0, sizeof(double) * (p->n_frames + 2 * HALO) * NP, s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.x[1], 0, sizeof(double) * (p->n_frames + 2 * HALO) * NP, s);
+  if (e == hipSuccess && !ctx->sched.elim.empty())
+    e = hipMemcpyAsync(ctx->b.sched, ctx->sched.elim.data(), sizeof(int) * ctx->sched.elim.size(),
+                       hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !ctx->sched.remain.empty())
+    e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size(), ctx->sched.remain.data(),
+                       sizeof(int) * ctx->sched.remain.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    set_error("context upload failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return ACINO_ERR_HIP;
+  }
+  ctx->chain.d_elim = ctx->b.sched;
+  ctx->chain.d_remain = ctx->b.sched + ctx->sched.elim.size();
+  ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
+  ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
+  rc = bcr_set_func_attributes();
+  if (rc) {
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return ACINO_OK;
+}
+
+int acino_fte_destroy(acino_fte_ctx* ctx) {
+  delete ctx;
+  return ACINO_OK;
+}
+
+int acino_fte_load_x(acino_fte_ctx* ctx, const double* d_x0, void* stream) {
+  ACINO_REQUIRE(ctx && d_x0, "null");
+  hipStream_t s = (hipStream_t)stream;
+  acino_fte_state st;
+  memset(&st, 0, sizeof(st));
+  st.lam = ctx->lam0;
+  st.nu = 2.0;
+  ACINO_HIP_CHECK(hipMemcpyAsync(ctx->b.state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  ACINO_HIP_CHECK(hipStreamSynchronize(s));   // st lives on this stack frame
+  ACINO_HIP_CHECK(hipMemsetAsync(ctx->b.nbehind, 0, 4 * sizeof(int), s));
+  hipLaunchKernelGGL(k_copy_x_in, dim3(ctx->n_blk_trial), dim3(256), 0, s, ctx->b.cst, ctx->b.state, 0, d_x0,
+                     ctx->b.x[0], ctx->b.x[1]);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_set_halo(acino_fte_ctx* ctx, int which, const double* d_halo_l, const double* d_halo_r, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(which == 0 || which == 1, "which");
+  hipLaunchKernelGGL(k_set_halo, dim3(1), dim3(128), 0, (hipStream_t)stream, ctx->b.state, which, ctx->b.x[0],
+                     ctx->b.x[1], ctx->h.n_frames, d_halo_l, d_halo_r);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_eval(acino_fte_ctx* ctx, int which, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(which == 0 || which == 1, "which");
+  return eval_iterate(ctx, which, true, which == 1, which == 1, (hipStream_t)stream);
+}
+
+int acino_fte_export_partials(acino_fte_ctx* ctx, double* d_partial, void* stream) {
+  ACINO_REQUIRE(ctx && d_partial, "null");
+  hipLaunchKernelGGL(k_copy_vec, dim3(1), dim3(256), 0, (hipStream_t)stream, ctx->b.totals, d_partial, 8);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_control(acino_fte_ctx* ctx, const double* d_total, int init, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->b.cst, ctx->b.state,
+                     d_total ? d_total : ctx->b.totals, ctx->b.numeric_err, init);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_set_x(acino_fte_ctx* ctx, const double* d_x0, void* stream) {
+  int rc = acino_fte_load_x(ctx, d_x0, stream);
+  if (rc) return rc;
+  rc = acino_fte_eval(ctx, 0, stream);
+  if (rc) return rc;
+  return acino_fte_control(ctx, nullptr, 1, stream);
+}
+
+int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  hipStream_t s = (hipStream_t)stream;
+  const Buffers& b = ctx->b;
+  hipLaunchKernelGGL(k_setup, dim3(ctx->chain.n_nodes), dim3(256), 0, s, b.cst, b.state, b.x[0], b.x[1], b.g[0],
+                     b.g[1], b.H[0], b.H[1], ctx->chain, b.gn_part);
+  ACINO_LAUNCH_CHECK();
+  return bcr_reduce(ctx->chain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s);
+}
+
+int acino_fte_export_separators(acino_fte_ctx* ctx, double* d_sep, int rank, int world, void* stream) {
+  ACINO_REQUIRE(ctx && d_sep, "null");
+  ACINO_REQUIRE(world >= 2 && rank >= 0 && rank < world, "rank/world");
+  ACINO_REQUIRE((ctx->h.pin_left != 0) == (rank > 0) && (ctx->h.pin_right != 0) == (rank + 1 < world),
+                "pins must match the rank position");
+  double* rec_left = ctx->h.pin_left ? d_sep + (size_t)(rank - 1) * ACINO_SEP_DOUBLES : nullptr;
+  double* rec_right = ctx->h.pin_right ? d_sep + (size_t)rank * ACINO_SEP_DOUBLES : nullptr;
+  hipLaunchKernelGGL(k_export_sep, dim3(8), dim3(256), 0, (hipStream_t)stream, ctx->chain, 0,
+                     ctx->chain.n_nodes - 1, rec_left, rec_right);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+size_t acino_sep_scratch_bytes(int n_sep) {
+  if (n_sep < 1) return 0;
+  BcrSchedule sch;
+  sch.build(n_sep, false, false);
+  size_t ints = sch.elim.size() + sch.remain.size() + 8;
+  return align_up((size_t)n_sep * (3 * BS * BS + BS) * sizeof(double)) + align_up(ints * sizeof(int)) + 512;
+}
+
+int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
+                           void* stream) {
+  ACINO_REQUIRE(d_sep && d_sep_x && d_scratch, "null");
+  ACINO_REQUIRE(n_sep >= 1 && n_sep <= 1024, "n_sep");
+  ACINO_REQUIRE(scratch_bytes >= acino_sep_scratch_bytes(n_sep), "separator scratch too small");
+  ACINO_REQUIRE(((uintptr_t)d_scratch & 255) == 0, "scratch must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local std::map<int, BcrSchedule> cache;   // schedules are immutable once built
+  auto it = cache.find(n_sep);
+  if (it == cache.end()) {
+    BcrSchedule sch;
+    sch.build(n_sep, false, false);
+    it = cache.emplace(n_sep, std::move(sch)).first;
+  }
+  const BcrSchedule& sch = it->second;
+  Carver c{(char*)d_scratch, 0};
+  BcrChain ch;
+  ch.n_nodes = n_sep;
+  ch.D = c.take<double>((size_t)n_sep * BS * BS);
+  ch.Cpl = c.take<double>((size_t)n_sep * BS * BS);
+  ch.Wl = c.take<double>((size_t)n_sep * BS * BS);
+  ch.b = c.take<double>((size_t)n_sep * BS);
+  int* d_sched = c.take<int>(sch.elim.size() + sch.remain.size() + 8);
+  ch.d_elim = d_sched;
+  ch.d_remain = d_sched + sch.elim.size();
+  ch.implicit_couplings = 0;
+  if (int rc = bcr_set_func_attributes()) return rc;
+  ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, sch.elim.data(), sizeof(int) * sch.elim.size(), hipMemcpyHostToDevice, s));
+  if (!sch.remain.empty())
+    ACINO_HIP_CHECK(hipMemcpyAsync(d_sched + sch.elim.size(), sch.remain.data(), sizeof(int) * sch.remain.size(),
+                                   hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_import_sep, dim3(8, n_sep), dim3(256), 0, s, d_sep, n_sep, ch);
+  ACINO_LAUNCH_CHECK();
+  int rc = bcr_reduce(ch, sch, nullptr, nullptr, nullptr, s);
+  if (rc) return rc;
+  rc = bcr_backsub(ch, sch, nullptr, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_copy_vec, dim3((n_sep * BS + 255) / 256), dim3(256), 0, s, ch.b, d_sep_x, n_sep * BS);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank, int world, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->h.pin_left) {
+    ACINO_REQUIRE(d_sep_x && rank >= 1, "separator solution");
+    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, ctx->chain, 0, d_sep_x + (size_t)(rank - 1) * BS);
+    ACINO_LAUNCH_CHECK();
+  }
+  if (ctx->h.pin_right) {
+    ACINO_REQUIRE(d_sep_x && rank + 1 < world, "separator solution");
+    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, ctx->chain, ctx->chain.n_nodes - 1,
+                       d_sep_x + (size_t)rank * BS);
+    ACINO_LAUNCH_CHECK();
+  }
+  return bcr_backsub(ctx->chain, ctx->sched, &ctx->b.state->status, s);
+}
+
+int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  const Buffers& b = ctx->b;
+  hipLaunchKernelGGL(k_trial, dim3(ctx->n_blk_trial), dim3(256), 0, (hipStream_t)stream, b.cst, b.state, b.x[0],
+                     b.x[1], b.g[0], b.g[1], b.H[0], b.H[1], ctx->chain.b, b.pred_part, b.step_part);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* stream) {
+  ACINO_REQUIRE(ctx && d_edge, "null");
+  ACINO_REQUIRE(ctx->h.n_frames >= 3, "need >= 3 frames");
+  hipLaunchKernelGGL(k_export_edges, dim3(1), dim3(128), 0, (hipStream_t)stream, ctx->b.state, which, ctx->b.x[0],
+                     ctx->b.x[1], ctx->h.n_frames, d_edge);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_step(acino_fte_ctx* ctx, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(!ctx->h.pin_left && !ctx->h.pin_right, "sharded contexts are stepped by the multi-GPU driver");
+  int rc = acino_fte_reduce_local(ctx, stream);
+  if (rc) return rc;
+  rc = acino_fte_backsub_local(ctx, nullptr, 0, 1, stream);
+  if (rc) return rc;
+  rc = acino_fte_trial(ctx, stream);
+  if (rc) return rc;
+  rc = acino_fte_eval(ctx, 1, stream);
+  if (rc) return rc;
+  return acino_fte_control(ctx, nullptr, 0, stream);
+}
+
+int acino_fte_get_state(acino_fte_ctx* ctx, acino_fte_state* out, void* stream) {
+  ACINO_REQUIRE(ctx && out, "null");
+  ACINO_HIP_CHECK(hipMemcpyAsync(out, ctx->b.state, sizeof(*out), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ACINO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return ACINO_OK;
+}
+
+int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(max_iter >= 0, "max_iter");
+  acino_fte_state st;
+  for (int it = 0; it < max_iter; ++it) {
+    int rc = acino_fte_step(ctx, stream);
+    if (rc) return rc;
+    if ((it & 7) == 7) {   // the device stops by itself; peek now and then to stop launching no-ops
+      rc = acino_fte_get_state(ctx, &st, stream);
+      if (rc) return rc;
+      if (st.status != 0) break;
+    }
+  }
+  int rc = acino_fte_get_state(ctx, &st, stream);
+  if (rc) return rc;
+  if (out) *out = st;
+  if (st.status == 5) {
+    set_error("non-positive pivot in the block factorisation (system not positive definite)");
+    return ACINO_ERR_NUMERIC;
+  }
+  return ACINO_OK;
+}
+
+int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* stream) {
+  ACINO_REQUIRE(ctx && d_x && d_cost, "null");
+  hipStream_t s = (hipStream_t)stream;
+  // evaluated in the TRIAL buffer (clobbers it; call between LM steps)
+  hipLaunchKernelGGL(k_copy_x_in, dim3(ctx->n_blk_trial), dim3(256), 0, s, ctx->b.cst, ctx->b.state, 1, d_x,
+                     ctx->b.x[0], ctx->b.x[1]);
+  ACINO_LAUNCH_CHECK();
+  int rc = eval_iterate(ctx, 1, false, false, false, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_copy_vec, dim3(1), dim3(256), 0, s, ctx->b.totals, d_cost, 1);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  const Buffers& b = ctx->b;
+  hipLaunchKernelGGL(k_export_HG, dim3(std::max(1, ctx->n_blk_trial)), dim3(256), 0, (hipStream_t)stream, b.state,
+                     b.g[0], b.g[1], b.H[0], b.H[1], (int64_t)ctx->h.n_frames, d_g, d_h);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_pos, double* d_dx, double* d_ddx,
+                         void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  hipStream_t s = (hipStream_t)stream;
+  const Buffers& b = ctx->b;
+  const int64_t n = ctx->h.n_frames;
+  acino_fte_state st;
+  int rc = acino_fte_get_state(ctx, &st, stream);
+  if (rc) return rc;
+  const double* xc = b.x[st.cur];
+  if (d_x) {
+    hipLaunchKernelGGL(k_copy_x_out, dim3(ctx->n_blk_trial), dim3(256), 0, s, b.state, 0, b.x[0], b.x[1], n, d_x);
+    ACINO_LAUNCH_CHECK();
+  }
+  if (d_pos) {
+    rc = launch_fk_active(xc, n, d_pos, s);
+    if (rc) return rc;
+  }
+  if (d_dx || d_ddx) {
+    ACINO_REQUIRE(ts > 0, "ts");
+    hipLaunchKernelGGL(k_derivatives, dim3(ctx->n_blk_trial), dim3(256), 0, s, xc + HALO * NP, n, ts, d_dx, d_ddx);
+    ACINO_LAUNCH_CHECK();
+  }
+  return ACINO_OK;
+}
+
+int acino_fte_derivatives(const double* d_x, int64_t n_frames, double ts, double* d_dx, double* d_ddx, void* stream) {
+  ACINO_REQUIRE(d_x && n_frames >= 0 && ts > 0, "args");
+  if (n_frames == 0) return ACINO_OK;
+  hipLaunchKernelGGL(k_derivatives, dim3((unsigned)((n_frames * NP + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, n_frames, ts, d_dx, d_ddx);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int acino_fk_active(const double* d_xa, int64_t n_frames, double* d_pos, void* stream) {
+  ACINO_REQUIRE(n_frames >= 0, "n_frames");
+  if (n_frames == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_xa && d_pos, "null buffer");
+  // d_xa[N][25] without halo rows: the kernel indexes (frame + halo) * stride with halo = 0
+  return launch_fk_active(d_xa - HALO * NP, n_frames, d_pos, (hipStream_t)stream);
+}
+
+}  // extern "C"

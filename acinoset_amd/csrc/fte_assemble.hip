@@ -1,0 +1,470 @@
+// FTE residual / Jacobian / normal-equation assembly (gfx950, fp64).
+//
+// Reference: cheetah FK src/all_optimizations.py:66-190, projection pt3d_to_2d :193-209, weights
+// :243-252,302-315, objective :486-500, loss src/build.py:382-395.
+//
+// One workgroup handles FPB frames in five LDS-staged phases:
+//   A  sin/cos of the 22 active angles                       (frame, angle)
+//   B  kinematic chain, column-parallel: RI_k[:,j], marker coordinate j, axis component j
+//                                                            (frame, column j)
+//   C  fisheye projection + analytic 2x3 Jacobian + robust weights for all cameras; per marker the
+//      3x3 M_l = sum_c J^T W J, v_l = sum_c J^T w rho' and their 6x6 "spatial" form
+//      Lambda_l = S_l^T M_l S_l, f_l = S_l^T v_l with S_l = [I, -[p_l]x]          (frame, marker)
+//   D  subtree sums of Lambda / f over the kinematic tree     (frame, component)
+//   E  H[a][b] = xi_a . (Lambda_sub(b) xi_b), g[b] = xi_b . f_sub(b) + smoothness      (frame, state)
+// where xi = (pivot x omega, omega) is the joint twist: dp_l/dq_a = omega_a x (p_l - pivot_a).
+// J (240x25 per frame) is never materialised; only H_n (25x25) and g_n leave the workgroup.
+#include "fte_kernels.hpp"
+
+namespace acino {
+
+// ---- kinematic tree tables (active-state index: 0-2 xyz, 3-5 phi0,phi1,phi3, 6-19 theta0-13, 20-24 psi0,1,3,4,5)
+__constant__ int8_t c_grp_phi[NGRP] = {3, 4, -1, 5, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int8_t c_grp_psi[NGRP] = {20, 21, -1, 22, 23, 24, -1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int8_t c_grp_pivot[NGRP] = {20, 20, 3, 4, 5, 6, 8, 9, 11, 12, 14, 15, 17, 18};  // pos index; 20 = head
+__constant__ int8_t c_state_grp[NP] = {-1, -1, -1, 0, 1, 3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 3, 4, 5};
+__constant__ uint16_t c_ancmask[NGRP] = {
+    0x0001, 0x0003, 0x0007, 0x000F, 0x001F, 0x003F, 0x0047, 0x00C7, 0x0107, 0x0307, 0x040F, 0x0C0F, 0x100F, 0x300F};
+__constant__ double c_off[NL][3] = {
+    {0, 0.03, 0},          {0, -0.03, 0},         {0.055, 0, -0.055},  {-0.28, 0, 0},       {-0.37, 0, 0},
+    {-0.37, 0, 0},         {-0.28, 0, 0},         {-0.36, 0, 0},       {-0.04, 0.08, -0.10}, {0, 0, -0.24},
+    {0, 0, -0.28},         {-0.04, -0.08, -0.10}, {0, 0, -0.24},       {0, 0, -0.28},       {0.12, 0.08, -0.06},
+    {0, 0, -0.32},         {0, 0, -0.25},         {0.12, -0.08, -0.06}, {0, 0, -0.32},      {0, 0, -0.25}};
+
+struct FrameLds {
+  double sc[22][2];       // sin, cos of active angle (index a-3)
+  double pos[21][3];      // markers 0..19, head = 20
+  double om[22][3];       // rotation axis of active angle in the inertial frame
+  double xi[22][6];       // twist (pivot x omega, omega)
+  double lam[NL][27];     // per-marker 6x6 symmetric (21) + wrench (6)
+  double sub[NGRP][27];   // subtree sums
+};
+
+// index of (i,j), i<=j, in the packed upper triangle of a 6x6
+__device__ __forceinline__ int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+// Apply the group's elementary rotations (reference sign convention) to one column of the parent frame.
+__device__ __forceinline__ void chain_col(FrameLds& F, int grp, const double pc[3], double out[3], int j) {
+  const int at = 6 + grp;  // theta_k
+  double s = F.sc[at - 3][0], c = F.sc[at - 3][1];
+  F.om[at - 3][j] = pc[1];                        // omega_theta = P^T e_y
+  double y0 = c * pc[0] - s * pc[2], y1 = pc[1], y2 = s * pc[0] + c * pc[2];
+  int ap = c_grp_phi[grp];
+  if (ap >= 0) {
+    F.om[ap - 3][j] = y0;                         // omega_phi = (Ry P)^T e_x
+    double sp = F.sc[ap - 3][0], cp = F.sc[ap - 3][1];
+    double n1 = cp * y1 + sp * y2, n2 = -sp * y1 + cp * y2;
+    y1 = n1;
+    y2 = n2;
+  }
+  int az = c_grp_psi[grp];
+  if (az >= 0) {
+    F.om[az - 3][j] = y2;                         // omega_psi = RI_k^T e_z
+    double sz = F.sc[az - 3][0], cz = F.sc[az - 3][1];
+    double n0 = cz * y0 + sz * y1, n1 = -sz * y0 + cz * y1;
+    y0 = n0;
+    y1 = n1;
+  }
+  out[0] = y0;
+  out[1] = y1;
+  out[2] = y2;
+}
+
+__device__ __forceinline__ void place(FrameLds& F, int m, int parent, const double col[3], int j) {
+  F.pos[m][j] = F.pos[parent][j] + col[0] * c_off[m][0] + col[1] * c_off[m][1] + col[2] * c_off[m][2];
+}
+
+__device__ __forceinline__ void fk_columns(FrameLds& F, int j) {
+  double e[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+  double c0[3], c1[3], c2[3], c3[3], t[3], t2[3];
+  chain_col(F, 0, e, c0, j);
+  place(F, 0, 20, c0, j);
+  place(F, 1, 20, c0, j);
+  place(F, 2, 20, c0, j);
+  chain_col(F, 1, c0, c1, j);
+  place(F, 3, 20, c1, j);
+  chain_col(F, 2, c1, c2, j);
+  place(F, 4, 3, c2, j);
+  place(F, 8, 3, c2, j);
+  place(F, 11, 3, c2, j);
+  chain_col(F, 3, c2, c3, j);
+  place(F, 5, 4, c3, j);
+  place(F, 14, 5, c3, j);
+  place(F, 17, 5, c3, j);
+  chain_col(F, 4, c3, t, j);
+  place(F, 6, 5, t, j);
+  chain_col(F, 5, t, t2, j);
+  place(F, 7, 6, t2, j);
+  chain_col(F, 6, c2, t, j);
+  place(F, 9, 8, t, j);
+  chain_col(F, 7, t, t2, j);
+  place(F, 10, 9, t2, j);
+  chain_col(F, 8, c2, t, j);
+  place(F, 12, 11, t, j);
+  chain_col(F, 9, t, t2, j);
+  place(F, 13, 12, t2, j);
+  chain_col(F, 10, c3, t, j);
+  place(F, 15, 14, t, j);
+  chain_col(F, 11, t, t2, j);
+  place(F, 16, 15, t2, j);
+  chain_col(F, 12, c3, t, j);
+  place(F, 18, 17, t, j);
+  chain_col(F, 13, t, t2, j);
+  place(F, 19, 18, t2, j);
+}
+
+template <bool JAC>
+__global__ void __launch_bounds__(256)
+k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
+               const double* __restrict__ det, const double* __restrict__ x0, const double* __restrict__ x1,
+               double* __restrict__ H0, double* __restrict__ H1, double* __restrict__ g0, double* __restrict__ g1,
+               double* __restrict__ cost_partials, int* __restrict__ nbehind, int respect_status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FrameLds* F = reinterpret_cast<FrameLds*>(smem_raw);
+  double* red = reinterpret_cast<double*>(smem_raw + sizeof(FrameLds) * FPB);
+  const int tid = threadIdx.x;
+  if (respect_status && st->status != 0) return;  // LM already converged: no-op
+  // which = 0: the current iterate, 1: the trial iterate (selected on the device, no host sync)
+  const int buf = st->cur ^ which;
+  const double* __restrict__ xh = buf ? x1 : x0;
+  double* __restrict__ D0 = buf ? H1 : H0;
+  double* __restrict__ gout = buf ? g1 : g0;
+  const FteConst& K = *cst;
+  const int N = K.n_frames;
+  const int f0 = blockIdx.x * FPB;
+  const int nf = min(FPB, N - f0);
+  double my_cost = 0.0;
+
+  // ---- A: sincos, head position
+  for (int task = tid; task < nf * 25; task += blockDim.x) {
+    int f = task / 25, a = task - f * 25;
+    double xv = xh[(int64_t)(f0 + f + HALO) * NP + a];
+    if (a < 3) {
+      F[f].pos[20][a] = xv;
+    } else {
+      double s, c;
+      sincos(xv, &s, &c);
+      F[f].sc[a - 3][0] = s;
+      F[f].sc[a - 3][1] = c;
+    }
+  }
+  __syncthreads();
+  // ---- B: chain, one thread per (frame, column)
+  for (int task = tid; task < nf * 3; task += blockDim.x) {
+    int f = task / 3, j = task - f * 3;
+    fk_columns(F[f], j);
+  }
+  __syncthreads();
+  // ---- C: projection (+ twists on the otherwise idle threads)
+  const int nproj = nf * NL;
+  if (JAC) {
+    for (int task = tid - nproj; task < nf * 22; task += (int)blockDim.x - nproj > 0 ? (int)blockDim.x - nproj : 1) {
+      if (task < 0) break;
+      int f = task / 22, a = task - f * 22;
+      int g = c_state_grp[a + 3];
+      const double* c = F[f].pos[c_grp_pivot[g]];
+      const double* w = F[f].om[a];
+      F[f].xi[a][0] = c[1] * w[2] - c[2] * w[1];
+      F[f].xi[a][1] = c[2] * w[0] - c[0] * w[2];
+      F[f].xi[a][2] = c[0] * w[1] - c[1] * w[0];
+      F[f].xi[a][3] = w[0];
+      F[f].xi[a][4] = w[1];
+      F[f].xi[a][5] = w[2];
+    }
+  }
+  if (tid < nproj) {
+    const int f = tid / NL, l = tid - f * NL;
+    const int n = f0 + f;
+    const double px = F[f].pos[l][0], py = F[f].pos[l][1], pz = F[f].pos[l][2];
+    double M[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+    double rho0, dd, hh;
+    redescending<false>(K.loss, 0.0, rho0, dd, hh);
+    int behind = 0;
+    const int C = K.n_cams;
+    for (int ci = 0; ci < C; ++ci) {
+      const Cam& cam = K.cams[ci];
+      const double* d = det + (((int64_t)n * C + ci) * NL + l) * 3;
+      double um = d[0], vm = d[1], lik = d[2];
+      double w = (lik > K.dlc_thresh && isfinite(um) && isfinite(vm)) ? K.inv_r : 0.0;
+      double xc = cam.R[0] * px + cam.R[1] * py + cam.R[2] * pz + cam.t[0];
+      double yc = cam.R[3] * px + cam.R[4] * py + cam.R[5] * pz + cam.t[1];
+      double zc = cam.R[6] * px + cam.R[7] * py + cam.R[8] * pz + cam.t[2];
+      if (zc < 1e-6) {
+        if (w > 0) ++behind;
+        w = 0.0;
+      }
+      if (w == 0.0) {
+        my_cost += 2.0 * rho0;
+        continue;
+      }
+      double iz = 1.0 / zc;
+      double a = xc * iz, b = yc * iz;
+      double r = sqrt(a * a + b * b + 1e-12);
+      double th = atan(r);
+      double th2 = th * th;
+      double poly = 1 + th2 * (cam.k1 + th2 * (cam.k2 + th2 * (cam.k3 + th2 * cam.k4)));
+      double thD = th * poly;
+      double m = thD / r;
+      double su = w * (cam.fx * a * m + cam.cx - um);
+      double sv = w * (cam.fy * b * m + cam.cy - vm);
+      double rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0;
+      redescending<JAC>(K.loss, su, rho_u, drho_u, h_u);
+      redescending<JAC>(K.loss, sv, rho_v, drho_v, h_v);
+      my_cost += rho_u + rho_v;
+      if (JAC) {
+        double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
+        double dm_dr = (dthD / (1 + r * r) * r - thD) / (r * r);
+        double dm_da = dm_dr * a / r, dm_db = dm_dr * b / r;
+        double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
+        double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
+        double uc0 = du_da * iz, uc1 = du_db * iz, uc2 = -(du_da * a + du_db * b) * iz;
+        double vc0 = dv_da * iz, vc1 = dv_db * iz, vc2 = -(dv_da * a + dv_db * b) * iz;
+        double ju[3], jv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          ju[j] = uc0 * cam.R[j] + uc1 * cam.R[3 + j] + uc2 * cam.R[6 + j];
+          jv[j] = vc0 * cam.R[j] + vc1 * cam.R[3 + j] + vc2 * cam.R[6 + j];
+        }
+        double gu = w * drho_u * (su > 0 ? 1.0 : (su < 0 ? -1.0 : 0.0));
+        double gv = w * drho_v * (sv > 0 ? 1.0 : (sv < 0 ? -1.0 : 0.0));
+        double hu = w * w * h_u, hv = w * w * h_v;
+        M[0] += hu * ju[0] * ju[0] + hv * jv[0] * jv[0];
+        M[1] += hu * ju[0] * ju[1] + hv * jv[0] * jv[1];
+        M[2] += hu * ju[0] * ju[2] + hv * jv[0] * jv[2];
+        M[3] += hu * ju[1] * ju[1] + hv * jv[1] * jv[1];
+        M[4] += hu * ju[1] * ju[2] + hv * jv[1] * jv[2];
+        M[5] += hu * ju[2] * ju[2] + hv * jv[2] * jv[2];
+        v[0] += gu * ju[0] + gv * jv[0];
+        v[1] += gu * ju[1] + gv * jv[1];
+        v[2] += gu * ju[2] + gv * jv[2];
+      }
+    }
+    if (behind) atomicAdd(nbehind, behind);
+    if (JAC) {
+      // Lambda = [[M, -B], [-B^T, -P B]],  B = M P,  P = [p]x ;  f = [v, p x v]
+      const double Mm[3][3] = {{M[0], M[1], M[2]}, {M[1], M[3], M[4]}, {M[2], M[4], M[5]}};
+      const double P[3][3] = {{0, -pz, py}, {pz, 0, -px}, {-py, px, 0}};
+      double B[3][3], PB[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B[i][j] = Mm[i][0] * P[0][j] + Mm[i][1] * P[1][j] + Mm[i][2] * P[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) PB[i][j] = P[i][0] * B[0][j] + P[i][1] * B[1][j] + P[i][2] * B[2][j];
+      double* L = F[f].lam[l];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) L[tri6(i, j)] = Mm[i][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) L[tri6(i, 3 + j)] = -B[i][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) L[tri6(3 + i, 3 + j)] = -PB[i][j];
+      L[21] = v[0];
+      L[22] = v[1];
+      L[23] = v[2];
+      L[24] = py * v[2] - pz * v[1];
+      L[25] = pz * v[0] - px * v[2];
+      L[26] = px * v[1] - py * v[0];
+    }
+  }
+  __syncthreads();
+  if (JAC) {
+    // ---- D: subtree sums (children have larger group index than parents)
+    for (int task = tid; task < nf * 27; task += blockDim.x) {
+      int f = task / 27, q = task - f * 27;
+      double(*Lm)[27] = F[f].lam;
+      double s13 = Lm[19][q], s12 = Lm[18][q] + s13;
+      double s11 = Lm[16][q], s10 = Lm[15][q] + s11;
+      double s9 = Lm[13][q], s8 = Lm[12][q] + s9;
+      double s7 = Lm[10][q], s6 = Lm[9][q] + s7;
+      double s5 = Lm[7][q], s4 = Lm[6][q] + s5;
+      double s3 = Lm[5][q] + Lm[14][q] + Lm[17][q] + s4 + s10 + s12;
+      double s2 = Lm[4][q] + Lm[8][q] + Lm[11][q] + s3 + s6 + s8;
+      double s1 = Lm[3][q] + s2;
+      double s0 = Lm[0][q] + Lm[1][q] + Lm[2][q] + s1;
+      double(*S)[27] = F[f].sub;
+      S[0][q] = s0; S[1][q] = s1; S[2][q] = s2; S[3][q] = s3; S[4][q] = s4; S[5][q] = s5; S[6][q] = s6;
+      S[7][q] = s7; S[8][q] = s8; S[9][q] = s9; S[10][q] = s10; S[11][q] = s11; S[12][q] = s12; S[13][q] = s13;
+    }
+    __syncthreads();
+  }
+  // ---- E: per (frame, state): smoothness, gradient, Hessian column
+  for (int task = tid; task < nf * NP; task += blockDim.x) {
+    const int f = task / NP, bq = task - f * NP;
+    const int n = f0 + f;
+    const int64_t ng = K.n_offset + n;  // global frame index
+    const double q = K.q_w[bq];
+    const double* xc = xh + (int64_t)(n + HALO) * NP + bq;   // x[n][bq]; neighbours at +-k*NP
+    // smoothness cost: rows whose last frame is this one
+    if (ng >= 3) {
+      double d3 = xc[0] - 3.0 * xc[-NP] + 3.0 * xc[-2 * NP] - xc[-3 * NP];
+      my_cost += q * d3 * d3;
+    }
+    if (JAC) {
+      double gs = 0.0;
+#pragma unroll
+      for (int k = -3; k <= 3; ++k) {
+        double bc = k >= 0 ? band_coef(ng, k, K.n_global) : band_coef(ng + k, -k, K.n_global);
+        if (bc != 0.0) gs += bc * xc[k * NP];
+      }
+      const double b0 = band_coef(ng, 0, K.n_global);
+      const int g = c_state_grp[bq];
+      const double* S = F[f].sub[g < 0 ? 0 : g];
+      double xb[6];
+      if (bq < 3) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xb[i] = (i == bq) ? 1.0 : 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xb[i] = F[f].xi[bq - 3][i];
+      }
+      double Y[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc += S[i <= j ? tri6(i, j) : tri6(j, i)] * xb[j];
+        Y[i] = acc;
+      }
+      double gm = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gm += xb[i] * S[21 + i];
+      gout[(int64_t)n * NP + bq] = gm + 2.0 * q * gs;
+      // Hessian column bq of this frame's 25x25 block
+      double* Dn = D0 + (int64_t)n * NP * NP;
+      const unsigned ancb = g < 0 ? 0u : c_ancmask[g];
+      for (int a = 0; a < NP; ++a) {
+        const int ga = c_state_grp[a];
+        // a is ancestor-or-same of bq ?   (root is an ancestor of everything; root-root only with itself)
+        bool a_anc_b = ga < 0 ? true : (g >= 0 && ((ancb >> ga) & 1u));
+        bool b_anc_a = g < 0 ? true : (ga >= 0 && ((c_ancmask[ga] >> g) & 1u));
+        if (a_anc_b) {
+          double val;
+          if (a < 3) {
+            val = Y[a];
+          } else {
+            const double* xa = F[f].xi[a - 3];
+            val = xa[0] * Y[0] + xa[1] * Y[1] + xa[2] * Y[2] + xa[3] * Y[3] + xa[4] * Y[4] + xa[5] * Y[5];
+          }
+          if (a == bq) val += 2.0 * q * b0;
+          Dn[a * NP + bq] = val;
+          if (!b_anc_a) Dn[bq * NP + a] = val;   // strict ancestor: mirror
+        } else if (!b_anc_a) {
+          Dn[a * NP + bq] = 0.0;                   // unrelated branches
+        }
+      }
+    }
+  }
+  // ---- block cost reduction (fixed order -> deterministic)
+  for (int off = 32; off > 0; off >>= 1) my_cost += __shfl_down(my_cost, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = my_cost;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    cost_partials[blockIdx.x] = t;
+  }
+}
+
+// ---- plain FK kernels (positions only) -----------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fk(const double* __restrict__ q, int64_t n_frames, int stride, int halo, int active_only, double* __restrict__ pos) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FrameLds* F = reinterpret_cast<FrameLds*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.x * FPB;
+  const int nf = (int)min((int64_t)FPB, n_frames - f0);
+  const int8_t act[NP] = {0, 1, 2, 3, 4, 6, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 34, 35, 36};
+  for (int task = tid; task < nf * NP; task += blockDim.x) {
+    int f = task / NP, a = task - f * NP;
+    double xv = q[(f0 + f + halo) * stride + (active_only ? a : act[a])];
+    if (a < 3) {
+      F[f].pos[20][a] = xv;
+    } else {
+      double s, c;
+      sincos(xv, &s, &c);
+      F[f].sc[a - 3][0] = s;
+      F[f].sc[a - 3][1] = c;
+    }
+  }
+  __syncthreads();
+  for (int task = tid; task < nf * 3; task += blockDim.x) fk_columns(F[task / 3], task % 3);
+  __syncthreads();
+  for (int task = tid; task < nf * NL * 3; task += blockDim.x) {
+    int f = task / (NL * 3), r = task - f * NL * 3;
+    pos[(f0 + f) * NL * 3 + r] = F[f].pos[r / 3][r % 3];
+  }
+}
+
+int n_assemble_blocks(int n_frames) { return (n_frames + FPB - 1) / FPB; }
+
+int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_state* d_st, int which,
+                    const double* d_det, double* const x[2], double* const H[2], double* const g[2],
+                    double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s) {
+  const int nb = n_assemble_blocks(h_c.n_frames);
+  if (nb == 0) return ACINO_OK;
+  const size_t lds = sizeof(FrameLds) * FPB + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
+    attr_done = true;
+  }
+  if (need_jac)
+    hipLaunchKernelGGL(k_fte_assemble<true>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
+                       H[1], g[0], g[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_fte_assemble<false>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
+                       H[1], g[0], g[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+static int fk_attr() {
+  static bool done = false;
+  if (!done) {
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
+    done = true;
+  }
+  return ACINO_OK;
+}
+
+int launch_fk(const double* d_q, int64_t n, double* d_pos, hipStream_t s) {
+  if (n == 0) return ACINO_OK;
+  if (int rc = fk_attr()) return rc;
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n + FPB - 1) / FPB)), dim3(256), sizeof(FrameLds) * FPB, s, d_q, n,
+                     ACINO_N_STATES, 0, 0, d_pos);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+int launch_fk_active(const double* d_xa_halo, int64_t n, double* d_pos, hipStream_t s) {
+  if (n == 0) return ACINO_OK;
+  if (int rc = fk_attr()) return rc;
+  hipLaunchKernelGGL(k_fk, dim3((unsigned)((n + FPB - 1) / FPB)), dim3(256), sizeof(FrameLds) * FPB, s, d_xa_halo,
+                     n, NP, HALO, 1, d_pos);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+}  // namespace acino
+
+extern "C" int acino_cheetah_fk(const double* d_q, int64_t n_frames, double* d_pos, void* stream) {
+  using namespace acino;
+  ACINO_REQUIRE(n_frames >= 0, "n_frames");
+  if (n_frames == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_q && d_pos, "null buffer");
+  return launch_fk(d_q, n_frames, d_pos, (hipStream_t)stream);
+}

@@ -1,0 +1,242 @@
+"""Full Trajectory Estimation: the drop-in for the reference's Pyomo model + ``opt.solve(m)``.
+
+Reference: src/all_optimizations.py:22-566 (``fte``).  The reference builds a Pyomo NLP
+(:283-500) and hands it to IPOPT (:503-522); here the same objective, in its equivalent reduced form
+(DESIGN.md), is minimised by a projected Levenberg-Marquardt that runs entirely on the GPU:
+residuals / analytic Jacobians / normal-equation assembly (fte_assemble.hip), the block-tridiagonal
+Gauss-Newton solve by block cyclic reduction on the fp64 matrix cores (bcr.hip) and the accept /
+reject controller (fte_api.hip).  ``fte_solve`` returns the reference's ``fte.pickle`` layout
+(:548-559): ``{positions [N,20,3], x [N,25], dx [N,25], ddx [N,25], start_frame}``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, calib
+from ._lib import N_ACTIVE, N_MARKERS, N_STATES, FteParams, FteState, check, lib, ptr, stream_ptr
+
+MARKERS = ["l_eye", "r_eye", "nose", "neck_base", "spine", "tail_base", "tail_mid", "tail_tip",
+           "l_shoulder", "l_front_knee", "l_front_ankle", "r_shoulder", "r_front_knee", "r_front_ankle",
+           "l_hip", "l_back_knee", "l_back_ankle", "r_hip", "r_back_knee", "r_back_ankle"]
+PHI, THETA, PSI = 3, 17, 31          # state layout [x y z | phi_0..13 | theta_0..13 | psi_0..13]  (:182-185)
+# the 25 states with Q != 0 (:245-252); convert_m (:530-556) drops the other 20 in this order
+ACTIVE = np.array([0, 1, 2, PHI + 0, PHI + 1, PHI + 3] + [THETA + i for i in range(14)] +
+                  [PSI + 0, PSI + 1, PSI + 3, PSI + 4, PSI + 5])
+Q_SIGMA = np.array([4, 7, 5,
+                    13, 32, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                    9, 18, 43, 53, 90, 118, 247, 186, 194, 164, 295, 243, 334, 149,
+                    26, 12, 0, 34, 43, 51, 0, 0, 0, 0, 0, 0, 0, 0], dtype=np.float64)
+R_MEAS = 5.0                          # measurement std-dev, px (:243)
+REDESC = (3.0, 10.0, 20.0)            # redescending a, b, c (:25-27)
+
+
+def bounds45():
+    """Box bounds of :403-483 (1-based Pyomo indices -> 0-based)."""
+    lo = np.full(N_STATES, -np.inf)
+    hi = np.full(N_STATES, np.inf)
+    for p in (4, 18, 5, 19, 33, 20, 21, 7, 35):
+        lo[p - 1], hi[p - 1] = -np.pi / 6, np.pi / 6
+    for p in (22, 36, 23, 37):
+        lo[p - 1], hi[p - 1] = -np.pi / 1.5, np.pi / 1.5
+    for p in (24, 26, 28, 30):
+        lo[p - 1], hi[p - 1] = -np.pi / 2, np.pi / 2
+    for p in (25, 27):
+        lo[p - 1], hi[p - 1] = -np.pi, 0.0
+    for p in (29, 31):
+        lo[p - 1], hi[p - 1] = 0.0, np.pi
+    return lo, hi
+
+
+def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
+                ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False):
+    p = FteParams()
+    p.n_frames, p.n_cams = int(n_frames), int(n_cams)
+    p.n_global = int(n_frames if n_global is None else n_global)
+    p.n_offset = int(n_offset)
+    p.pin_left, p.pin_right = int(bool(pin_left)), int(bool(pin_right))
+    p.dlc_thresh, p.inv_r_meas = float(dlc_thresh), 1.0 / float(r_meas)
+    p.redesc_a, p.redesc_b, p.redesc_c = (float(v) for v in redesc)
+    Qs = Q_SIGMA ** 2 if Q is None else np.asarray(Q, dtype=np.float64)
+    if Qs.shape != (N_STATES,):
+        raise ValueError("Q must have 45 entries")
+    if set(np.nonzero(Qs)[0].tolist()) != set(ACTIVE.tolist()):
+        raise ValueError("the cheetah kernels are specialised to the reference's 25 active states "
+                         "(Q must be non-zero exactly where all_optimizations.py:245-252 is)")
+    wq = (1.0 / Qs[ACTIVE]) / float(Ts) ** 4
+    lo, hi = bounds45()
+    for i in range(N_ACTIVE):
+        p.q_w[i] = wq[i]
+        p.lo[i] = lo[ACTIVE[i]]
+        p.hi[i] = hi[ACTIVE[i]]
+    p.lam0, p.ftol, p.xtol, p.gtol = float(lam0), float(ftol), float(xtol), float(gtol)
+    return p
+
+
+class FTEContext:
+    """Owns the device buffers of one FTE problem (one shard of a sequence on one GPU)."""
+
+    def __init__(self, det, k_arr, d_arr, r_arr, t_arr, Ts, **kw):
+        _lib.require_gpu()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.det = calib._to_dev(det, dev)
+        if self.det.dim() != 4 or self.det.shape[2] != N_MARKERS or self.det.shape[3] != 3:
+            raise ValueError("det must be [N, C, 20, 3] = (x, y, likelihood)")
+        self.N, self.C = int(self.det.shape[0]), int(self.det.shape[1])
+        self.Ts = float(Ts)
+        self.cams = torch.as_tensor(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
+        if self.cams.shape[0] != self.C:
+            raise ValueError("camera count mismatch between det and the rig")
+        self.params = make_params(self.N, self.C, Ts, **kw)
+        nbytes = lib().acino_fte_workspace_bytes(C.byref(self.params))
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        base = self.workspace.data_ptr()
+        self._ws_ptr = (base + 255) // 256 * 256
+        self._h = C.c_void_p()
+        check(lib().acino_fte_create(C.byref(self._h), C.byref(self.params), ptr(self.det), ptr(self.cams),
+                                     C.c_void_p(self._ws_ptr), nbytes, stream_ptr()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().acino_fte_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- single-GPU driver -----------------------------------------------------------------------
+    def set_x(self, x_active):
+        x = calib._to_dev(x_active, self.device)
+        if tuple(x.shape) != (self.N, N_ACTIVE):
+            raise ValueError(f"x0 must be [{self.N}, 25] active states")
+        self._x0 = x
+        check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
+
+    def step(self):
+        check(lib().acino_fte_step(self._h, stream_ptr()))
+
+    def solve(self, max_iter):
+        st = FteState()
+        check(lib().acino_fte_solve(self._h, int(max_iter), C.byref(st), stream_ptr()))
+        return st.as_dict()
+
+    def state(self):
+        st = FteState()
+        check(lib().acino_fte_get_state(self._h, C.byref(st), stream_ptr()))
+        return st.as_dict()
+
+    def result(self):
+        dev = self.device
+        x = torch.empty((self.N, N_ACTIVE), dtype=torch.float64, device=dev)
+        pos = torch.empty((self.N, N_MARKERS, 3), dtype=torch.float64, device=dev)
+        dx = torch.empty_like(x)
+        ddx = torch.empty_like(x)
+        check(lib().acino_fte_get_result(self._h, self.Ts, ptr(x), ptr(pos), ptr(dx), ptr(ddx), stream_ptr()))
+        return x, pos, dx, ddx
+
+    def cost(self, x_active):
+        x = calib._to_dev(x_active, self.device)
+        out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        check(lib().acino_fte_cost(self._h, ptr(x), ptr(out), stream_ptr()))
+        return float(out.item())
+
+    def grad_hess(self):
+        g = torch.empty((self.N, N_ACTIVE), dtype=torch.float64, device=self.device)
+        h = torch.empty((self.N, N_ACTIVE, N_ACTIVE), dtype=torch.float64, device=self.device)
+        check(lib().acino_fte_get_grad_hess(self._h, ptr(g), ptr(h), stream_ptr()))
+        return g, h
+
+
+def cheetah_fk(q):
+    """pose_to_3d of :170-186: q[N,45] full state -> positions[N,20,3]."""
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    qd = calib._to_dev(q, dev).reshape(-1, N_STATES)
+    pos = torch.empty((qd.shape[0], N_MARKERS, 3), dtype=torch.float64, device=dev)
+    check(lib().acino_cheetah_fk(ptr(qd), qd.shape[0], ptr(pos), stream_ptr()))
+    return calib._ret(pos, q)
+
+
+def nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, n_frames=None, start_frame=0):
+    """Initial guess of :262-277,333-337: adjacent-pair triangulation of the detections above the
+    likelihood threshold, least-squares line (linregress) through the nose (marker 2) over frames,
+    psi_0 = atan2(y_slope, x_slope), every other state 0.  Returns x0[N,45] (numpy)."""
+    tri = calib.triangulate_pairs_dense(det, dlc_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
+    nose = tri[:, 2] if isinstance(tri, np.ndarray) else tri[:, 2].cpu().numpy()
+    N = nose.shape[0] if n_frames is None else n_frames
+    ok = np.isfinite(nose).all(1)
+    if ok.sum() < 2:
+        raise ValueError("fewer than two triangulated nose points: cannot fit the initial line")
+    f = np.arange(nose.shape[0], dtype=np.float64)[ok] + start_frame
+    A = np.stack([f, np.ones_like(f)], 1)
+    coef, *_ = np.linalg.lstsq(A, nose[ok], rcond=None)
+    frames = np.arange(start_frame, start_frame + N, dtype=np.float64)
+    x0 = np.zeros((N, N_STATES))
+    x0[:, 0:3] = frames[:, None] * coef[0][None, :] + coef[1][None, :]
+    x0[:, PSI + 0] = np.arctan2(coef[0][1], coef[0][0])
+    return x0
+
+
+def triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh):
+    """Per-frame initial guess for LONG sequences (an extension: the reference's straight nose line
+    cannot follow a trajectory that turns): head position from the triangulated head markers, heading
+    from the neck_base->nose direction, gaps filled by linear interpolation; other states 0."""
+    tri = calib.triangulate_pairs_dense(det, dlc_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
+    tri = tri if isinstance(tri, np.ndarray) else tri.cpu().numpy()
+    N = tri.shape[0]
+    head = np.nanmean(tri[:, 0:3], axis=1)               # eyes + nose
+    fwd = tri[:, 2] - tri[:, 3]                          # neck_base -> nose
+    idx = np.arange(N)
+    x0 = np.zeros((N, N_STATES))
+    for j in range(3):
+        ok = np.isfinite(head[:, j])
+        if ok.sum() == 0:
+            raise ValueError("no triangulated head marker in the whole sequence")
+        x0[:, j] = np.interp(idx, idx[ok], head[ok, j])
+    ok = np.isfinite(fwd).all(1)
+    if ok.sum() >= 1:
+        psi = np.unwrap(np.arctan2(fwd[ok, 1], fwd[ok, 0]))
+        x0[:, PSI + 0] = np.interp(idx, idx[ok], psi)
+    return x0
+
+
+def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thresh=0.5, start_frame=0,
+              max_iter=100, init="nose_line", return_numpy=True, **kw):
+    """The FTE solve call.
+
+    meas[N,C,20,2] pixel detections, likelihood[N,C,20], cameras as in the scene file (k_arr[C,3,3],
+    d_arr[C,4(,1)], r_arr[C,3,3], t_arr[C,3(,1)]), Ts = 1/fps.  x0[N,45] optional initial state
+    (default: the reference's nose-line initialisation).  Returns (results, info) where results has the
+    reference's fte.pickle layout and info the solver status (iterations, final cost, |g|_inf, ...)."""
+    meas_t = meas if isinstance(meas, torch.Tensor) else torch.as_tensor(np.asarray(meas, dtype=np.float64))
+    lik_t = likelihood if isinstance(likelihood, torch.Tensor) else torch.as_tensor(np.asarray(likelihood, dtype=np.float64))
+    det = torch.cat([meas_t.to(torch.float64), lik_t.to(torch.float64).unsqueeze(-1).to(meas_t.device)], dim=-1)
+    if x0 is None:
+        if init == "nose_line":
+            x0 = nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, start_frame=start_frame)
+        elif init == "triangulation":
+            x0 = triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh)
+        else:
+            raise ValueError("init must be 'nose_line' or 'triangulation'")
+    x0 = np.asarray(x0.cpu().numpy() if isinstance(x0, torch.Tensor) else x0, dtype=np.float64)
+    if x0.shape != (det.shape[0], N_STATES):
+        raise ValueError("x0 must be [N, 45]")
+    inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
+    if np.any(x0[:, inactive] != 0):
+        raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
+    ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+    try:
+        ctx.set_x(x0[:, ACTIVE])
+        info = ctx.solve(max_iter)
+        x, pos, dx, ddx = ctx.result()
+    finally:
+        ctx.close()
+    if info["status"] == 5:
+        raise RuntimeError("FTE: block factorisation hit a non-positive pivot")
+    conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
+    results = dict(positions=conv(pos), x=conv(x), dx=conv(dx), ddx=conv(ddx), start_frame=start_frame)
+    return results, info

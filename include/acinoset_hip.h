@@ -1,0 +1,209 @@
+/*
+ * acinoset_hip.h - C ABI of libacinoset_hip.so (MI355X / gfx950, fp64).
+ *
+ * Drop-in boundary for the AcinoSet triangulation + Full-Trajectory-Estimation hot path.
+ * The reference (pure Python) has no FFI; these are the entry points a binding for that path
+ * binds, one per reference interface it replaces (paths relative to the AcinoSet tree):
+ *
+ *   acino_undistort_fisheye          cv2.fisheye.undistortPoints      src/calib/calib.py:124-125
+ *   acino_triangulate_fisheye        triangulate_points_fisheye       src/calib/calib.py:121-130
+ *   acino_triangulate_pinhole        triangulate_points               src/calib/calib.py:52-61
+ *   acino_project_fisheye            project_points_fisheye           src/calib/calib.py:132-136
+ *   acino_project_pinhole            project_points                   src/calib/calib.py:64-66
+ *   acino_triangulate_pairs          get_pairwise_3d_points_from_df   src/calib/calib.py:394-423
+ *   acino_reproject_residuals        project(triangulate(.)) - pts    src/calib/calib.py:312-316 (cost_func_points_only)
+ *   acino_cheetah_fk                 pose_to_3d                       src/all_optimizations.py:66-190
+ *   acino_fte_*                      the Pyomo model + opt.solve()    src/all_optimizations.py:283-556
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative acino_status; no C++ exception and no
+ *     abort crosses the boundary; acino_last_error_string() describes the last failure (thread-local).
+ *   - all pointers named d_* are DEVICE pointers (HBM), caller-allocated and caller-owned; the
+ *     library allocates no device memory.  FTE scratch is one caller buffer whose size comes
+ *     from acino_fte_workspace_bytes().
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
+ *     nothing synchronises the device unless stated.
+ *   - all arrays are dense, C-contiguous, double (fp64) unless stated.
+ */
+#ifndef ACINOSET_HIP_H
+#define ACINOSET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACINO_ABI_VERSION 1
+
+typedef enum acino_status {
+  ACINO_OK = 0,
+  ACINO_ERR_INVALID_ARG = -1,
+  ACINO_ERR_HIP = -2,            /* a HIP runtime call or kernel launch failed        */
+  ACINO_ERR_WORKSPACE = -3,      /* workspace too small / misaligned                 */
+  ACINO_ERR_NO_DEVICE = -4,
+  ACINO_ERR_UNSUPPORTED = -5,
+  ACINO_ERR_NUMERIC = -6         /* non-positive pivot in the block factorisation    */
+} acino_status;
+
+/* ---- camera records -------------------------------------------------------------------------
+ * Fisheye camera: 24 doubles  [fx fy cx cy | k1 k2 k3 k4 | R(9,row-major) | t(3) | alpha 0 0 0]
+ * Pinhole camera: 32 doubles  [fx fy cx cy | d(14: k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 tx ty) | R(9) | t(3) | 0 0]
+ * (alpha = K[0][1]/fx, OpenCV's skew; zero for every reference rig.) */
+#define ACINO_CAM_STRIDE 24
+#define ACINO_PINHOLE_STRIDE 32
+#define ACINO_MAX_CAMS 16
+#define ACINO_N_MARKERS 20     /* cheetah markers (all_optimizations.py:170-179)            */
+#define ACINO_N_STATES 45      /* x,y,z, phi_0..13, theta_0..13, psi_0..13                   */
+#define ACINO_N_ACTIVE 25      /* states with Q != 0 (all_optimizations.py:245-252)          */
+
+const char* acino_last_error_string(void);
+int acino_abi_version(void);
+/* Number of visible HIP devices, or a negative status. */
+int acino_device_count(void);
+
+/* ---- point-wise camera model (a-1, a-2) ------------------------------------------------------ */
+/* d_pts[M][2] pixel -> d_out[M][2] normalised coordinates; OpenCV criteria (max_iter=10, eps=1e-8);
+ * non-converged / sign-flipped points are written as -1e6 like OpenCV >= 4.5. */
+int acino_undistort_fisheye(const double* d_pts, int64_t m, const double* d_cam24, double* d_out,
+                            int max_iter, double eps, void* stream);
+/* Two-view triangulation: undistort both, 4x4 DLT, smallest right-singular vector, dehomogenise.
+ * d_pts1/d_pts2 [M][2], d_cam_a/d_cam_b one camera record each, d_out[M][3]. */
+int acino_triangulate_fisheye(const double* d_pts1, const double* d_pts2, int64_t m,
+                              const double* d_cam_a24, const double* d_cam_b24, double* d_out, void* stream);
+int acino_triangulate_pinhole(const double* d_pts1, const double* d_pts2, int64_t m,
+                              const double* d_cam_a32, const double* d_cam_b32, double* d_out, void* stream);
+/* d_obj[M][3] -> d_out[M][2]. */
+int acino_project_fisheye(const double* d_obj, int64_t m, const double* d_cam24, double* d_out, void* stream);
+int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32, double* d_out, void* stream);
+
+/* ---- dense adjacent-pair triangulation (a-3, BASELINE configs[1]) ---------------------------
+ * d_det[N][C][L][3] = (x, y, likelihood).  A detection is valid iff likelihood > thresh.
+ * For each (frame, marker): triangulate every adjacent camera pair (c, c+1) with both valid, take
+ * the Kahan-compensated mean in pair order (what pandas' groupby().mean() computes).
+ * d_tri[N][L][3] (NaN when no pair), d_npairs[N][L] u8, d_pairmask[N][L] u8 (bit c = pair (c,c+1)).
+ * d_npairs / d_pairmask may be NULL. */
+int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                            const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                            void* stream);
+/* Reprojection residual of d_pts3[N][L][3] in every camera against d_det:
+ * d_res[N][C][L][2] = project(pts3) - det.xy where det valid and pts3 finite, else NaN.
+ * d_sums[4] (may be NULL) += {count, sum r, sum r^2, 0.5*sum log1p(r^2)} over valid residual components. */
+int acino_reproject_residuals(const double* d_pts3, const double* d_det, int64_t n_frames, int n_cams,
+                              int n_markers, double thresh, const double* d_cams24, double* d_res,
+                              double* d_sums, void* stream);
+
+/* ---- cheetah forward kinematics (a-4) ---------------------------------------------------------
+ * d_q[N][45] full state -> d_pos[N][20][3]. */
+int acino_cheetah_fk(const double* d_q, int64_t n_frames, double* d_pos, void* stream);
+
+/* ---- Full Trajectory Estimation (a-5 .. a-11) -------------------------------------------------
+ * Reduced problem of the reference NLP: unknowns xa[N][25] (active states),
+ *   F = sum rho(w*(pi_c(FK_l(x_n)) - z)) + sum_{n>=3} q_p (x_n - 3x_{n-1} + 3x_{n-2} - x_{n-3})_p^2,
+ * box bounds lo/hi, solved by a projected Levenberg-Marquardt whose Gauss-Newton system is
+ * block-tridiagonal in super-blocks of 3 frames and solved by block cyclic reduction. */
+typedef struct acino_fte_params {
+  int32_t n_frames;        /* local frames on this GPU                                      */
+  int32_t n_cams;
+  int64_t n_global;        /* frames in the whole sequence (== n_frames on one GPU)         */
+  int64_t n_offset;        /* global index of local frame 0 (multiple of 3 when > 0)        */
+  int32_t pin_left;        /* 1: local chain starts with a separator owned by the left rank */
+  int32_t pin_right;       /* 1: the last local super-block is a separator (not eliminated) */
+  double dlc_thresh;       /* likelihood threshold (all_optimizations.py:304)               */
+  double inv_r_meas;       /* 1/R, R = 5 px (all_optimizations.py:243)                      */
+  double redesc_a, redesc_b, redesc_c;   /* 3, 10, 20 (all_optimizations.py:25-27)          */
+  double q_w[ACINO_N_ACTIVE];            /* (1/Q_p) / Ts^4 per active state                 */
+  double lo[ACINO_N_ACTIVE], hi[ACINO_N_ACTIVE];   /* box bounds (+-inf = free)             */
+  double lam0;             /* initial LM damping                                            */
+  double ftol, xtol, gtol; /* stopping tolerances (0 disables a test)                       */
+} acino_fte_params;
+
+/* LM state mirrored in device memory (read back with acino_fte_get_state). */
+typedef struct acino_fte_state {
+  double cost;             /* F at the current iterate (this rank's share when sharded)     */
+  double cost_trial;
+  double lam, nu;
+  double gain, pred, step_inf, gnorm_inf;
+  int32_t iter;            /* LM iterations performed                                       */
+  int32_t accepted;
+  int32_t status;          /* 0 running, 1 ftol, 2 xtol, 3 gtol, 4 lambda overflow, 5 numeric */
+  int32_t cur;             /* which of the two iterate buffers is current                   */
+  int32_t n_behind;        /* weighted detections dropped because z_cam < 1e-6              */
+  int32_t last_accept;
+  int32_t pad0, pad1;
+} acino_fte_state;
+
+typedef struct acino_fte_ctx acino_fte_ctx;   /* opaque host handle */
+
+size_t acino_fte_workspace_bytes(const acino_fte_params* p);
+/* Creates a handle over caller-owned buffers.  d_det[N][C][L=20][3], d_cams24[C][24],
+ * d_workspace >= acino_fte_workspace_bytes(p), 256-byte aligned.  Synchronises the stream once. */
+int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det,
+                     const double* d_cams24, void* d_workspace, size_t workspace_bytes, void* stream);
+int acino_fte_destroy(acino_fte_ctx* ctx);
+/* Loads the initial iterate (d_x0[N][25], clipped to the bounds), restarts the LM controller and evaluates
+ * cost / gradient / Gauss-Newton blocks.  = load_x + eval(0) + control(NULL, init=1). */
+int acino_fte_set_x(acino_fte_ctx* ctx, const double* d_x0, void* stream);
+/* One LM iteration, entirely stream-ordered (no host sync): damped block system -> block cyclic reduction ->
+ * trial iterate -> residuals, Jacobians, normal-equation assembly at the trial -> accept/reject + lambda. */
+int acino_fte_step(acino_fte_ctx* ctx, void* stream);
+/* Up to max_iter LM iterations (the device stops by itself on convergence; the host peeks every 8 steps);
+ * synchronises at the end and fills *out (may be NULL). */
+int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void* stream);
+int acino_fte_get_state(acino_fte_ctx* ctx, acino_fte_state* out, void* stream);   /* synchronises */
+/* Current iterate -> d_x[N][25]; positions d_pos[N][20][3]; dx/ddx by the reference's backward-Euler
+ * relations (all_optimizations.py:369-383).  Any output may be NULL.  Synchronises. */
+int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_pos, double* d_dx, double* d_ddx,
+                         void* stream);
+/* Cost only at d_x[N][25] -> d_cost[1]; evaluated in the trial buffer (call between LM steps). */
+int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* stream);
+/* Gradient d_g[N][25] and Gauss-Newton blocks d_h[N][25][25] (measurement part + smoothness diagonal) of the
+ * CURRENT iterate, for parity checks.  Either may be NULL. */
+int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
+/* Stand-alone helpers: dx/ddx of a trajectory d_x[N][25]; FK of active states d_xa[N][25] -> d_pos[N][20][3]. */
+int acino_fte_derivatives(const double* d_x, int64_t n_frames, double ts, double* d_dx, double* d_ddx, void* stream);
+int acino_fk_active(const double* d_xa, int64_t n_frames, double* d_pos, void* stream);
+
+/* ---- pieces of one LM iteration, for the multi-GPU driver (acinoset_amd/dist.py) ---------------
+ * A sharded sequence gives every rank a contiguous frame block; the last super-block (3 frames) of every
+ * rank but the last is a SEPARATOR that the rank does not eliminate (pin_right), and every rank but the
+ * first sees its left neighbour's separator as chain node 0 (pin_left).  Per iteration:
+ *   reduce_local -> export_separators -> [all-reduce SUM] -> solve_separators -> backsub_local -> trial
+ *   -> export_edges(1) -> [all-gather] -> set_halo(1) -> eval(1) -> export_partials -> [all-gather + combine]
+ *   -> control(total, 0).
+ * `which`: 0 = current iterate, 1 = trial iterate (resolved on the device). */
+#define ACINO_BS 80
+/* Doubles in the exchange record of ONE separator: D[80][80] | C[80][80] (coupling to the previous separator) | b[80]. */
+#define ACINO_SEP_DOUBLES (2 * ACINO_BS * ACINO_BS + ACINO_BS)
+int acino_fte_load_x(acino_fte_ctx* ctx, const double* d_x0, void* stream);
+/* d_halo_l[3][25] = the 3 frames left of the shard, d_halo_r[3][25] the 3 frames right of it; NULL = zeros
+ * (sequence end: the coefficients there are zero anyway). */
+int acino_fte_set_halo(acino_fte_ctx* ctx, int which, const double* d_halo_l, const double* d_halo_r, void* stream);
+/* Residuals + Jacobians + assembly of iterate `which`; local sums {cost, pred, step_inf, gnorm_inf,
+ * n_behind, 0, 0, 0} are left in the context (export_partials copies them to d_partial[8]). */
+int acino_fte_eval(acino_fte_ctx* ctx, int which, void* stream);
+int acino_fte_export_partials(acino_fte_ctx* ctx, double* d_partial, void* stream);
+/* Accept/reject + lambda update from d_total[8] (NULL = this context's own sums); init=1 only records the
+ * cost of the freshly loaded iterate. */
+int acino_fte_control(acino_fte_ctx* ctx, const double* d_total, int init, void* stream);
+int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream);
+/* WRITES this rank's contributions into d_sep[world-1][ACINO_SEP_DOUBLES] (caller zero-fills before;
+ * contributions of different ranks never overlap except D and b, which the all-reduce sums). */
+int acino_fte_export_separators(acino_fte_ctx* ctx, double* d_sep, int rank, int world, void* stream);
+size_t acino_sep_scratch_bytes(int n_sep);
+/* Solves the all-reduced separator chain (every rank redundantly): d_sep_x[n_sep][80]. */
+int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
+                           void* stream);
+int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank, int world, void* stream);
+int acino_fte_trial(acino_fte_ctx* ctx, void* stream);
+/* First / last 3 frames of iterate `which` -> d_edge[6][25]. */
+int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* stream);
+
+/* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
+int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACINOSET_HIP_H */
