@@ -65,6 +65,8 @@ SIGNATURES = {
     "acino_reproject_residuals": (_I, [_P, _P, _L, _I, _I, _D, _P, _P, _P, _P]),
     "acino_cheetah_fk": (_I, [_P, _L, _P, _P]),
     "acino_fk_active": (_I, [_P, _L, _P, _P]),
+    "acino_sizeof_fte_params": (_Z, []),
+    "acino_sizeof_fte_state": (_Z, []),
     "acino_fte_workspace_bytes": (_Z, [C.POINTER(FteParams)]),
     "acino_fte_create": (_I, [C.POINTER(_P), C.POINTER(FteParams), _P, _P, _P, _Z, _P]),
     "acino_fte_destroy": (_I, [_P]),
@@ -88,6 +90,9 @@ SIGNATURES = {
     "acino_fte_backsub_local": (_I, [_P, _P, _I, _I, _P]),
     "acino_fte_trial": (_I, [_P, _P]),
     "acino_fte_export_edges": (_I, [_P, _I, _P, _P]),
+    "acino_fte_profile_begin": (_I, [_P]),
+    "acino_fte_debug_stamps": (_I, [_P, _P]),
+    "acino_fte_profile_end": (_I, [_P, _P, _P, _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
 }
 
@@ -139,6 +144,8 @@ def lib():
         fn = getattr(handle, name)   # AttributeError = ABI mismatch, let it surface
         fn.restype = res
         fn.argtypes = args
+    if handle.acino_sizeof_fte_params() != C.sizeof(FteParams) or handle.acino_sizeof_fte_state() != C.sizeof(FteState):
+        raise RuntimeError("libacinoset_hip.so struct layout differs from the Python binding (stale build?)")
     _lib = handle
     return _lib
 

@@ -51,6 +51,7 @@ __device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
 #pragma unroll
   for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[r * LD + c] : 0.0;
   bool bad = false;
+  double dinv[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     double ajj = readlane_d(a[j], j);
@@ -58,8 +59,9 @@ __device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
       bad = true;
       ajj = 1.0;
     }
-    double d = sqrt(ajj), inv = 1.0 / d;
-    a[j] = (r == j) ? d : a[j] * inv;
+    const double inv = rsqrt(ajj);        // one v_rsq_f64 + refinement instead of sqrt + divide
+    dinv[j] = inv;
+    a[j] = (r == j) ? ajj * inv : a[j] * inv;
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) {
       double lc = readlane_d(a[j], c);
@@ -69,14 +71,13 @@ __device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
   double x[16];
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
-    double lrr = readlane_d(a[rr], rr);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < rr; ++k) {
       double lrk = readlane_d(a[k], rr);
       acc += lrk * x[k];
     }
-    x[rr] = (rr == r) ? 1.0 / lrr : ((rr > r) ? -acc / lrr : 0.0);
+    x[rr] = (rr == r) ? dinv[rr] : ((rr > r) ? -acc * dinv[rr] : 0.0);
   }
   if (lane < 16) {
 #pragma unroll
@@ -192,6 +193,8 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
+#define ACINO_STAMP(k) do { if (ch.dbg && blockIdx.x == 0 && tid == 0) ch.dbg[k] = (long long)wall_clock64(); } while (0)
+  ACINO_STAMP(0);
   load_mat(Lm, ch.D + i * MB, tid);
   if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
   if (l >= 0) {
@@ -203,7 +206,9 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     else load_mat_t(WR, ch.Cpl + i * MB, tid);         // block(r, i)^T: rows i, cols r
   }
   __syncthreads();
+  ACINO_STAMP(1);
   chol80(Lm, tid, numeric_err);
+  ACINO_STAMP(2);
   // W_l, W_r: ten column tiles over four waves
   for (int ct = wave; ct < 10; ct += 4) {
     if (ct < 5) {
@@ -213,6 +218,8 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     }
   }
   // y = L^-1 b (blocked forward substitution, VALU)
+  __syncthreads();
+  ACINO_STAMP(3);
   for (int ib = 0; ib < NT; ++ib) {
     if (tid < 16) {
       const int row = ib * 16 + tid;
@@ -229,10 +236,13 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     }
     __syncthreads();
   }
+  ACINO_STAMP(4);
   store_mat(ch.D + i * MB, Lm, tid);
   if (l >= 0) store_mat(ch.Wl + i * MB, WL, tid);
   if (r >= 0) store_mat(ch.Cpl + i * MB, WR, tid);
   if (tid < BS) ch.b[(size_t)i * BS + tid] = yv[tid];
+  __syncthreads();
+  ACINO_STAMP(5);
 }
 
 // role 0: D_j / b_j update; role 1: new coupling block(jn, j)
@@ -432,25 +442,34 @@ int bcr_set_func_attributes() {
 }
 
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
-               const int* d_status, hipStream_t s) {
+               const int* d_status, hipStream_t s, Profiler* prof) {
   for (const BcrLevel& lv : sch.levels) {
-    hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off, d_c,
-                       d_numeric_err, d_status);
+    {
+      ProfSpan sp(prof, PC_ELIM, s);
+      hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
+                         d_c, d_numeric_err, d_status);
+    }
     ACINO_LAUNCH_CHECK();
     if (lv.n_remain > 0) {
-      hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
-                         ch.d_remain + 4 * lv.remain_off, d_status);
+      {
+        ProfSpan sp(prof, PC_UPDATE, s);
+        hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
+                           ch.d_remain + 4 * lv.remain_off, d_status);
+      }
       ACINO_LAUNCH_CHECK();
     }
   }
   return ACINO_OK;
 }
 
-int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s) {
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s, Profiler* prof) {
   for (int k = (int)sch.levels.size() - 1; k >= 0; --k) {
     const BcrLevel& lv = sch.levels[k];
-    hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
-                       ch.d_elim + 3 * lv.elim_off, d_status);
+    {
+      ProfSpan sp(prof, PC_BACKSUB, s);
+      hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
+                         ch.d_elim + 3 * lv.elim_off, d_status);
+    }
     ACINO_LAUNCH_CHECK();
   }
   return ACINO_OK;

@@ -29,11 +29,13 @@ struct BcrChain {
   const int* d_elim;
   const int* d_remain;
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
+  long long* dbg;            // optional [16] phase timestamps of workgroup 0 (debug builds of the probe)
 };
 
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
-               const int* d_status, hipStream_t s);
-int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s);
+               const int* d_status, hipStream_t s, Profiler* prof = nullptr);
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s,
+                Profiler* prof = nullptr);
 int bcr_set_func_attributes();
 
 }  // namespace acino

@@ -277,6 +277,8 @@ extern "C" {
 
 const char* acino_last_error_string(void) { return acino::last_error(); }
 int acino_abi_version(void) { return ACINO_ABI_VERSION; }
+size_t acino_sizeof_fte_params(void) { return sizeof(acino_fte_params); }
+size_t acino_sizeof_fte_state(void) { return sizeof(acino_fte_state); }
 int acino_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

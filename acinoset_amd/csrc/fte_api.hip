@@ -35,6 +35,7 @@ struct acino_fte_ctx {
   const double* d_det;
   int n_blk_asm, n_blk_trial;
   size_t ws_bytes;
+  acino::Profiler prof;
 };
 
 namespace acino {
@@ -80,6 +81,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.d_elim = nullptr;
   chn.d_remain = nullptr;
   chn.implicit_couplings = 1;
+  chn.dbg = nullptr;
   if (out) *out = b;
   if (ch) *ch = chn;
   return c.off;
@@ -393,7 +395,7 @@ __global__ void k_import_sep(const double* __restrict__ rec, int n_sep, BcrChain
   const double* r = rec + (size_t)s * ACINO_SEP_DOUBLES;
   for (int e = threadIdx.x + blockIdx.x * 256; e < (int)MB; e += gridDim.x * 256) {
     ch.D[(size_t)s * MB + e] = r[e];
-    if (s + 1 < n_sep) ch.Cpl[(size_t)s * MB + e] = rec[(size_t)(s + 1) * ACINO_SEP_DOUBLES + MB + e];
+    if (s + 1 < n_sep) ch.Cpl[(size_t)s * MB + e] = r[MB + e];   // record s carries block(s+1, s)
   }
   if (blockIdx.x == 0 && threadIdx.x < BS) ch.b[(size_t)s * BS + threadIdx.x] = r[2 * MB + threadIdx.x];
 }
@@ -452,12 +454,19 @@ using namespace acino;
 static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_step, bool respect_status,
                         hipStream_t s) {
   const Buffers& b = ctx->b;
-  int rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.cost_part, b.nbehind,
-                           need_jac, respect_status, s);
+  int rc;
+  {
+    ProfSpan sp(&ctx->prof, PC_ASSEMBLE, s);
+    rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.cost_part, b.nbehind,
+                         need_jac, respect_status, s);
+  }
   if (rc) return rc;
-  hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
-                     b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
-                     with_step ? 1 : 0);
+  {
+    ProfSpan sp(&ctx->prof, PC_TOTALS, s);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
+                       b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
+                       with_step ? 1 : 0);
+  }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }
@@ -585,8 +594,11 @@ int acino_fte_export_partials(acino_fte_ctx* ctx, double* d_partial, void* strea
 
 int acino_fte_control(acino_fte_ctx* ctx, const double* d_total, int init, void* stream) {
   ACINO_REQUIRE(ctx, "null");
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->b.cst, ctx->b.state,
-                     d_total ? d_total : ctx->b.totals, ctx->b.numeric_err, init);
+  {
+    ProfSpan sp(&ctx->prof, PC_CONTROL, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, (hipStream_t)stream, ctx->b.cst, ctx->b.state,
+                       d_total ? d_total : ctx->b.totals, ctx->b.numeric_err, init);
+  }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }
@@ -603,10 +615,13 @@ int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   hipStream_t s = (hipStream_t)stream;
   const Buffers& b = ctx->b;
-  hipLaunchKernelGGL(k_setup, dim3(ctx->chain.n_nodes), dim3(256), 0, s, b.cst, b.state, b.x[0], b.x[1], b.g[0],
-                     b.g[1], b.H[0], b.H[1], ctx->chain, b.gn_part);
+  {
+    ProfSpan sp(&ctx->prof, PC_SETUP, s);
+    hipLaunchKernelGGL(k_setup, dim3(ctx->chain.n_nodes), dim3(256), 0, s, b.cst, b.state, b.x[0], b.x[1], b.g[0],
+                       b.g[1], b.H[0], b.H[1], ctx->chain, b.gn_part);
+  }
   ACINO_LAUNCH_CHECK();
-  return bcr_reduce(ctx->chain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s);
+  return bcr_reduce(ctx->chain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s, &ctx->prof);
 }
 
 int acino_fte_export_separators(acino_fte_ctx* ctx, double* d_sep, int rank, int world, void* stream) {
@@ -656,6 +671,7 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
   ch.d_elim = d_sched;
   ch.d_remain = d_sched + sch.elim.size();
   ch.implicit_couplings = 0;
+  ch.dbg = nullptr;
   if (int rc = bcr_set_func_attributes()) return rc;
   ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, sch.elim.data(), sizeof(int) * sch.elim.size(), hipMemcpyHostToDevice, s));
   if (!sch.remain.empty())
@@ -686,14 +702,17 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
                        d_sep_x + (size_t)rank * BS);
     ACINO_LAUNCH_CHECK();
   }
-  return bcr_backsub(ctx->chain, ctx->sched, &ctx->b.state->status, s);
+  return bcr_backsub(ctx->chain, ctx->sched, &ctx->b.state->status, s, &ctx->prof);
 }
 
 int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   const Buffers& b = ctx->b;
-  hipLaunchKernelGGL(k_trial, dim3(ctx->n_blk_trial), dim3(256), 0, (hipStream_t)stream, b.cst, b.state, b.x[0],
-                     b.x[1], b.g[0], b.g[1], b.H[0], b.H[1], ctx->chain.b, b.pred_part, b.step_part);
+  {
+    ProfSpan sp(&ctx->prof, PC_TRIAL, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_trial, dim3(ctx->n_blk_trial), dim3(256), 0, (hipStream_t)stream, b.cst, b.state, b.x[0],
+                       b.x[1], b.g[0], b.g[1], b.H[0], b.H[1], ctx->chain.b, b.pred_part, b.step_part);
+  }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }
@@ -797,6 +816,42 @@ int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_p
     hipLaunchKernelGGL(k_derivatives, dim3(ctx->n_blk_trial), dim3(256), 0, s, xc + HALO * NP, n, ts, d_dx, d_ddx);
     ACINO_LAUNCH_CHECK();
   }
+  return ACINO_OK;
+}
+
+// Debug: phase timestamps (100 MHz wall clock) of workgroup 0 of every k_bcr_elim launch go to d_dbg[16].
+int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
+  ACINO_REQUIRE(ctx, "null");
+  ctx->chain.dbg = d_dbg;
+  return ACINO_OK;
+}
+
+int acino_fte_profile_begin(acino_fte_ctx* ctx) {
+  ACINO_REQUIRE(ctx, "null");
+  ctx->prof.on = true;
+  ctx->prof.used = 0;
+  ctx->prof.spans.clear();
+  return ACINO_OK;
+}
+
+// Stops profiling, synchronises `stream` and returns per kernel class the summed HIP-event time (ms) and
+// the number of launches.  Class order: setup, elim, update, backsub, trial, assemble, totals, control.
+int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, void* stream) {
+  ACINO_REQUIRE(ctx && ms_by_class && launches_by_class, "null");
+  ctx->prof.on = false;
+  ACINO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  for (int c = 0; c < PC_COUNT; ++c) {
+    ms_by_class[c] = 0.0;
+    launches_by_class[c] = 0;
+  }
+  for (const Profiler::Span& sp : ctx->prof.spans) {
+    float ms = 0.f;
+    ACINO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->prof.pool[sp.a], ctx->prof.pool[sp.b]));
+    ms_by_class[sp.cls] += ms;
+    launches_by_class[sp.cls] += 1;
+  }
+  ctx->prof.spans.clear();
+  ctx->prof.used = 0;
   return ACINO_OK;
 }
 

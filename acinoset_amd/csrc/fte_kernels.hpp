@@ -1,5 +1,8 @@
 // Internal declarations shared by the FTE translation units (not part of the C ABI).
 #pragma once
+#include <utility>
+#include <vector>
+
 #include "common.hpp"
 
 namespace acino {
@@ -35,6 +38,51 @@ __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
   for (int64_t j = jlo; j <= jhi; ++j) tot += c[n - j] * c[n + k - j];
   return tot;
 }
+
+// Per-kernel-class HIP-event profiler (bench.py's live roofline measurement).  Events are recorded on
+// the stream the kernels are launched on; nothing is recorded unless enabled.
+enum ProfClass { PC_SETUP = 0, PC_ELIM, PC_UPDATE, PC_BACKSUB, PC_TRIAL, PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_COUNT };
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Span { int cls; size_t a, b; };
+  std::vector<Span> spans;
+  hipEvent_t next() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  ~Profiler() {
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  }
+};
+struct ProfSpan {
+  Profiler* p;
+  hipStream_t s;
+  size_t a = 0;
+  int cls;
+  ProfSpan(Profiler* prof, int c, hipStream_t st) : p(prof && prof->on ? prof : nullptr), s(st), cls(c) {
+    if (p) {
+      a = p->used;
+      hipEvent_t e = p->next();
+      if (e) (void)hipEventRecord(e, s); else p = nullptr;
+    }
+  }
+  ~ProfSpan() {
+    if (p) {
+      size_t b = p->used;
+      hipEvent_t e = p->next();
+      if (e) {
+        (void)hipEventRecord(e, s);
+        p->spans.push_back({cls, a, b});
+      }
+    }
+  }
+};
 
 // x iterate buffers carry 3 halo frames on each side: row (i + 3) holds local frame i.
 constexpr int HALO = 3;

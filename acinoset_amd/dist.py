@@ -1,0 +1,213 @@
+"""Frame-sharded FTE across the GPUs of one node (one process per GPU, torch.distributed over RCCL).
+
+The reference has no parallelism at all; this is new.  The Gauss-Newton system of
+the FTE is block-tridiagonal in super-blocks of 3 frames, so contiguous frame blocks shard naturally:
+
+  * rank g owns super-blocks [m0_g, m1_g); the LAST super-block of every rank but the last is a
+    *separator* the rank assembles but does not eliminate, and every rank but the first also sees its
+    left neighbour's separator as chain node 0;
+  * per LM iteration each rank reduces its interior onto its (<= 2) separators, ONE all-reduce(SUM)
+    over xGMI carries the separator system ("temporal-coupling rows": (world-1) x (2*80*80+80) doubles,
+    ~0.7 MB at 8 GPUs), every rank solves that tiny chain redundantly and back-substitutes locally;
+  * two small all-gathers carry the 3+3 edge frames of the trial iterate (the third-difference stencil
+    reaches 3 frames across a boundary) and the 8 scalars of the accept/reject decision, which every
+    rank then takes identically on its own device.
+
+The numerical work lives behind a small backend interface; ``HipBackend`` drives libacinoset_hip.so.
+(tests/ plug a CPU oracle backend into the same driver to exercise this host logic under gloo.)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, fte
+from ._lib import BS, N_ACTIVE, SEP_DOUBLES, check, lib, ptr, stream_ptr
+
+
+def shard_plan(n_frames, world):
+    """Frame ranges [(n0, n1)] per rank: boundaries at multiples of 3, super-blocks split evenly."""
+    n_sb = (n_frames + 2) // 3
+    if world < 1 or n_sb < 2 * world:
+        raise ValueError(f"sequence of {n_frames} frames is too short to shard over {world} ranks "
+                         "(each rank needs >= 2 super-blocks of 3 frames)")
+    bounds = [(n_sb * g) // world for g in range(world + 1)]
+    return [(3 * bounds[g], min(3 * bounds[g + 1], n_frames)) for g in range(world)]
+
+
+class HipBackend:
+    """Local shard on this process's GPU: thin calls into the C ABI (include/acinoset_hip.h)."""
+
+    def __init__(self, det_local, k_arr, d_arr, r_arr, t_arr, Ts, n_global, n_offset, rank, world, **kw):
+        self.rank, self.world = rank, world
+        self.ctx = fte.FTEContext(det_local, k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=n_offset,
+                                  pin_left=rank > 0, pin_right=rank + 1 < world, **kw)
+        self.device = self.ctx.device
+        self.n_sep = world - 1
+        if self.n_sep > 0:
+            nb = lib().acino_sep_scratch_bytes(self.n_sep)
+            self._scratch = torch.empty(nb + 256, dtype=torch.uint8, device=self.device)
+            self._scratch_ptr = (self._scratch.data_ptr() + 255) // 256 * 256
+            self._scratch_bytes = nb
+
+    def new(self, *shape):
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def load_x(self, x_local):
+        self._x0 = x_local.to(self.device, torch.float64).contiguous()
+        check(lib().acino_fte_load_x(self.ctx._h, ptr(self._x0), stream_ptr()))
+
+    def export_edges(self, which, out):
+        check(lib().acino_fte_export_edges(self.ctx._h, which, ptr(out), stream_ptr()))
+
+    def set_halo(self, which, left, right):
+        check(lib().acino_fte_set_halo(self.ctx._h, which, ptr(left), ptr(right), stream_ptr()))
+
+    def eval(self, which):
+        check(lib().acino_fte_eval(self.ctx._h, which, stream_ptr()))
+
+    def export_partials(self, out):
+        check(lib().acino_fte_export_partials(self.ctx._h, ptr(out), stream_ptr()))
+
+    def control(self, total, init):
+        check(lib().acino_fte_control(self.ctx._h, ptr(total), int(init), stream_ptr()))
+
+    def reduce_local(self):
+        check(lib().acino_fte_reduce_local(self.ctx._h, stream_ptr()))
+
+    def export_separators(self, sep):
+        check(lib().acino_fte_export_separators(self.ctx._h, ptr(sep), self.rank, self.world, stream_ptr()))
+
+    def solve_separators(self, sep, sep_x):
+        check(lib().acino_solve_separators(ptr(sep), self.n_sep, ptr(sep_x), C.c_void_p(self._scratch_ptr),
+                                           self._scratch_bytes, stream_ptr()))
+
+    def backsub_local(self, sep_x):
+        check(lib().acino_fte_backsub_local(self.ctx._h, ptr(sep_x) if sep_x is not None else C.c_void_p(0),
+                                            self.rank, self.world, stream_ptr()))
+
+    def trial(self):
+        check(lib().acino_fte_trial(self.ctx._h, stream_ptr()))
+
+    def state(self):
+        return self.ctx.state()
+
+    def result_x(self):
+        return self.ctx.result()[0]
+
+
+class TorchComm:
+    """torch.distributed collectives (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_gather(self, out, inp):
+        # flat views: gloo only accepts the concatenated 1-D layout, RCCL accepts both
+        dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=self.group)
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def combine_partials(gathered):
+    """[world, 8] local sums -> global {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}; fixed (rank)
+    order, so every rank computes bit-identical totals."""
+    total = torch.zeros(8, dtype=gathered.dtype, device=gathered.device)
+    total[0] = gathered[:, 0].sum()
+    total[1] = gathered[:, 1].sum()
+    total[2] = gathered[:, 2].max()
+    total[3] = gathered[:, 3].max()
+    total[4] = gathered[:, 4].sum()
+    return total
+
+
+class ShardedFTE:
+    """One LM solve over a sequence sharded across the process group (strong scaling)."""
+
+    def __init__(self, backend, rank, world, group=None, comm=None):
+        self.b, self.rank, self.world, self.group = backend, rank, world, group
+        self.comm = comm if comm is not None else TorchComm(group)
+        self._edges = backend.new(6, N_ACTIVE)
+        self._all_edges = backend.new(world, 6, N_ACTIVE)
+        self._partial = backend.new(8)
+        self._all_partials = backend.new(world, 8)
+        self._sep = backend.new(max(world - 1, 1), SEP_DOUBLES)
+        self._sep_x = backend.new(max(world - 1, 1), BS)
+
+    # -- collectives ---------------------------------------------------------------------------------
+    def _exchange_halo(self, which):
+        if self.world == 1:
+            self.b.set_halo(which, None, None)
+            return
+        self.b.export_edges(which, self._edges)
+        self.comm.all_gather(self._all_edges, self._edges)
+        left = self._all_edges[self.rank - 1, 3:6].contiguous() if self.rank > 0 else None
+        right = self._all_edges[self.rank + 1, 0:3].contiguous() if self.rank + 1 < self.world else None
+        self._halo_keep = (left, right)     # keep alive until the kernels that read them have run
+        self.b.set_halo(which, left, right)
+
+    def _global_control(self, init):
+        self.b.export_partials(self._partial)
+        if self.world > 1:
+            self.comm.all_gather(self._all_partials, self._partial)
+            total = combine_partials(self._all_partials)
+        else:
+            total = self._partial
+        self._total_keep = total
+        self.b.control(total, init)
+
+    # -- driver --------------------------------------------------------------------------------------
+    def set_x(self, x_local):
+        self.b.load_x(x_local)
+        self._exchange_halo(0)
+        self.b.eval(0)
+        self._global_control(True)
+
+    def step(self):
+        self.b.reduce_local()
+        if self.world > 1:
+            self._sep.zero_()
+            self.b.export_separators(self._sep)
+            self.comm.all_reduce_sum(self._sep)
+            self.b.solve_separators(self._sep, self._sep_x)
+            self.b.backsub_local(self._sep_x)
+        else:
+            self.b.backsub_local(None)
+        self.b.trial()
+        self._exchange_halo(1)
+        self.b.eval(1)
+        self._global_control(False)
+
+    def solve(self, max_iter, peek_every=8):
+        st = None
+        for it in range(max_iter):
+            self.step()
+            if (it % peek_every) == peek_every - 1:
+                st = self.b.state()
+                if st["status"] != 0:
+                    break
+        return self.b.state()
+
+    def gather_x(self, n_max):
+        """Full trajectory x[N,25] on every rank: all-gather of the local shards padded to n_max frames
+        (n_max = the largest shard of the plan)."""
+        x = self.b.result_x()
+        if self.world == 1:
+            return x
+        pad = self.b.new(n_max + 1, N_ACTIVE)
+        pad[: x.shape[0]] = x
+        pad[n_max, 0] = float(x.shape[0])
+        out = self.b.new(self.world, n_max + 1, N_ACTIVE)
+        self.comm.all_gather(out, pad)
+        return torch.cat([out[g, : int(out[g, n_max, 0].item())] for g in range(self.world)], dim=0)
+
+
+def make_sharded(det_full, k_arr, d_arr, r_arr, t_arr, Ts, rank, world, group=None, comm=None, **kw):
+    """Convenience: slice this rank's frames out of a full det[N,C,20,3] and build the HIP-backed driver."""
+    n_global = int(det_full.shape[0])
+    plan = shard_plan(n_global, world) if world > 1 else [(0, n_global)]
+    n0, n1 = plan[rank]
+    backend = HipBackend(det_full[n0:n1], k_arr, d_arr, r_arr, t_arr, Ts, n_global, n0, rank, world, **kw)
+    return ShardedFTE(backend, rank, world, group, comm), (n0, n1)

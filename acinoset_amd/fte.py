@@ -138,6 +138,17 @@ class FTEContext:
         check(lib().acino_fte_get_result(self._h, self.Ts, ptr(x), ptr(pos), ptr(dx), ptr(ddx), stream_ptr()))
         return x, pos, dx, ddx
 
+    PROF_CLASSES = ("setup", "elim", "update", "backsub", "trial", "assemble", "totals", "control")
+
+    def profile_begin(self):
+        check(lib().acino_fte_profile_begin(self._h))
+
+    def profile_end(self):
+        ms = (C.c_double * 8)()
+        n = (C.c_int * 8)()
+        check(lib().acino_fte_profile_end(self._h, ms, n, stream_ptr()))
+        return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(self.PROF_CLASSES)}
+
     def cost(self, x_active):
         x = calib._to_dev(x_active, self.device)
         out = torch.zeros(1, dtype=torch.float64, device=self.device)

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the FTE hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE Levenberg-Marquardt iteration over the whole synthetic sequence: damped block system ->
+block-cyclic-reduction solve -> trial iterate -> reprojection residuals + analytic Jacobians + normal-
+equation assembly at the trial -> accept/reject.  Workload = BASELINE.json's metric configuration:
+6 cameras x 20 markers x 10 000 frames, fp64, detections resident in HBM before the timed region.
+With N GPUs the SAME 10 000-frame sequence is sharded by frames (strong scaling) with one RCCL all-reduce
+on the separator ("temporal-coupling") rows per step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_FRAMES = 10000
+N_CAMS = 6
+# Algorithmic flops per frame per LM iteration (dense accounting), by kernel class.
+ALG_FLOPS = {"assemble": 218.0e3,   # FK 1.1k + projection 7.8k + Jacobians 14.4k + chain 16.7k + weights 10k + J^T W J 156k + J^T r 12k
+             "elim": 52.0e3,        # block Cholesky 25^3/3 + three 25x25 triangular solves
+             "update": 187.5e3,     # six 2*25^3 trailing GEMM updates of the banded factorisation
+             "backsub": 10.0e3}     # forward/backward substitution
+ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
+ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
+FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(det, rig, Ts, x0_full, sample_frames=1500, iters=2):
+    """The numpy/scipy oracle's LM iteration timed on the host, 1 thread, on a bounded sample."""
+    from oracle import fk as ofk
+    from oracle import fte as ofte
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:                                  # pragma: no cover
+        limiter = None
+    n = min(sample_frames, det.shape[0])
+    K, D, R, t = rig
+    prob = ofte.FTEProblem(det[:n, ..., :2], det[:n, ..., 2], K, D, R, t, Ts)
+    x = np.clip(x0_full[:n, ofk.ACTIVE], prob.lo, prob.hi)
+    t0 = time.perf_counter()
+    F, g, H, _ = prob.evaluate(x)
+    lam = 1e-3
+    for _ in range(iters):
+        fixed = ((x <= prob.lo) & (g > 0)) | ((x >= prob.hi) & (g < 0))
+        delta, _diag = prob.solve_banded(H, g, lam, fixed)
+        xt = np.clip(x + delta, prob.lo, prob.hi)
+        Ft, gt, Ht, _ = prob.evaluate(xt)
+        if Ft < F:
+            x, F, g, H = xt, Ft, gt, Ht
+            lam /= 3
+        else:
+            lam *= 2
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    per_iter = dt / (iters + 0.5)      # the initial evaluation is ~half an iteration of work
+    return dict(value=n / per_iter, unit="frames/s", cores=1, kind="port",
+                sample=f"{iters} LM iterations (+ initial evaluation) of the numpy/scipy oracle on the first {n} "
+                       f"frames of the same sequence, 1 thread, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=N_FRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from acinoset_amd import dist as adist
+    from acinoset_amd import fte, synth
+
+    # ---- synthetic workload (every rank builds the same sequence, then keeps its shard) ----
+    seq = synth.make_sequence(args.frames, "loop")
+    det = seq["det"]
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0_full = fte.triangulation_init(det, *rig, 0.5)
+    solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world,
+                                          ftol=0.0, xtol=0.0, gtol=0.0)
+    x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
+    solver.set_x(x0_local)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.step()
+    sync()
+    ctx = solver.b.ctx
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    st = solver.b.state()
+
+    if rank == 0:
+        n_loc = n1 - n0
+        ms_step = 1e3 * dt / args.steps
+        value = args.frames * args.steps / dt
+        dom = max(ALG_FLOPS, key=lambda k: prof[k]["ms"])
+        launches = max(prof[dom]["launches"], 1)
+        avg_ms = prof[dom]["ms"] / launches
+        flops_per_launch = ALG_FLOPS[dom] * n_loc * args.steps / launches
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
+        out = {
+            "metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"FTE LM iteration, {N_CAMS} cam x 20 markers x {args.frames} frames (BASELINE configs[3] shape"
+                                   f"{'' if world > 1 else ' on one GPU'}), loop trajectory, seed 20210313",
+                       "frames": args.frames, "cams": N_CAMS, "markers": 20, "states": 25,
+                       "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": {"elim": "k_bcr_elim", "update": "k_bcr_update",
+                                                      "assemble": "k_fte_assemble", "backsub": "k_bcr_backsub"}[dom],
+                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": launches / args.steps, "avg_launch_ms": avg_ms,
+                         "algorithmic_flops_per_launch": flops_per_launch,
+                         "step": {"achieved_tflops": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12,
+                                  "frac_fp64": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                  "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
+                                  "frac_hbm": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "gpu_kernel_ms_per_step": gpu_ms_step},
+                         "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
+            "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(det, rig, seq["Ts"], x0_full)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

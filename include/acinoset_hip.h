@@ -136,6 +136,9 @@ typedef struct acino_fte_state {
 
 typedef struct acino_fte_ctx acino_fte_ctx;   /* opaque host handle */
 
+/* sizeof() of the two ABI structs as this library was compiled (bindings assert their own layout against it). */
+size_t acino_sizeof_fte_params(void);
+size_t acino_sizeof_fte_state(void);
 size_t acino_fte_workspace_bytes(const acino_fte_params* p);
 /* Creates a handle over caller-owned buffers.  d_det[N][C][L=20][3], d_cams24[C][24],
  * d_workspace >= acino_fte_workspace_bytes(p), 256-byte aligned.  Synchronises the stream once. */
@@ -161,6 +164,14 @@ int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* 
 /* Gradient d_g[N][25] and Gauss-Newton blocks d_h[N][25][25] (measurement part + smoothness diagonal) of the
  * CURRENT iterate, for parity checks.  Either may be NULL. */
 int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
+/* Live per-kernel timing for bench.py: HIP events recorded on the launch stream around every kernel between
+ * begin and end.  end synchronises and returns, per class {setup, elim, update, backsub, trial, assemble,
+ * totals, control}, the summed event time in ms and the launch count. */
+#define ACINO_PROF_CLASSES 8
+int acino_fte_profile_begin(acino_fte_ctx* ctx);
+/* Debug aid: phase timestamps (wall_clock64 ticks) of workgroup 0 of the elimination kernel -> d_dbg[16]; NULL disables. */
+int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);
+int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, void* stream);
 /* Stand-alone helpers: dx/ddx of a trajectory d_x[N][25]; FK of active states d_xa[N][25] -> d_pos[N][20][3]. */
 int acino_fte_derivatives(const double* d_x, int64_t n_frames, double ts, double* d_dx, double* d_ddx, void* stream);
 int acino_fk_active(const double* d_xa, int64_t n_frames, double* d_pos, void* stream);
@@ -174,7 +185,7 @@ int acino_fk_active(const double* d_xa, int64_t n_frames, double* d_pos, void* s
  *   -> control(total, 0).
  * `which`: 0 = current iterate, 1 = trial iterate (resolved on the device). */
 #define ACINO_BS 80
-/* Doubles in the exchange record of ONE separator: D[80][80] | C[80][80] (coupling to the previous separator) | b[80]. */
+/* Doubles in the exchange record of ONE separator: D[80][80] | C[80][80] = block(next separator, this one) | b[80]. */
 #define ACINO_SEP_DOUBLES (2 * ACINO_BS * ACINO_BS + ACINO_BS)
 int acino_fte_load_x(acino_fte_ctx* ctx, const double* d_x0, void* stream);
 /* d_halo_l[3][25] = the 3 frames left of the shard, d_halo_r[3][25] the 3 frames right of it; NULL = zeros

@@ -1,0 +1,107 @@
+"""CPU: the C-ABI library loads and exports every symbol include/acinoset_hip.h declares; host-side
+argument handling; the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from acinoset_amd import _lib, calib, fte
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    ge.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "acinoset_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(acino_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= declared
+    assert lib.acino_abi_version() == 1
+    assert lib.acino_sizeof_fte_params() == C.sizeof(_lib.FteParams)
+    assert lib.acino_sizeof_fte_state() == C.sizeof(_lib.FteState)
+
+
+def test_argument_validation_happens_before_any_device_call(lib):
+    null = C.c_void_p(0)
+    rc = lib.acino_triangulate_pairs(null, 10, 9, 20, 0.5, null, null, null, null, null)
+    assert rc == -1 and b"n_cams" in lib.acino_last_error_string()
+    rc = lib.acino_project_fisheye(null, -1, null, null, null)
+    assert rc == -1
+    assert lib.acino_project_fisheye(null, 0, C.c_void_p(8), null, null) == 0      # empty input is a no-op
+    assert lib.acino_selftest_mfma(null, null, 6, null, null) == -1
+    p = fte.make_params(100, 6, 1 / 120)
+    nbytes = lib.acino_fte_workspace_bytes(C.byref(p))
+    assert nbytes > 34 * 3 * 80 * 80 * 8                       # three 80x80 matrices per super-block
+    p_bad = fte.make_params(100, 6, 1 / 120, pin_left=True, n_global=200, n_offset=50)   # offset not a multiple of 3
+    h = C.c_void_p()
+    assert lib.acino_fte_create(C.byref(h), C.byref(p_bad), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), nbytes, null) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1)
+    with pytest.raises(RuntimeError):
+        _lib.check(-2)
+
+
+def test_params_mirror_reference_constants():
+    p = fte.make_params(10, 6, 1 / 120)
+    lo, hi = fte.bounds45()
+    assert np.isfinite(lo).sum() == 21
+    assert abs(p.inv_r_meas - 0.2) < 1e-15 and (p.redesc_a, p.redesc_b, p.redesc_c) == (3.0, 10.0, 20.0)
+    assert abs(p.q_w[0] - (1 / 16) * 120 ** 4) < 1e-3                                  # x: sigma 4 -> 1/16 / Ts^4
+    assert [p.lo[i] for i in range(3)] == [-np.inf] * 3 and p.hi[20] == np.inf        # x, y, z and psi_0 are free
+    assert abs(p.lo[13] + np.pi) < 1e-15 and p.hi[13] == 0.0                          # theta_7 in [-pi, 0]
+    with pytest.raises(ValueError):
+        fte.make_params(10, 6, 1 / 120, Q=np.ones(45))
+    assert len(fte.MARKERS) == 20 and fte.ACTIVE.tolist()[:6] == [0, 1, 2, 3, 4, 6]
+
+
+def test_camera_records_and_shapes():
+    k = np.array([[1000.0, 2.0, 640], [0, 1001.0, 360], [0, 0, 1]])
+    rec = calib.fisheye_record(k, np.array([[0.1], [0.2], [0.3], [0.4]]), np.eye(3), np.array([[1.0], [2.0], [3.0]]))
+    assert rec.shape == (24,) and rec[20] == 2.0 / 1000.0 and rec[4:8].tolist() == [0.1, 0.2, 0.3, 0.4]
+    rec2 = calib.fisheye_record(k, np.zeros(4), np.array([0.0, 0.0, np.pi / 2]), np.zeros(3))     # rvec accepted
+    assert np.allclose(rec2[8:17].reshape(3, 3), [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    with pytest.raises(ValueError):
+        calib.fisheye_record(k, np.zeros(5), np.eye(3), np.zeros(3))
+    pin = calib.pinhole_record(k, np.arange(8) * 0.01, np.eye(3), np.zeros(3))
+    assert pin.shape == (32,) and pin[4:12].tolist() == (np.arange(8) * 0.01).tolist()
+    with pytest.raises(ValueError):
+        calib.pinhole_record(k, np.zeros(6), np.eye(3), np.zeros(3))
+
+
+def test_dataframe_to_dense_layout():
+    import pandas as pd
+    rows = [dict(frame=f, camera=c, marker=m, x=f + c, y=10 * f, likelihood=0.9)
+            for f in (3, 5) for c in (0, 2) for m in ("nose", "l_eye")]
+    det, frames, markers = calib.dataframe_to_dense(pd.DataFrame(rows), 3)
+    assert det.shape == (2, 3, 2, 3) and frames.tolist() == [3, 5] and markers.tolist() == ["l_eye", "nose"]
+    assert det[1, 2, 1].tolist() == [7.0, 50.0, 0.9]
+    assert np.isneginf(det[:, 1, :, 2]).all()                  # camera 1 never saw anything
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the behaviour WITHOUT a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        calib.project_points_fisheye(np.zeros((1, 3)), np.eye(3), np.zeros(4), np.eye(3), np.zeros(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fte.cheetah_fk(np.zeros((1, 45)))
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "acinoset_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{fn} imports the oracle"

@@ -1,0 +1,179 @@
+"""CPU: the oracle against the golden vectors generated from the reference (tests/golden/make_golden.py)
+and the reference's own recorded numbers (KAT-1, KAT-4)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import camera, fk, index_path, loss
+from oracle import fte as ofte
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_redescending_loss_table(golden_dir):
+    g = _g(golden_dir, "ref_helpers.npz")
+    assert np.abs(loss.redescending_loss(g["e"], 3, 10, 20) - g["rho_3_10_20"]).max() < 1e-12
+    assert np.abs(loss.redescending_loss(g["e"], 3, 5, 15) - g["rho_3_5_15"]).max() < 1e-12
+    # SURVEY 8c spot values of build.redescending_loss(e, 3, 10, 20)
+    for e, v in ((2, 1.862311), (5, 10.713318), (15, 36.800639), (40, 40.5), (0, -0.214097)):
+        assert abs(loss.redescending_loss(e, 3, 10, 20) - v) < 1e-6
+
+
+def test_redescending_derivative_and_weight():
+    e = np.linspace(0.01, 45, 3000)
+    rho, d, h = loss.redescending_dloss(e, 3, 10, 20)
+    num = (loss.redescending_loss(e + 1e-6, 3, 10, 20) - loss.redescending_loss(e - 1e-6, 3, 10, 20)) / 2e-6
+    assert np.abs(num - d).max() < 1e-6
+    assert np.abs(rho - loss.redescending_loss(e, 3, 10, 20)).max() < 1e-13
+    assert h.min() >= 0 and h.max() <= 1
+    assert abs(loss.drho_at_zero(3, 10, 20) - loss.redescending_dloss(np.array([0.0]), 3, 10, 20)[1][0]) < 1e-15
+
+
+def _scene(golden_dir):
+    sc = json.load(open(os.path.join(golden_dir, "dummy_scene.json")))
+    K = np.array([c["k"] for c in sc["cameras"]])
+    D = np.array([c["d"] for c in sc["cameras"]]).reshape(-1, 4)
+    R = np.array([c["r"] for c in sc["cameras"]])
+    t = np.array([c["t"] for c in sc["cameras"]])
+    return K, D, R, t
+
+
+def test_pt3d_to_2d_matches_reference(golden_dir):
+    g = _g(golden_dir, "ref_helpers.npz")
+    K, D, R, t = _scene(golden_dir)
+    uv = np.array([camera.pt3d_to_2d(X, K[c], D[c], R[c], t[c]) for X, c in zip(g["p2d_X"], g["p2d_cam"])])
+    assert np.abs(uv - g["p2d_uv"]).max() < 1e-9
+    # analytic Jacobian against central differences
+    X = g["p2d_X"][3]
+    _, J, _ = camera.pt3d_to_2d(X, K[1], D[1], R[1], t[1], with_jac=True)
+    Jn = np.zeros((2, 3))
+    for j in range(3):
+        d = np.zeros(3)
+        d[j] = 1e-6
+        Jn[:, j] = (camera.pt3d_to_2d(X + d, K[1], D[1], R[1], t[1]) - camera.pt3d_to_2d(X - d, K[1], D[1], R[1], t[1])) / 2e-6
+    assert np.abs(J - Jn).max() < 1e-5
+    # the closed form equals cv2-style fisheye projection to <= 1e-6 px
+    uv2 = np.array([camera.project_points_fisheye(X, K[c], D[c], R[c], t[c])[0] for X, c in zip(g["p2d_X"], g["p2d_cam"])])
+    assert np.abs(uv2 - g["p2d_uv"]).max() < 1e-5
+
+
+def test_rotation_convention(golden_dir):
+    g = _g(golden_dir, "ref_helpers.npz")
+    for ax, key in (("x", "rot_x"), ("y", "rot_y"), ("z", "rot_z")):
+        R, _ = fk._rot(ax, g["rot_ang"])
+        assert np.abs(R - g[key]).max() < 1e-15
+
+
+def test_cheetah_fk_positions_and_jacobian(golden_dir):
+    g = _g(golden_dir, "cheetah_fk.npz")
+    P, J = fk.cheetah_fk(g["q"], with_jac=True)
+    assert np.abs(P - g["positions"]).max() < 1e-13
+    assert np.abs(J.reshape(-1, 60, 45) - g["jac"]).max() < 1e-13
+    assert (fk.ACTIVE == g["active"]).all()
+    dep = (np.abs(J).max(0).reshape(60, 45) > 0)
+    assert (dep <= g["dep"].astype(bool)).all()          # never depends on more than the symbolic pattern
+    # the 20 states with Q == 0 are exactly the inactive ones and never move a marker
+    inactive = np.setdiff1d(np.arange(45), fk.ACTIVE)
+    assert set(inactive.tolist()) == set(np.where(fk.Q_SIGMA == 0)[0].tolist())
+    assert np.abs(J[..., inactive]).max() == 0
+    assert np.isfinite(fk.bounds45()[0]).sum() == 21
+
+
+def test_index_path_matches_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "index_path.json")))["cases"]
+
+    def fake_tri(a, b, k1, d1, r1, t1, k2, d2, r2, t2):
+        a = np.asarray(a, dtype=np.float64).reshape(-1, 2)
+        b = np.asarray(b, dtype=np.float64).reshape(-1, 2)
+        return np.stack([a[:, 0] + 2.0 * b[:, 0] + k1[0, 0], a[:, 1] - b[:, 1] + 3.0 * k2[0, 0],
+                         a[:, 0] * 0.5 + b[:, 1] * 0.25 + k1[0, 0] * k2[0, 0]], axis=1)
+
+    import pandas as pd
+    for case in cases:
+        det = np.array(case["det"])
+        N, C, L = case["N"], case["C"], case["L"]
+        k_arr = np.array([np.diag([kd[0], kd[1], 1.0]) for kd in case["kdiag"]])
+        z = np.zeros((C, 4))
+        r_arr = np.tile(np.eye(3), (C, 1, 1))
+        t_arr = np.zeros((C, 3, 1))
+        rows = [dict(frame=n, camera=c, marker=case["markers"][l], x=det[n, c, l, 0], y=det[n, c, l, 1],
+                     likelihood=det[n, c, l, 2]) for c in range(C) for n in range(N) for l in range(L)]
+        df = pd.DataFrame(rows)
+        df = df[df["likelihood"] > case["thresh"]]
+        if case.get("raises"):
+            with pytest.raises(KeyError):
+                index_path.get_pairwise_3d_points_from_df(df, k_arr, z, r_arr, t_arr, fake_tri)
+            continue
+        out = index_path.get_pairwise_3d_points_from_df(df, k_arr, z, r_arr, t_arr, fake_tri)
+        assert list(out["frame"]) == case["out_frame"]                    # index path: exact
+        assert list(out["marker"]) == case["out_marker"]
+        assert out["frame"].dtype == np.float64
+        ref = np.array(case["out_xyz"])
+        assert np.array_equal(out[["x", "y", "z"]].to_numpy(), ref)       # Kahan mean in pair order: bit-exact
+
+
+def test_kat1_triangulate_project_statistics(golden_dir):
+    """KAT-1: residual statistics recorded in src/calib_with_gui.ipynb cell 29 (before SBA)."""
+    g = _g(golden_dir, "kat1_sunday_amelia.npz")
+    for row, (tag, ca, cb) in enumerate((("rotating", 1, 2), ("static", 3, 4))):
+        K, D, R, t = g[f"{tag}_K"], g[f"{tag}_D"], g[f"{tag}_R"], g[f"{tag}_t"]
+        pa, pb = g[f"cam{ca}_points"], g[f"cam{cb}_points"]
+        assert (g[f"cam{ca}_fnames"] == g[f"cam{cb}_fnames"]).all()
+        res = []
+        for f in range(pa.shape[0]):
+            p3 = camera.triangulate_points_fisheye(pa[f], pb[f], K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
+            p3 = p3.astype(np.float32).astype(np.float64)                 # calib.py:259-260 stores float32
+            for ci, pp in ((0, pa), (1, pb)):
+                pr = camera.project_points_fisheye(p3, K[ci], D[ci], R[ci], t[ci])
+                res.append((pr - pp[f].reshape(-1, 2)).ravel())
+        r = np.concatenate(res)
+        assert r.size == 3456
+        mean, std, cost = g["recorded"][row]
+        assert abs(r.std() - std) / std < 1e-6
+        assert abs(0.5 * np.sum(np.log1p(r ** 2)) - cost) / cost < 5e-5     # recorded to 5 significant digits
+        assert abs(r.mean() - mean) < 1e-5
+
+
+def test_kat4_integration_identities(golden_dir):
+    """KAT-4: the stored IPOPT runs satisfy the backward-Euler relations, hence the third-difference form."""
+    g = _g(golden_dir, "kat34_build_runs.npz")
+    h = 1.0 / 120
+    for tag in ("traj", "run1"):
+        x, dx, ddx = g[f"{tag}_x"], g[f"{tag}_dx"], g[f"{tag}_ddx"]
+        assert np.abs(x[1:] - x[:-1] - h * dx[1:]).max() < 1e-12
+        assert np.abs(dx[1:] - dx[:-1] - h * ddx[1:]).max() < 1e-11
+        slack = ddx[1:] - ddx[:-1]                                            # slack_n, n = 2..N (1-based)
+        third = (x[3:] - 3 * x[2:-1] + 3 * x[1:-2] - x[:-3]) / h ** 2
+        assert np.abs(slack[2:] - third).max() < 1e-6 * max(1.0, np.abs(third).max())
+        assert np.abs(slack[:2]).max() < 1e-4 * np.median(np.abs(slack[2:]) + 1e-12) + 1e-4
+
+
+def test_smoothness_term_equals_third_difference():
+    rng = np.random.default_rng(3)
+    N = 12
+    det = np.zeros((N, 2, 20, 3))
+    K = np.tile(np.eye(3), (2, 1, 1))
+    prob = ofte.FTEProblem(det[..., :2], det[..., 2], K, np.zeros((2, 4)), K, np.zeros((2, 3)), 1 / 120)
+    x = rng.normal(size=(N, 25))
+    cost, grad = prob.smooth_terms(x)
+    d = x[3:] - 3 * x[2:-1] + 3 * x[1:-2] - x[:-3]
+    assert abs(cost - (prob.q_w * d * d).sum()) < 1e-6 * abs(cost)
+    band = prob.s_band()
+    gb = np.zeros_like(x)
+    for n in range(N):
+        for k in range(-3, 4):
+            if 0 <= n + k < N:
+                gb[n] += 2 * prob.q_w * band[abs(k), min(n, n + k)] * x[n + k]
+    assert np.abs(gb - grad).max() < 1e-9 * np.abs(grad).max()
+    # shard consistency: two halves with halos reproduce the full gradient and cost
+    pl = ofte.FTEProblem(det[:6, ..., :2], det[:6, ..., 2], K, np.zeros((2, 4)), K, np.zeros((2, 3)), 1 / 120, n_global=N, n_offset=0)
+    pr = ofte.FTEProblem(det[6:, ..., :2], det[6:, ..., 2], K, np.zeros((2, 4)), K, np.zeros((2, 3)), 1 / 120, n_global=N, n_offset=6)
+    cl, gl = pl.smooth_terms(x[:6], None, x[6:9])
+    cr, gr = pr.smooth_terms(x[6:], x[3:6], None)
+    assert abs(cl + cr - cost) < 1e-9 * abs(cost)
+    assert np.abs(np.vstack([gl, gr]) - grad).max() < 1e-9 * np.abs(grad).max()
+    assert np.allclose(np.hstack([pl.s_band(), pr.s_band()]), band)
