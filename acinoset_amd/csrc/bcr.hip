@@ -4,12 +4,12 @@
 // of 16 with identity rows, so every block operation is a 5x5 grid of 16x16 fp64 tiles executed on
 // the matrix cores (v_mfma_f64_16x16x4_f64).  One level = two launches:
 //   elim   (one workgroup per eliminated node i with neighbours l, r):
-//            D_i = L L^T (blocked Cholesky in LDS, explicit inverses of the diagonal tiles),
-//            W_l = L^-1 A_il, W_r = L^-1 A_ir, y = L^-1 b_i                         -> HBM
+//            D_i = L L^T (blocked Cholesky in LDS), U = L^-T by blocked inversion on the matrix cores,
+//            W_l = U^T A_il, W_r = U^T A_ir (plain tile GEMMs), y = U^T b_i         -> HBM
 //   update (two workgroups per remaining node j):
 //            D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+),  b_j -= W^T y,
 //            new coupling block(j', j) = -W_r(i+)^T W_l(i+)
-// and back-substitution x_i = L^-T (y - W_l x_l - W_r x_r) walks the levels in reverse.
+// and back-substitution x_i = U (y - W_l x_l - W_r x_r) (three mat-vecs) walks the levels in reverse.
 // Level-0 couplings are the constant third-difference blocks and are generated in LDS, never stored.
 // LDS: three 80x81 fp64 matrices (155.5 KB of the 160 KB) - leading dimension 81 makes both the
 // row-pattern and the column-pattern MFMA operand reads bank-conflict free.
@@ -33,19 +33,10 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// spare (strictly upper) tiles of the factor matrix hold the inverses of the diagonal tiles
-__device__ __forceinline__ int inv_tile_off(int kb) {
-  const int r[5] = {0, 0, 0, 0, 1}, c[5] = {1, 2, 3, 4, 2};
-  return (r[kb] * 16) * LD + c[kb] * 16;
-}
-__host__ __device__ inline int inv_tile_off_g(int kb) {  // same positions with leading dimension 80
-  const int r[5] = {0, 0, 0, 0, 1}, c[5] = {1, 2, 3, 4, 2};
-  return (r[kb] * 16) * BS + c[kb] * 16;
-}
-
 // One wave: Cholesky of the 16x16 tile T (LDS, leading dim LD) in registers (lane = row, cross-lane
-// broadcast by v_readlane), then its inverse (lane = column) into Tinv.
-__device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
+// broadcast by v_readlane), then the inverse of the factor (lane = column).  The tile is OVERWRITTEN by
+// U_kk = (L_kk^-1)^T (upper triangular): the factor L_kk itself is not needed once its inverse exists.
+__device__ void chol16_inv(double* T, int lane, int* err) {
   const int r = lane & 15;
   double a[16];
 #pragma unroll
@@ -68,7 +59,7 @@ __device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
       a[c] = (r >= c) ? a[c] - a[j] * lc : a[c];
     }
   }
-  double x[16];
+  double x[16];   // lane r holds column r of L_kk^-1
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     double acc = 0.0;
@@ -81,28 +72,26 @@ __device__ void chol16_inv(double* T, double* Tinv, int lane, int* err) {
   }
   if (lane < 16) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) T[r * LD + c] = a[c];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) Tinv[rr * LD + r] = x[rr];
+    for (int rr = 0; rr < 16; ++rr) T[r * LD + rr] = x[rr];     // U_kk[r][rr] = Linv_kk[rr][r]
     if (bad && err) atomicExch(err, 1);
   }
 }
 
-// Blocked Cholesky of the 80x80 matrix in LDS (lower triangle in place, inverse diagonal tiles in the
-// spare upper tiles).  All 256 threads.
+// Blocked Cholesky of the 80x80 matrix in LDS.  On exit: strictly-lower tiles hold L(ib,jb), diagonal
+// tiles hold U_kk = (L_kk^-1)^T.  All 256 threads.
 __device__ void chol80(double* Lm, int tid, int* err) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   for (int kb = 0; kb < NT; ++kb) {
-    double* Tinv = Lm + inv_tile_off(kb);
-    if (wave == 0) chol16_inv(Lm + (kb * 16) * LD + kb * 16, Tinv, lane, err);
+    double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+    if (wave == 0) chol16_inv(Ukk, lane, err);
     __syncthreads();
-    for (int ib = kb + 1 + wave; ib < NT; ib += 4) {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T
+    for (int ib = kb + 1 + wave; ib < NT; ib += 4) {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T = A(ib,kb) * U_kk
       double* A = Lm + (ib * 16) * LD + kb * 16;
       double av[4], bv[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         av[s] = A[li * LD + 4 * s + lk];
-        bv[s] = Tinv[li * LD + 4 * s + lk];
+        bv[s] = Ukk[(4 * s + lk) * LD + li];
       }
       d4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -130,35 +119,89 @@ __device__ void chol80(double* Lm, int tid, int* err) {
   }
 }
 
-// W <- L^-1 W for the column tile starting at column cc of W (one wave; no workgroup barrier needed).
-__device__ __forceinline__ void trsm_coltile(const double* Lm, double* W, int cc, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  for (int ib = 0; ib < NT; ++ib) {
-    d4 acc;
+// Blocked inversion of the Cholesky factor: fills the strictly-upper tiles with U = (L^-1)^T, i.e. tile
+// (jb, ib) = X(ib,jb)^T where X = L^-1, X(ib,jb) = -X(ib,ib) * sum_{k=jb}^{ib-1} L(ib,k) X(k,jb).
+// Block column jb is one wave's sequential chain (no workgroup barrier inside); 4 waves = columns 0..3.
+__device__ void linv80(double* Lm, int tid) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int jb = wave;
+  if (jb >= NT - 1) return;
+  for (int ib = jb + 1; ib < NT; ++ib) {
+    d4 t = {0, 0, 0, 0};
+    for (int k = jb; k < ib; ++k) {
+      const double* A = Lm + (ib * 16) * LD + k * 16;         // L(ib,k)[i][kk]
+      // X(k,jb)[kk][j] = U[jb16+j][k16+kk]  (diagonal tile k == jb included: U_jj[j][kk] = X_jj[kk][j])
+      const double* B = Lm + (jb * 16) * LD + k * 16;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) acc[rr] = W[(ib * 16 + lk + 4 * rr) * LD + cc + li];
-    for (int kb = 0; kb < ib; ++kb) {
-      const double* A = Lm + (ib * 16) * LD + kb * 16;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma(-A[li * LD + 4 * s + lk], W[(kb * 16 + 4 * s + lk) * LD + cc + li], acc);
+      for (int s = 0; s < 4; ++s) t = mfma(A[li * LD + 4 * s + lk], B[li * LD + 4 * s + lk], t);
     }
-    const double* Tinv = Lm + inv_tile_off(ib);
-    d4 out = {0, 0, 0, 0};
+    const double* Uii = Lm + (ib * 16) * LD + ib * 16;         // X(ib,ib)[i][kk] = U_ii[kk][i]
+    d4 x = {0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) out = mfma(Tinv[li * LD + 4 * s + lk], acc[s], out);
+    for (int s = 0; s < 4; ++s) x = mfma(-Uii[(4 * s + lk) * LD + li], t[s], x);
+    double* Ut = Lm + (jb * 16) * LD + ib * 16;                 // tile (jb, ib) <- X(ib,jb)^T
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) W[(ib * 16 + lk + 4 * rr) * LD + cc + li] = out[rr];
+    for (int rr = 0; rr < 4; ++rr) Ut[li * LD + lk + 4 * rr] = x[rr];
   }
 }
 
+// W <- L^-1 W = U^T W for the column strip starting at column cc (one wave, in place, descending row tiles).
+__device__ __forceinline__ void linv_gemm_strip(const double* Lm, double* W, int cc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  for (int ib = NT - 1; ib >= 0; --ib) {
+    d4 acc = {0, 0, 0, 0};
+    for (int k = 0; k <= ib; ++k) {
+      const double* Uk = Lm + (k * 16) * LD + ib * 16;          // X(ib,k)[i][kk] = U[k16+kk][ib16+i]
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = mfma(Uk[(4 * s + lk) * LD + li], W[(k * 16 + 4 * s + lk) * LD + cc + li], acc);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) W[(ib * 16 + lk + 4 * rr) * LD + cc + li] = acc[rr];
+  }
+}
+
+// 80x80 fp64 matrix HBM <-> LDS with all loads of a thread in flight before the first use (13 x 16 B).
+template <bool TRANSPOSE>
+__device__ __forceinline__ void load_mat_any(double* dst, const double* __restrict__ src, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2 v[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) v[k] = s2[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      if (TRANSPOSE) {
+        dst[c * LD + r] = v[k].x;
+        dst[(c + 1) * LD + r] = v[k].y;
+      } else {
+        dst[r * LD + c] = v[k].x;
+        dst[r * LD + c + 1] = v[k].y;
+      }
+    }
+  }
+}
 __device__ __forceinline__ void load_mat(double* dst, const double* __restrict__ src, int tid) {
-  for (int e = tid; e < BS * BS; e += 256) dst[(e / BS) * LD + (e % BS)] = src[e];
+  load_mat_any<false>(dst, src, tid);
 }
 __device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict__ src, int tid) {
-  for (int e = tid; e < BS * BS; e += 256) dst[(e % BS) * LD + (e / BS)] = src[e];
+  load_mat_any<true>(dst, src, tid);
 }
 __device__ __forceinline__ void store_mat(double* __restrict__ dst, const double* src, int tid) {
-  for (int e = tid; e < BS * BS; e += 256) dst[e] = src[(e / BS) * LD + (e % BS)];
+  double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      d2[idx] = make_double2(src[r * LD + c], src[r * LD + c + 1]);
+    }
+  }
 }
 
 // Analytic level-0 coupling between node `i` (rows) and its chain neighbour (cols): third-difference blocks.
@@ -180,6 +223,8 @@ __device__ void gen_coupling(double* W, const FteConst& K, int node_i, bool left
   }
 }
 
+// Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the
+// D slot), W_l, W_r (in the coupling slot) and y.
 __global__ void __launch_bounds__(256)
 k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst, int* numeric_err,
            const int* __restrict__ status) {
@@ -188,8 +233,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   double* Lm = reinterpret_cast<double*>(smem_raw);
   double* WL = Lm + MAT;
   double* WR = WL + MAT;
-  double* yv = WR + MAT;       // [80] rhs, then y
-  double* sv = yv + BS;        // [80] scratch
+  double* yv = WR + MAT;       // [80] rhs
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
@@ -209,41 +253,32 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(1);
   chol80(Lm, tid, numeric_err);
   ACINO_STAMP(2);
-  // W_l, W_r: ten column tiles over four waves
-  for (int ct = wave; ct < 10; ct += 4) {
-    if (ct < 5) {
-      if (l >= 0) trsm_coltile(Lm, WL, ct * 16, lane);
-    } else {
-      if (r >= 0) trsm_coltile(Lm, WR, (ct - 5) * 16, lane);
-    }
-  }
-  // y = L^-1 b (blocked forward substitution, VALU)
+  linv80(Lm, tid);
   __syncthreads();
   ACINO_STAMP(3);
-  for (int ib = 0; ib < NT; ++ib) {
-    if (tid < 16) {
-      const int row = ib * 16 + tid;
-      double s = yv[row];
-      for (int c = 0; c < ib * 16; ++c) s -= Lm[row * LD + c] * yv[c];
-      sv[tid] = s;
+  for (int ct = wave; ct < 10; ct += 4) {               // W_l, W_r: ten column strips over four waves
+    if (ct < 5) {
+      if (l >= 0) linv_gemm_strip(Lm, WL, ct * 16, lane);
+    } else {
+      if (r >= 0) linv_gemm_strip(Lm, WR, (ct - 5) * 16, lane);
     }
-    __syncthreads();
-    if (tid < 16) {
-      const double* Tinv = Lm + inv_tile_off(ib);
-      double s = 0;
-      for (int c = 0; c <= tid; ++c) s += Tinv[tid * LD + c] * sv[c];
-      yv[ib * 16 + tid] = s;
-    }
-    __syncthreads();
   }
+  double yy = 0.0;
+  if (tid < BS)
+    for (int c = 0; c <= tid; ++c) yy += Lm[c * LD + tid] * yv[c];   // y = U^T b
+  __syncthreads();
   ACINO_STAMP(4);
   store_mat(ch.D + i * MB, Lm, tid);
   if (l >= 0) store_mat(ch.Wl + i * MB, WL, tid);
   if (r >= 0) store_mat(ch.Cpl + i * MB, WR, tid);
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = yv[tid];
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = yy;
   __syncthreads();
   ACINO_STAMP(5);
 }
+
+// lower-triangular tile enumeration t -> (ib, jb)
+__constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+__constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 
 // role 0: D_j / b_j update; role 1: new coupling block(jn, j)
 __global__ void __launch_bounds__(256)
@@ -268,27 +303,38 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict_
       load_mat(WB, ch.Wl + ip * MB, tid);    // W_l of the eliminated right neighbour (cols = j)
       if (tid < BS) yb[tid] = ch.b[(size_t)ip * BS + tid];
     }
-    __syncthreads();
     double* Dj = ch.D + j * MB;
-    int cnt = 0;
-    for (int ib = 0; ib < NT; ++ib)
-      for (int jb = 0; jb <= ib; ++jb) {
-        if ((cnt++ & 3) != wave) continue;
-        d4 acc;
+    // this wave's (<= 4) output tiles of D_j (C layout) are fetched while the W matrices land in LDS
+    d4 acc[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+    for (int q = 0; q < 4; ++q) {
+      const int t = wave + 4 * q;
+      if (t < 15) {
+        const int ib = c_tri_i[t], jb = c_tri_j[t];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = wave + 4 * q;
+      if (t < 15) {
+        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        d4 a = acc[q];
         if (im >= 0)
           for (int s = 0; s < BS / 4; ++s)
-            acc = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WA[(4 * s + lk) * LD + jb * 16 + li], acc);
+            a = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WA[(4 * s + lk) * LD + jb * 16 + li], a);
         if (ip >= 0)
           for (int s = 0; s < BS / 4; ++s)
-            acc = mfma(-WB[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], acc);
+            a = mfma(-WB[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], a);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
-          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[rr];
+          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = a[rr];
+          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = a[rr];
         }
       }
+    }
     if (tid < BS) {
       double s = ch.b[(size_t)j * BS + tid];
       if (im >= 0)
@@ -314,65 +360,42 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict_
   }
 }
 
-// x_i = L^-T (y_i - W_l x_l - W_r x_r)
+// x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T
 __global__ void __launch_bounds__(256)
 k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
-  double* Lm = reinterpret_cast<double*>(smem_raw);
-  double* xl = Lm + MAT;
+  double* Um = reinterpret_cast<double*>(smem_raw);
+  double* WL = Um + MAT;
+  double* WR = WL + MAT;
+  double* xl = WR + MAT;
   double* xr = xl + BS;
   double* tv = xr + BS;
-  double* part = tv + BS;      // [16][16] partial sums
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
-  load_mat(Lm, ch.D + i * MB, tid);
+  load_mat(Um, ch.D + i * MB, tid);
+  if (l >= 0) load_mat(WL, ch.Wl + i * MB, tid);
+  if (r >= 0) load_mat(WR, ch.Cpl + i * MB, tid);
   if (tid < BS) {
     xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
     xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
-    tv[tid] = ch.b[(size_t)i * BS + tid];
   }
   __syncthreads();
-  // t = y - W_l x_l - W_r x_r : one wave per row, lanes along the (contiguous) columns
-  const double* Wl = ch.Wl + i * MB;
-  const double* Wr = ch.Cpl + i * MB;
-  for (int row = wave; row < BS; row += 4) {
-    double s = 0.0;
-    if (l >= 0) {
-      s += Wl[row * BS + lane] * xl[lane];
-      if (lane < BS - 64) s += Wl[row * BS + 64 + lane] * xl[64 + lane];
-    }
-    if (r >= 0) {
-      s += Wr[row * BS + lane] * xr[lane];
-      if (lane < BS - 64) s += Wr[row * BS + 64 + lane] * xr[64 + lane];
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) tv[row] -= s;
+  if (tid < BS) {                          // t = y - W_l x_l - W_r x_r  (row tid; stride-81 rows: conflict free)
+    double s0 = ch.b[(size_t)i * BS + tid], s1 = 0.0;
+    if (l >= 0)
+      for (int c = 0; c < BS; ++c) s0 -= WL[tid * LD + c] * xl[c];
+    if (r >= 0)
+      for (int c = 0; c < BS; ++c) s1 -= WR[tid * LD + c] * xr[c];
+    tv[tid] = s0 + s1;
   }
   __syncthreads();
-  // blocked backward substitution with L^T; x overwrites tv
-  for (int ib = NT - 1; ib >= 0; --ib) {
-    const int jc = tid & 15, grp = tid >> 4;   // 16 column lanes x 16 row groups
+  if (tid < BS) {                          // x = U t (U upper triangular)
     double s = 0.0;
-    for (int row = (ib + 1) * 16 + grp; row < BS; row += 16) s += Lm[row * LD + ib * 16 + jc] * tv[row];
-    part[grp * 16 + jc] = s;
-    __syncthreads();
-    if (tid < 16) {
-      double acc = tv[ib * 16 + tid];
-      for (int g = 0; g < 16; ++g) acc -= part[g * 16 + tid];
-      part[256 + tid] = acc;
-    }
-    __syncthreads();
-    if (tid < 16) {
-      const double* Tinv = Lm + inv_tile_off(ib);
-      double acc = 0.0;
-      for (int c = tid; c < 16; ++c) acc += Tinv[c * LD + tid] * part[256 + c];   // Linv^T
-      tv[ib * 16 + tid] = acc;
-    }
-    __syncthreads();
+    for (int c = tid; c < BS; ++c) s += Um[tid * LD + c] * tv[c];
+    ch.b[(size_t)i * BS + tid] = s;
   }
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = tv[tid];
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -429,7 +452,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
 
 static constexpr size_t kElimLds = (3 * MAT + 2 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (2 * MAT + 2 * BS) * sizeof(double);
-static constexpr size_t kBacksubLds = (MAT + 3 * BS + 256 + 16) * sizeof(double);
+static constexpr size_t kBacksubLds = (3 * MAT + 3 * BS) * sizeof(double);
 
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
