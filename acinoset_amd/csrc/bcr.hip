@@ -21,6 +21,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int LD = 81;
 constexpr int MAT = BS * LD;
 constexpr int NT = 5;
+// lower-triangular tile enumeration t -> (ib, jb)
+__constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+__constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 
 __device__ __forceinline__ double readlane_d(double x, int lane) {
   long long b = __builtin_bit_cast(long long, x);
@@ -33,58 +36,102 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// One wave: Cholesky of the 16x16 tile T (LDS, leading dim LD) in registers (lane = row, cross-lane
-// broadcast by v_readlane), then the inverse of the factor (lane = column).  The tile is OVERWRITTEN by
-// U_kk = (L_kk^-1)^T (upper triangular): the factor L_kk itself is not needed once its inverse exists.
+// NS back-to-back MFMAs on one accumulator with ALL operand reads issued first (software pipelining:
+// an LDS read costs ~100+ cycles of latency, an fp64 MFMA 64 cycles of issue).  pa/pb are this lane's
+// operand pointers for k-step 0; k-step s reads pa[s*sa], pb[s*sb].
+template <int NS, bool NEG>
+__device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const double* pb, int sb) {
+  double av[NS], bv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    av[s] = pa[s * sa];
+    bv[s] = pb[s * sb];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc = mfma(NEG ? -av[s] : av[s], bv[s], acc);
+  return acc;
+}
+
+// One wave (all 64 lanes): Cholesky of the symmetric 16x16 tile T (LDS, leading dim LD) and the inverse of
+// its factor, entirely in registers.  Lane (i = lane & 15, k = lane >> 4) holds row i, columns {k, k+4, k+8,
+// k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  Columns are processed in
+// four panels of four: inside a panel the rank-1 updates touch only the panel (two cross-lane fetches and
+// one FMA per pivot), then ONE v_mfma_f64_16x16x4 applies the rank-4 update C -= P P^T to the rest of the
+// tile - the finished panel register is already both the A and the B operand.  The inverse X = L^-1 is
+// built by 4-row blocks the same way (4x4 diagonal inverses in scalars, one MFMA per block accumulates
+// L X for the rows below).  The tile is OVERWRITTEN by U_kk = X^T (upper triangular); L_kk is not kept.
 __device__ void chol16_inv(double* T, int lane, int* err) {
-  const int r = lane & 15;
-  double a[16];
+  const int i = lane & 15, k = lane >> 4;
+  d4 acc;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[r * LD + c] : 0.0;
-  bool bad = false;
+  for (int r = 0; r < 4; ++r) acc[r] = T[(k + 4 * r) * LD + i];
   double dinv[16];
+  d4 Lp;
+  bool bad = false;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double ajj = readlane_d(a[j], j);
-    if (!(ajj > 0.0)) {
-      bad = true;
-      ajj = 1.0;
+  for (int s = 0; s < 4; ++s) {
+    double p = acc[s];
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) {
+      const int c = 4 * s + k0;
+      double piv = readlane_d(p, c + 16 * k0);
+      if (!(piv > 0.0)) {
+        bad = true;
+        piv = 1.0;
+      }
+      const double inv = rsqrt(piv);
+      dinv[c] = inv;
+      const double pc = (i == c) ? piv * inv : (i > c ? p * inv : 0.0);
+      p = (k == k0) ? pc : p;
+      if (k0 < 3) {
+        const double lic = __shfl(p, i + 16 * k0, 64);           // L[i][c]      (my row)
+        const double lkc = __shfl(p, 4 * s + k + 16 * k0, 64);   // L[4s+k][c]   (my column, used when k > k0)
+        p = (k > k0) ? p - lic * lkc : p;
+      }
     }
-    const double inv = rsqrt(ajj);        // one v_rsq_f64 + refinement instead of sqrt + divide
-    dinv[j] = inv;
-    a[j] = (r == j) ? ajj * inv : a[j] * inv;
-#pragma unroll
-    for (int c = j + 1; c < 16; ++c) {
-      double lc = readlane_d(a[j], c);
-      a[c] = (r >= c) ? a[c] - a[j] * lc : a[c];
-    }
+    Lp[s] = p;
+    if (s < 3) acc = mfma(-p, p, acc);
   }
-  double x[16];   // lane r holds column r of L_kk^-1
+  d4 X;
+  d4 tacc = {0, 0, 0, 0};
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < rr; ++k) {
-      double lrk = readlane_d(a[k], rr);
-      acc += lrk * x[k];
-    }
-    x[rr] = (rr == r) ? dinv[rr] : ((rr > r) ? -acc * dinv[rr] : 0.0);
+  for (int a = 0; a < 4; ++a) {
+    const double l10 = readlane_d(Lp[a], 4 * a + 1), l20 = readlane_d(Lp[a], 4 * a + 2),
+                 l30 = readlane_d(Lp[a], 4 * a + 3), l21 = readlane_d(Lp[a], 4 * a + 2 + 16),
+                 l31 = readlane_d(Lp[a], 4 * a + 3 + 16), l32 = readlane_d(Lp[a], 4 * a + 3 + 32);
+    const double x00 = dinv[4 * a], x11 = dinv[4 * a + 1], x22 = dinv[4 * a + 2], x33 = dinv[4 * a + 3];
+    const double x10 = -x11 * (l10 * x00);
+    const double x20 = -x22 * (l20 * x00 + l21 * x10), x21 = -x22 * (l21 * x11);
+    const double x30 = -x33 * (l30 * x00 + l31 * x10 + l32 * x20), x31 = -x33 * (l31 * x11 + l32 * x21),
+                 x32 = -x33 * (l32 * x22);
+    const double c0 = k == 0 ? x00 : (k == 1 ? x10 : (k == 2 ? x20 : x30));
+    const double c1 = k == 1 ? x11 : (k == 2 ? x21 : (k == 3 ? x31 : 0.0));
+    const double c2 = k == 2 ? x22 : (k == 3 ? x32 : 0.0);
+    const double c3 = k == 3 ? x33 : 0.0;
+    const double t = tacc[a];
+    const double t0 = __shfl(t, i, 64), t1 = __shfl(t, i + 16, 64), t2 = __shfl(t, i + 32, 64),
+                 t3 = __shfl(t, i + 48, 64);
+    const double lower = -(c0 * t0 + c1 * t1 + c2 * t2 + c3 * t3);
+    const int v = i - 4 * a;
+    const double diag = v == 0 ? c0 : (v == 1 ? c1 : (v == 2 ? c2 : c3));
+    X[a] = (v < 0) ? lower : (v < 4 ? diag : 0.0);             // lane (n=i, kk=k): X[4a+kk][n]
+    if (a < 3) tacc = mfma(Lp[a], X[a], tacc);
   }
-  if (lane < 16) {
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) T[r * LD + rr] = x[rr];     // U_kk[r][rr] = Linv_kk[rr][r]
-    if (bad && err) atomicExch(err, 1);
-  }
+  for (int a = 0; a < 4; ++a) T[i * LD + 4 * a + k] = X[a];    // U_kk[n][4a+kk] = X[4a+kk][n]
+  if (bad && err && lane == 0) atomicExch(err, 1);
 }
 
 // Blocked Cholesky of the 80x80 matrix in LDS.  On exit: strictly-lower tiles hold L(ib,jb), diagonal
 // tiles hold U_kk = (L_kk^-1)^T.  All 256 threads.
-__device__ void chol80(double* Lm, int tid, int* err) {
+__device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   for (int kb = 0; kb < NT; ++kb) {
     double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+    if (dbg && kb == 1 && tid == 0) dbg[16] = (long long)wall_clock64();
     if (wave == 0) chol16_inv(Ukk, lane, err);
     __syncthreads();
+    if (dbg && kb == 1 && tid == 0) dbg[17] = (long long)wall_clock64();
     for (int ib = kb + 1 + wave; ib < NT; ib += 4) {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T = A(ib,kb) * U_kk
       double* A = Lm + (ib * 16) * LD + kb * 16;
       double av[4], bv[4];
@@ -100,21 +147,41 @@ __device__ void chol80(double* Lm, int tid, int* err) {
       for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
     }
     __syncthreads();
-    int cnt = 0;
-    for (int ib = kb + 1; ib < NT; ++ib)
-      for (int jb = kb + 1; jb <= ib; ++jb) {
-        if ((cnt++ & 3) != wave) continue;
-        double* Cc = Lm + (ib * 16) * LD + jb * 16;
-        const double* A = Lm + (ib * 16) * LD + kb * 16;
-        const double* B = Lm + (jb * 16) * LD + kb * 16;
-        d4 acc;
+    {  // trailing update A(ib,jb) -= L(ib,kb) L(jb,kb)^T, kb < jb <= ib: <= 3 tiles per wave, operands first
+      const int ntile = (NT - 1 - kb) * (NT - kb) / 2;
+      d4 acc[3];
+      double av[3][4], bv[3][4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = Cc[(lk + 4 * rr) * LD + li];
+      for (int q = 0; q < 3; ++q) {
+        const int t = wave + 4 * q;
+        if (t < ntile) {
+          const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
+          const double* Cc = Lm + (ib * 16) * LD + jb * 16;
+          const double* A = Lm + (ib * 16) * LD + kb * 16;
+          const double* B = Lm + (jb * 16) * LD + kb * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma(-A[li * LD + 4 * s + lk], B[li * LD + 4 * s + lk], acc);
+          for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Cc[(lk + 4 * rr) * LD + li];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = acc[rr];
+          for (int s = 0; s < 4; ++s) {
+            av[q][s] = A[li * LD + 4 * s + lk];
+            bv[q][s] = B[li * LD + 4 * s + lk];
+          }
+        }
       }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = wave + 4 * q;
+        if (t < ntile) {
+          const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
+          double* Cc = Lm + (ib * 16) * LD + jb * 16;
+          d4 a = acc[q];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a = mfma(-av[q][s], bv[q][s], a);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[rr];
+        }
+      }
+    }
     __syncthreads();
   }
 }
@@ -122,43 +189,50 @@ __device__ void chol80(double* Lm, int tid, int* err) {
 // Blocked inversion of the Cholesky factor: fills the strictly-upper tiles with U = (L^-1)^T, i.e. tile
 // (jb, ib) = X(ib,jb)^T where X = L^-1, X(ib,jb) = -X(ib,ib) * sum_{k=jb}^{ib-1} L(ib,k) X(k,jb).
 // Block column jb is one wave's sequential chain (no workgroup barrier inside); 4 waves = columns 0..3.
+template <int NK>   // NK = ib - jb k-tiles
+__device__ __forceinline__ void linv80_tile(double* Lm, int ib, int jb, int li, int lk) {
+  // t = sum_{k=jb}^{ib-1} L(ib,k) X(k,jb);  L(ib,k)[i][kk] and X(k,jb)[kk][j] = U[jb16+j][k16+kk] are both
+  // contiguous in the running k index, so the whole sum is one pipelined MFMA sequence
+  d4 t = {0, 0, 0, 0};
+  t = mma_seq<4 * NK, false>(t, Lm + (ib * 16 + li) * LD + jb * 16 + lk, 4, Lm + (jb * 16 + li) * LD + jb * 16 + lk, 4);
+  const double* Uii = Lm + (ib * 16) * LD + ib * 16;           // X(ib,ib)[i][kk] = U_ii[kk][i]
+  double uv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) uv[s] = Uii[(4 * s + lk) * LD + li];
+  d4 x = {0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) x = mfma(-uv[s], t[s], x);
+  double* Ut = Lm + (jb * 16) * LD + ib * 16;                   // tile (jb, ib) <- X(ib,jb)^T
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) Ut[li * LD + lk + 4 * rr] = x[rr];
+}
+
 __device__ void linv80(double* Lm, int tid) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int jb = wave;
-  if (jb >= NT - 1) return;
-  for (int ib = jb + 1; ib < NT; ++ib) {
-    d4 t = {0, 0, 0, 0};
-    for (int k = jb; k < ib; ++k) {
-      const double* A = Lm + (ib * 16) * LD + k * 16;         // L(ib,k)[i][kk]
-      // X(k,jb)[kk][j] = U[jb16+j][k16+kk]  (diagonal tile k == jb included: U_jj[j][kk] = X_jj[kk][j])
-      const double* B = Lm + (jb * 16) * LD + k * 16;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(A[li * LD + 4 * s + lk], B[li * LD + 4 * s + lk], t);
-    }
-    const double* Uii = Lm + (ib * 16) * LD + ib * 16;         // X(ib,ib)[i][kk] = U_ii[kk][i]
-    d4 x = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) x = mfma(-Uii[(4 * s + lk) * LD + li], t[s], x);
-    double* Ut = Lm + (jb * 16) * LD + ib * 16;                 // tile (jb, ib) <- X(ib,jb)^T
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Ut[li * LD + lk + 4 * rr] = x[rr];
-  }
+  const int jb = wave;   // block column jb is this wave's sequential chain (columns 0..3; column 4 is only U_44)
+  if (jb + 1 < NT) linv80_tile<1>(Lm, jb + 1, jb, li, lk);
+  if (jb + 2 < NT) linv80_tile<2>(Lm, jb + 2, jb, li, lk);
+  if (jb + 3 < NT) linv80_tile<3>(Lm, jb + 3, jb, li, lk);
+  if (jb + 4 < NT) linv80_tile<4>(Lm, jb + 4, jb, li, lk);
 }
 
 // W <- L^-1 W = U^T W for the column strip starting at column cc (one wave, in place, descending row tiles).
+template <int IB>
+__device__ __forceinline__ void strip_row(const double* Lm, double* W, int cc, int li, int lk) {
+  // W(IB, strip) = sum_{k<=IB} X(IB,k) W(k, strip);  X(IB,k)[i][kk] = U[k16+kk][IB16+i]: both operands walk
+  // down the rows 0 .. 16(IB+1)-1 with stride 4 rows per k-step
+  d4 acc = {0, 0, 0, 0};
+  acc = mma_seq<4 * (IB + 1), false>(acc, Lm + lk * LD + IB * 16 + li, 4 * LD, W + lk * LD + cc + li, 4 * LD);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) W[(IB * 16 + lk + 4 * rr) * LD + cc + li] = acc[rr];
+}
 __device__ __forceinline__ void linv_gemm_strip(const double* Lm, double* W, int cc, int lane) {
   const int li = lane & 15, lk = lane >> 4;
-  for (int ib = NT - 1; ib >= 0; --ib) {
-    d4 acc = {0, 0, 0, 0};
-    for (int k = 0; k <= ib; ++k) {
-      const double* Uk = Lm + (k * 16) * LD + ib * 16;          // X(ib,k)[i][kk] = U[k16+kk][ib16+i]
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = mfma(Uk[(4 * s + lk) * LD + li], W[(k * 16 + 4 * s + lk) * LD + cc + li], acc);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) W[(ib * 16 + lk + 4 * rr) * LD + cc + li] = acc[rr];
-  }
+  strip_row<4>(Lm, W, cc, li, lk);   // descending: row tile ib only reads W row tiles <= ib
+  strip_row<3>(Lm, W, cc, li, lk);
+  strip_row<2>(Lm, W, cc, li, lk);
+  strip_row<1>(Lm, W, cc, li, lk);
+  strip_row<0>(Lm, W, cc, li, lk);
 }
 
 // 80x80 fp64 matrix HBM <-> LDS with all loads of a thread in flight before the first use (13 x 16 B).
@@ -251,7 +325,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   }
   __syncthreads();
   ACINO_STAMP(1);
-  chol80(Lm, tid, numeric_err);
+  chol80(Lm, tid, numeric_err, (ch.dbg && blockIdx.x == 0) ? ch.dbg : nullptr);
   ACINO_STAMP(2);
   linv80(Lm, tid);
   __syncthreads();
@@ -276,38 +350,45 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(5);
 }
 
-// lower-triangular tile enumeration t -> (ib, jb)
-__constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
-__constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+// Half-height (40-row) staging of an 80x80 matrix: rows [r0, r0+40) -> dst[40][LD].
+__device__ __forceinline__ void load_half(double* dst, const double* __restrict__ src, int r0, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src + (size_t)r0 * BS);
+  double2 v[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < 40 * BS / 2) v[k] = s2[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < 40 * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      dst[r * LD + c] = v[k].x;
+      dst[r * LD + c + 1] = v[k].y;
+    }
+  }
+}
 
-// role 0: D_j / b_j update; role 1: new coupling block(jn, j)
+// role 0: D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+), b_j -= W^T y ; role 1: block(jn, j) = -W_r(i+)^T W_l(i+).
+// Both roles stream through ONE 80x81 LDS buffer (52 KB) so three workgroups share a CU and the staging of
+// one overlaps the matrix-core phase of another.
 __global__ void __launch_bounds__(256)
 k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
-  double* WA = reinterpret_cast<double*>(smem_raw);
-  double* WB = WA + MAT;
-  double* ya = WB + MAT;
-  double* yb = ya + BS;
+  double* Wb = reinterpret_cast<double*>(smem_raw);
+  double* yv = Wb + MAT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ent = blockIdx.x >> 1, role = blockIdx.x & 1;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
   if (role == 0) {
     if (im < 0 && ip < 0) return;
-    if (im >= 0) {
-      load_mat(WA, ch.Cpl + im * MB, tid);   // W_r of the eliminated left neighbour (cols = j)
-      if (tid < BS) ya[tid] = ch.b[(size_t)im * BS + tid];
-    }
-    if (ip >= 0) {
-      load_mat(WB, ch.Wl + ip * MB, tid);    // W_l of the eliminated right neighbour (cols = j)
-      if (tid < BS) yb[tid] = ch.b[(size_t)ip * BS + tid];
-    }
     double* Dj = ch.D + j * MB;
-    // this wave's (<= 4) output tiles of D_j (C layout) are fetched while the W matrices land in LDS
     d4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {   // this wave's (<= 4) output tiles of D_j, fetched while W lands in LDS
       const int t = wave + 4 * q;
       if (t < 15) {
         const int ib = c_tri_i[t], jb = c_tri_j[t];
@@ -315,85 +396,110 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict_
         for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
       }
     }
-    __syncthreads();
+    double bs = (tid < BS) ? ch.b[(size_t)j * BS + tid] : 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int nb = side == 0 ? im : ip;
+      if (nb < 0) continue;
+      if (side == 1 && im >= 0) __syncthreads();               // everyone done with the previous W
+      load_mat(Wb, (side == 0 ? ch.Cpl : ch.Wl) + nb * MB, tid);  // W_r of the left / W_l of the right neighbour
+      if (tid < BS) yv[tid] = ch.b[(size_t)nb * BS + tid];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        if (t < 15) {
+          const int ib = c_tri_i[t], jb = c_tri_j[t];
+          acc[q] = mma_seq<BS / 4, true>(acc[q], Wb + lk * LD + ib * 16 + li, 4 * LD, Wb + lk * LD + jb * 16 + li,
+                                         4 * LD);
+        }
+      }
+      if (tid < BS)
+        for (int k = 0; k < BS; ++k) bs -= Wb[k * LD + tid] * yv[k];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = wave + 4 * q;
       if (t < 15) {
         const int ib = c_tri_i[t], jb = c_tri_j[t];
-        d4 a = acc[q];
-        if (im >= 0)
-          for (int s = 0; s < BS / 4; ++s)
-            a = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WA[(4 * s + lk) * LD + jb * 16 + li], a);
-        if (ip >= 0)
-          for (int s = 0; s < BS / 4; ++s)
-            a = mfma(-WB[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], a);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = a[rr];
-          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = a[rr];
+          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
+          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[q][rr];
         }
       }
     }
-    if (tid < BS) {
-      double s = ch.b[(size_t)j * BS + tid];
-      if (im >= 0)
-        for (int k = 0; k < BS; ++k) s -= WA[k * LD + tid] * ya[k];
-      if (ip >= 0)
-        for (int k = 0; k < BS; ++k) s -= WB[k * LD + tid] * yb[k];
-      ch.b[(size_t)j * BS + tid] = s;
-    }
+    if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
   } else {
     if (ip < 0 || jn < 0) return;
-    load_mat(WA, ch.Cpl + ip * MB, tid);     // W_r(ip): cols = jn
-    load_mat(WB, ch.Wl + ip * MB, tid);      // W_l(ip): cols = j
-    __syncthreads();
-    double* Cj = ch.Cpl + j * MB;            // block(jn, j): rows jn, cols j
-    for (int t = wave; t < NT * NT; t += 4) {
-      const int ib = t / NT, jb = t % NT;
-      d4 acc = {0, 0, 0, 0};
-      for (int s = 0; s < BS / 4; ++s)
-        acc = mfma(-WA[(4 * s + lk) * LD + ib * 16 + li], WB[(4 * s + lk) * LD + jb * 16 + li], acc);
+    double* Ha = Wb;                  // rows [h*40, h*40+40) of W_r(ip)   (cols = jn)
+    double* Hb = Wb + 40 * LD;        // same rows of W_l(ip)             (cols = j)
+    d4 acc[7];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
+    for (int q = 0; q < 7; ++q) acc[q] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) __syncthreads();
+      load_half(Ha, ch.Cpl + ip * MB, 40 * h, tid);
+      load_half(Hb, ch.Wl + ip * MB, 40 * h, tid);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int t = wave + 4 * q;
+        if (t < NT * NT) {
+          const int ib = t / NT, jb = t % NT;
+          acc[q] = mma_seq<10, true>(acc[q], Ha + lk * LD + ib * 16 + li, 4 * LD, Hb + lk * LD + jb * 16 + li, 4 * LD);
+        }
+      }
+    }
+    double* Cj = ch.Cpl + j * MB;     // block(jn, j): rows jn, cols j
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int t = wave + 4 * q;
+      if (t < NT * NT) {
+        const int ib = t / NT, jb = t % NT;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
+      }
     }
   }
 }
 
-// x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T
+// x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T ; the three matrices stream through one LDS buffer.
 __global__ void __launch_bounds__(256)
 k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
-  double* Um = reinterpret_cast<double*>(smem_raw);
-  double* WL = Um + MAT;
-  double* WR = WL + MAT;
-  double* xl = WR + MAT;
-  double* xr = xl + BS;
-  double* tv = xr + BS;
+  double* Mb = reinterpret_cast<double*>(smem_raw);
+  double* xv = Mb + MAT;
+  double* tv = xv + BS;
   const int tid = threadIdx.x;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
-  load_mat(Um, ch.D + i * MB, tid);
-  if (l >= 0) load_mat(WL, ch.Wl + i * MB, tid);
-  if (r >= 0) load_mat(WR, ch.Cpl + i * MB, tid);
-  if (tid < BS) {
-    xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
-    xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
+  double t = (tid < BS) ? ch.b[(size_t)i * BS + tid] : 0.0;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side == 0 ? l : r;
+    if (nb < 0) continue;
+    load_mat(Mb, (side == 0 ? ch.Wl : ch.Cpl) + i * MB, tid);
+    if (tid < BS) xv[tid] = ch.b[(size_t)nb * BS + tid];
+    __syncthreads();
+    if (tid < BS) {                         // row tid of W (stride-81 rows: conflict free)
+      double s0 = 0.0, s1 = 0.0;
+      for (int c = 0; c < BS; c += 2) {
+        s0 += Mb[tid * LD + c] * xv[c];
+        s1 += Mb[tid * LD + c + 1] * xv[c + 1];
+      }
+      t -= s0 + s1;
+    }
+    __syncthreads();
   }
+  load_mat(Mb, ch.D + i * MB, tid);
+  if (tid < BS) tv[tid] = t;
   __syncthreads();
-  if (tid < BS) {                          // t = y - W_l x_l - W_r x_r  (row tid; stride-81 rows: conflict free)
-    double s0 = ch.b[(size_t)i * BS + tid], s1 = 0.0;
-    if (l >= 0)
-      for (int c = 0; c < BS; ++c) s0 -= WL[tid * LD + c] * xl[c];
-    if (r >= 0)
-      for (int c = 0; c < BS; ++c) s1 -= WR[tid * LD + c] * xr[c];
-    tv[tid] = s0 + s1;
-  }
-  __syncthreads();
-  if (tid < BS) {                          // x = U t (U upper triangular)
+  if (tid < BS) {                           // x = U t (U upper triangular)
     double s = 0.0;
-    for (int c = tid; c < BS; ++c) s += Um[tid * LD + c] * tv[c];
+    for (int c = tid; c < BS; ++c) s += Mb[tid * LD + c] * tv[c];
     ch.b[(size_t)i * BS + tid] = s;
   }
 }
@@ -451,8 +557,8 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
 }
 
 static constexpr size_t kElimLds = (3 * MAT + 2 * BS) * sizeof(double);
-static constexpr size_t kUpdateLds = (2 * MAT + 2 * BS) * sizeof(double);
-static constexpr size_t kBacksubLds = (3 * MAT + 3 * BS) * sizeof(double);
+static constexpr size_t kUpdateLds = (MAT + BS) * sizeof(double);
+static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
 
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
