@@ -36,7 +36,7 @@ FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD data
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(det, rig, Ts, x0_full, sample_frames=1500, iters=2):
+def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
     """The numpy/scipy oracle's LM iteration timed on the host, 1 thread, on a bounded sample."""
     from oracle import fk as ofk
     from oracle import fte as ofte
