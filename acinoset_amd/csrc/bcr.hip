@@ -11,8 +11,9 @@
 //            new coupling block(j', j) = -W_r(i+)^T W_l(i+)
 // and back-substitution x_i = U (y - W_l x_l - W_r x_r) (three mat-vecs) walks the levels in reverse.
 // Level-0 couplings are the constant third-difference blocks and are generated in LDS, never stored.
-// LDS: three 80x81 fp64 matrices (155.5 KB of the 160 KB) - leading dimension 81 makes both the
-// row-pattern and the column-pattern MFMA operand reads bank-conflict free.
+// LDS: ONE 80x81 fp64 matrix per workgroup (52 KB -> three workgroups per CU); leading dimension 81 makes both
+// the row-pattern and the column-pattern MFMA operand reads bank-conflict free.  The damped system itself is
+// built inside the level-0 kernels from the assembly's H/g (no separate set-up pass through HBM).
 #include "bcr.hpp"
 
 namespace acino {
@@ -216,25 +217,6 @@ __device__ void linv80(double* Lm, int tid) {
   if (jb + 4 < NT) linv80_tile<4>(Lm, jb + 4, jb, li, lk);
 }
 
-// W <- L^-1 W = U^T W for the column strip starting at column cc (one wave, in place, descending row tiles).
-template <int IB>
-__device__ __forceinline__ void strip_row(const double* Lm, double* W, int cc, int li, int lk) {
-  // W(IB, strip) = sum_{k<=IB} X(IB,k) W(k, strip);  X(IB,k)[i][kk] = U[k16+kk][IB16+i]: both operands walk
-  // down the rows 0 .. 16(IB+1)-1 with stride 4 rows per k-step
-  d4 acc = {0, 0, 0, 0};
-  acc = mma_seq<4 * (IB + 1), false>(acc, Lm + lk * LD + IB * 16 + li, 4 * LD, W + lk * LD + cc + li, 4 * LD);
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) W[(IB * 16 + lk + 4 * rr) * LD + cc + li] = acc[rr];
-}
-__device__ __forceinline__ void linv_gemm_strip(const double* Lm, double* W, int cc, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  strip_row<4>(Lm, W, cc, li, lk);   // descending: row tile ib only reads W row tiles <= ib
-  strip_row<3>(Lm, W, cc, li, lk);
-  strip_row<2>(Lm, W, cc, li, lk);
-  strip_row<1>(Lm, W, cc, li, lk);
-  strip_row<0>(Lm, W, cc, li, lk);
-}
-
 // 80x80 fp64 matrix HBM <-> LDS with all loads of a thread in flight before the first use (13 x 16 B).
 template <bool TRANSPOSE>
 __device__ __forceinline__ void load_mat_any(double* dst, const double* __restrict__ src, int tid) {
@@ -278,50 +260,182 @@ __device__ __forceinline__ void store_mat(double* __restrict__ dst, const double
   }
 }
 
-// Analytic level-0 coupling between node `i` (rows) and its chain neighbour (cols): third-difference blocks.
-__device__ void gen_coupling(double* W, const FteConst& K, int node_i, bool left, int tid) {
-  for (int e = tid; e < BS * LD; e += 256) W[e] = 0.0;
-  __syncthreads();
-  const int64_t f_i = K.n_offset + 3 * (int64_t)(node_i - K.pin_left);
-  for (int e = tid; e < 9 * NP; e += 256) {
-    int p = e % NP, pair = e / NP, ii = pair / 3, jj = pair % 3;
-    if (ii > jj) continue;
-    int k = 3 + ii - jj;
-    if (left) {   // rows (ii,p) of node i, cols (jj,p) of node i-1 ; column frame is the earlier one
-      double v = 2.0 * K.q_w[p] * band_coef(f_i - 3 + jj, k, K.n_global);
-      W[(ii * NP + p) * LD + jj * NP + p] = v;
-    } else {      // rows (jj,p) of node i, cols (ii,p) of node i+1 ; row frame is the earlier one
-      double v = 2.0 * K.q_w[p] * band_coef(f_i + jj, k, K.n_global);
-      W[(jj * NP + p) * LD + ii * NP + p] = v;
+// Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
+// assembly's H/g (what k_setup used to write to HBM): D = H_gn + lam*diag(H_gn), bound-active variables
+// pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).
+// Returns this thread's max |projected gradient| contribution.  All 256 threads; one barrier inside (the
+// caller's publish_gmax barrier completes the block).  (Two barriers inside.)
+__device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const FteConst& K, int t, int tid) {
+  const int cur = ch.st->cur;
+  const double* x = cur ? ch.x1 : ch.x0;
+  const double* g = cur ? ch.g1 : ch.g0;
+  const double* H = cur ? ch.H1 : ch.H0;
+  const double lam = ch.st->lam;
+  const bool sep_left = K.pin_left && t == 0;
+  const int fbase = 3 * (t - K.pin_left);
+  // (1) the three 25x25 Gauss-Newton blocks: all of a thread's (<= 8) loads are issued before any use
+  double hv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k;
+    hv[k] = 0.0;
+    if (!sep_left && idx < 3 * NP * NP) {
+      const int n = fbase + idx / (NP * NP);
+      if (n < K.n_frames) hv[k] = H[(size_t)n * NP * NP + idx % (NP * NP)];
     }
+  }
+  // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
+  for (int e = tid; e < BS * LD; e += 256) Dm[e] = 0.0;
+  __syncthreads();
+  if (!sep_left) {
+    if (tid < BS) {
+      const int nfr = fbase + tid / NP;
+      if (tid >= 3 * NP || nfr >= K.n_frames) Dm[tid * LD + tid] = 1.0;
+    } else if (tid < BS + 3 * NP) {
+      const int q = tid - BS, pr = q / NP, p = q % NP;          // frame pairs (0,1), (0,2), (1,2)
+      const int ii = pr == 2 ? 1 : 0, jj = pr == 0 ? 1 : 2;
+      if (fbase + jj < K.n_frames) {
+        const double v = 2.0 * K.q_w[p] * band_coef(K.n_offset + fbase + ii, jj - ii, K.n_global);
+        Dm[(ii * NP + p) * LD + jj * NP + p] = v;
+        Dm[(jj * NP + p) * LD + ii * NP + p] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // (3) drop the H blocks in, damping / pinning the diagonal
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k;
+    if (!sep_left && idx < 3 * NP * NP) {
+      const int ii = idx / (NP * NP), rem = idx % (NP * NP), p = rem / NP, pc = rem % NP;
+      const int n = fbase + ii;
+      if (n < K.n_frames) {
+        double v = hv[k];
+        if (p == pc) {
+          const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
+          const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+          v = v + lam * v;
+          if (fixed) v *= FIX_SCALE;
+        }
+        Dm[(ii * NP + p) * LD + ii * NP + pc] = v;
+      }
+    }
+  }
+  double gmax = 0.0;
+  if (tid < BS) {
+    double b = 0.0;
+    if (!sep_left && tid < 3 * NP) {
+      const int ii = tid / NP, p = tid % NP, n = fbase + ii;
+      if (n < K.n_frames) {
+        const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
+        const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+        b = fixed ? 0.0 : -gv;
+        gmax = fabs(b);
+      }
+    }
+    bv[tid] = b;
+  }
+  return gmax;
+}
+
+// max over the workgroup -> gn_part[node]
+__device__ void publish_gmax(double gmax, double* red, double* gn_part, int node, int tid) {
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = gmax;
+  __syncthreads();
+  if (tid == 0) gn_part[node] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Level-0 couplings are the constant third-difference blocks E (<= 3 non-zeros per column, all on the
+// state's own diagonal), so W = U^T E needs no GEMM: column (jj,p) of W is a combination of <= 3 ROWS of U.
+//   left  (neighbour i-1): W_l[r][(jj,p)] = sum_{ii<=jj} U[(ii,p)][r] * 2 q_p band(f_i-3+jj, 3+ii-jj)
+//   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
+// coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
+// right: columns in node i+1).  450 doubles, filled once per workgroup.
+__device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
+  const int64_t f_i = K.n_offset + 3 * (int64_t)(node_i - K.pin_left);
+  for (int e = tid; e < 2 * 9 * NP; e += 256) {
+    const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
+    double v = 0.0;
+    if (ii <= jj) {
+      const int k = 3 + ii - jj;
+      v = 2.0 * K.q_w[p] * (side == 0 ? band_coef(f_i - 3 + jj, k, K.n_global) : band_coef(f_i + jj, k, K.n_global));
+    }
+    (side == 0 ? coefL : coefR)[q] = v;
   }
 }
 
-// Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the
-// D slot), W_l, W_r (in the coupling slot) and y.
+__device__ void sparse_coupling_w(const double* Um, double* __restrict__ Wout, const double* coef, bool left, int tid) {
+  for (int e = tid; e < BS * BS; e += 256) {
+    const int r = e / BS, c = e % BS;
+    double v = 0.0;
+    if (c < 3 * NP) {
+      const int cj = c / NP, p = c % NP;
+      if (left) {
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+          const int row = ii * NP + p;
+          if (ii <= cj && row <= r) v += Um[row * LD + r] * coef[(ii * 3 + cj) * NP + p];
+        }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          const int row = jj * NP + p;
+          if (jj >= cj && row <= r) v += Um[row * LD + r] * coef[(cj * 3 + jj) * NP + p];
+        }
+      }
+    }
+    Wout[e] = v;
+  }
+}
+
+// W(IB, strip) = sum_{k<=IB} X(IB,k) A(k, strip) with the B operand read straight from HBM/L2:
+// element A[row][col] at Ag[row * rs + col * cs] (rs/cs select the plain or the transposed coupling block).
+template <int IB>
+__device__ __forceinline__ void strip_row_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
+                                            double* __restrict__ Wg, int cc, int li, int lk) {
+  d4 acc = {0, 0, 0, 0};
+  acc = mma_seq<4 * (IB + 1), false>(acc, Lm + lk * LD + IB * 16 + li, 4 * LD, Ag + lk * rs + (cc + li) * cs, 4 * rs);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) Wg[(IB * 16 + lk + 4 * rr) * BS + cc + li] = acc[rr];
+}
+__device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
+                                             double* __restrict__ Wg, int cc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  strip_row_g<4>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+  strip_row_g<3>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+  strip_row_g<2>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+  strip_row_g<1>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+  strip_row_g<0>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+}
+
+// Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the D
+// slot), W_l, W_r and y.  LDS holds ONE 80x81 matrix (the factor), so three workgroups share a CU: the serial
+// pivot chains of one overlap the matrix-core / memory phases of the others.
 __global__ void __launch_bounds__(256)
 k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst, int* numeric_err,
-           const int* __restrict__ status) {
+           const int* __restrict__ status, int level) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Lm = reinterpret_cast<double*>(smem_raw);
-  double* WL = Lm + MAT;
-  double* WR = WL + MAT;
-  double* yv = WR + MAT;       // [80] rhs
+  double* yv = Lm + MAT;       // [80] rhs
+  double* red = yv + BS;       // [8]
+  double* coefL = red + 8;     // [225]
+  double* coefR = coefL + 9 * NP;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
+  const bool fused = ch.st != nullptr && level == 0;
+  const bool impl_l = ch.implicit_couplings && l >= 0 && l == i - 1, impl_r = ch.implicit_couplings && r >= 0 && r == i + 1;
+  if (impl_l || impl_r) fill_coupling_coef(coefL, coefR, *cst, i, tid);   // visible after the barriers below
 #define ACINO_STAMP(k) do { if (ch.dbg && blockIdx.x == 0 && tid == 0) ch.dbg[k] = (long long)wall_clock64(); } while (0)
   ACINO_STAMP(0);
-  load_mat(Lm, ch.D + i * MB, tid);
-  if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
-  if (l >= 0) {
-    if (ch.implicit_couplings && l == i - 1) gen_coupling(WL, *cst, i, true, tid);
-    else load_mat(WL, ch.Cpl + l * MB, tid);           // block(i, l): rows i, cols l
-  }
-  if (r >= 0) {
-    if (ch.implicit_couplings && r == i + 1) gen_coupling(WR, *cst, i, false, tid);
-    else load_mat_t(WR, ch.Cpl + i * MB, tid);         // block(r, i)^T: rows i, cols r
+  if (fused) {
+    double gmax = build_node(Lm, yv, ch, *cst, i, tid);
+    publish_gmax(gmax, red, ch.gn_part, i, tid);
+  } else {
+    load_mat(Lm, ch.D + i * MB, tid);
+    if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
   }
   __syncthreads();
   ACINO_STAMP(1);
@@ -330,23 +444,28 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   linv80(Lm, tid);
   __syncthreads();
   ACINO_STAMP(3);
-  for (int ct = wave; ct < 10; ct += 4) {               // W_l, W_r: ten column strips over four waves
-    if (ct < 5) {
-      if (l >= 0) linv_gemm_strip(Lm, WL, ct * 16, lane);
+  if (l >= 0) {
+    if (impl_l) {
+      sparse_coupling_w(Lm, ch.Wl + i * MB, coefL, true, tid);
     } else {
-      if (r >= 0) linv_gemm_strip(Lm, WR, (ct - 5) * 16, lane);
+      const double* A = ch.Cpl + l * MB;                  // block(i, l): rows i, cols l
+      for (int ct = wave; ct < 5; ct += 4) gemm_strip_g(Lm, A, BS, 1, ch.Wl + i * MB, ct * 16, lane);
+    }
+  }
+  if (r >= 0) {
+    if (impl_r) {
+      sparse_coupling_w(Lm, ch.Wr + i * MB, coefR, false, tid);
+    } else {
+      const double* A = ch.Cpl + i * MB;                  // block(r, i)^T: rows i, cols r
+      for (int ct = 3 - wave; ct < 5; ct += 4) gemm_strip_g(Lm, A, 1, BS, ch.Wr + i * MB, ct * 16, lane);
     }
   }
   double yy = 0.0;
   if (tid < BS)
     for (int c = 0; c <= tid; ++c) yy += Lm[c * LD + tid] * yv[c];   // y = U^T b
-  __syncthreads();
   ACINO_STAMP(4);
   store_mat(ch.D + i * MB, Lm, tid);
-  if (l >= 0) store_mat(ch.Wl + i * MB, WL, tid);
-  if (r >= 0) store_mat(ch.Cpl + i * MB, WR, tid);
   if (tid < BS) ch.b[(size_t)i * BS + tid] = yy;
-  __syncthreads();
   ACINO_STAMP(5);
 }
 
@@ -374,35 +493,48 @@ __device__ __forceinline__ void load_half(double* dst, const double* __restrict_
 // Both roles stream through ONE 80x81 LDS buffer (52 KB) so three workgroups share a CU and the staging of
 // one overlaps the matrix-core phase of another.
 __global__ void __launch_bounds__(256)
-k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status) {
+k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __restrict__ cst,
+             const int* __restrict__ status, int level) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Wb = reinterpret_cast<double*>(smem_raw);
   double* yv = Wb + MAT;
+  double* red = yv + BS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ent = blockIdx.x >> 1, role = blockIdx.x & 1;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
   if (role == 0) {
-    if (im < 0 && ip < 0) return;
+    const bool fused = ch.st != nullptr && level == 0;
+    if (im < 0 && ip < 0 && !fused) return;    // (fused level 0 still has to build and store D_j, b_j)
     double* Dj = ch.D + j * MB;
     d4 acc[4];
+    double bs = 0.0;
+    if (fused) {                    // level 0: D_j and b_j are built here, never read from HBM
+      double gmax = build_node(Wb, yv, ch, *cst, j, tid);
+      publish_gmax(gmax, red, ch.gn_part, j, tid);   // (contains a barrier: the block is complete in LDS)
+      if (tid < BS) bs = yv[tid];
+    } else if (tid < BS) {
+      bs = ch.b[(size_t)j * BS + tid];
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {   // this wave's (<= 4) output tiles of D_j, fetched while W lands in LDS
+    for (int q = 0; q < 4; ++q) {   // this wave's (<= 4) output tiles of D_j (C layout)
       const int t = wave + 4 * q;
       if (t < 15) {
         const int ib = c_tri_i[t], jb = c_tri_j[t];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+        for (int rr = 0; rr < 4; ++rr)
+          acc[q][rr] = fused ? Wb[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li]
+                             : Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
       }
     }
-    double bs = (tid < BS) ? ch.b[(size_t)j * BS + tid] : 0.0;
+    if (fused) __syncthreads();     // tiles are in registers before the buffer is reused for W
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int nb = side == 0 ? im : ip;
       if (nb < 0) continue;
       if (side == 1 && im >= 0) __syncthreads();               // everyone done with the previous W
-      load_mat(Wb, (side == 0 ? ch.Cpl : ch.Wl) + nb * MB, tid);  // W_r of the left / W_l of the right neighbour
+      load_mat(Wb, (side == 0 ? ch.Wr : ch.Wl) + nb * MB, tid);   // W_r of the left / W_l of the right neighbour
       if (tid < BS) yv[tid] = ch.b[(size_t)nb * BS + tid];
       __syncthreads();
 #pragma unroll
@@ -440,7 +572,7 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const int* __restrict_
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h == 1) __syncthreads();
-      load_half(Ha, ch.Cpl + ip * MB, 40 * h, tid);
+      load_half(Ha, ch.Wr + ip * MB, 40 * h, tid);
       load_half(Hb, ch.Wl + ip * MB, 40 * h, tid);
       __syncthreads();
 #pragma unroll
@@ -481,7 +613,7 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
   for (int side = 0; side < 2; ++side) {
     const int nb = side == 0 ? l : r;
     if (nb < 0) continue;
-    load_mat(Mb, (side == 0 ? ch.Wl : ch.Cpl) + i * MB, tid);
+    load_mat(Mb, (side == 0 ? ch.Wl : ch.Wr) + i * MB, tid);
     if (tid < BS) xv[tid] = ch.b[(size_t)nb * BS + tid];
     __syncthreads();
     if (tid < BS) {                         // row tid of W (stride-81 rows: conflict free)
@@ -542,7 +674,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
       int im = (p > 0 && pick[p - 1]) ? act[p - 1] : -1;
       int ip = (p + 1 < R && pick[p + 1]) ? act[p + 1] : -1;
       int jn = (ip >= 0 && p + 2 < R) ? act[p + 2] : -1;
-      if (im < 0 && ip < 0) continue;
+      if (im < 0 && ip < 0 && !levels.empty()) continue;   // level 0 lists every remaining node (fused build)
       remain.push_back(act[p]);
       remain.push_back(im);
       remain.push_back(ip);
@@ -556,8 +688,8 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
   }
 }
 
-static constexpr size_t kElimLds = (3 * MAT + 2 * BS) * sizeof(double);
-static constexpr size_t kUpdateLds = (MAT + BS) * sizeof(double);
+static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP) * sizeof(double);
+static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
 
 int bcr_set_func_attributes() {
@@ -572,21 +704,23 @@ int bcr_set_func_attributes() {
 
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof) {
+  int level = 0;
   for (const BcrLevel& lv : sch.levels) {
     {
       ProfSpan sp(prof, PC_ELIM, s);
       hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
-                         d_c, d_numeric_err, d_status);
+                         d_c, d_numeric_err, d_status, level);
     }
     ACINO_LAUNCH_CHECK();
     if (lv.n_remain > 0) {
       {
         ProfSpan sp(prof, PC_UPDATE, s);
         hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
-                           ch.d_remain + 4 * lv.remain_off, d_status);
+                           ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
       }
       ACINO_LAUNCH_CHECK();
     }
+    ++level;
   }
   return ACINO_OK;
 }

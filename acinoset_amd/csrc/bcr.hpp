@@ -23,13 +23,20 @@ struct BcrSchedule {
 struct BcrChain {
   int n_nodes;
   double* D;     // [n][80][80] working diagonal blocks -> Cholesky factors (+ inverse diagonal tiles)
-  double* Cpl;   // [n][80][80] coupling block (right neighbour rows, own cols) -> W_r once eliminated
+  double* Cpl;   // [n][80][80] coupling block (right neighbour rows, own cols)
   double* Wl;    // [n][80][80] W_l of eliminated nodes
+  double* Wr;    // [n][80][80] W_r of eliminated nodes
   double* b;     // [n][80] rhs -> y -> solution
   const int* d_elim;
   const int* d_remain;
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
-  long long* dbg;            // optional [16] phase timestamps of workgroup 0 (debug builds of the probe)
+  long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
+  // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build
+  // D = H_gn + lam*diag(H_gn) (+ 2^70 boost on bound-active variables) and b = -g themselves, so the damped
+  // system never makes a round trip through HBM.
+  const acino_fte_state* st;
+  const double *x0, *x1, *g0, *g1, *H0, *H1;
+  double* gn_part;           // [n] max |projected gradient| per node
 };
 
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,

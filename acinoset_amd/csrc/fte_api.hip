@@ -77,11 +77,17 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.D = c.take<double>(T * BS * BS);
   chn.Cpl = c.take<double>(T * BS * BS);
   chn.Wl = c.take<double>(T * BS * BS);
+  chn.Wr = c.take<double>(T * BS * BS);
   chn.b = c.take<double>(T * BS);
   chn.d_elim = nullptr;
   chn.d_remain = nullptr;
   chn.implicit_couplings = 1;
   chn.dbg = nullptr;
+  chn.st = b.state;
+  chn.x0 = b.x[0]; chn.x1 = b.x[1];
+  chn.g0 = b.g[0]; chn.g1 = b.g[1];
+  chn.H0 = b.H[0]; chn.H1 = b.H[1];
+  chn.gn_part = b.gn_part;
   if (out) *out = b;
   if (ch) *ch = chn;
   return c.off;
@@ -615,12 +621,7 @@ int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   hipStream_t s = (hipStream_t)stream;
   const Buffers& b = ctx->b;
-  {
-    ProfSpan sp(&ctx->prof, PC_SETUP, s);
-    hipLaunchKernelGGL(k_setup, dim3(ctx->chain.n_nodes), dim3(256), 0, s, b.cst, b.state, b.x[0], b.x[1], b.g[0],
-                       b.g[1], b.H[0], b.H[1], ctx->chain, b.gn_part);
-  }
-  ACINO_LAUNCH_CHECK();
+  // the damped system is built inside the level-0 BCR kernels (no separate set-up launch)
   return bcr_reduce(ctx->chain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s, &ctx->prof);
 }
 
@@ -642,7 +643,7 @@ size_t acino_sep_scratch_bytes(int n_sep) {
   BcrSchedule sch;
   sch.build(n_sep, false, false);
   size_t ints = sch.elim.size() + sch.remain.size() + 8;
-  return align_up((size_t)n_sep * (3 * BS * BS + BS) * sizeof(double)) + align_up(ints * sizeof(int)) + 512;
+  return 5 * align_up((size_t)n_sep * BS * BS * sizeof(double)) + align_up(ints * sizeof(int)) + 1024;
 }
 
 int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
@@ -666,12 +667,16 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
   ch.D = c.take<double>((size_t)n_sep * BS * BS);
   ch.Cpl = c.take<double>((size_t)n_sep * BS * BS);
   ch.Wl = c.take<double>((size_t)n_sep * BS * BS);
+  ch.Wr = c.take<double>((size_t)n_sep * BS * BS);
   ch.b = c.take<double>((size_t)n_sep * BS);
   int* d_sched = c.take<int>(sch.elim.size() + sch.remain.size() + 8);
   ch.d_elim = d_sched;
   ch.d_remain = d_sched + sch.elim.size();
   ch.implicit_couplings = 0;
   ch.dbg = nullptr;
+  ch.st = nullptr;
+  ch.x0 = ch.x1 = ch.g0 = ch.g1 = ch.H0 = ch.H1 = nullptr;
+  ch.gn_part = nullptr;
   if (int rc = bcr_set_func_attributes()) return rc;
   ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, sch.elim.data(), sizeof(int) * sch.elim.size(), hipMemcpyHostToDevice, s));
   if (!sch.remain.empty())

@@ -3,7 +3,7 @@ f = sys.argv[1]
 db = sqlite3.connect(f); cur = db.cursor()
 rows = list(cur.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
 sel = [r for r in rows if any(k in r[0] for k in ('bcr', 'assemble', 'k_setup', 'k_trial', 'k_totals', 'k_control'))]
-idx = max(i for i, r in enumerate(sel) if 'k_setup' in r[0])
+idx = [i for i, r in enumerate(sel) if 'k_control' in r[0]][-2] + 1
 prev = None; tot = 0; gaps = 0
 for r in sel[idx:idx + 48]:
     nm = r[0].split('(')[0].replace('acino::', '').replace('void ', '')[:22]
