@@ -36,6 +36,9 @@ struct acino_fte_ctx {
   int n_blk_asm, n_blk_trial;
   size_t ws_bytes;
   acino::Profiler prof;
+  bool graph_on = false;            // replay the LM step as a hipGraph (single-shard contexts, non-null stream)
+  hipGraphExec_t gexec = nullptr;
+  hipStream_t gstream = nullptr;
 };
 
 namespace acino {
@@ -301,7 +304,14 @@ __global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st,
     st->last_accept = 0;
     st->lam *= st->nu;
     st->nu *= 2.0;
-    if (st->lam > 1e16) st->status = 4;
+    if (st->lam > K.lam_max) {
+      if (K.clamp_lambda) {
+        st->lam = K.lam_max;
+        st->nu = 2.0;
+      } else {
+        st->status = 4;
+      }
+    }
   }
 }
 
@@ -435,6 +445,8 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->ftol = p->ftol;
   c->xtol = p->xtol;
   c->gtol = p->gtol;
+  c->lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
+  c->clamp_lambda = p->clamp_lambda;
   memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
   return ACINO_OK;
 }
@@ -556,7 +568,14 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
 }
 
 int acino_fte_destroy(acino_fte_ctx* ctx) {
+  if (ctx && ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
   delete ctx;
+  return ACINO_OK;
+}
+
+int acino_fte_enable_graph(acino_fte_ctx* ctx, int on) {
+  ACINO_REQUIRE(ctx, "null");
+  ctx->graph_on = on != 0;
   return ACINO_OK;
 }
 
@@ -731,9 +750,7 @@ int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* 
   return ACINO_OK;
 }
 
-int acino_fte_step(acino_fte_ctx* ctx, void* stream) {
-  ACINO_REQUIRE(ctx, "null");
-  ACINO_REQUIRE(!ctx->h.pin_left && !ctx->h.pin_right, "sharded contexts are stepped by the multi-GPU driver");
+static int step_eager(acino_fte_ctx* ctx, void* stream) {
   int rc = acino_fte_reduce_local(ctx, stream);
   if (rc) return rc;
   rc = acino_fte_backsub_local(ctx, nullptr, 0, 1, stream);
@@ -743,6 +760,45 @@ int acino_fte_step(acino_fte_ctx* ctx, void* stream) {
   rc = acino_fte_eval(ctx, 1, stream);
   if (rc) return rc;
   return acino_fte_control(ctx, nullptr, 0, stream);
+}
+
+int acino_fte_step(acino_fte_ctx* ctx, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(!ctx->h.pin_left && !ctx->h.pin_right, "sharded contexts are stepped by the multi-GPU driver");
+  hipStream_t s = (hipStream_t)stream;
+  // The step is a fixed launch sequence (buffer selection and the accept/reject decision live on the
+  // device), so it can be captured once and replayed: ~40 launch boundaries shrink to graph-node edges.
+  if (ctx->graph_on && !ctx->prof.on && s != nullptr) {
+    if (!ctx->gexec || ctx->gstream != s) {
+      if (ctx->gexec) {
+        (void)hipGraphExecDestroy(ctx->gexec);
+        ctx->gexec = nullptr;
+      }
+      ACINO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = step_eager(ctx, stream);
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e != hipSuccess) {
+        set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return ACINO_ERR_HIP;
+      }
+      e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) {
+        ctx->gexec = nullptr;
+        set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return ACINO_ERR_HIP;
+      }
+      ctx->gstream = s;
+    }
+    ACINO_HIP_CHECK(hipGraphLaunch(ctx->gexec, s));
+    return ACINO_OK;
+  }
+  return step_eager(ctx, stream);
 }
 
 int acino_fte_get_state(acino_fte_ctx* ctx, acino_fte_state* out, void* stream) {

@@ -25,6 +25,8 @@ struct FteConst {
   LossC loss;
   double q_w[NP], lo[NP], hi[NP];
   double ftol, xtol, gtol;
+  double lam_max;
+  int32_t clamp_lambda, pad1;
   Cam cams[ACINO_MAX_CAMS];
 };
 

@@ -49,7 +49,8 @@ def bounds45():
 
 
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
-                ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False):
+                ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
+                lam_max=1e16, clamp_lambda=False):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -70,6 +71,7 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
         p.lo[i] = lo[ACTIVE[i]]
         p.hi[i] = hi[ACTIVE[i]]
     p.lam0, p.ftol, p.xtol, p.gtol = float(lam0), float(ftol), float(xtol), float(gtol)
+    p.lam_max, p.clamp_lambda = float(lam_max), int(bool(clamp_lambda))
     return p
 
 
@@ -115,6 +117,10 @@ class FTEContext:
             raise ValueError(f"x0 must be [{self.N}, 25] active states")
         self._x0 = x
         check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
+
+    def enable_graph(self, on=True):
+        """Replay the LM step as a hipGraph (takes effect on a non-default stream)."""
+        check(lib().acino_fte_enable_graph(self._h, int(bool(on))))
 
     def step(self):
         check(lib().acino_fte_step(self._h, stream_ptr()))

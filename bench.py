@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,26 +108,44 @@ def main():
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     x0_full = fte.triangulation_init(det, *rig, 0.5)
     solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world,
-                                          ftol=0.0, xtol=0.0, gtol=0.0)
+                                          ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)   # never stops: every step is full work
     x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
-    solver.set_x(x0_local)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        solver.step()
-    sync()
     ctx = solver.b.ctx
-    ctx.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.step()
-    sync()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_end()
+    use_graph = world == 1 and not args.no_graph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        if use_graph:
+            ctx.enable_graph(True)        # the step has no host sync: capture once, replay (single GPU)
+        solver.set_x(x0_local)
+        for _ in range(args.warmup):
+            solver.step()
+        sync()
+        # ---- timed region: exactly K steps -------------------------------------------------------------
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            solver.step()
+        sync()
+        dt = time.perf_counter() - t0
+        # ---- the same K steps again, launched eagerly with HIP events around every kernel (events cannot be
+        #      recorded inside a captured graph); kernel durations do not depend on how they were launched ----
+        solver.set_x(x0_local)            # same start, same LM trajectory as the timed region
+        for _ in range(args.warmup):
+            solver.step()
+        sync()
+        ctx.profile_begin()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            solver.step()
+        sync()
+        dt_eager = time.perf_counter() - t1
+        prof = ctx.profile_end()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,7 +181,9 @@ def main():
                                   "frac_fp64": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
                                   "frac_hbm": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "gpu_kernel_ms_per_step": gpu_ms_step},
+                                  "gpu_kernel_ms_per_step": gpu_ms_step,
+                                  "launch": "hipGraph replay" if use_graph else "eager",
+                                  "ms_per_step_eager_with_events": 1e3 * dt_eager / args.steps},
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name")},
         }

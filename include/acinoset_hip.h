@@ -117,6 +117,9 @@ typedef struct acino_fte_params {
   double lo[ACINO_N_ACTIVE], hi[ACINO_N_ACTIVE];   /* box bounds (+-inf = free)             */
   double lam0;             /* initial LM damping                                            */
   double ftol, xtol, gtol; /* stopping tolerances (0 disables a test)                       */
+  double lam_max;          /* damping ceiling (0 = 1e16)                                    */
+  int32_t clamp_lambda;    /* 0: stop with status 4 when lam exceeds lam_max; 1: clamp and keep iterating */
+  int32_t pad0;
 } acino_fte_params;
 
 /* LM state mirrored in device memory (read back with acino_fte_get_state). */
@@ -151,6 +154,9 @@ int acino_fte_set_x(acino_fte_ctx* ctx, const double* d_x0, void* stream);
 /* One LM iteration, entirely stream-ordered (no host sync): damped block system -> block cyclic reduction ->
  * trial iterate -> residuals, Jacobians, normal-equation assembly at the trial -> accept/reject + lambda. */
 int acino_fte_step(acino_fte_ctx* ctx, void* stream);
+/* on != 0: acino_fte_step captures its launch sequence into a hipGraph on first use and replays it afterwards
+ * (needs a non-null stream; ignored while profiling is active and for sharded contexts). */
+int acino_fte_enable_graph(acino_fte_ctx* ctx, int on);
 /* Up to max_iter LM iterations (the device stops by itself on convergence; the host peeks every 8 steps);
  * synchronises at the end and fills *out (may be NULL). */
 int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void* stream);
