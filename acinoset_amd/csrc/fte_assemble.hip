@@ -181,10 +181,20 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     redescending<false>(K.loss, 0.0, rho0, dd, hh);
     int behind = 0;
     const int C = K.n_cams;
+    // software-pipelined detection reads: camera ci+1's (x, y, likelihood) is requested before camera ci is
+    // processed - the loop body branches (zero weight, behind camera), which would otherwise expose one HBM
+    // latency per camera
+    const double* dbase = det + ((int64_t)n * C * NL + l) * 3;
+    double nx = dbase[0], ny = dbase[1], nlik = dbase[2];
     for (int ci = 0; ci < C; ++ci) {
       const Cam& cam = K.cams[ci];
-      const double* d = det + (((int64_t)n * C + ci) * NL + l) * 3;
-      double um = d[0], vm = d[1], lik = d[2];
+      const double um = nx, vm = ny, lik = nlik;
+      if (ci + 1 < C) {
+        const double* d = dbase + (int64_t)(ci + 1) * NL * 3;
+        nx = d[0];
+        ny = d[1];
+        nlik = d[2];
+      }
       double w = (lik > K.dlc_thresh && isfinite(um) && isfinite(vm)) ? K.inv_r : 0.0;
       double xc = cam.R[0] * px + cam.R[1] * py + cam.R[2] * pz + cam.t[0];
       double yc = cam.R[3] * px + cam.R[4] * py + cam.R[5] * pz + cam.t[1];
