@@ -162,6 +162,15 @@ def main():
         flops_per_launch = ALG_FLOPS[dom] * n_loc * args.steps / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
+        kname = {"elim": "k_bcr_elim", "update": "k_bcr_update", "assemble": "k_fte_assemble<true>",
+                 "backsub": "k_bcr_backsub"}[dom]
+        traffic = None     # HBM bytes / launch of the dominant kernel from the committed PMC passes (profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_final", "pmc_traffic.json")))
+            if args.frames == N_FRAMES and world == 1:
+                traffic = pmc["kernels"]["acino::" + kname]["bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,10 +180,9 @@ def main():
                                    f"{'' if world > 1 else ' on one GPU'}), loop trajectory, seed 20210313",
                        "frames": args.frames, "cams": N_CAMS, "markers": 20, "states": 25,
                        "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": {"elim": "k_bcr_elim", "update": "k_bcr_update",
-                                                      "assemble": "k_fte_assemble", "backsub": "k_bcr_backsub"}[dom],
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "launches_per_step": launches / args.steps, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "step": {"achieved_tflops": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12,
