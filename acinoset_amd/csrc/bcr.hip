@@ -273,7 +273,8 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
   const double lam = ch.st->lam;
   const bool sep_left = K.pin_left && t == 0;
   const int fbase = 3 * (t - K.pin_left);
-  // (1) the three 25x25 Gauss-Newton blocks: all of a thread's (<= 8) loads are issued before any use
+  // (1) every global read of the node is issued up front: the three 25x25 Gauss-Newton blocks (<= 8 per
+  //     thread) and, for the 75 row-owner threads, the state and gradient entry of their row
   double hv[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -282,6 +283,16 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
     if (!sep_left && idx < 3 * NP * NP) {
       const int n = fbase + idx / (NP * NP);
       if (n < K.n_frames) hv[k] = H[(size_t)n * NP * NP + idx % (NP * NP)];
+    }
+  }
+  double xv = 0.0, gv = 0.0;
+  bool row_live = false;
+  if (!sep_left && tid < 3 * NP) {
+    const int n = fbase + tid / NP, p = tid % NP;
+    if (n < K.n_frames) {
+      row_live = true;
+      xv = x[(size_t)(n + HALO) * NP + p];
+      gv = g[(size_t)n * NP + p];
     }
   }
   // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
@@ -301,37 +312,29 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
       }
     }
   }
-  __syncthreads();
-  // (3) drop the H blocks in, damping / pinning the diagonal
+  // (3) drop the H blocks in (their targets are disjoint from the entries written in (2))
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int idx = tid + 256 * k;
     if (!sep_left && idx < 3 * NP * NP) {
       const int ii = idx / (NP * NP), rem = idx % (NP * NP), p = rem / NP, pc = rem % NP;
-      const int n = fbase + ii;
-      if (n < K.n_frames) {
-        double v = hv[k];
-        if (p == pc) {
-          const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
-          const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
-          v = v + lam * v;
-          if (fixed) v *= FIX_SCALE;
-        }
-        Dm[(ii * NP + p) * LD + ii * NP + pc] = v;
-      }
+      if (fbase + ii < K.n_frames) Dm[(ii * NP + p) * LD + ii * NP + pc] = hv[k];
     }
   }
+  __syncthreads();
+  // (4) Marquardt damping and pinning of the diagonal, right-hand side, projected-gradient norm
   double gmax = 0.0;
   if (tid < BS) {
     double b = 0.0;
-    if (!sep_left && tid < 3 * NP) {
-      const int ii = tid / NP, p = tid % NP, n = fbase + ii;
-      if (n < K.n_frames) {
-        const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
-        const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
-        b = fixed ? 0.0 : -gv;
-        gmax = fabs(b);
-      }
+    if (row_live) {
+      const int p = tid % NP;
+      const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+      double d = Dm[tid * LD + tid];
+      d = d + lam * d;
+      if (fixed) d *= FIX_SCALE;
+      Dm[tid * LD + tid] = d;
+      b = fixed ? 0.0 : -gv;
+      gmax = fabs(b);
     }
     bv[tid] = b;
   }
@@ -427,7 +430,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   const size_t MB = (size_t)BS * BS;
   const bool fused = ch.st != nullptr && level == 0;
   const bool impl_l = ch.implicit_couplings && l >= 0 && l == i - 1, impl_r = ch.implicit_couplings && r >= 0 && r == i + 1;
-  if (impl_l || impl_r) fill_coupling_coef(coefL, coefR, *cst, i, tid);   // visible after the barriers below
+  if (!fused && (impl_l || impl_r)) fill_coupling_coef(coefL, coefR, *cst, i, tid);   // visible after the barriers below
 #define ACINO_STAMP(k) do { if (ch.dbg && blockIdx.x == 0 && tid == 0) ch.dbg[k] = (long long)wall_clock64(); } while (0)
   ACINO_STAMP(0);
   if (fused) {
@@ -444,6 +447,48 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   linv80(Lm, tid);
   __syncthreads();
   ACINO_STAMP(3);
+  if (fused) {
+    // Level 0 of an FTE chain: both couplings are the sparse third-difference blocks E, so the consumers
+    // need only G = D_i^-1 = U U^T (W^T W = E^T G E is a <= 9-term stencil) and z = D_i^-1 b = U y.
+    double yy = 0.0;
+    if (tid < BS)
+      for (int c = 0; c <= tid; ++c) yy += Lm[c * LD + tid] * yv[c];   // y = U^T b
+    __syncthreads();
+    if (tid < BS) yv[tid] = yy;
+    __syncthreads();
+    if (tid < BS) {
+      double z = 0.0;
+      for (int c = tid; c < BS; ++c) z += Lm[tid * LD + c] * yv[c];     // z = U y
+      ch.b[(size_t)i * BS + tid] = z;
+    }
+    double* Gg = ch.D + i * MB;
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = wave + 4 * q;
+      if (t < 15) {
+        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        const double* pa = Lm + (ib * 16 + li) * LD + ib * 16 + lk;   // U(ib, k >= ib)[i][kk]
+        const double* pb = Lm + (jb * 16 + li) * LD + ib * 16 + lk;   // U(jb, k >= ib)[j][kk]
+        d4 acc = {0, 0, 0, 0};
+        switch (ib) {
+          case 0: acc = mma_seq<20, false>(acc, pa, 4, pb, 4); break;
+          case 1: acc = mma_seq<16, false>(acc, pa, 4, pb, 4); break;
+          case 2: acc = mma_seq<12, false>(acc, pa, 4, pb, 4); break;
+          case 3: acc = mma_seq<8, false>(acc, pa, 4, pb, 4); break;
+          default: acc = mma_seq<4, false>(acc, pa, 4, pb, 4); break;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          Gg[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
+          if (ib != jb) Gg[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[rr];
+        }
+      }
+    }
+    ACINO_STAMP(4);
+    ACINO_STAMP(5);
+    return;
+  }
   if (l >= 0) {
     if (impl_l) {
       sparse_coupling_w(Lm, ch.Wl + i * MB, coefL, true, tid);
@@ -636,6 +681,153 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
   }
 }
 
+// ---- level 0 of an FTE chain: stencil forms --------------------------------------------------
+// coefficient tables (fill_coupling_coef): cL/cR[(ii*3 + jj)*NP + p], ii <= jj.
+//   E_l(n) = block(n, n-1): rows (ii,p) of n, cols (jj,p) of n-1, value cL_n[(ii*3+jj)*NP+p]
+//   E_r(n) = block(n, n+1): rows (jj,p) of n, cols (ii,p) of n+1, value cR_n[(ii*3+jj)*NP+p]
+// One workgroup per remaining node j: builds D_j, b_j from the assembly output, subtracts
+//   E_r(im)^T G(im) E_r(im) + E_l(ip)^T G(ip) E_l(ip)   and   E_r(im)^T z(im) + E_l(ip)^T z(ip),
+// and writes the new coupling block(jn, j) = -E_r(ip)^T G(ip) E_l(ip).  Every thread keeps its 25 matrix
+// entries in registers while the neighbour's G streams through the single LDS buffer.
+__global__ void __launch_bounds__(256)
+k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __restrict__ cst,
+              const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Gb = reinterpret_cast<double*>(smem_raw);
+  double* yv = Gb + MAT;             // [80] b_j, then z of the neighbour
+  double* red = yv + BS;             // [8]
+  double* cLm = red + 8;             // coupling coefficients of node im (only cR used) and ip (cL, cR)
+  double* cRm = cLm + 9 * NP;
+  double* cLp = cRm + 9 * NP;
+  double* cRp = cLp + 9 * NP;
+  const int tid = threadIdx.x;
+  const int j = remain[4 * blockIdx.x], im = remain[4 * blockIdx.x + 1], ip = remain[4 * blockIdx.x + 2],
+            jn = remain[4 * blockIdx.x + 3];
+  const size_t MB = (size_t)BS * BS;
+  const FteConst& K = *cst;
+  if (im >= 0) fill_coupling_coef(cLm, cRm, K, im, tid);
+  if (ip >= 0) fill_coupling_coef(cLp, cRp, K, ip, tid);
+  double gmax = build_node(Gb, yv, ch, K, j, tid);
+  publish_gmax(gmax, red, ch.gn_part, j, tid);            // barrier: D_j complete in LDS, tables visible
+  double dv[25], cv[25];
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    const int e = tid + 256 * k;
+    dv[k] = Gb[(e / BS) * LD + e % BS];
+    cv[k] = 0.0;
+  }
+  double bs = (tid < BS) ? yv[tid] : 0.0;
+  __syncthreads();
+  if (im >= 0) {
+    load_mat(Gb, ch.D + im * MB, tid);                     // G of the eliminated left neighbour
+    if (tid < BS) yv[tid] = ch.b[(size_t)im * BS + tid];   // its z
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+      const int e = tid + 256 * k, ra = e / BS, cb = e % BS;
+      if (ra < 3 * NP && cb < 3 * NP) {
+        const int ja = ra / NP, pa = ra % NP, jb = cb / NP, pb = cb % NP;
+        double acc = 0.0;
+        for (int j1 = ja; j1 < 3; ++j1) {
+          const double ca = cRm[(ja * 3 + j1) * NP + pa];
+          for (int j2 = jb; j2 < 3; ++j2)
+            acc += ca * cRm[(jb * 3 + j2) * NP + pb] * Gb[(j1 * NP + pa) * LD + j2 * NP + pb];
+        }
+        dv[k] -= acc;
+      }
+    }
+    if (tid < 3 * NP) {
+      const int ja = tid / NP, pa = tid % NP;
+      for (int j1 = ja; j1 < 3; ++j1) bs -= cRm[(ja * 3 + j1) * NP + pa] * yv[j1 * NP + pa];
+    }
+    __syncthreads();
+  }
+  if (ip >= 0) {
+    load_mat(Gb, ch.D + ip * MB, tid);                     // G of the eliminated right neighbour
+    if (tid < BS) yv[tid] = ch.b[(size_t)ip * BS + tid];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+      const int e = tid + 256 * k, ra = e / BS, cb = e % BS;
+      if (ra < 3 * NP && cb < 3 * NP) {
+        const int ja = ra / NP, pa = ra % NP, jb = cb / NP, pb = cb % NP;
+        double acc = 0.0;
+        for (int i1 = 0; i1 <= ja; ++i1) {
+          const double ca = cLp[(i1 * 3 + ja) * NP + pa];
+          for (int i2 = 0; i2 <= jb; ++i2)
+            acc += ca * cLp[(i2 * 3 + jb) * NP + pb] * Gb[(i1 * NP + pa) * LD + i2 * NP + pb];
+        }
+        dv[k] -= acc;
+        if (jn >= 0) {     // block(jn, j)[(ia,pa)][(jb,pb)] = -sum_{j1>=ia} sum_{i2<=jb} cR[(ia,j1,pa)] cL[(i2,jb,pb)] G[(j1,pa)][(i2,pb)]
+          double cacc = 0.0;
+          for (int j1 = ja; j1 < 3; ++j1) {
+            const double ca = cRp[(ja * 3 + j1) * NP + pa];
+            for (int i2 = 0; i2 <= jb; ++i2)
+              cacc += ca * cLp[(i2 * 3 + jb) * NP + pb] * Gb[(j1 * NP + pa) * LD + i2 * NP + pb];
+          }
+          cv[k] = -cacc;
+        }
+      }
+    }
+    if (tid < 3 * NP) {
+      const int ja = tid / NP, pa = tid % NP;
+      for (int i1 = 0; i1 <= ja; ++i1) bs -= cLp[(i1 * 3 + ja) * NP + pa] * yv[i1 * NP + pa];
+    }
+  }
+  double* Dj = ch.D + j * MB;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) Dj[tid + 256 * k] = dv[k];
+  if (ip >= 0 && jn >= 0) {
+    double* Cj = ch.Cpl + j * MB;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) Cj[tid + 256 * k] = cv[k];
+  }
+  if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
+}
+
+// Level-0 back-substitution: x_i = z_i - G_i (E_l x_l + E_r x_r).
+__global__ void __launch_bounds__(256)
+k_bcr_backsub0(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst,
+               const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Gb = reinterpret_cast<double*>(smem_raw);
+  double* xl = Gb + MAT;
+  double* xr = xl + BS;
+  double* vv = xr + BS;
+  double* cL = vv + BS;
+  double* cR = cL + 9 * NP;
+  const int tid = threadIdx.x;
+  const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
+  const size_t MB = (size_t)BS * BS;
+  fill_coupling_coef(cL, cR, *cst, i, tid);
+  load_mat(Gb, ch.D + i * MB, tid);
+  if (tid < BS) {
+    xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
+    xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
+  }
+  __syncthreads();
+  if (tid < BS) {
+    double v = 0.0;
+    if (tid < 3 * NP) {
+      const int a = tid / NP, p = tid % NP;
+      for (int jj = a; jj < 3; ++jj) v += cL[(a * 3 + jj) * NP + p] * xl[jj * NP + p];   // (E_l x_l)[(ii=a,p)]
+      for (int ii = 0; ii <= a; ++ii) v += cR[(ii * 3 + a) * NP + p] * xr[ii * NP + p];  // (E_r x_r)[(jj=a,p)]
+    }
+    vv[tid] = v;
+  }
+  __syncthreads();
+  if (tid < BS) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = 0; c < BS; c += 2) {
+      s0 += Gb[tid * LD + c] * vv[c];
+      s1 += Gb[tid * LD + c + 1] * vv[c + 1];
+    }
+    ch.b[(size_t)i * BS + tid] = ch.b[(size_t)i * BS + tid] - (s0 + s1);
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------
 void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
   levels.clear();
@@ -691,6 +883,8 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
 static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
+static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
+static constexpr size_t kBacksub0Lds = (MAT + 3 * BS + 18 * NP) * sizeof(double);
 
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
@@ -699,6 +893,10 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdate0Lds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub0),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksub0Lds));
   return ACINO_OK;
 }
 
@@ -715,8 +913,12 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     if (lv.n_remain > 0) {
       {
         ProfSpan sp(prof, PC_UPDATE, s);
-        hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
-                           ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
+        if (level == 0 && ch.st != nullptr)
+          hipLaunchKernelGGL(k_bcr_update0, dim3(lv.n_remain), dim3(256), kUpdate0Lds, s, ch,
+                             ch.d_remain + 4 * lv.remain_off, d_c, d_status);
+        else
+          hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
+                             ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
       }
       ACINO_LAUNCH_CHECK();
     }
@@ -725,13 +927,18 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
   return ACINO_OK;
 }
 
-int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s, Profiler* prof) {
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
+                Profiler* prof) {
   for (int k = (int)sch.levels.size() - 1; k >= 0; --k) {
     const BcrLevel& lv = sch.levels[k];
     {
       ProfSpan sp(prof, PC_BACKSUB, s);
-      hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
-                         ch.d_elim + 3 * lv.elim_off, d_status);
+      if (k == 0 && ch.st != nullptr)
+        hipLaunchKernelGGL(k_bcr_backsub0, dim3(lv.n_elim), dim3(256), kBacksub0Lds, s, ch,
+                           ch.d_elim + 3 * lv.elim_off, d_c, d_status);
+      else
+        hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
+                           ch.d_elim + 3 * lv.elim_off, d_status);
     }
     ACINO_LAUNCH_CHECK();
   }

@@ -41,7 +41,7 @@ struct BcrChain {
 
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof = nullptr);
-int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const int* d_status, hipStream_t s,
+int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof = nullptr);
 int bcr_set_func_attributes();
 

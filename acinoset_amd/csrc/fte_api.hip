@@ -705,7 +705,7 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
   ACINO_LAUNCH_CHECK();
   int rc = bcr_reduce(ch, sch, nullptr, nullptr, nullptr, s);
   if (rc) return rc;
-  rc = bcr_backsub(ch, sch, nullptr, s);
+  rc = bcr_backsub(ch, sch, nullptr, nullptr, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_copy_vec, dim3((n_sep * BS + 255) / 256), dim3(256), 0, s, ch.b, d_sep_x, n_sep * BS);
   ACINO_LAUNCH_CHECK();
@@ -726,7 +726,7 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
                        d_sep_x + (size_t)rank * BS);
     ACINO_LAUNCH_CHECK();
   }
-  return bcr_backsub(ctx->chain, ctx->sched, &ctx->b.state->status, s, &ctx->prof);
+  return bcr_backsub(ctx->chain, ctx->sched, ctx->b.cst, &ctx->b.state->status, s, &ctx->prof);
 }
 
 int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
