@@ -687,8 +687,10 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
 //   E_r(n) = block(n, n+1): rows (jj,p) of n, cols (ii,p) of n+1, value cR_n[(ii*3+jj)*NP+p]
 // One workgroup per remaining node j: builds D_j, b_j from the assembly output, subtracts
 //   E_r(im)^T G(im) E_r(im) + E_l(ip)^T G(ip) E_l(ip)   and   E_r(im)^T z(im) + E_l(ip)^T z(ip),
-// and writes the new coupling block(jn, j) = -E_r(ip)^T G(ip) E_l(ip).  Every thread keeps its 25 matrix
-// entries in registers while the neighbour's G streams through the single LDS buffer.
+// and writes the new coupling block(jn, j) = -E_r(ip)^T G(ip) E_l(ip).  Each product with the sparse E is
+// done as two passes of <= 3 terms: T = G E in place in LDS (item = (row, state p): the three frame
+// columns of p), then E^T T (item = (state p, column): the three frame rows of p), accumulated into the
+// thread's registers (8 items x 3 rows of D_j) while the neighbour's G streams through the one LDS buffer.
 __global__ void __launch_bounds__(256)
 k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __restrict__ cst,
               const int* __restrict__ status) {
@@ -710,78 +712,96 @@ k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __res
   if (ip >= 0) fill_coupling_coef(cLp, cRp, K, ip, tid);
   double gmax = build_node(Gb, yv, ch, K, j, tid);
   publish_gmax(gmax, red, ch.gn_part, j, tid);            // barrier: D_j complete in LDS, tables visible
-  double dv[25], cv[25];
+  // ownership: item q = tid + 256 m (m < 8, q < 25*80): state p = q / 80, column c = q % 80, rows (0..2, p)
+  double dv[8][3];
 #pragma unroll
-  for (int k = 0; k < 25; ++k) {
-    const int e = tid + 256 * k;
-    dv[k] = Gb[(e / BS) * LD + e % BS];
-    cv[k] = 0.0;
-  }
-  double bs = (tid < BS) ? yv[tid] : 0.0;
-  __syncthreads();
-  if (im >= 0) {
-    load_mat(Gb, ch.D + im * MB, tid);                     // G of the eliminated left neighbour
-    if (tid < BS) yv[tid] = ch.b[(size_t)im * BS + tid];   // its z
-    __syncthreads();
+  for (int m = 0; m < 8; ++m) {
+    const int q = tid + 256 * m;
+    if (q < NP * BS) {
+      const int p = q / BS, c = q % BS;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) {
-      const int e = tid + 256 * k, ra = e / BS, cb = e % BS;
-      if (ra < 3 * NP && cb < 3 * NP) {
-        const int ja = ra / NP, pa = ra % NP, jb = cb / NP, pb = cb % NP;
-        double acc = 0.0;
-        for (int j1 = ja; j1 < 3; ++j1) {
-          const double ca = cRm[(ja * 3 + j1) * NP + pa];
-          for (int j2 = jb; j2 < 3; ++j2)
-            acc += ca * cRm[(jb * 3 + j2) * NP + pb] * Gb[(j1 * NP + pa) * LD + j2 * NP + pb];
-        }
-        dv[k] -= acc;
-      }
-    }
-    if (tid < 3 * NP) {
-      const int ja = tid / NP, pa = tid % NP;
-      for (int j1 = ja; j1 < 3; ++j1) bs -= cRm[(ja * 3 + j1) * NP + pa] * yv[j1 * NP + pa];
-    }
-    __syncthreads();
-  }
-  if (ip >= 0) {
-    load_mat(Gb, ch.D + ip * MB, tid);                     // G of the eliminated right neighbour
-    if (tid < BS) yv[tid] = ch.b[(size_t)ip * BS + tid];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 25; ++k) {
-      const int e = tid + 256 * k, ra = e / BS, cb = e % BS;
-      if (ra < 3 * NP && cb < 3 * NP) {
-        const int ja = ra / NP, pa = ra % NP, jb = cb / NP, pb = cb % NP;
-        double acc = 0.0;
-        for (int i1 = 0; i1 <= ja; ++i1) {
-          const double ca = cLp[(i1 * 3 + ja) * NP + pa];
-          for (int i2 = 0; i2 <= jb; ++i2)
-            acc += ca * cLp[(i2 * 3 + jb) * NP + pb] * Gb[(i1 * NP + pa) * LD + i2 * NP + pb];
-        }
-        dv[k] -= acc;
-        if (jn >= 0) {     // block(jn, j)[(ia,pa)][(jb,pb)] = -sum_{j1>=ia} sum_{i2<=jb} cR[(ia,j1,pa)] cL[(i2,jb,pb)] G[(j1,pa)][(i2,pb)]
-          double cacc = 0.0;
-          for (int j1 = ja; j1 < 3; ++j1) {
-            const double ca = cRp[(ja * 3 + j1) * NP + pa];
-            for (int i2 = 0; i2 <= jb; ++i2)
-              cacc += ca * cLp[(i2 * 3 + jb) * NP + pb] * Gb[(j1 * NP + pa) * LD + i2 * NP + pb];
-          }
-          cv[k] = -cacc;
-        }
-      }
-    }
-    if (tid < 3 * NP) {
-      const int ja = tid / NP, pa = tid % NP;
-      for (int i1 = 0; i1 <= ja; ++i1) bs -= cLp[(i1 * 3 + ja) * NP + pa] * yv[i1 * NP + pa];
+      for (int a = 0; a < 3; ++a) dv[m][a] = Gb[(a * NP + p) * LD + c];
     }
   }
   double* Dj = ch.D + j * MB;
+  for (int e = tid; e < 5 * BS; e += 256) Dj[3 * NP * BS + e] = Gb[(3 * NP + e / BS) * LD + e % BS];   // padding rows
+  double bs = (tid < BS) ? yv[tid] : 0.0;
+  __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 25; ++k) Dj[tid + 256 * k] = dv[k];
-  if (ip >= 0 && jn >= 0) {
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side == 0 ? im : ip;
+    if (nb < 0) continue;
+    const double* cE = side == 0 ? cRm : cLp;              // E_r(im) or E_l(ip): the coupling towards j
+    load_mat(Gb, ch.D + nb * MB, tid);                     // G of the eliminated neighbour
+    if (tid < BS) yv[tid] = ch.b[(size_t)nb * BS + tid];   // its z
+    __syncthreads();
+    // pass 1: T = G E (columns of j), in place.  item (row r, state p): T[r][(jb,p)] for jb = 0..2
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int q = tid + 256 * m;
+      if (q < BS * NP) {
+        const int r = q / NP, p = q % NP;
+        const double g0 = Gb[r * LD + p], g1 = Gb[r * LD + NP + p], g2 = Gb[r * LD + 2 * NP + p];
+        double t0, t1, t2;
+        if (side == 0) {   // E_r: column (jb,p) has rows (j2 >= jb, p), coefficient c[(jb*3+j2)*NP+p]
+          t0 = g0 * cE[(0 * 3 + 0) * NP + p] + g1 * cE[(0 * 3 + 1) * NP + p] + g2 * cE[(0 * 3 + 2) * NP + p];
+          t1 = g1 * cE[(1 * 3 + 1) * NP + p] + g2 * cE[(1 * 3 + 2) * NP + p];
+          t2 = g2 * cE[(2 * 3 + 2) * NP + p];
+        } else {           // E_l: column (jb,p) has rows (i2 <= jb, p), coefficient c[(i2*3+jb)*NP+p]
+          t0 = g0 * cE[(0 * 3 + 0) * NP + p];
+          t1 = g0 * cE[(0 * 3 + 1) * NP + p] + g1 * cE[(1 * 3 + 1) * NP + p];
+          t2 = g0 * cE[(0 * 3 + 2) * NP + p] + g1 * cE[(1 * 3 + 2) * NP + p] + g2 * cE[(2 * 3 + 2) * NP + p];
+        }
+        Gb[r * LD + p] = t0;
+        Gb[r * LD + NP + p] = t1;
+        Gb[r * LD + 2 * NP + p] = t2;
+      }
+    }
+    __syncthreads();
+    // pass 2: D_j -= E^T T ; (right neighbour only) block(jn, j) = -E_r(ip)^T T.  item (state p, column c)
     double* Cj = ch.Cpl + j * MB;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) Cj[tid + 256 * k] = cv[k];
+    for (int m = 0; m < 8; ++m) {
+      const int q = tid + 256 * m;
+      if (q < NP * BS) {
+        const int p = q / BS, c = q % BS;
+        const double t0 = Gb[p * LD + c], t1 = Gb[(NP + p) * LD + c], t2 = Gb[(2 * NP + p) * LD + c];
+        if (side == 0) {   // rows (ja,p) of E_r^T: sum over j1 >= ja
+          dv[m][0] -= cE[(0 * 3 + 0) * NP + p] * t0 + cE[(0 * 3 + 1) * NP + p] * t1 + cE[(0 * 3 + 2) * NP + p] * t2;
+          dv[m][1] -= cE[(1 * 3 + 1) * NP + p] * t1 + cE[(1 * 3 + 2) * NP + p] * t2;
+          dv[m][2] -= cE[(2 * 3 + 2) * NP + p] * t2;
+        } else {           // rows (ja,p) of E_l^T: sum over i1 <= ja
+          dv[m][0] -= cE[(0 * 3 + 0) * NP + p] * t0;
+          dv[m][1] -= cE[(0 * 3 + 1) * NP + p] * t0 + cE[(1 * 3 + 1) * NP + p] * t1;
+          dv[m][2] -= cE[(0 * 3 + 2) * NP + p] * t0 + cE[(1 * 3 + 2) * NP + p] * t1 + cE[(2 * 3 + 2) * NP + p] * t2;
+          if (jn >= 0) {   // rows (ia,p) of -E_r(ip)^T: sum over j1 >= ia
+            Cj[(0 * NP + p) * BS + c] = -(cRp[(0 * 3 + 0) * NP + p] * t0 + cRp[(0 * 3 + 1) * NP + p] * t1 + cRp[(0 * 3 + 2) * NP + p] * t2);
+            Cj[(1 * NP + p) * BS + c] = -(cRp[(1 * 3 + 1) * NP + p] * t1 + cRp[(1 * 3 + 2) * NP + p] * t2);
+            Cj[(2 * NP + p) * BS + c] = -(cRp[(2 * 3 + 2) * NP + p] * t2);
+          }
+        }
+      }
+    }
+    if (side == 1 && jn >= 0)
+      for (int e = tid; e < 5 * BS; e += 256) Cj[3 * NP * BS + e] = 0.0;    // padding rows of the coupling
+    if (tid < 3 * NP) {        // b_j -= E^T z
+      const int ja = tid / NP, pa = tid % NP;
+      if (side == 0) {
+        for (int j1 = ja; j1 < 3; ++j1) bs -= cE[(ja * 3 + j1) * NP + pa] * yv[j1 * NP + pa];
+      } else {
+        for (int i1 = 0; i1 <= ja; ++i1) bs -= cE[(i1 * 3 + ja) * NP + pa] * yv[i1 * NP + pa];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int q = tid + 256 * m;
+    if (q < NP * BS) {
+      const int p = q / BS, c = q % BS;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) Dj[(a * NP + p) * BS + c] = dv[m][a];
+    }
   }
   if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
 }
