@@ -20,6 +20,7 @@ Outputs (all DATA: inputs + expected outputs):
   kat1_sunday_amelia.npz   scene (K,D,R,t) + checkerboard points of cams 1-4 (KAT-1 inputs)
   kat34_build_runs.npz     stored IPOPT runs x,dx,ddx,positions + skeletons (KAT-3/4)
   dummy_scene.json    the 6-camera rig (configs/dummy_scene.json is a data file)
+  dlc_tables.json     synthetic wide DLC tables -> utils.create_dlc_points_2d_file long table (read_hdf patched)
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -232,6 +233,39 @@ def gen_kat34():
     print("kat34:", {k: v.shape for k, v in out.items()})
 
 
+def gen_dlc_tables():
+    """utils.create_dlc_points_2d_file (utils.py:105-120) on synthetic wide DLC tables: pandas.read_hdf is
+    monkey-patched (pytables is absent) so the reference's own reshaping code produces the expected rows."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from calib import utils as ref_utils  # noqa: E402
+    rng = np.random.default_rng(21)
+    parts = ["nose", "l_eye", "r_eye", "neck_base", "spine"]
+    wide = []
+    for cam in range(3):
+        n = 6
+        cols = pd.MultiIndex.from_product([["DLC_resnet50_test"], parts, ["x", "y", "likelihood"]],
+                                          names=["scorer", "bodyparts", "coords"])
+        arr = rng.uniform(0, 1000, (n, len(parts) * 3))
+        arr[:, 2::3] = rng.uniform(0, 1, (n, len(parts)))
+        wide.append(pd.DataFrame(arr, columns=cols, index=np.arange(n)))
+    orig = pd.read_hdf
+    pd.read_hdf = lambda path, *a, **k: wide[int(path)].copy()
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            long_df = ref_utils.create_dlc_points_2d_file(["0", "1", "2"])
+    finally:
+        pd.read_hdf = orig
+    out = dict(parts=parts, wide=[w.to_numpy().tolist() for w in wide],
+               long_columns=list(long_df.columns),
+               long_frame=[int(v) for v in long_df["frame"]], long_camera=[int(v) for v in long_df["camera"]],
+               long_marker=list(long_df["marker"]),
+               long_xyl=long_df[["x", "y", "likelihood"]].astype(float).values.tolist())
+    json.dump(out, open(os.path.join(OUT, "dlc_tables.json"), "w"))
+    print("dlc_tables:", len(long_df), "rows, columns", list(long_df.columns))
+
+
 def gen_dummy_scene():
     s = json.load(open(os.path.join(REF, "configs", "dummy_scene.json")))
     json.dump(s, open(os.path.join(OUT, "dummy_scene.json"), "w"))
@@ -240,8 +274,8 @@ def gen_dummy_scene():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: golden fixtures can only be regenerated in the build container"
     install_stubs()
-    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene"]
+    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc"]
     for name, fn in (("helpers", gen_ref_helpers), ("fk", gen_cheetah_fk), ("index", gen_index_path),
-                     ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene)):
+                     ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
         if name in parts:
             fn()
