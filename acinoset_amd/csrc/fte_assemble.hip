@@ -19,13 +19,13 @@
 namespace acino {
 
 // ---- kinematic tree tables (active-state index: 0-2 xyz, 3-5 phi0,phi1,phi3, 6-19 theta0-13, 20-24 psi0,1,3,4,5)
-__constant__ int8_t c_grp_phi[NGRP] = {3, 4, -1, 5, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-__constant__ int8_t c_grp_psi[NGRP] = {20, 21, -1, 22, 23, 24, -1, -1, -1, -1, -1, -1, -1, -1};
-__constant__ int8_t c_grp_pivot[NGRP] = {20, 20, 3, 4, 5, 6, 8, 9, 11, 12, 14, 15, 17, 18};  // pos index; 20 = head
-__constant__ int8_t c_state_grp[NP] = {-1, -1, -1, 0, 1, 3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 3, 4, 5};
-__constant__ uint16_t c_ancmask[NGRP] = {
+__device__ const int8_t c_grp_phi[NGRP] = {3, 4, -1, 5, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int8_t c_grp_psi[NGRP] = {20, 21, -1, 22, 23, 24, -1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int8_t c_grp_pivot[NGRP] = {20, 20, 3, 4, 5, 6, 8, 9, 11, 12, 14, 15, 17, 18};  // pos index; 20 = head
+__device__ const int8_t c_state_grp[NP] = {-1, -1, -1, 0, 1, 3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 3, 4, 5};
+__device__ const uint16_t c_ancmask[NGRP] = {
     0x0001, 0x0003, 0x0007, 0x000F, 0x001F, 0x003F, 0x0047, 0x00C7, 0x0107, 0x0307, 0x040F, 0x0C0F, 0x100F, 0x300F};
-__constant__ double c_off[NL][3] = {
+__device__ const double c_off[NL][3] = {
     {0, 0.03, 0},          {0, -0.03, 0},         {0.055, 0, -0.055},  {-0.28, 0, 0},       {-0.37, 0, 0},
     {-0.37, 0, 0},         {-0.28, 0, 0},         {-0.36, 0, 0},       {-0.04, 0.08, -0.10}, {0, 0, -0.24},
     {0, 0, -0.28},         {-0.04, -0.08, -0.10}, {0, 0, -0.24},       {0, 0, -0.28},       {0.12, 0.08, -0.06},
@@ -350,6 +350,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       // Hessian column bq of this frame's 25x25 block
       double* Dn = D0 + (int64_t)n * NP * NP;
       const unsigned ancb = g < 0 ? 0u : c_ancmask[g];
+#pragma unroll
       for (int a = 0; a < NP; ++a) {
         const int ga = c_state_grp[a];
         // a is ancestor-or-same of bq ?   (root is an ancestor of everything; root-root only with itself)

@@ -33,6 +33,7 @@ struct FteConst {
 // (D3^T D3)[n, n+k] for global frame n, 0 <= k <= 3, sequence length ng (stencil -1, 3, -3, 1).
 __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
   if (n < 0 || n + k >= ng) return 0.0;
+  if (n + k >= 3 && n <= ng - 4) return k == 0 ? 20.0 : (k == 1 ? -15.0 : (k == 2 ? 6.0 : -1.0));   // interior rows
   const double c[4] = {-1.0, 3.0, -3.0, 1.0};
   int64_t jlo = n + k - 3 > 0 ? n + k - 3 : 0;
   int64_t jhi = n < ng - 4 ? n : ng - 4;
