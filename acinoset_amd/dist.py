@@ -98,17 +98,30 @@ class HipBackend:
 
 
 class TorchComm:
-    """torch.distributed collectives (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)."""
+    """torch.distributed collectives: backend "nccl" (= RCCL over xGMI) on the GPU node.  With the "gloo"
+    backend (CPU tests, or several ranks sharing one GPU when no multi-GPU node is at hand) device tensors
+    are staged through the host."""
 
     def __init__(self, group=None):
         self.group = group
+        self._stage = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     def all_gather(self, out, inp):
         # flat views: gloo only accepts the concatenated 1-D layout, RCCL accepts both
-        dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=self.group)
+        if self._stage and inp.is_cuda:
+            o, i = out.cpu().view(-1), inp.detach().cpu().contiguous().view(-1)
+            dist.all_gather_into_tensor(o, i, group=self.group)
+            out.view(-1).copy_(o)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=self.group)
 
     def all_reduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self._stage and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
 def combine_partials(gathered):

@@ -88,11 +88,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
+    # ACINO_DIST_BACKEND=gloo ACINO_FORCE_DEVICE=0 lets several ranks share one GPU (functional check of the
+    # multi-process path on a single-GPU box); the driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("ACINO_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("ACINO_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -146,7 +153,7 @@ def main():
         sync()
         dt_eager = time.perf_counter() - t1
         prof = ctx.profile_end()
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" or world == 1 else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
