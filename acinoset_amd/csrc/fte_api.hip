@@ -97,73 +97,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
 }
 
 // ---- kernels ----------------------------------------------------------------------------------
-// Working system of one LM step: D = H_gn + lam*diag(H_gn) (bound-active variables pinned by a 2^70
-// diagonal boost), b = -g.  One workgroup per chain node.
-__global__ void __launch_bounds__(256)
-k_setup(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, const double* __restrict__ x0,
-        const double* __restrict__ x1, const double* __restrict__ g0, const double* __restrict__ g1,
-        const double* __restrict__ H0, const double* __restrict__ H1, BcrChain ch, double* __restrict__ gn_part) {
-  if (st->status != 0) return;
-  const FteConst& K = *cst;
-  const int cur = st->cur;
-  const double* x = cur ? x1 : x0;
-  const double* g = cur ? g1 : g0;
-  const double* H = cur ? H1 : H0;
-  const double lam = st->lam;
-  const int t = blockIdx.x, tid = threadIdx.x;
-  double* D = ch.D + (size_t)t * BS * BS;
-  double* b = ch.b + (size_t)t * BS;
-  __shared__ double red[4];
-  double gmax = 0.0;
-  const bool sep_left = K.pin_left && t == 0;
-  const int fbase = 3 * (t - K.pin_left);   // local frame of sub-row 0
-  for (int e = tid; e < BS * BS; e += 256) {
-    const int r = e / BS, c = e % BS;
-    double v = 0.0;
-    if (sep_left) {
-      v = 0.0;
-    } else if (r >= 3 * NP || c >= 3 * NP) {
-      v = (r == c) ? 1.0 : 0.0;
-    } else {
-      const int ii = r / NP, p = r % NP, jj = c / NP, pc = c % NP;
-      const int nr = fbase + ii, nc = fbase + jj;
-      const bool er = nr < K.n_frames, ec = nc < K.n_frames;
-      if (!er || !ec) {
-        v = (r == c) ? 1.0 : 0.0;
-      } else if (ii == jj) {
-        v = H[((size_t)nr * NP + p) * NP + pc];
-        if (p == pc) {
-          const double xv = x[(size_t)(nr + HALO) * NP + p], gv = g[(size_t)nr * NP + p];
-          const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
-          v = v + lam * v;
-          if (fixed) v *= FIX_SCALE;
-        }
-      } else if (p == pc) {
-        const int lo_f = ii < jj ? nr : nc, k = ii < jj ? jj - ii : ii - jj;
-        v = 2.0 * K.q_w[p] * band_coef(K.n_offset + lo_f, k, K.n_global);
-      }
-    }
-    D[e] = v;
-  }
-  if (tid < BS) {
-    double bv = 0.0;
-    if (!sep_left && tid < 3 * NP) {
-      const int ii = tid / NP, p = tid % NP, n = fbase + ii;
-      if (n < K.n_frames) {
-        const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[(size_t)n * NP + p];
-        const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
-        bv = fixed ? 0.0 : -gv;
-        gmax = fabs(bv);
-      }
-    }
-    b[tid] = bv;
-  }
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = gmax;
-  __syncthreads();
-  if (tid == 0) gn_part[t] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-
+// (the damped system D = H_gn + lam*diag(H_gn), b = -g is built inside the level-0 BCR kernels: bcr.hip build_node)
 // Trial iterate x_t = clip(x + delta) and the model quantities of the step.
 __global__ void __launch_bounds__(256)
 k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, double* __restrict__ x0,
