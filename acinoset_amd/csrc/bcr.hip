@@ -392,24 +392,34 @@ __device__ void sparse_coupling_w(const double* Um, double* __restrict__ Wout, c
   }
 }
 
-// W(IB, strip) = sum_{k<=IB} X(IB,k) A(k, strip) with the B operand read straight from HBM/L2:
-// element A[row][col] at Ag[row * rs + col * cs] (rs/cs select the plain or the transposed coupling block).
+// W(:, strip) = U^T A(:, strip) with the B operand read straight from HBM/L2 ONCE per strip: lane (li, lk)
+// holds A[4t+lk][cc+li] for t = 0..19 (element A[row][col] at Ag[row*rs + col*cs]; rs/cs select the plain or
+// the transposed coupling block) and every row tile IB reuses the first 4(IB+1) of them:
+//   W(IB, strip) = sum_{k<=IB} X(IB,k) A(k, strip),   X(IB,k)[i][kk] = U[k16+kk][IB16+i]  (A operand, from LDS).
 template <int IB>
-__device__ __forceinline__ void strip_row_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
-                                            double* __restrict__ Wg, int cc, int li, int lk) {
+__device__ __forceinline__ void strip_row_r(const double* Lm, const double (&bv)[20], double* __restrict__ Wg, int cc,
+                                            int li, int lk) {
+  constexpr int NS = 4 * (IB + 1);
+  double av[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) av[t] = Lm[(4 * t + lk) * LD + IB * 16 + li];
   d4 acc = {0, 0, 0, 0};
-  acc = mma_seq<4 * (IB + 1), false>(acc, Lm + lk * LD + IB * 16 + li, 4 * LD, Ag + lk * rs + (cc + li) * cs, 4 * rs);
+#pragma unroll
+  for (int t = 0; t < NS; ++t) acc = mfma(av[t], bv[t], acc);
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) Wg[(IB * 16 + lk + 4 * rr) * BS + cc + li] = acc[rr];
 }
 __device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
                                              double* __restrict__ Wg, int cc, int lane) {
   const int li = lane & 15, lk = lane >> 4;
-  strip_row_g<4>(Lm, Ag, rs, cs, Wg, cc, li, lk);
-  strip_row_g<3>(Lm, Ag, rs, cs, Wg, cc, li, lk);
-  strip_row_g<2>(Lm, Ag, rs, cs, Wg, cc, li, lk);
-  strip_row_g<1>(Lm, Ag, rs, cs, Wg, cc, li, lk);
-  strip_row_g<0>(Lm, Ag, rs, cs, Wg, cc, li, lk);
+  double bv[20];
+#pragma unroll
+  for (int t = 0; t < 20; ++t) bv[t] = Ag[(4 * t + lk) * rs + (cc + li) * cs];
+  strip_row_r<4>(Lm, bv, Wg, cc, li, lk);
+  strip_row_r<3>(Lm, bv, Wg, cc, li, lk);
+  strip_row_r<2>(Lm, bv, Wg, cc, li, lk);
+  strip_row_r<1>(Lm, bv, Wg, cc, li, lk);
+  strip_row_r<0>(Lm, bv, Wg, cc, li, lk);
 }
 
 // Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the D

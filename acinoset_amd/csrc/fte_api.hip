@@ -172,10 +172,14 @@ __device__ double block_max(const double* v, int n, double* sh) {
 }
 
 // totals = {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}   (fixed summation order)
+__device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
+                           int init);
+
+// fused_control: -1 none (sharded: the decision needs the cross-rank sums), 0 LM step, 1 initial evaluation
 __global__ void __launch_bounds__(256)
-k_totals(const acino_fte_state* __restrict__ st, const double* cost_part, int n_cost, const double* pred_part,
+k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double* pred_part,
          const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
-         int with_step) {
+         int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control) {
   if (st->status != 0) return;
   __shared__ double sh[256];
   double c = block_sum(cost_part, n_cost, sh);
@@ -190,15 +194,14 @@ k_totals(const acino_fte_state* __restrict__ st, const double* cost_part, int n_
     totals[4] = (double)*nbehind;
     totals[5] = totals[6] = totals[7] = 0.0;
     *nbehind = 0;
+    if (fused_control >= 0) lm_control(*cst, st, totals, numeric_err, fused_control);
   }
 }
 
 // Accept / reject + Nielsen lambda update; mirrors oracle/fte.py:lm_solve step for step.
-__global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st, const double* __restrict__ totals,
-                          const int* __restrict__ numeric_err, int init) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
+                           int init) {
   if (st->status != 0) return;
-  const FteConst& K = *cst;
   if (init) {
     st->cost = totals[0];
     st->cost_trial = totals[0];
@@ -247,6 +250,12 @@ __global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st,
       }
     }
   }
+}
+
+__global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st, const double* __restrict__ totals,
+                          const int* __restrict__ numeric_err, int init) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  lm_control(*cst, st, totals, numeric_err, init);
 }
 
 __global__ void k_copy_x_in(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
@@ -404,7 +413,7 @@ static int validate(const acino_fte_params* p) {
 using namespace acino;
 
 static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_step, bool respect_status,
-                        hipStream_t s) {
+                        hipStream_t s, int fused_control = -1) {
   const Buffers& b = ctx->b;
   int rc;
   {
@@ -417,7 +426,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
                        b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
-                       with_step ? 1 : 0);
+                       with_step ? 1 : 0, b.cst, b.numeric_err, fused_control);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
@@ -565,9 +574,7 @@ int acino_fte_control(acino_fte_ctx* ctx, const double* d_total, int init, void*
 int acino_fte_set_x(acino_fte_ctx* ctx, const double* d_x0, void* stream) {
   int rc = acino_fte_load_x(ctx, d_x0, stream);
   if (rc) return rc;
-  rc = acino_fte_eval(ctx, 0, stream);
-  if (rc) return rc;
-  return acino_fte_control(ctx, nullptr, 1, stream);
+  return eval_iterate(ctx, 0, true, false, false, (hipStream_t)stream, 1);
 }
 
 int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream) {
@@ -691,9 +698,7 @@ static int step_eager(acino_fte_ctx* ctx, void* stream) {
   if (rc) return rc;
   rc = acino_fte_trial(ctx, stream);
   if (rc) return rc;
-  rc = acino_fte_eval(ctx, 1, stream);
-  if (rc) return rc;
-  return acino_fte_control(ctx, nullptr, 0, stream);
+  return eval_iterate(ctx, 1, true, true, true, (hipStream_t)stream, 0);   // assembly + sums + accept/reject
 }
 
 int acino_fte_step(acino_fte_ctx* ctx, void* stream) {

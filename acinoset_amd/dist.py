@@ -96,6 +96,13 @@ class HipBackend:
     def result_x(self):
         return self.ctx.result()[0]
 
+    # unsharded fast path: the whole iteration is one C-ABI call (and one hipGraph replay when enabled)
+    def set_x_single(self, x_local):
+        self.ctx.set_x(x_local)
+
+    def step_single(self):
+        self.ctx.step()
+
 
 class TorchComm:
     """torch.distributed collectives: backend "nccl" (= RCCL over xGMI) on the GPU node.  With the "gloo"
@@ -173,12 +180,18 @@ class ShardedFTE:
 
     # -- driver --------------------------------------------------------------------------------------
     def set_x(self, x_local):
+        if self.world == 1 and hasattr(self.b, "set_x_single"):
+            self.b.set_x_single(x_local)
+            return
         self.b.load_x(x_local)
         self._exchange_halo(0)
         self.b.eval(0)
         self._global_control(True)
 
     def step(self):
+        if self.world == 1 and hasattr(self.b, "step_single"):
+            self.b.step_single()
+            return
         self.b.reduce_local()
         if self.world > 1:
             self._sep.zero_()
