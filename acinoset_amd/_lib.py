@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
-SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip"]
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip"]
 HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
 N_ACTIVE = 25
@@ -40,6 +40,23 @@ class FteState(C.Structure):
 
     def as_dict(self):
         names = {0: "running", 1: "ftol", 2: "xtol", 3: "gtol", 4: "lambda_overflow", 5: "numeric"}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
+        d["status_name"] = names.get(self.status, "?")
+        return d
+
+
+class SbaParams(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("optimize_cameras", C.c_int32), ("n_points", C.c_int64), ("n_obs", C.c_int64),
+                ("f_scale", C.c_double), ("lam0", C.c_double), ("ftol", C.c_double), ("gtol", C.c_double),
+                ("max_iter", C.c_int32), ("pad0", C.c_int32)]
+
+
+class SbaInfo(C.Structure):
+    _fields_ = [("cost_initial", C.c_double), ("cost_final", C.c_double), ("gnorm_inf", C.c_double), ("lam", C.c_double),
+                ("iterations", C.c_int32), ("accepted", C.c_int32), ("status", C.c_int32), ("pad0", C.c_int32)]
+
+    def as_dict(self):
+        names = {0: "max_iter", 1: "ftol", 3: "gtol", 4: "lambda_overflow", 5: "numeric"}
         d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
         d["status_name"] = names.get(self.status, "?")
         return d
@@ -94,6 +111,10 @@ SIGNATURES = {
     "acino_fte_profile_begin": (_I, [_P]),
     "acino_fte_debug_stamps": (_I, [_P, _P]),
     "acino_fte_profile_end": (_I, [_P, _P, _P, _P]),
+    "acino_sizeof_sba_params": (_Z, []),
+    "acino_sizeof_sba_info": (_Z, []),
+    "acino_sba_workspace_bytes": (_Z, [_I, _L, _L]),
+    "acino_sba_solve": (_I, [C.POINTER(SbaParams), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P, C.POINTER(SbaInfo), _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
 }
 
@@ -147,6 +168,8 @@ def lib():
         fn.argtypes = args
     if handle.acino_sizeof_fte_params() != C.sizeof(FteParams) or handle.acino_sizeof_fte_state() != C.sizeof(FteState):
         raise RuntimeError("libacinoset_hip.so struct layout differs from the Python binding (stale build?)")
+    if handle.acino_sizeof_sba_params() != C.sizeof(SbaParams) or handle.acino_sizeof_sba_info() != C.sizeof(SbaInfo):
+        raise RuntimeError("libacinoset_hip.so SBA struct layout differs from the Python binding (stale build?)")
     _lib = handle
     return _lib
 

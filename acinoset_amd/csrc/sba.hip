@@ -1,0 +1,528 @@
+// Sparse bundle adjustment of 3-D points (+ optionally the 6-DoF camera extrinsics) on fisheye cameras.
+//
+// Reference: src/calib/calib.py:307-341 (points only), :345-390 (points + extrinsics) - scipy least_squares(method='trf', loss='cauchy') over
+// [rvecs, tvecs, points] with a finite-difference Jacobian and one cv2.fisheye.projectPoints call per
+// observation.  Here: analytic Jacobians, Cauchy IRLS weights w = 1/(1 + (r/f)^2), Levenberg-Marquardt on the
+// Schur complement of the point blocks (3x3 per point) onto the camera block (6C x 6C), rotations updated by a
+// left perturbation R <- exp([dw]x) R (same minimiser, no rvec singularities).  One thread per POINT walks its
+// observations (CSR built by the host); camera-block sums are reduced in LDS, then one atomic per entry.
+#include "common.hpp"
+
+namespace acino {
+
+constexpr int SBA_MAXC = ACINO_MAX_CAMS;
+
+struct SbaIntr {
+  double fx, fy, cx, cy, k1, k2, k3, k4;
+};
+
+// cv2.fisheye projection of a camera-frame point and d(uv)/d(Xc)
+template <bool JAC>
+__device__ __forceinline__ void fisheye_cam(const SbaIntr& c, const double Xc[3], double uv[2], double J[2][3]) {
+  const double iz = 1.0 / Xc[2];
+  const double a = Xc[0] * iz, b = Xc[1] * iz;
+  const double r = sqrt(a * a + b * b);
+  const double th = atan(r), th2 = th * th;
+  const double thd = th * (1 + th2 * (c.k1 + th2 * (c.k2 + th2 * (c.k3 + th2 * c.k4))));
+  const bool small = !(r > 1e-8);
+  const double m = small ? 1.0 : thd / r;
+  uv[0] = c.fx * a * m + c.cx;
+  uv[1] = c.fy * b * m + c.cy;
+  if (JAC) {
+    double dm_da = 0.0, dm_db = 0.0;
+    if (!small) {
+      const double dthd = 1 + th2 * (3 * c.k1 + th2 * (5 * c.k2 + th2 * (7 * c.k3 + th2 * 9 * c.k4)));
+      const double dm_dr = (dthd / (1 + r * r) * r - thd) / (r * r);
+      dm_da = dm_dr * a / r;
+      dm_db = dm_dr * b / r;
+    }
+    const double du_da = c.fx * (m + a * dm_da), du_db = c.fx * a * dm_db;
+    const double dv_da = c.fy * b * dm_da, dv_db = c.fy * (m + b * dm_db);
+    J[0][0] = du_da * iz;
+    J[0][1] = du_db * iz;
+    J[0][2] = -(du_da * a + du_db * b) * iz;
+    J[1][0] = dv_da * iz;
+    J[1][1] = dv_db * iz;
+    J[1][2] = -(dv_da * a + dv_db * b) * iz;
+  }
+}
+
+struct SbaBuf {
+  int C, P, M, opt_cams;
+  double fs;
+  const double* intr;    // [C][8]
+  const double* uv;      // [M][2]
+  const int* cam_idx;    // [M]
+  const int* pt_start;   // [P+1]
+  const int* pt_obs;     // [M] observation ids grouped by point
+  double* V;             // [P][6]
+  double* gp;            // [P][3]
+  double* Vinv;          // [P][6]
+  double* Wpc;           // [M][18]  (6x3, row-major)
+  double* U;             // [C][21]
+  double* gc;            // [C][6]
+  double* S;             // [6C][6C]
+  double* rhs;           // [6C]
+  double* dc;            // [6C]
+  double* dp;            // [P][3]
+  double* scal;          // [8]: 0 cost, 1 pred, 2 max|g|, 3 numeric flag
+};
+
+// Evaluate at (Rt, pts): cost; with JAC also V, gp, Wpc, U, gc; optionally the residuals.
+template <bool JAC>
+__global__ void __launch_bounds__(256)
+k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ pts, double* __restrict__ res_out) {
+  __shared__ double sU[SBA_MAXC][27];
+  __shared__ double sred[4];
+  const int tid = threadIdx.x;
+  if (JAC)
+    for (int e = tid; e < B.C * 27; e += 256) (&sU[0][0])[e] = 0.0;
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  double cost = 0.0, gmax = 0.0;
+  if (p < B.P) {
+    const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    const double ifs2 = 1.0 / (B.fs * B.fs);
+    for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
+      const int k = B.pt_obs[o], c = B.cam_idx[k];
+      const double* R = Rt + 12 * c;
+      const SbaIntr& in = *reinterpret_cast<const SbaIntr*>(B.intr + 8 * c);
+      const double RX[3] = {R[0] * X[0] + R[1] * X[1] + R[2] * X[2], R[3] * X[0] + R[4] * X[1] + R[5] * X[2],
+                            R[6] * X[0] + R[7] * X[1] + R[8] * X[2]};
+      const double Xc[3] = {RX[0] + R[9], RX[1] + R[10], RX[2] + R[11]};
+      double uvp[2], Jpi[2][3];
+      fisheye_cam<JAC>(in, Xc, uvp, Jpi);
+      const double r0 = uvp[0] - B.uv[2 * k], r1 = uvp[1] - B.uv[2 * k + 1];
+      if (res_out) {
+        res_out[2 * k] = r0;
+        res_out[2 * k + 1] = r1;
+      }
+      const double z0 = r0 * r0 * ifs2, z1 = r1 * r1 * ifs2;
+      cost += 0.5 * B.fs * B.fs * (log1p(z0) + log1p(z1));
+      if (JAC) {
+        const double w0 = 1.0 / (1.0 + z0), w1 = 1.0 / (1.0 + z1);
+        double Jp[2][3], Jc[2][6];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Jp[d][j] = Jpi[d][0] * R[j] + Jpi[d][1] * R[3 + j] + Jpi[d][2] * R[6 + j];
+          // d(Xc)/d(dw) = -[RX]x ;  d(Xc)/d(dt) = I
+          Jc[d][0] = Jpi[d][1] * (-RX[2]) + Jpi[d][2] * RX[1];
+          Jc[d][1] = Jpi[d][0] * RX[2] - Jpi[d][2] * RX[0];
+          Jc[d][2] = -Jpi[d][0] * RX[1] + Jpi[d][1] * RX[0];
+          Jc[d][3] = Jpi[d][0];
+          Jc[d][4] = Jpi[d][1];
+          Jc[d][5] = Jpi[d][2];
+        }
+        V[0] += w0 * Jp[0][0] * Jp[0][0] + w1 * Jp[1][0] * Jp[1][0];
+        V[1] += w0 * Jp[0][0] * Jp[0][1] + w1 * Jp[1][0] * Jp[1][1];
+        V[2] += w0 * Jp[0][0] * Jp[0][2] + w1 * Jp[1][0] * Jp[1][2];
+        V[3] += w0 * Jp[0][1] * Jp[0][1] + w1 * Jp[1][1] * Jp[1][1];
+        V[4] += w0 * Jp[0][1] * Jp[0][2] + w1 * Jp[1][1] * Jp[1][2];
+        V[5] += w0 * Jp[0][2] * Jp[0][2] + w1 * Jp[1][2] * Jp[1][2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[j] += w0 * r0 * Jp[0][j] + w1 * r1 * Jp[1][j];
+        double* W = B.Wpc + 18 * (size_t)k;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) W[a * 3 + j] = w0 * Jc[0][a] * Jp[0][j] + w1 * Jc[1][a] * Jp[1][j];
+        if (B.opt_cams) {
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int bq = a; bq < 6; ++bq) atomicAdd(&sU[c][q++], w0 * Jc[0][a] * Jc[0][bq] + w1 * Jc[1][a] * Jc[1][bq]);
+#pragma unroll
+          for (int a = 0; a < 6; ++a) atomicAdd(&sU[c][21 + a], w0 * r0 * Jc[0][a] + w1 * r1 * Jc[1][a]);
+        }
+      }
+    }
+    if (JAC) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) B.V[6 * (size_t)p + q] = V[q];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        B.gp[3 * (size_t)p + j] = g[j];
+        gmax = fmax(gmax, fabs(g[j]));
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cost += __shfl_down(cost, off, 64);
+    gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  }
+  if ((tid & 63) == 0) sred[tid >> 6] = cost;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&B.scal[0], (sred[0] + sred[1]) + (sred[2] + sred[3]));
+  if (JAC && (tid & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(&B.scal[2]),
+                                         (unsigned long long)__double_as_longlong(gmax));   // gmax >= 0: order-preserving
+  if (JAC && B.opt_cams) {
+    __syncthreads();
+    for (int e = tid; e < B.C * 27; e += 256) {
+      const int c = e / 27, q = e % 27;
+      const double v = sU[c][q];
+      if (v != 0.0) atomicAdd(q < 21 ? &B.U[21 * c + q] : &B.gc[6 * c + (q - 21)], v);
+    }
+  }
+}
+
+// Per point: Vinv = (V + lam diag V)^-1; Schur contributions S -= W Vinv W'^T, rhs -= W Vinv gp.
+__global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
+  extern __shared__ double sS[];   // [6C][6C] + [6C]
+  const int n = 6 * B.C, tid = threadIdx.x;
+  if (B.opt_cams)
+    for (int e = tid; e < n * n + n; e += 256) sS[e] = 0.0;
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  if (p < B.P) {
+    const double* V = B.V + 6 * (size_t)p;
+    const double a = V[0] * (1 + lam), b = V[1], c = V[2], d = V[3] * (1 + lam), e = V[4], f = V[5] * (1 + lam);
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    double det = a * c00 + b * c01 + c * c02;
+    if (!(fabs(det) > 0.0)) det = 1.0;   // point without observations: harmless (gp = 0)
+    const double id = 1.0 / det;
+    double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) B.Vinv[6 * (size_t)p + q] = Vi[q];
+    if (B.opt_cams) {
+      const double* g = B.gp + 3 * (size_t)p;
+      const double Vg[3] = {Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2], Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2],
+                            Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]};
+      for (int o1 = B.pt_start[p]; o1 < B.pt_start[p + 1]; ++o1) {
+        const int k1 = B.pt_obs[o1], c1 = B.cam_idx[k1];
+        const double* W1 = B.Wpc + 18 * (size_t)k1;
+        double T[6][3];   // W1 Vinv
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          T[r][0] = W1[r * 3] * Vi[0] + W1[r * 3 + 1] * Vi[1] + W1[r * 3 + 2] * Vi[2];
+          T[r][1] = W1[r * 3] * Vi[1] + W1[r * 3 + 1] * Vi[3] + W1[r * 3 + 2] * Vi[4];
+          T[r][2] = W1[r * 3] * Vi[2] + W1[r * 3 + 1] * Vi[4] + W1[r * 3 + 2] * Vi[5];
+          atomicAdd(&sS[n * n + 6 * c1 + r], -(W1[r * 3] * Vg[0] + W1[r * 3 + 1] * Vg[1] + W1[r * 3 + 2] * Vg[2]));
+        }
+        for (int o2 = B.pt_start[p]; o2 < B.pt_start[p + 1]; ++o2) {
+          const int k2 = B.pt_obs[o2], c2 = B.cam_idx[k2];
+          const double* W2 = B.Wpc + 18 * (size_t)k2;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+              atomicAdd(&sS[(6 * c1 + r) * n + 6 * c2 + s],
+                        -(T[r][0] * W2[s * 3] + T[r][1] * W2[s * 3 + 1] + T[r][2] * W2[s * 3 + 2]));
+        }
+      }
+    }
+  }
+  if (B.opt_cams) {
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256)
+      if (sS[e] != 0.0) atomicAdd(&B.S[e], sS[e]);
+    for (int e = tid; e < n; e += 256)
+      if (sS[n * n + e] != 0.0) atomicAdd(&B.rhs[e], sS[n * n + e]);
+  }
+}
+
+// Reduced camera system (U + lam diag U + S) dc = -(gc + rhs_schur): dense Cholesky in LDS, n = 6C <= 96.
+__global__ void __launch_bounds__(256) k_sba_cam_solve(SbaBuf B, double lam) {
+  extern __shared__ double sA[];   // [n][n+1] + [n]
+  const int n = 6 * B.C, ld = n + 1, tid = threadIdx.x;
+  double* sb = sA + n * ld;
+  for (int e = tid; e < n * n; e += 256) {
+    const int r = e / n, c = e % n;
+    double v = B.S[e];
+    if (r / 6 == c / 6) {
+      const int cam = r / 6, a = r % 6, b = c % 6;
+      const int lo = a < b ? a : b, hi = a < b ? b : a;
+      const int q = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+      double u = B.U[21 * cam + q];
+      if (a == b) u += lam * u + 1e-300;
+      v += u;
+    }
+    sA[r * ld + c] = v;
+  }
+  for (int e = tid; e < n; e += 256) sb[e] = -(B.gc[e] + B.rhs[e]);
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) {
+      double d = sA[j * ld + j];
+      if (!(d > 0.0)) {
+        B.scal[3] = 1.0;
+        d = 1.0;
+      }
+      sA[j * ld + j] = sqrt(d);
+    }
+    __syncthreads();
+    const double dj = sA[j * ld + j];
+    for (int i = j + 1 + tid; i < n; i += 256) sA[i * ld + j] /= dj;
+    __syncthreads();
+    for (int e = tid; e < (n - j - 1) * (n - j - 1); e += 256) {
+      const int i = j + 1 + e / (n - j - 1), k = j + 1 + e % (n - j - 1);
+      if (k <= i) sA[i * ld + k] -= sA[i * ld + j] * sA[k * ld + j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {   // tiny triangular solves
+    for (int i = 0; i < n; ++i) {
+      double s = sb[i];
+      for (int k = 0; k < i; ++k) s -= sA[i * ld + k] * sb[k];
+      sb[i] = s / sA[i * ld + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = sb[i];
+      for (int k = i + 1; k < n; ++k) s -= sA[k * ld + i] * sb[k];
+      sb[i] = s / sA[i * ld + i];
+    }
+    double pred = 0.0;
+    for (int i = 0; i < n; ++i) {
+      B.dc[i] = sb[i];
+      const int cam = i / 6, a = i % 6, q = a * 6 - (a * (a - 1)) / 2;
+      pred += 0.5 * sb[i] * (lam * B.U[21 * cam + q] * sb[i] - B.gc[i]);
+    }
+    atomicAdd(&B.scal[1], pred);
+  }
+}
+
+// dp = -Vinv (gp + sum_c W_pc^T dc); trial points; predicted reduction
+__global__ void __launch_bounds__(256)
+k_sba_backsub(SbaBuf B, double lam, const double* __restrict__ pts, double* __restrict__ pts_t) {
+  __shared__ double sred[4];
+  const int tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+  double pred = 0.0;
+  if (p < B.P) {
+    double s[3] = {B.gp[3 * (size_t)p], B.gp[3 * (size_t)p + 1], B.gp[3 * (size_t)p + 2]};
+    const double g0 = s[0], g1 = s[1], g2 = s[2];
+    if (B.opt_cams)
+      for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
+        const int k = B.pt_obs[o], c = B.cam_idx[k];
+        const double* W = B.Wpc + 18 * (size_t)k;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double dca = B.dc[6 * c + a];
+          s[0] += W[a * 3] * dca;
+          s[1] += W[a * 3 + 1] * dca;
+          s[2] += W[a * 3 + 2] * dca;
+        }
+      }
+    const double* Vi = B.Vinv + 6 * (size_t)p;
+    const double d0 = -(Vi[0] * s[0] + Vi[1] * s[1] + Vi[2] * s[2]), d1 = -(Vi[1] * s[0] + Vi[3] * s[1] + Vi[4] * s[2]),
+                 d2 = -(Vi[2] * s[0] + Vi[4] * s[1] + Vi[5] * s[2]);
+    pts_t[3 * (size_t)p] = pts[3 * (size_t)p] + d0;
+    pts_t[3 * (size_t)p + 1] = pts[3 * (size_t)p + 1] + d1;
+    pts_t[3 * (size_t)p + 2] = pts[3 * (size_t)p + 2] + d2;
+    const double* V = B.V + 6 * (size_t)p;
+    pred = 0.5 * (d0 * (lam * V[0] * d0 - g0) + d1 * (lam * V[3] * d1 - g1) + d2 * (lam * V[5] * d2 - g2));
+  }
+  for (int off = 32; off > 0; off >>= 1) pred += __shfl_down(pred, off, 64);
+  if ((tid & 63) == 0) sred[tid >> 6] = pred;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&B.scal[1], (sred[0] + sred[1]) + (sred[2] + sred[3]));
+}
+
+// R_t = exp([dw]x) R, t_t = t + dt
+__global__ void k_sba_apply_cams(SbaBuf B, const double* __restrict__ Rt, double* __restrict__ Rt_t) {
+  const int c = threadIdx.x;
+  if (c >= B.C) return;
+  const double* R = Rt + 12 * c;
+  double* Ro = Rt_t + 12 * c;
+  double w[3] = {0, 0, 0}, dt[3] = {0, 0, 0};
+  if (B.opt_cams) {
+    for (int j = 0; j < 3; ++j) {
+      w[j] = B.dc[6 * c + j];
+      dt[j] = B.dc[6 * c + 3 + j];
+    }
+  }
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+  double A, Bc;   // exp([w]x) = I + A [w]x + Bc [w]x^2
+  if (th < 1e-8) {
+    A = 1.0 - th2 / 6.0;
+    Bc = 0.5 - th2 / 24.0;
+  } else {
+    A = sin(th) / th;
+    Bc = (1.0 - cos(th)) / th2;
+  }
+  const double Kx[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+  double E[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double k2 = Kx[i][0] * Kx[0][j] + Kx[i][1] * Kx[1][j] + Kx[i][2] * Kx[2][j];
+      E[i][j] = (i == j ? 1.0 : 0.0) + A * Kx[i][j] + Bc * k2;
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Ro[3 * i + j] = E[i][0] * R[j] + E[i][1] * R[3 + j] + E[i][2] * R[6 + j];
+  for (int j = 0; j < 3; ++j) Ro[9 + j] = R[9 + j] + dt[j];
+}
+
+static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace acino
+
+using namespace acino;
+
+extern "C" {
+
+size_t acino_sizeof_sba_params(void) { return sizeof(acino_sba_params); }
+size_t acino_sizeof_sba_info(void) { return sizeof(acino_sba_info); }
+
+size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs) {
+  if (n_cams < 1 || n_points < 0 || n_obs < 0) return 0;
+  const size_t P = (size_t)n_points, M = (size_t)n_obs, n = 6 * (size_t)n_cams;
+  size_t b = 0;
+  b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3 + a256(M * 18 * 8);        // V, Vinv, gp, dp, pts_t, Wpc
+  b += a256(n_cams * 21 * 8) + a256(n * 8) * 3 + a256(n * n * 8) + a256(n_cams * 12 * 8) + a256(64);
+  return b + 1024;
+}
+
+// Solves in place: d_Rt[C][12] (R row-major | t) and d_pts[P][3].  d_res_before / d_res_after [M][2] may be NULL.
+int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,
+                    const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start, const int32_t* d_pt_obs,
+                    void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,
+                    void* stream) {
+  ACINO_REQUIRE(prm && info, "params/info");
+  ACINO_REQUIRE(prm->n_cams >= 1 && prm->n_cams <= SBA_MAXC, "n_cams in 1..16");
+  ACINO_REQUIRE(prm->n_points >= 1 && prm->n_obs >= 1, "sizes");
+  ACINO_REQUIRE(prm->f_scale > 0 && prm->lam0 > 0 && prm->max_iter >= 0, "f_scale, lam0, max_iter");
+  ACINO_REQUIRE(d_intr && d_Rt && d_pts && d_uv && d_cam_idx && d_pt_start && d_pt_obs && d_ws, "null buffer");
+  ACINO_REQUIRE(((uintptr_t)d_ws & 255) == 0, "workspace must be 256-byte aligned");
+  ACINO_REQUIRE(ws_bytes >= acino_sba_workspace_bytes(prm->n_cams, prm->n_points, prm->n_obs), "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = prm->n_cams;
+  const size_t P = (size_t)prm->n_points, M = (size_t)prm->n_obs, n = 6 * (size_t)C;
+  char* w = (char*)d_ws;
+  auto take = [&](size_t bytes) {
+    char* p = w;
+    w += a256(bytes);
+    return p;
+  };
+  SbaBuf B;
+  B.C = C;
+  B.P = (int)P;
+  B.M = (int)M;
+  B.opt_cams = prm->optimize_cameras ? 1 : 0;
+  B.fs = prm->f_scale;
+  B.intr = d_intr;
+  B.uv = d_uv;
+  B.cam_idx = d_cam_idx;
+  B.pt_start = d_pt_start;
+  B.pt_obs = d_pt_obs;
+  B.V = (double*)take(P * 6 * 8);
+  B.Vinv = (double*)take(P * 6 * 8);
+  B.gp = (double*)take(P * 3 * 8);
+  B.dp = (double*)take(P * 3 * 8);
+  double* pts_t = (double*)take(P * 3 * 8);
+  B.Wpc = (double*)take(M * 18 * 8);
+  B.U = (double*)take(C * 21 * 8);
+  B.gc = (double*)take(n * 8);
+  B.rhs = (double*)take(n * 8);
+  B.dc = (double*)take(n * 8);
+  B.S = (double*)take(n * n * 8);
+  double* Rt_t = (double*)take(C * 12 * 8);
+  B.scal = (double*)take(64);
+  const int nblk = (int)((P + 255) / 256);
+  const size_t lds_s = (n * n + n) * 8, lds_c = (n * (n + 1) + n) * 8;
+
+  auto eval = [&](const double* Rt, const double* pts, bool jac, double* res, double h[4]) -> int {
+    ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
+    if (jac) {
+      ACINO_HIP_CHECK(hipMemsetAsync(B.U, 0, C * 21 * 8, s));
+      ACINO_HIP_CHECK(hipMemsetAsync(B.gc, 0, n * 8, s));
+      hipLaunchKernelGGL(k_sba_point<true>, dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+    } else {
+      hipLaunchKernelGGL(k_sba_point<false>, dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+    }
+    ACINO_LAUNCH_CHECK();
+    ACINO_HIP_CHECK(hipMemcpyAsync(h, B.scal, 32, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    return ACINO_OK;
+  };
+
+  double h[4];
+  int rc = eval(d_Rt, d_pts, true, d_res_before, h);
+  if (rc) return rc;
+  double F = h[0], lam = prm->lam0, nu = 2.0;
+  info->cost_initial = F;
+  info->iterations = 0;
+  info->accepted = 0;
+  info->status = 0;
+  double gmax = h[2];
+  if (B.opt_cams) {
+    double hgc[6 * SBA_MAXC];
+    ACINO_HIP_CHECK(hipMemcpyAsync(hgc, B.gc, n * 8, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; ++i) gmax = fmax(gmax, fabs(hgc[i]));
+  }
+  for (int it = 0; it < prm->max_iter; ++it) {
+    if (gmax <= prm->gtol) {
+      info->status = 3;
+      break;
+    }
+    info->iterations = it + 1;
+    ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
+    if (B.opt_cams) {
+      ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, n * n * 8, s));
+      ACINO_HIP_CHECK(hipMemsetAsync(B.rhs, 0, n * 8, s));
+    }
+    hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
+    ACINO_LAUNCH_CHECK();
+    if (B.opt_cams) {
+      hipLaunchKernelGGL(k_sba_cam_solve, dim3(1), dim3(256), lds_c, s, B, lam);
+      ACINO_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_sba_backsub, dim3(nblk), dim3(256), 0, s, B, lam, d_pts, pts_t);
+    ACINO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sba_apply_cams, dim3(1), dim3(64), 0, s, B, d_Rt, Rt_t);
+    ACINO_LAUNCH_CHECK();
+    double hp[4];
+    ACINO_HIP_CHECK(hipMemcpyAsync(hp, B.scal, 32, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    const double pred = hp[1];
+    double ht[4] = {INFINITY, 0, 0, 0};
+    if (hp[3] == 0.0) {   // else: the damped reduced camera system lost definiteness to round-off along the free
+      rc = eval(Rt_t, pts_t, false, nullptr, ht);   // gauge (7 DoF when every camera moves) - a rejected step
+      if (rc) return rc;
+    }
+    const double Ft = ht[0];
+    const double gain = pred > 0 ? (F - Ft) / pred : -1.0;
+    if (Ft < F) {
+      const double dF = F - Ft;
+      ACINO_HIP_CHECK(hipMemcpyAsync(d_pts, pts_t, P * 3 * 8, hipMemcpyDeviceToDevice, s));
+      ACINO_HIP_CHECK(hipMemcpyAsync(d_Rt, Rt_t, C * 12 * 8, hipMemcpyDeviceToDevice, s));
+      rc = eval(d_Rt, d_pts, true, nullptr, h);
+      if (rc) return rc;
+      F = h[0];
+      gmax = h[2];
+      if (B.opt_cams) {
+        double hgc[6 * SBA_MAXC];
+        ACINO_HIP_CHECK(hipMemcpyAsync(hgc, B.gc, n * 8, hipMemcpyDeviceToHost, s));
+        ACINO_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n; ++i) gmax = fmax(gmax, fabs(hgc[i]));
+      }
+      info->accepted += 1;
+      const double t = 2.0 * gain - 1.0;
+      lam *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+      nu = 2.0;
+      if (dF <= prm->ftol * fabs(F)) {
+        info->status = 1;
+        break;
+      }
+    } else {
+      lam *= nu;
+      nu *= 2.0;
+      if (lam > 1e16) {
+        info->status = hp[3] != 0.0 ? 5 : 4;
+        if (info->status == 5) set_error("SBA: reduced camera system not positive definite at any damping");
+        break;
+      }
+    }
+  }
+  if (d_res_after) {
+    rc = eval(d_Rt, d_pts, false, d_res_after, h);
+    if (rc) return rc;
+  }
+  info->cost_final = F;
+  info->gnorm_inf = gmax;
+  info->lam = lam;
+  return info->status == 5 ? ACINO_ERR_NUMERIC : ACINO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""Sparse bundle adjustment on the GPU - drop-ins for the SBA entry points of ``src/calib/calib.py``.
+
+    prepare_calib_board_data_for_bundle_adjustment(...)            calib.py:210-263
+    prepare_manual_points_for_bundle_adjustment(...)               calib.py:266-304
+    bundle_adjust_points_only(..., project_func, f_scale=50)       calib.py:327-341
+    bundle_adjust_board_points_only(...)                           calib.py:319-324
+    bundle_adjust_points_and_extrinsics(..., project_func)         calib.py:369-390
+    bundle_adjust_board_points_and_extrinsics(...)                 calib.py:362-366
+
+Same argument order and return values (``obj_pts[, r_arr, t_arr], residuals`` with ``residuals = dict(before=,
+after=)`` flat ``(reprojected - points_2d).ravel()`` vectors).  ``project_func`` is accepted for signature
+compatibility and must be the fisheye projection (the only camera model the reference's SBA call sites inject,
+app.py:215-223); the arithmetic is the analytic-Jacobian Levenberg-Marquardt solver in csrc/sba.hip, which
+minimises the SAME robust cost as scipy's ``least_squares(loss='cauchy', f_scale=...)``.  The last solve's
+summary (costs, iterations, status) is kept in ``last_info``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, calib
+from ._lib import SbaInfo, SbaParams, check, lib, ptr, stream_ptr
+
+last_info = None
+
+
+def _check_project_func(project_func):
+    name = getattr(project_func, "__name__", "")
+    if project_func is not None and name and "fisheye" not in name:
+        raise NotImplementedError("GPU bundle adjustment implements the fisheye camera model only "
+                                  f"(got project_func={name})")
+
+
+def _csr_by_point(point_3d_indices, n_points):
+    idx = np.asarray(point_3d_indices, dtype=np.int64)
+    if idx.size and (idx.min() < 0 or idx.max() >= n_points):
+        raise ValueError("point_3d_indices out of range")
+    order = np.argsort(idx, kind="stable").astype(np.int32)
+    start = np.zeros(n_points + 1, dtype=np.int32)
+    np.cumsum(np.bincount(idx, minlength=n_points), out=start[1:])
+    return start, order
+
+
+def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, optimize_cameras,
+           f_scale, max_iter, ftol, gtol, lam0=1e-3):
+    global last_info
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n_cams = len(k_arr)
+    pts0 = np.ascontiguousarray(np.asarray(points_3d, dtype=np.float64).reshape(-1, 3))
+    uv = np.ascontiguousarray(np.asarray(points_2d, dtype=np.float64).reshape(-1, 2))
+    cam_idx = np.ascontiguousarray(np.asarray(camera_indices, dtype=np.int32).reshape(-1))
+    n_points, n_obs = pts0.shape[0], uv.shape[0]
+    if cam_idx.size != n_obs or len(point_3d_indices) != n_obs:
+        raise ValueError("points_2d, point_3d_indices and camera_indices must have one entry per observation")
+    if n_obs and (cam_idx.min() < 0 or cam_idx.max() >= n_cams):
+        raise ValueError("camera_indices out of range")
+    intr = np.zeros((n_cams, 8))
+    Rt = np.zeros((n_cams, 12))
+    for c in range(n_cams):
+        k = np.asarray(k_arr[c], dtype=np.float64)
+        if abs(k[0, 1]) > 1e-12 * abs(k[0, 0]):
+            raise NotImplementedError("skewed intrinsics are not supported by the GPU bundle adjustment "
+                                      "(calib.py:78 calibrates with CALIB_FIX_SKEW)")
+        intr[c] = [k[0, 0], k[1, 1], k[0, 2], k[1, 2], *np.asarray(d_arr[c], dtype=np.float64).reshape(-1)[:4]]
+        r = np.asarray(r_arr[c], dtype=np.float64)
+        r = calib._rodrigues(r) if r.size == 3 else r
+        if optimize_cameras:                      # calib.py:373 passes every rotation through cv2.Rodrigues, which
+            u, _s, vt = np.linalg.svd(r)          # projects it onto SO(3) (scene files carry ~1e-8 of round-off)
+            r = u @ vt
+        Rt[c, :9] = r.reshape(-1)
+        Rt[c, 9:] = np.asarray(t_arr[c], dtype=np.float64).reshape(-1)
+    start, order = _csr_by_point(point_3d_indices, n_points)
+
+    prm = SbaParams(n_cams=n_cams, optimize_cameras=int(bool(optimize_cameras)), n_points=n_points, n_obs=n_obs,
+                    f_scale=float(f_scale), lam0=float(lam0), ftol=float(ftol), gtol=float(gtol), max_iter=int(max_iter))
+    nbytes = lib().acino_sba_workspace_bytes(n_cams, n_points, n_obs)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+    d = lambda a: torch.as_tensor(a, device=dev)
+    d_intr, d_Rt, d_pts, d_uv = d(intr), d(Rt), d(pts0), d(uv)
+    d_cam, d_start, d_order = d(cam_idx), d(start), d(order)
+    res_b = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
+    res_a = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
+    info = SbaInfo()
+    check(lib().acino_sba_solve(C.byref(prm), ptr(d_intr), ptr(d_Rt), ptr(d_pts), ptr(d_uv), ptr(d_cam), ptr(d_start),
+                                ptr(d_order), C.c_void_p(ws_ptr), nbytes, ptr(res_b), ptr(res_a), C.byref(info),
+                                stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    last_info = info.as_dict()
+    Rt_o = d_Rt.cpu().numpy()
+    return (d_pts.cpu().numpy(), Rt_o[:, :9].reshape(n_cams, 3, 3).copy(), Rt_o[:, 9:].reshape(n_cams, 3, 1).copy(),
+            dict(before=res_b.cpu().numpy().ravel(), after=res_a.cpu().numpy().ravel()))
+
+
+def bundle_adjust_points_only(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr,
+                              project_func=None, f_scale=50, max_iter=200, ftol=1e-15, gtol=1e-10):
+    """calib.py:327-341: refine the 3-D points, cameras fixed; Cauchy loss with scale ``f_scale`` px."""
+    _check_project_func(project_func)
+    pts, _r, _t, residuals = _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr,
+                                    False, f_scale, max_iter, ftol, gtol)
+    return pts, residuals
+
+
+def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr,
+                                        t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10):
+    """calib.py:369-390: refine the 3-D points and every camera's rotation + translation (Cauchy loss, scale 1)."""
+    _check_project_func(project_func)
+    return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
+                  max_iter, ftol, gtol)
+
+
+def prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,
+                                                   triangulate_func=None):
+    """calib.py:210-263.  Boards seen by >= 2 cameras, in sorted file-name order (the reference iterates a
+    set-built dict, i.e. an arbitrary order; the optimum does not depend on it).  Initial points from the first two
+    cameras that see each board, all boards triangulated in one batched launch per camera pair."""
+    triangulate_func = triangulate_func or calib.triangulate_points_fisheye
+    n_cam = len(img_pts_arr)
+    fnames_arr = [list(f) for f in fnames_arr]
+    count = {}
+    for fnames in fnames_arr:
+        for f in set(fnames):
+            count[f] = count.get(f, 0) + 1
+    keep = sorted(f for f, v in count.items() if v >= 2)
+    per_img = int(board_shape[0] * board_shape[1])
+    lookup = [{f: i for i, f in reversed(list(enumerate(fnames)))} for fnames in fnames_arr]   # .index() = first hit
+    points_2d, point_3d_indices, camera_indices = [], [], []
+    pair_jobs = {}
+    for b, fname in enumerate(keep):
+        seen = [(cam, lookup[cam][fname]) for cam in range(n_cam) if fname in lookup[cam]]
+        for cam, f_idx in seen:
+            points_2d.append(np.asarray(img_pts_arr[cam][f_idx], dtype=np.float64).reshape(per_img, 2))
+            point_3d_indices.append(np.arange(b * per_img, (b + 1) * per_img))
+            camera_indices.append(np.full(per_img, cam))
+        (ca, fa), (cb, fb) = seen[0], seen[1]
+        pair_jobs.setdefault((ca, cb), []).append((b, fa, fb))
+    points_3d = np.zeros((len(keep) * per_img, 3))
+    for (ca, cb), jobs in pair_jobs.items():
+        pa = np.concatenate([np.asarray(img_pts_arr[ca][fa], dtype=np.float64).reshape(per_img, 2) for _, fa, _ in jobs])
+        pb = np.concatenate([np.asarray(img_pts_arr[cb][fb], dtype=np.float64).reshape(per_img, 2) for _, _, fb in jobs])
+        est = np.asarray(triangulate_func(pa, pb, k_arr[ca], d_arr[ca], r_arr[ca], t_arr[ca],
+                                          k_arr[cb], d_arr[cb], r_arr[cb], t_arr[cb])).reshape(-1, 3)
+        for j, (b, _, _) in enumerate(jobs):
+            points_3d[b * per_img:(b + 1) * per_img] = est[j * per_img:(j + 1) * per_img]
+    if not keep:
+        return (np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, int), np.zeros(0, int))
+    return (np.concatenate(points_2d).astype(np.float32), points_3d.astype(np.float32),
+            np.concatenate(point_3d_indices).astype(int), np.concatenate(camera_indices).astype(int))
+
+
+def prepare_manual_points_for_bundle_adjustment(img_pts_arr, k_arr, d_arr, r_arr, t_arr, triangulate_func=None):
+    """calib.py:266-304: img_pts_arr[n_points, n_cameras, 2] with NaN where a camera does not see the point."""
+    triangulate_func = triangulate_func or calib.triangulate_points_fisheye
+    pts = np.asarray(img_pts_arr, dtype=np.float64).swapaxes(0, 1)
+    n_cam, n_pts = pts.shape[0], pts.shape[1]
+    points_2d, point_3d_indices, camera_indices, first_two = [], [], [], []
+    p = 0
+    for i in range(n_pts):
+        cams = [c for c in range(n_cam) if not np.isnan(pts[c, i]).any()]
+        if len(cams) > 1:
+            points_2d.extend(pts[c, i] for c in cams)
+            camera_indices.extend(cams)
+            point_3d_indices.extend([p] * len(cams))
+            first_two.append((cams[0], cams[1], i))
+            p += 1
+    points_3d = np.zeros((p, 1, 3))
+    groups = {}
+    for j, (a, b, i) in enumerate(first_two):
+        groups.setdefault((a, b), []).append((j, i))
+    for (a, b), items in groups.items():
+        ia = np.array([i for _, i in items])
+        est = np.asarray(triangulate_func(pts[a, ia], pts[b, ia], k_arr[a], d_arr[a], r_arr[a], t_arr[a],
+                                          k_arr[b], d_arr[b], r_arr[b], t_arr[b])).reshape(-1, 3)
+        points_3d[[j for j, _ in items], 0] = est
+    return (np.array(points_2d, dtype=np.float32).reshape(-1, 2), points_3d.astype(np.float32),
+            np.array(point_3d_indices, dtype=int), np.array(camera_indices, dtype=int))
+
+
+def bundle_adjust_board_points_only(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,
+                                    triangulate_func=None, project_func=None):
+    """calib.py:319-324."""
+    data = prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr,
+                                                          t_arr, triangulate_func)
+    return bundle_adjust_points_only(*data, k_arr, d_arr, r_arr, t_arr, project_func)
+
+
+def bundle_adjust_board_points_and_extrinsics(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,
+                                              triangulate_func=None, project_func=None):
+    """calib.py:362-366."""
+    data = prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr,
+                                                          t_arr, triangulate_func)
+    return bundle_adjust_points_and_extrinsics(*data, k_arr, d_arr, r_arr, t_arr, project_func)

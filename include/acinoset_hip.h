@@ -217,6 +217,40 @@ int acino_fte_trial(acino_fte_ctx* ctx, void* stream);
 /* First / last 3 frames of iterate `which` -> d_edge[6][25]. */
 int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* stream);
 
+/* ---- sparse bundle adjustment ------------------------------------------------------
+ * Replaces scipy.optimize.least_squares(method='trf', loss='cauchy', f_scale=...) inside
+ * bundle_adjust_points_and_extrinsics (src/calib/calib.py:345-390) and bundle_adjust_points_only
+ * (src/calib/calib.py:307-341).  Cost = sum over observations and both pixel axes of 0.5 f^2 log1p((r/f)^2),
+ * scipy's definition, so costs compare 1:1 with `res.cost`.  Observations arrive flat: uv[M][2], cam_idx[M]; the host
+ * also supplies the CSR grouping by point (pt_start[P+1], pt_obs[M]).  Poses are [R row-major 9 | t 3] per camera and
+ * are updated in place together with the points. */
+typedef struct acino_sba_params {
+  int32_t n_cams;
+  int32_t optimize_cameras;   /* 0 = points only (calib.py:327), 1 = points + extrinsics (calib.py:369) */
+  int64_t n_points;
+  int64_t n_obs;
+  double f_scale;             /* Cauchy scale in px: 1 (scipy default, calib.py:381) or 50 (calib.py:327,335) */
+  double lam0;                /* initial Marquardt damping (1e-3) */
+  double ftol;                /* stop when an accepted step lowers the cost by <= ftol * cost */
+  double gtol;                /* stop when ||J^T W r||_inf <= gtol */
+  int32_t max_iter;
+  int32_t pad0;
+} acino_sba_params;
+typedef struct acino_sba_info {
+  double cost_initial, cost_final, gnorm_inf, lam;
+  int32_t iterations, accepted;
+  int32_t status;             /* 0 max_iter, 1 ftol, 3 gtol, 4 lambda overflow, 5 numeric failure */
+  int32_t pad0;
+} acino_sba_info;
+size_t acino_sizeof_sba_params(void);
+size_t acino_sizeof_sba_info(void);
+size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs);
+/* d_intr[C][8] = fx fy cx cy k1..k4; d_res_before / d_res_after [M][2] (projected - observed, as calib.py:316,359) or NULL. */
+int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,
+                    const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start, const int32_t* d_pt_obs,
+                    void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,
+                    void* stream);
+
 /* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
 

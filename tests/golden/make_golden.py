@@ -214,6 +214,9 @@ def gen_kat1():
     # recorded in src/calib_with_gui.ipynb cell 29 outputs
     out["recorded"] = np.array([[-8.4537e-05, 0.18570246, 5.4156e+01],
                                 [9.63562157113121e-05, 0.11887400393186973, 2.3636e+01]])
+    # KAT-2, same cell: SBA end state [final cost, nfev, after-mean, after-std] (rotating, static)
+    out["recorded_sba"] = np.array([[5.3361e+01, 690, 0.000692245847955209, 0.18554028389811675],
+                                    [2.2845e+01, 50, 0.0013407166365445877, 0.1167727653391298]])
     np.savez_compressed(os.path.join(OUT, "kat1_sunday_amelia.npz"), **out)
     print("kat1:", {k: v.shape for k, v in out.items() if "points" in k})
 
