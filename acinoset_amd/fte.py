@@ -257,3 +257,80 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
     results = dict(positions=conv(pos), x=conv(x), dx=conv(dx), ddx=conv(ddx), start_frame=start_frame)
     return results, info
+
+
+def fte_solve_batch(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0.5, start_frames=None, max_iter=100,
+                    init="nose_line", n_streams=8, peek_every=8, return_numpy=True, **kw):
+    """Several independent sequences (BASELINE config 5's "batched FTE": one rig, many clips) solved concurrently
+    on ONE GPU.  Every sequence gets its own context and runs on one of ``n_streams`` HIP streams; a Levenberg-
+    Marquardt step never synchronises with the host (the accept/reject controller is a device kernel and the step is
+    one hipGraph launch), so the streams interleave and the narrow levels of one sequence's block-cyclic reduction
+    overlap with the wide levels of another's (HIP multiplexes the streams onto 4 hardware queues by default; 8 streams
+    keep all of them busy whatever the stream-to-queue assignment).  ``dets``: list of det[N_b, C, 20, 3] (lengths may differ).
+    Returns a list of (results, info) exactly as ``fte_solve`` would for each sequence alone.  The reference solves
+    clips one after another (src/all_optimizations.py:22, one ``fte()`` call per data directory)."""
+    _lib.require_gpu()
+    B = len(dets)
+    if B == 0:
+        return []
+    start_frames = list(start_frames) if start_frames is not None else [0] * B
+    streams = [torch.cuda.Stream() for _ in range(max(1, min(int(n_streams), B)))]
+    inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
+    ctxs = []
+    try:
+        for b, det in enumerate(dets):
+            det = det if isinstance(det, torch.Tensor) else torch.as_tensor(np.asarray(det, dtype=np.float64))
+            if x0s is not None and x0s[b] is not None:
+                x0 = x0s[b]
+            elif init == "nose_line":
+                x0 = nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, start_frame=start_frames[b])
+            elif init == "triangulation":
+                x0 = triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh)
+            else:
+                raise ValueError("init must be 'nose_line' or 'triangulation'")
+            x0 = np.asarray(x0.cpu().numpy() if isinstance(x0, torch.Tensor) else x0, dtype=np.float64)
+            if x0.shape != (det.shape[0], N_STATES):
+                raise ValueError(f"x0 of sequence {b} must be [N, 45]")
+            if np.any(x0[:, inactive] != 0):
+                raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
+            s = streams[b % len(streams)]
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+                ctxs.append(ctx)
+                ctx.enable_graph(True)
+                ctx.set_x(x0[:, ACTIVE])
+        infos = [None] * B
+        running = list(range(B))
+        done_iter = 0
+        while running and done_iter < max_iter:
+            chunk = min(int(peek_every), max_iter - done_iter)
+            for _ in range(chunk):
+                for b in running:
+                    with torch.cuda.stream(streams[b % len(streams)]):
+                        ctxs[b].step()
+            done_iter += chunk
+            still = []
+            for b in running:
+                with torch.cuda.stream(streams[b % len(streams)]):
+                    infos[b] = ctxs[b].state()
+                if infos[b]["status"] == 0:
+                    still.append(b)
+            running = still
+        out = []
+        conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
+        for b in range(B):
+            with torch.cuda.stream(streams[b % len(streams)]):
+                if infos[b] is None:
+                    infos[b] = ctxs[b].state()
+                if infos[b]["status"] == 5:
+                    raise RuntimeError(f"FTE: block factorisation hit a non-positive pivot (sequence {b})")
+                x, pos, dx, ddx = ctxs[b].result()
+                out.append((dict(positions=conv(pos), x=conv(x), dx=conv(dx), ddx=conv(ddx), start_frame=start_frames[b]),
+                            infos[b]))
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
+        return out
+    finally:
+        for ctx in ctxs:
+            ctx.close()

@@ -71,6 +71,86 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
                        f"frames of the same sequence, 1 thread, {dt:.1f} s")
 
 
+def secondary_metrics(det, rig, Ts):
+    """SURVEY 8(d)'s other two quantities, single GPU: config 2 (triangulation + reprojection residual over the
+    whole 10 000-frame detection tensor, HBM-resident) and the end-to-end solve wall-clock to a fixed tolerance
+    (config 3: 1 000 frames from the reference's nose-line initialisation; and the benchmark sequence itself)."""
+    from acinoset_amd import calib, fte, synth
+    from acinoset_amd._lib import check, lib, ptr, stream_ptr
+    out = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.as_tensor(det, device=dev)
+    N, Cn, L, _ = d.shape
+    cams = torch.as_tensor(calib.fisheye_records(*rig), device=dev)
+    tri = torch.empty((N, L, 3), dtype=torch.float64, device=dev)
+    npairs = torch.empty((N, L), dtype=torch.uint8, device=dev)
+    mask = torch.empty((N, L), dtype=torch.uint8, device=dev)
+    res = torch.empty((N, Cn, L, 2), dtype=torch.float64, device=dev)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def once():
+        check(lib().acino_triangulate_pairs(ptr(d), N, Cn, L, 0.5, ptr(cams), ptr(tri), ptr(npairs), ptr(mask), stream_ptr()))
+        check(lib().acino_reproject_residuals(ptr(tri), ptr(d), N, Cn, L, 0.5, ptr(cams), ptr(res), ptr(sums), stream_ptr()))
+    for _ in range(3):
+        once()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per_frame = Cn * L * 3 * 8 + L * 3 * 8 + 2 * L + (L * 3 * 8 + Cn * L * 3 * 8 + Cn * L * 2 * 8)   # both kernels, in + out
+    out["config2_triangulate_reproject"] = dict(frames=N, ms=ms, frames_per_s=N / (ms * 1e-3),
+                                                hbm_gbs=N * bytes_per_frame / (ms * 1e-3) / 1e9,
+                                                frac_hbm=N * bytes_per_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                algorithmic_bytes_per_frame=bytes_per_frame)
+    # config 3: 1 000-frame sprint, nose-line init (all_optimizations.py:268-277), solve to the default tolerances (ftol = xtol = 1e-10)
+    seq = synth.make_sequence(1000, "sprint")
+    r3 = (seq["K"], seq["D"], seq["R"], seq["t"])
+    det3 = torch.as_tensor(seq["det"], device=dev)
+    for tag in ("warm", "timed"):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _res, info = fte.fte_solve(det3[..., :2], det3[..., 2], *r3, Ts=seq["Ts"], max_iter=200, return_numpy=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out["config3_solve_1k_frames"] = dict(seconds=dt, iterations=info["iter"], status=info["status_name"], cost=info["cost"],
+                                          init="nose line", includes="init triangulation, workspace setup, LM loop, outputs")
+    # config 5's FTE half on one GPU: 8 clips x 1 000 frames, one HIP stream each (the runtime multiplexes them onto its 4 hardware queues), 20 LM steps
+    x3 = fte.nose_line_init(det3, *r3, 0.5)[:, fte.ACTIVE]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    ctxs = []
+    for b in range(8):
+        with torch.cuda.stream(streams[b % 8]):
+            c = fte.FTEContext(det3, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+            c.enable_graph(True)
+            c.set_x(x3)
+            for _ in range(3):
+                c.step()
+            ctxs.append(c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        for b, c in enumerate(ctxs):
+            with torch.cuda.stream(streams[b % 8]):
+                c.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    out["config5_batched_fte_8x1k"] = dict(sequences=8, frames_each=1000, steps=20, streams=8, ms_per_round=1e3 * dt / 20,
+                                           frames_per_s=8 * 1000 * 20 / dt, precision="f64 (the bf16-residual variant is not built)")
+    t0 = time.perf_counter()
+    _res, info = fte.fte_solve(d[..., :2], d[..., 2], *rig, Ts=Ts, max_iter=200, init="triangulation", return_numpy=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["solve_10k_frames"] = dict(seconds=dt, iterations=info["iter"], status=info["status_name"], cost=info["cost"],
+                                   init="per-frame triangulation", frames_per_s_end_to_end=N / dt)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / solve-to-tolerance extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
     args = ap.parse_args()
 
@@ -202,6 +283,8 @@ def main():
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name")},
         }
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_metrics(det, rig, seq["Ts"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det, rig, seq["Ts"], x0_full)
         elif world > 1:

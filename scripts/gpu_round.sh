@@ -9,8 +9,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/rocprof_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/rocprof_pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_write.err
 cd $R
 tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log | tail -2; cat $OUT/bench.json | cut -c1-600; ls -R $OUT | head -40

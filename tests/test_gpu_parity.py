@@ -326,3 +326,20 @@ def test_full_size_properties(mods):
     st = ctx.state()
     assert st["status"] in (0, 1, 2, 3) and st["n_behind"] == 0
     ctx.close()
+
+
+def test_batched_sequences_equal_individual_solves(mods):
+    """fte_solve_batch (config 5's batched FTE: one context + HIP stream per clip, interleaved launches) returns for
+    every clip what fte_solve returns for it alone."""
+    calib, fte, synth = mods
+    seqs = [synth.make_sequence(n, "sprint", seed=20210313 + i) for i, n in enumerate((48, 61, 90, 33, 75))]
+    rig = (seqs[0]["K"], seqs[0]["D"], seqs[0]["R"], seqs[0]["t"])
+    batch = fte.fte_solve_batch([s["det"] for s in seqs], *rig, seqs[0]["Ts"], max_iter=60, n_streams=3)
+    assert len(batch) == 5
+    for s, (res, info) in zip(seqs, batch):
+        one, info1 = fte.fte_solve(s["det"][..., :2], s["det"][..., 2], *rig, Ts=s["Ts"], max_iter=60)
+        assert info["status_name"] == info1["status_name"] and info["iter"] == info1["iter"]
+        assert abs(info["cost"] - info1["cost"]) <= 1e-9 * abs(info1["cost"])
+        for k in ("x", "positions", "dx", "ddx"):
+            assert res[k].shape == one[k].shape and np.abs(res[k] - one[k]).max() < 1e-7 * max(1.0, np.abs(one[k]).max())
+    assert fte.fte_solve_batch([], *rig, seqs[0]["Ts"]) == []
