@@ -45,6 +45,11 @@ class FteState(C.Structure):
         return d
 
 
+class SkelOp(C.Structure):
+    _fields_ = [("child", C.c_int32), ("parent", C.c_int32), ("angle", C.c_int32), ("flags", C.c_int32),
+                ("off", C.c_double * 3)]
+
+
 class SbaParams(C.Structure):
     _fields_ = [("n_cams", C.c_int32), ("optimize_cameras", C.c_int32), ("n_points", C.c_int64), ("n_obs", C.c_int64),
                 ("f_scale", C.c_double), ("lam0", C.c_double), ("ftol", C.c_double), ("gtol", C.c_double),
@@ -115,6 +120,7 @@ SIGNATURES = {
     "acino_sizeof_sba_info": (_Z, []),
     "acino_sba_workspace_bytes": (_Z, [_I, _L, _L]),
     "acino_sba_solve": (_I, [C.POINTER(SbaParams), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P, C.POINTER(SbaInfo), _P]),
+    "acino_skeleton_fk": (_I, [_P, _L, _I, _I, C.POINTER(SkelOp), _I, _P, _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
 }
 

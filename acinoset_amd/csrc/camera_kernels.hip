@@ -376,3 +376,93 @@ int acino_reproject_residuals(const double* d_pts3, const double* d_det, int64_t
 }
 
 }  // extern "C"
+
+// ---- generic-skeleton forward kinematics (build.py:28-86) ---------------------------------------------------
+namespace acino {
+struct SkelProgram {
+  int n_ops, n_pose, n_angles, pad;
+  acino_skel_op op[ACINO_SKEL_MAX_OPS];
+};
+
+// One thread per frame; the program is tiny and uniform, poses live in the output array (each thread re-reads
+// only what it wrote itself).
+__global__ void __launch_bounds__(256)
+k_skeleton_fk(const double* __restrict__ q, int64_t n_frames, SkelProgram P, double* __restrict__ pos) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= n_frames) return;
+  const int L = P.n_angles;
+  const double* x = q + n * (3 + 3 * L);
+  double* out = pos + n * P.n_pose * 3;
+  const double rx = x[0], ry = x[1], rz = x[2];
+  for (int s = 0; s < P.n_pose; ++s) {
+    out[3 * s] = rx;
+    out[3 * s + 1] = ry;
+    out[3 * s + 2] = rz;
+  }
+  for (int k = 0; k < P.n_ops; ++k) {
+    const acino_skel_op& o = P.op[k];
+    // R_loc = Rz(psi) Rx(phi) Ry(theta), reference convention rot_x = [[1,0,0],[0,c,s],[0,-s,c]] etc.
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (o.flags & 2) {
+      double s, c;
+      sincos(x[3 + L + o.angle], &s, &c);
+      R[0][0] = c; R[0][2] = -s; R[2][0] = s; R[2][2] = c;
+    }
+    if (o.flags & 1) {   // R = Rx @ R
+      double s, c;
+      sincos(x[3 + o.angle], &s, &c);
+      for (int j = 0; j < 3; ++j) {
+        const double r1 = R[1][j], r2 = R[2][j];
+        R[1][j] = c * r1 + s * r2;
+        R[2][j] = -s * r1 + c * r2;
+      }
+    }
+    if (o.flags & 4) {   // R = Rz @ R
+      double s, c;
+      sincos(x[3 + 2 * L + o.angle], &s, &c);
+      for (int j = 0; j < 3; ++j) {
+        const double r0 = R[0][j], r1 = R[1][j];
+        R[0][j] = c * r0 + s * r1;
+        R[1][j] = -s * r0 + c * r1;
+      }
+    }
+    const double* pp = out + 3 * o.parent;
+    const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    double d[3];
+    if (o.flags & 8) {
+      for (int i = 0; i < 3; ++i) d[i] = R[i][0] * o.off[0] + R[i][1] * o.off[1] + R[i][2] * o.off[2];
+    } else {
+      for (int i = 0; i < 3; ++i) d[i] = R[0][i] * o.off[0] + R[1][i] * o.off[1] + R[2][i] * o.off[2];
+    }
+    double* pc = out + 3 * o.child;
+    pc[0] = p0 + d[0];
+    pc[1] = p1 + d[1];
+    pc[2] = p2 + d[2];
+  }
+}
+}  // namespace acino
+
+extern "C" int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_pose,
+                                 const acino_skel_op* h_ops, int n_ops, double* d_pos, void* stream) {
+  using namespace acino;
+  ACINO_REQUIRE(n_frames >= 0, "n_frames");
+  ACINO_REQUIRE(n_angles >= 1 && n_pose >= 1 && n_pose <= ACINO_SKEL_MAX_OPS + 1, "n_angles, n_pose");
+  ACINO_REQUIRE(n_ops >= 0 && n_ops <= ACINO_SKEL_MAX_OPS, "n_ops <= ACINO_SKEL_MAX_OPS");
+  if (n_frames == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_q && d_pos && (h_ops || n_ops == 0), "null buffer");
+  SkelProgram P;
+  memset(&P, 0, sizeof(P));
+  P.n_ops = n_ops;
+  P.n_pose = n_pose;
+  P.n_angles = n_angles;
+  for (int k = 0; k < n_ops; ++k) {
+    const acino_skel_op& o = h_ops[k];
+    ACINO_REQUIRE(o.child >= 0 && o.child < n_pose && o.parent >= 0 && o.parent < n_pose, "op slot out of range");
+    ACINO_REQUIRE(o.angle >= 0 && o.angle < n_angles, "op angle index out of range");
+    P.op[k] = o;
+  }
+  hipLaunchKernelGGL(k_skeleton_fk, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_q,
+                     n_frames, P, d_pos);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}

@@ -251,6 +251,20 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
                     void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,
                     void* stream);
 
+/* ---- generic-skeleton forward kinematics (src/build.py:28-86) ---------------------------
+ * The host compiles a skeleton dictionary into <= ACINO_SKEL_MAX_OPS link operations, evaluated in order for every
+ * frame:  pose[child] = pose[parent] + M @ off,  M = R_loc or R_loc^T of the PARENT part's own angles
+ * (phi, theta, psi at q[3+angle], q[3+L+angle], q[3+2L+angle]; R_loc = Rz(psi) Rx(phi) Ry(theta) restricted to the
+ * dofs in flags bits 0..2; bit 3 set = use R_loc, clear = R_loc^T).  All n_pose slots start at the root (x, y, z). */
+#define ACINO_SKEL_MAX_OPS 64
+typedef struct acino_skel_op {
+  int32_t child, parent, angle, flags;
+  double off[3];
+} acino_skel_op;
+/* d_q[N][3 + 3 L] -> d_pos[N][n_pose][3]; h_ops is a HOST array. */
+int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_pose, const acino_skel_op* h_ops,
+                      int n_ops, double* d_pos, void* stream);
+
 /* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
 
