@@ -55,71 +55,63 @@ __device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const do
 
 // One wave (all 64 lanes): Cholesky of the symmetric 16x16 tile T (LDS, leading dim LD) and the inverse of
 // its factor, entirely in registers.  Lane (i = lane & 15, k = lane >> 4) holds row i, columns {k, k+4, k+8,
-// k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  Columns are processed in
-// four panels of four: inside a panel the rank-1 updates touch only the panel (two cross-lane fetches and
-// one FMA per pivot), then ONE v_mfma_f64_16x16x4 applies the rank-4 update C -= P P^T to the rest of the
-// tile - the finished panel register is already both the A and the B operand.  The inverse X = L^-1 is
-// built by 4-row blocks the same way (4x4 diagonal inverses in scalars, one MFMA per block accumulates
-// L X for the rows below).  The tile is OVERWRITTEN by U_kk = X^T (upper triangular); L_kk is not kept.
+// k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  The right-looking column
+// operations that turn C into L are applied at the same time to an identity tile (uacc), which they turn into
+// U = L^-T: no separate triangular inversion.  Columns go in four panels of four: every lane gathers its row's
+// four panel entries (one cross-lane exchange per PANEL), the pivots and multipliers L[4s+k'][c] are
+// wave-uniform and travel through SGPRs (v_readlane), so the 16-pivot dependency chain is readlane -> rsq ->
+// Newton -> mul -> readlane -> fma; ONE v_mfma_f64_16x16x4 per tile then applies the rank-4 update to the
+// remaining columns (the finished panel register is already both the A and the B operand).  The tile is
+// OVERWRITTEN by U_kk (upper triangular); L_kk is not kept.
 __device__ void chol16_inv(double* T, int lane, int* err) {
   const int i = lane & 15, k = lane >> 4;
-  d4 acc;
+  d4 acc, uacc;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = T[(k + 4 * r) * LD + i];
-  double dinv[16];
-  d4 Lp;
+  for (int r = 0; r < 4; ++r) {
+    acc[r] = T[(k + 4 * r) * LD + i];
+    uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
+  }
   bool bad = false;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    double p = acc[s];
+    double col[4], ucol[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      col[kk] = __shfl(acc[s], i + 16 * kk, 64);
+      ucol[kk] = __shfl(uacc[s], i + 16 * kk, 64);
+    }
 #pragma unroll
     for (int k0 = 0; k0 < 4; ++k0) {
       const int c = 4 * s + k0;
-      double piv = readlane_d(p, c + 16 * k0);
-      if (!(piv > 0.0)) {
-        bad = true;
-        piv = 1.0;
-      }
-      const double inv = rsqrt(piv);
-      dinv[c] = inv;
-      const double pc = (i == c) ? piv * inv : (i > c ? p * inv : 0.0);
-      p = (k == k0) ? pc : p;
-      if (k0 < 3) {
-        const double lic = __shfl(p, i + 16 * k0, 64);           // L[i][c]      (my row)
-        const double lkc = __shfl(p, 4 * s + k + 16 * k0, 64);   // L[4s+k][c]   (my column, used when k > k0)
-        p = (k > k0) ? p - lic * lkc : p;
+      const double piv0 = readlane_d(col[k0], c);
+      bad |= !(piv0 > 0.0);                                   // flagged off the dependency chain
+      const double piv = fmax(piv0, 1e-300);
+      // 1/sqrt(piv): hardware estimate + one coupled Newton step (4 fp64 ops on the chain, no range fix-ups:
+      // piv is a positive normal number here)
+      double y = __builtin_amdgcn_rsq(piv);
+      const double e = fma(-(piv * y), y, 1.0);
+      y = fma(y * e, fma(e, 0.375, 0.5), y);
+      col[k0] *= y;                                           // row c becomes sqrt(piv); rows < c hold don't-cares
+      ucol[k0] *= y;
+#pragma unroll
+      for (int kk = k0 + 1; kk < 4; ++kk) {
+        const double m = readlane_d(col[k0], 4 * s + kk);     // L[4s+kk][c]
+        col[kk] -= col[k0] * m;
+        ucol[kk] -= ucol[k0] * m;
       }
     }
-    Lp[s] = p;
-    if (s < 3) acc = mfma(-p, p, acc);
-  }
-  d4 X;
-  d4 tacc = {0, 0, 0, 0};
+    if (k == 0) {                                             // U[i][4s .. 4s+3] is final
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const double l10 = readlane_d(Lp[a], 4 * a + 1), l20 = readlane_d(Lp[a], 4 * a + 2),
-                 l30 = readlane_d(Lp[a], 4 * a + 3), l21 = readlane_d(Lp[a], 4 * a + 2 + 16),
-                 l31 = readlane_d(Lp[a], 4 * a + 3 + 16), l32 = readlane_d(Lp[a], 4 * a + 3 + 32);
-    const double x00 = dinv[4 * a], x11 = dinv[4 * a + 1], x22 = dinv[4 * a + 2], x33 = dinv[4 * a + 3];
-    const double x10 = -x11 * (l10 * x00);
-    const double x20 = -x22 * (l20 * x00 + l21 * x10), x21 = -x22 * (l21 * x11);
-    const double x30 = -x33 * (l30 * x00 + l31 * x10 + l32 * x20), x31 = -x33 * (l31 * x11 + l32 * x21),
-                 x32 = -x33 * (l32 * x22);
-    const double c0 = k == 0 ? x00 : (k == 1 ? x10 : (k == 2 ? x20 : x30));
-    const double c1 = k == 1 ? x11 : (k == 2 ? x21 : (k == 3 ? x31 : 0.0));
-    const double c2 = k == 2 ? x22 : (k == 3 ? x32 : 0.0);
-    const double c3 = k == 3 ? x33 : 0.0;
-    const double t = tacc[a];
-    const double t0 = __shfl(t, i, 64), t1 = __shfl(t, i + 16, 64), t2 = __shfl(t, i + 32, 64),
-                 t3 = __shfl(t, i + 48, 64);
-    const double lower = -(c0 * t0 + c1 * t1 + c2 * t2 + c3 * t3);
-    const int v = i - 4 * a;
-    const double diag = v == 0 ? c0 : (v == 1 ? c1 : (v == 2 ? c2 : c3));
-    X[a] = (v < 0) ? lower : (v < 4 ? diag : 0.0);             // lane (n=i, kk=k): X[4a+kk][n]
-    if (a < 3) tacc = mfma(Lp[a], X[a], tacc);
+      for (int kk = 0; kk < 4; ++kk) T[i * LD + 4 * s + kk] = ucol[kk];
+    }
+    if (s < 3) {
+      const double pk = k == 0 ? col[0] : (k == 1 ? col[1] : (k == 2 ? col[2] : col[3]));
+      const double p = (i >= 4 * s + k) ? pk : 0.0;           // strictly-upper entries are discarded here, once
+      const double pu = k == 0 ? ucol[0] : (k == 1 ? ucol[1] : (k == 2 ? ucol[2] : ucol[3]));
+      acc = mfma(-p, p, acc);
+      uacc = mfma(-p, pu, uacc);     // register r of lane (i,k) is result[4r+k][i] = -(P PU^T)[4r+k][i] = dU[i][4r+k]
+    }
   }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) T[i * LD + 4 * a + k] = X[a];    // U_kk[n][4a+kk] = X[4a+kk][n]
   if (bad && err && lane == 0) atomicExch(err, 1);
 }
 

@@ -12,5 +12,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/rocprof_pmc_sq -o sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_sq.err
 cd $R
+python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log | tail -2; cat $OUT/bench.json | cut -c1-600; ls -R $OUT | head -40
