@@ -63,14 +63,11 @@ __device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const do
 // Newton -> mul -> readlane -> fma; ONE v_mfma_f64_16x16x4 per tile then applies the rank-4 update to the
 // remaining columns (the finished panel register is already both the A and the B operand).  The tile is
 // OVERWRITTEN by U_kk (upper triangular); L_kk is not kept.
-__device__ void chol16_inv(double* T, int lane, int* err) {
+__device__ __forceinline__ void chol16_inv_acc(double* T, d4 acc, int lane, int* err) {
   const int i = lane & 15, k = lane >> 4;
-  d4 acc, uacc;
+  d4 uacc;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    acc[r] = T[(k + 4 * r) * LD + i];
-    uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
-  }
+  for (int r = 0; r < 4; ++r) uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
   bool bad = false;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -114,39 +111,64 @@ __device__ void chol16_inv(double* T, int lane, int* err) {
   }
   if (bad && err && lane == 0) atomicExch(err, 1);
 }
+__device__ void chol16_inv(double* T, int lane, int* err) {
+  const int i = lane & 15, k = lane >> 4;
+  d4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T[(k + 4 * r) * LD + i];
+  chol16_inv_acc(T, acc, lane, err);
+}
 
 // Blocked Cholesky of the 80x80 matrix in LDS.  On exit: strictly-lower tiles hold L(ib,jb), diagonal
 // tiles hold U_kk = (L_kk^-1)^T.  All 256 threads.
 __device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  for (int kb = 0; kb < NT; ++kb) {
+  if (wave == 0) chol16_inv(Lm, lane, err);
+  __syncthreads();
+  for (int kb = 0; kb < NT - 1; ++kb) {
     double* Ukk = Lm + (kb * 16) * LD + kb * 16;
-    if (dbg && kb == 1 && tid == 0) dbg[16] = (long long)wall_clock64();
-    if (wave == 0) chol16_inv(Ukk, lane, err);
-    __syncthreads();
-    if (dbg && kb == 1 && tid == 0) dbg[17] = (long long)wall_clock64();
-    for (int ib = kb + 1 + wave; ib < NT; ib += 4) {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T = A(ib,kb) * U_kk
-      double* A = Lm + (ib * 16) * LD + kb * 16;
-      double av[4], bv[4];
+    {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T = A(ib,kb) * U_kk ; wave w takes row tile kb+1+w
+      const int ib = kb + 1 + wave;
+      if (ib < NT) {
+        double* A = Lm + (ib * 16) * LD + kb * 16;
+        double av[4], bv[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        av[s] = A[li * LD + 4 * s + lk];
-        bv[s] = Ukk[(4 * s + lk) * LD + li];
+        for (int s = 0; s < 4; ++s) {
+          av[s] = A[li * LD + 4 * s + lk];
+          bv[s] = Ukk[(4 * s + lk) * LD + li];
+        }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
       }
-      d4 acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
     }
     __syncthreads();
-    {  // trailing update A(ib,jb) -= L(ib,kb) L(jb,kb)^T, kb < jb <= ib: <= 3 tiles per wave, operands first
-      const int ntile = (NT - 1 - kb) * (NT - kb) / 2;
+    // trailing update A(ib,jb) -= L(ib,kb) L(jb,kb)^T, kb < jb <= ib.  LOOK-AHEAD: wave 0 takes only the next
+    // diagonal tile, keeps the result in registers (the MFMA C layout is the factorisation's layout) and goes
+    // straight into its 16-pivot chain while waves 1..3 update the other <= 9 tiles (<= 3 each).
+    const int ntile = (NT - 1 - kb) * (NT - kb) / 2;
+    if (wave == 0) {
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      if (dbg && kb == 0 && tid == 0) dbg[16] = (long long)wall_clock64();
+      chol16_inv_acc(Cc, a, lane, err);
+      if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
+    } else {
       d4 acc[3];
       double av[3][4], bv[3][4];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const int t = wave + 4 * q;
+        const int t = wave + 3 * q;          // tiles 1 .. ntile-1 (tile 0 is the look-ahead tile)
         if (t < ntile) {
           const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
           const double* Cc = Lm + (ib * 16) * LD + jb * 16;
@@ -163,7 +185,7 @@ __device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) 
       }
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const int t = wave + 4 * q;
+        const int t = wave + 3 * q;
         if (t < ntile) {
           const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
           double* Cc = Lm + (ib * 16) * LD + jb * 16;
@@ -427,6 +449,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   double* red = yv + BS;       // [8]
   double* coefL = red + 8;     // [225]
   double* coefR = coefL + 9 * NP;
+  double* ysc = coefR + 9 * NP;   // [3][80] partial sums of the triangular mat-vecs
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
@@ -452,17 +475,25 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   if (fused) {
     // Level 0 of an FTE chain: both couplings are the sparse third-difference blocks E, so the consumers
     // need only G = D_i^-1 = U U^T (W^T W = E^T G E is a <= 9-term stencil) and z = D_i^-1 b = U y.
-    double yy = 0.0;
-    if (tid < BS)
-      for (int c = 0; c <= tid; ++c) yy += Lm[c * LD + tid] * yv[c];   // y = U^T b
-    __syncthreads();
-    if (tid < BS) yv[tid] = yy;
-    __syncthreads();
-    if (tid < BS) {
-      double z = 0.0;
-      for (int c = tid; c < BS; ++c) z += Lm[tid * LD + c] * yv[c];     // z = U y
-      ch.b[(size_t)i * BS + tid] = z;
+    // y = U^T b, then z = U y: three partial sums per row (240 threads), so a row costs <= 27 dependent FMAs
+    const int row = tid % BS, part = tid / BS;
+    if (tid < 3 * BS) {
+      double yy = 0.0;
+      const int c1 = min(27 * part + 27, row + 1);
+      for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
+      ysc[tid] = yy;
     }
+    __syncthreads();
+    if (tid < BS) yv[tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    __syncthreads();
+    if (tid < 3 * BS) {
+      double z = 0.0;
+      const int c1 = min(27 * part + 27, BS);
+      for (int c = max(27 * part, row); c < c1; ++c) z += Lm[row * LD + c] * yv[c];
+      ysc[tid] = z;
+    }
+    __syncthreads();
+    if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
     double* Gg = ch.D + i * MB;
     const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -507,12 +538,17 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
       for (int ct = 3 - wave; ct < 5; ct += 4) gemm_strip_g(Lm, A, 1, BS, ch.Wr + i * MB, ct * 16, lane);
     }
   }
-  double yy = 0.0;
-  if (tid < BS)
-    for (int c = 0; c <= tid; ++c) yy += Lm[c * LD + tid] * yv[c];   // y = U^T b
+  if (tid < 3 * BS) {                                                  // y = U^T b in three partial sums per row
+    const int row = tid % BS, part = tid / BS;
+    double yy = 0.0;
+    const int c1 = min(27 * part + 27, row + 1);
+    for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
+    ysc[tid] = yy;
+  }
   ACINO_STAMP(4);
   store_mat(ch.D + i * MB, Lm, tid);
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = yy;
+  __syncthreads();
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
   ACINO_STAMP(5);
 }
 
@@ -902,7 +938,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
   }
 }
 
-static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP) * sizeof(double);
+static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
