@@ -119,36 +119,48 @@ __device__ void chol16_inv(double* T, int lane, int* err) {
   chol16_inv_acc(T, acc, lane, err);
 }
 
-// Blocked Cholesky of the 80x80 matrix in LDS.  On exit: strictly-lower tiles hold L(ib,jb), diagonal
-// tiles hold U_kk = (L_kk^-1)^T.  All 256 threads.
+// Blocked Cholesky of the 80x80 matrix in LDS, with the inverse factor built alongside.  On exit: strictly-lower
+// tiles hold L(ib,jb), diagonal tiles U_kk = L_kk^-T and strictly-upper tiles (j,c) hold U(j,c), U = L^-T
+// (80x80 upper triangular).  The column operations that reduce A to L are applied at block level to the identity as
+// well ([A; I] L^-T = [L; L^-T]); the work tiles of that second matrix live in the (otherwise unused) strictly-upper
+// tiles, so nothing is zero-filled: tile (j,c) is first WRITTEN at step kb = j and accumulated afterwards.
+// Per block column kb:  panel  tile(t,kb) <- tile(t,kb) U_kk for every t != kb (4 tiles, one per wave);
+//                       trailing tile(t,c) -= tile(t,kb) L(c,kb)^T for c > kb, t in {0..kb} u {c..4}.
+// LOOK-AHEAD: in the trailing phase wave 0 takes only the next diagonal tile, keeps the result in registers (the
+// MFMA C layout is the factorisation's layout) and goes straight into its 16-pivot chain, while waves 1..3 do all
+// other trailing tiles (<= 5 each) - the inverse costs no time on the critical path.
+// task tables for waves 1..3: [kb][n] = 16*ti + tj ; ti <= kb marks a tile of U (overwrite when ti == kb)
+__constant__ uint8_t c_trail_n[4] = {13, 11, 8, 4};
+__constant__ uint8_t c_trail[4][13] = {
+    {0x21, 0x22, 0x31, 0x32, 0x33, 0x41, 0x42, 0x43, 0x44, 0x01, 0x02, 0x03, 0x04},
+    {0x32, 0x33, 0x42, 0x43, 0x44, 0x02, 0x03, 0x04, 0x12, 0x13, 0x14, 0, 0},
+    {0x43, 0x44, 0x03, 0x04, 0x13, 0x14, 0x23, 0x24, 0, 0, 0, 0, 0},
+    {0x04, 0x14, 0x24, 0x34, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// panel: row tile taken by wave w at block column kb (wave 0 always takes the tile the look-ahead needs next)
+__constant__ uint8_t c_panel[5][4] = {{1, 2, 3, 4}, {2, 0, 3, 4}, {3, 0, 1, 4}, {4, 0, 1, 2}, {0, 1, 2, 3}};
+
 __device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   if (wave == 0) chol16_inv(Lm, lane, err);
   __syncthreads();
-  for (int kb = 0; kb < NT - 1; ++kb) {
-    double* Ukk = Lm + (kb * 16) * LD + kb * 16;
-    {  // panel: L(ib,kb) = A(ib,kb) * Linv_kk^T = A(ib,kb) * U_kk ; wave w takes row tile kb+1+w
-      const int ib = kb + 1 + wave;
-      if (ib < NT) {
-        double* A = Lm + (ib * 16) * LD + kb * 16;
-        double av[4], bv[4];
+  for (int kb = 0; kb < NT; ++kb) {
+    const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+    {  // panel: tile(t,kb) <- tile(t,kb) * U_kk   (L(ib,kb) = A(ib,kb) L_kk^-T below, U(j,kb) above the diagonal)
+      double* A = Lm + (c_panel[kb][wave] * 16) * LD + kb * 16;
+      double av[4], bv[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          av[s] = A[li * LD + 4 * s + lk];
-          bv[s] = Ukk[(4 * s + lk) * LD + li];
-        }
-        d4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+      for (int s = 0; s < 4; ++s) {
+        av[s] = A[li * LD + 4 * s + lk];
+        bv[s] = Ukk[(4 * s + lk) * LD + li];
       }
+      d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
     }
     __syncthreads();
-    // trailing update A(ib,jb) -= L(ib,kb) L(jb,kb)^T, kb < jb <= ib.  LOOK-AHEAD: wave 0 takes only the next
-    // diagonal tile, keeps the result in registers (the MFMA C layout is the factorisation's layout) and goes
-    // straight into its 16-pivot chain while waves 1..3 update the other <= 9 tiles (<= 3 each).
-    const int ntile = (NT - 1 - kb) * (NT - kb) / 2;
+    if (kb == NT - 1) break;
     if (wave == 0) {
       double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
       const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
@@ -164,71 +176,31 @@ __device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) 
       chol16_inv_acc(Cc, a, lane, err);
       if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
     } else {
-      d4 acc[3];
-      double av[3][4], bv[3][4];
+      const int ntask = c_trail_n[kb];
+      for (int t = wave - 1; t < ntask; t += 3) {
+        const int code = c_trail[kb][t], ti = code >> 4, tj = code & 15;
+        double* Cc = Lm + (ti * 16) * LD + tj * 16;
+        const double* A = Lm + (ti * 16) * LD + kb * 16;
+        const double* B = Lm + (tj * 16) * LD + kb * 16;
+        d4 a = {0, 0, 0, 0};
+        double av[4], bv[4];
+        if (ti != kb) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int t = wave + 3 * q;          // tiles 1 .. ntile-1 (tile 0 is the look-ahead tile)
-        if (t < ntile) {
-          const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
-          const double* Cc = Lm + (ib * 16) * LD + jb * 16;
-          const double* A = Lm + (ib * 16) * LD + kb * 16;
-          const double* B = Lm + (jb * 16) * LD + kb * 16;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Cc[(lk + 4 * rr) * LD + li];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            av[q][s] = A[li * LD + 4 * s + lk];
-            bv[q][s] = B[li * LD + 4 * s + lk];
-          }
+          for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
         }
-      }
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int t = wave + 3 * q;
-        if (t < ntile) {
-          const int ib = kb + 1 + c_tri_i[t], jb = kb + 1 + c_tri_j[t];
-          double* Cc = Lm + (ib * 16) * LD + jb * 16;
-          d4 a = acc[q];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) a = mfma(-av[q][s], bv[q][s], a);
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[rr];
+        for (int s = 0; s < 4; ++s) {
+          av[s] = A[li * LD + 4 * s + lk];
+          bv[s] = B[li * LD + 4 * s + lk];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[rr];
       }
     }
     __syncthreads();
   }
-}
-
-// Blocked inversion of the Cholesky factor: fills the strictly-upper tiles with U = (L^-1)^T, i.e. tile
-// (jb, ib) = X(ib,jb)^T where X = L^-1, X(ib,jb) = -X(ib,ib) * sum_{k=jb}^{ib-1} L(ib,k) X(k,jb).
-// Block column jb is one wave's sequential chain (no workgroup barrier inside); 4 waves = columns 0..3.
-template <int NK>   // NK = ib - jb k-tiles
-__device__ __forceinline__ void linv80_tile(double* Lm, int ib, int jb, int li, int lk) {
-  // t = sum_{k=jb}^{ib-1} L(ib,k) X(k,jb);  L(ib,k)[i][kk] and X(k,jb)[kk][j] = U[jb16+j][k16+kk] are both
-  // contiguous in the running k index, so the whole sum is one pipelined MFMA sequence
-  d4 t = {0, 0, 0, 0};
-  t = mma_seq<4 * NK, false>(t, Lm + (ib * 16 + li) * LD + jb * 16 + lk, 4, Lm + (jb * 16 + li) * LD + jb * 16 + lk, 4);
-  const double* Uii = Lm + (ib * 16) * LD + ib * 16;           // X(ib,ib)[i][kk] = U_ii[kk][i]
-  double uv[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) uv[s] = Uii[(4 * s + lk) * LD + li];
-  d4 x = {0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < 4; ++s) x = mfma(-uv[s], t[s], x);
-  double* Ut = Lm + (jb * 16) * LD + ib * 16;                   // tile (jb, ib) <- X(ib,jb)^T
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) Ut[li * LD + lk + 4 * rr] = x[rr];
-}
-
-__device__ void linv80(double* Lm, int tid) {
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int jb = wave;   // block column jb is this wave's sequential chain (columns 0..3; column 4 is only U_44)
-  if (jb + 1 < NT) linv80_tile<1>(Lm, jb + 1, jb, li, lk);
-  if (jb + 2 < NT) linv80_tile<2>(Lm, jb + 2, jb, li, lk);
-  if (jb + 3 < NT) linv80_tile<3>(Lm, jb + 3, jb, li, lk);
-  if (jb + 4 < NT) linv80_tile<4>(Lm, jb + 4, jb, li, lk);
 }
 
 // 80x80 fp64 matrix HBM <-> LDS with all loads of a thread in flight before the first use (13 x 16 B).
@@ -439,7 +411,7 @@ __device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __r
 // Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the D
 // slot), W_l, W_r and y.  LDS holds ONE 80x81 matrix (the factor), so three workgroups share a CU: the serial
 // pivot chains of one overlap the matrix-core / memory phases of the others.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // <= 256 VGPR+AGPR: two workgroups per CU overlap each other's pivot chains
 k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst, int* numeric_err,
            const int* __restrict__ status, int level) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -469,8 +441,6 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(1);
   chol80(Lm, tid, numeric_err, (ch.dbg && blockIdx.x == 0) ? ch.dbg : nullptr);
   ACINO_STAMP(2);
-  linv80(Lm, tid);
-  __syncthreads();
   ACINO_STAMP(3);
   if (fused) {
     // Level 0 of an FTE chain: both couplings are the sparse third-difference blocks E, so the consumers
