@@ -11,8 +11,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
-SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip"]
-HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
+HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
 N_ACTIVE = 25
 N_STATES = 45
@@ -43,6 +43,11 @@ class FteState(C.Structure):
         d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
         d["status_name"] = names.get(self.status, "?")
         return d
+
+
+class EkfParams(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("n_seq", C.c_int32), ("n_cams", C.c_int32), ("fps", C.c_double),
+                ("dlc_thresh", C.c_double), ("cam_width", C.c_double)]
 
 
 class SkelOp(C.Structure):
@@ -120,6 +125,9 @@ SIGNATURES = {
     "acino_sizeof_sba_info": (_Z, []),
     "acino_sba_workspace_bytes": (_Z, [_I, _L, _L]),
     "acino_sba_solve": (_I, [C.POINTER(SbaParams), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P, C.POINTER(SbaInfo), _P]),
+    "acino_sizeof_ekf_params": (_Z, []),
+    "acino_ekf_workspace_bytes": (_Z, [_L, _I]),
+    "acino_ekf_run": (_I, [C.POINTER(EkfParams), _P, _P, _P, _P, _Z, _P, _P, _P, _P]),
     "acino_skeleton_fk": (_I, [_P, _L, _I, _I, C.POINTER(SkelOp), _I, _P, _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
 }
@@ -176,6 +184,8 @@ def lib():
         raise RuntimeError("libacinoset_hip.so struct layout differs from the Python binding (stale build?)")
     if handle.acino_sizeof_sba_params() != C.sizeof(SbaParams) or handle.acino_sizeof_sba_info() != C.sizeof(SbaInfo):
         raise RuntimeError("libacinoset_hip.so SBA struct layout differs from the Python binding (stale build?)")
+    if handle.acino_sizeof_ekf_params() != C.sizeof(EkfParams):
+        raise RuntimeError("libacinoset_hip.so EKF struct layout differs from the Python binding (stale build?)")
     _lib = handle
     return _lib
 

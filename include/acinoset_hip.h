@@ -265,6 +265,26 @@ typedef struct acino_skel_op {
 int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_pose, const acino_skel_op* h_ops,
                       int n_ops, double* d_pos, void* stream);
 
+/* ---- extended Kalman filter + RTS smoother (src/all_optimizations.py:569-865) ---------
+ * One call filters and smooths n_seq independent sequences of n_frames frames (same rig).  States are the reference's
+ * 75 = 3 x 25 [pose | velocity | acceleration], pose parameters in the order of qb_list (:734-746).  d_det is
+ * [n_seq][n_frames][n_cams][20][3] (x, y, likelihood), d_states0 [n_seq][75] the state BEFORE the first prediction
+ * (:700-711), d_est / d_smooth [n_seq][n_frames][75] the filtered and the smoothed states (:848-856 slices them into
+ * x, dx, ddx), d_outliers [n_seq] the gated pixel pairs (:818).  Model constants (P0, Q, R, the 3-sigma gate, the
+ * forward-difference step 1e-3) are the reference's literals. */
+typedef struct acino_ekf_params {
+  int64_t n_frames;
+  int32_t n_seq;
+  int32_t n_cams;             /* <= 6 */
+  double fps;
+  double dlc_thresh;          /* likelihood < thresh -> measurement sigma = cam_width (:805-808) */
+  double cam_width;           /* camera_resolution[0], the reference's max_pixel_err (:611) */
+} acino_ekf_params;
+size_t acino_sizeof_ekf_params(void);
+size_t acino_ekf_workspace_bytes(int64_t n_frames, int n_seq);
+int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double* d_cams24, const double* d_states0,
+                  void* d_ws, size_t ws_bytes, double* d_est, double* d_smooth, int32_t* d_outliers, void* stream);
+
 /* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
 

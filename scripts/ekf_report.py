@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""EKF + RTS smoother timing on the GPU box: one 10 000-frame clip, 64 clips x 1 000
+frames in one launch, and the numpy oracle on a short clip.  Writes gpurun_out/ekf/report.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from acinoset_amd import ekf, synth  # noqa: E402
+from oracle import ekf as oekf  # noqa: E402
+
+out = {}
+seq = synth.make_sequence(10000, "loop")
+rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+det = torch.as_tensor(seq["det"], device="cuda")
+s0 = ekf.initial_state(det[:200], *rig, 120.0, 0.5)
+ekf.ekf(det[:100], *rig, 120.0, 0.5, (2704, 1520), states0=s0, with_positions=False)     # warm
+for name, dets in (("one_clip_10000_frames", [det]), ("64_clips_x_1000_frames", [det[:1000]] * 64)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = ekf.ekf_batch(dets, *rig, 120.0, 0.5, (2704, 1520), states0=[s0] * len(dets), with_positions=False)
+    dt = time.perf_counter() - t0
+    frames = sum(int(d.shape[0]) for d in dets)
+    out[name] = dict(seconds_incl_transfers=dt, frames=frames, frames_per_s=frames / dt,
+                     us_per_frame_per_clip=1e6 * dt / int(dets[0].shape[0]),
+                     note="timing only: the loop trajectory turns, and the reference's straight-line initialisation + 3-sigma "
+                          "gate lose it (oracle and GPU alike)")
+sp = synth.make_sequence(150, "sprint")
+rs = ekf.ekf(sp["det"], *rig, 120.0, 0.5, (2704, 1520))
+qs = sp["q_true"][:, ekf.EKF_ORDER]
+out["sprint_150_frames_accuracy"] = dict(max_head_err_filtered_m=float(np.abs(rs["x"][10:, :3] - qs[10:, :3]).max()),
+                                         max_head_err_smoothed_m=float(np.abs(rs["smoothed_x"][10:, :3] - qs[10:, :3]).max()),
+                                         rms_angle_err_smoothed_rad=float(np.sqrt(np.mean((rs["smoothed_x"][10:, 3:] - qs[10:, 3:]) ** 2))),
+                                         outliers=rs["outliers_ignored"])
+t0 = time.perf_counter()
+oekf.ekf(seq["det"][:40], *rig, 120.0, 0.5, 2704, s0)
+dt = time.perf_counter() - t0
+out["oracle_numpy_40_frames"] = dict(seconds=dt, frames_per_s=40 / dt)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "ekf"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ekf", "report.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
