@@ -246,6 +246,34 @@ __device__ __forceinline__ void store_mat(double* __restrict__ dst, const double
   }
 }
 
+// Two 80x80 matrices HBM -> LDS with ALL loads of both in flight before the first LDS write (the narrow levels
+// of the reduction are latency-bound: one HBM round trip instead of two).
+__device__ __forceinline__ void load_mat2(double* dst0, const double* __restrict__ src0, double* dst1,
+                                          const double* __restrict__ src1, int tid) {
+  const double2* s0 = reinterpret_cast<const double2*>(src0);
+  const double2* s1 = reinterpret_cast<const double2*>(src1);
+  double2 v0[13], v1[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      v0[k] = s0[idx];
+      v1[k] = s1[idx];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      dst0[r * LD + c] = v0[k].x;
+      dst0[r * LD + c + 1] = v0[k].y;
+      dst1[r * LD + c] = v1[k].x;
+      dst1[r * LD + c + 1] = v1[k].y;
+    }
+  }
+}
+
 // Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
 // assembly's H/g (what k_setup used to write to HBM): D = H_gn + lam*diag(H_gn), bound-active variables
 // pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).
@@ -650,6 +678,92 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
   }
 }
 
+// The same update for the NARROW levels of the reduction (a handful of nodes: the chip is almost idle and every
+// kernel is a latency chain).  One node's work is spread over 2 S workgroups - role 0 / role 1 as above, each split S
+// ways by output tile - so the matrix-core phase of a workgroup is one or two tiles per wave instead of four to
+// seven (that phase is LDS-bandwidth bound inside one CU); both neighbour matrices are requested at once into two
+// LDS buffers, the D_j tile is requested with them and only added at the end.  grid = n_remain * 2 * S.
+__global__ void __launch_bounds__(256)
+k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Wb = reinterpret_cast<double*>(smem_raw);
+  double* Wb2 = Wb + MAT;
+  double* yv = Wb2 + MAT;
+  double* yv2 = yv + BS;
+  double* ysc = yv2 + BS;            // [3][80]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ent = blockIdx.x / (2 * S), role = (blockIdx.x / S) & 1, sub = blockIdx.x % S;
+  const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
+  const size_t MB = (size_t)BS * BS;
+  if (role == 0) {
+    if (im < 0 && ip < 0) return;
+    double* Dj = ch.D + j * MB;
+    d4 dt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {    // this wave's output tiles of D_j, requested first, consumed last
+      const int t = sub + S * (wave + 4 * q);
+      if (t < 15) {
+        const int ib = c_tri_i[t], jb = c_tri_j[t];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dt[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+      }
+    }
+    const bool both = im >= 0 && ip >= 0;
+    if (both) load_mat2(Wb, ch.Wr + im * MB, Wb2, ch.Wl + ip * MB, tid);
+    else load_mat(Wb, im >= 0 ? ch.Wr + im * MB : ch.Wl + ip * MB, tid);
+    if (tid < BS) {
+      yv[tid] = ch.b[(size_t)(im >= 0 ? im : ip) * BS + tid];
+      if (both) yv2[tid] = ch.b[(size_t)ip * BS + tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = sub + S * (wave + 4 * q);
+      if (t < 15) {
+        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        d4 a = {0, 0, 0, 0};
+        a = mma_seq<BS / 4, true>(a, Wb + lk * LD + ib * 16 + li, 4 * LD, Wb + lk * LD + jb * 16 + li, 4 * LD);
+        if (both) a = mma_seq<BS / 4, true>(a, Wb2 + lk * LD + ib * 16 + li, 4 * LD, Wb2 + lk * LD + jb * 16 + li, 4 * LD);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const double v = dt[q][rr] + a[rr];
+          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = v;
+          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = v;
+        }
+      }
+    }
+    if (sub == 0) {                  // b_j -= W^T y, three partial sums per row
+      if (tid < 3 * BS) {
+        const int col = tid % BS, k0 = 27 * (tid / BS), k1 = min(k0 + 27, BS);
+        double sp = 0.0;
+        for (int k = k0; k < k1; ++k) sp += Wb[k * LD + col] * yv[k];
+        if (both)
+          for (int k = k0; k < k1; ++k) sp += Wb2[k * LD + col] * yv2[k];
+        ysc[tid] = sp;
+      }
+      __syncthreads();
+      if (tid < BS) ch.b[(size_t)j * BS + tid] -= ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    }
+  } else {
+    if (ip < 0 || jn < 0) return;
+    load_mat2(Wb, ch.Wr + ip * MB, Wb2, ch.Wl + ip * MB, tid);    // W_r(ip): cols = jn ; W_l(ip): cols = j
+    __syncthreads();
+    double* Cj = ch.Cpl + j * MB;     // block(jn, j): rows jn, cols j
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int t = sub + S * (wave + 4 * q);
+      if (t < NT * NT) {
+        const int ib = t / NT, jb = t % NT;
+        d4 a = {0, 0, 0, 0};
+        a = mma_seq<BS / 4, true>(a, Wb + lk * LD + ib * 16 + li, 4 * LD, Wb2 + lk * LD + jb * 16 + li, 4 * LD);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = a[rr];
+      }
+    }
+  }
+}
+
 // x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T ; the three matrices stream through one LDS buffer.
 __global__ void __launch_bounds__(256)
 k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
@@ -910,6 +1024,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
 
 static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
+static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
 static constexpr size_t kBacksub0Lds = (MAT + 3 * BS + 18 * NP) * sizeof(double);
@@ -919,6 +1034,8 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kElimLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update_deep),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateDeepLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
@@ -944,7 +1061,11 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
         if (level == 0 && ch.st != nullptr)
           hipLaunchKernelGGL(k_bcr_update0, dim3(lv.n_remain), dim3(256), kUpdate0Lds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status);
-        else
+        else if (lv.n_remain <= 128) {     // narrow level: <= 512 workgroups after the 2 S-way split
+          const int S = lv.n_remain <= 32 ? 4 : (lv.n_remain <= 64 ? 2 : 1);
+          hipLaunchKernelGGL(k_bcr_update_deep, dim3(2 * S * lv.n_remain), dim3(256), kUpdateDeepLds, s, ch,
+                             ch.d_remain + 4 * lv.remain_off, d_status, S);
+        } else
           hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
       }
