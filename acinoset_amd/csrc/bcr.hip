@@ -550,6 +550,74 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(5);
 }
 
+// Elimination at the NARROW levels (explicit couplings only).  The ten 16-column strips of [W_l | W_r] of one node
+// are spread over T workgroups, each of which repeats the factorisation (the chip is idle: redundant work is free,
+// the pivot chain is not) and then computes only its strips - row tiles spread over the four waves - from B operands
+// that were requested from HBM BEFORE the factorisation.  Workgroup 0 of a node also stores U and y.
+// grid = n_elim * T;  strips s = g, g + T, ... < 10;  s < 5: W_l strip s, else W_r strip s - 5.
+__device__ __forceinline__ void deep_strip_operands(const BcrChain& ch, int i, int l, int r, int sidx, double (&bv)[20],
+                                                    int li, int lk) {
+  const size_t MB = (size_t)BS * BS;
+  const bool left = sidx < 5;
+  const int cc = 16 * (left ? sidx : sidx - 5);
+  const int nb = left ? l : r;
+  if (nb < 0) return;
+  // W_l: block(i, l) stored at Cpl[l], element [row i][col l] ; W_r: block(r, i)^T stored at Cpl[i], [row r][col i]
+  const double* Ag = ch.Cpl + (left ? (size_t)l : (size_t)i) * MB;
+  const int rs = left ? BS : 1, cs = left ? 1 : BS;
+#pragma unroll
+  for (int t = 0; t < 20; ++t) bv[t] = Ag[(4 * t + lk) * rs + (cc + li) * cs];
+}
+template <int IB>
+__device__ __forceinline__ void deep_row_tile(const double* Lm, const double (&bv)[20], double* __restrict__ Wg, int cc,
+                                              int li, int lk) {
+  strip_row_r<IB>(Lm, bv, Wg, cc, li, lk);
+}
+__global__ void __launch_bounds__(256, 2)
+k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Lm = reinterpret_cast<double*>(smem_raw);
+  double* yv = Lm + MAT;       // [80] rhs
+  double* ysc = yv + BS;       // [3][80]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ent = blockIdx.x / T, g = blockIdx.x % T;
+  const int i = elim[3 * ent], l = elim[3 * ent + 1], r = elim[3 * ent + 2];
+  const size_t MB = (size_t)BS * BS;
+  double bv[20];
+  deep_strip_operands(ch, i, l, r, g, bv, li, lk);       // first strip: in flight during the factorisation
+  load_mat(Lm, ch.D + i * MB, tid);
+  if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
+  __syncthreads();
+  chol80(Lm, tid, g == 0 ? numeric_err : nullptr);
+  for (int sidx = g; sidx < 10; sidx += T) {
+    if (sidx != g) deep_strip_operands(ch, i, l, r, sidx, bv, li, lk);
+    const bool left = sidx < 5;
+    if ((left ? l : r) < 0) continue;
+    double* Wg = (left ? ch.Wl : ch.Wr) + i * MB;
+    const int cc = 16 * (left ? sidx : sidx - 5);
+    // row tiles of the strip over the waves: {4}, {3}, {2, 0}, {1}  (20, 16, 16, 8 matrix-core steps)
+    if (wave == 0) deep_row_tile<4>(Lm, bv, Wg, cc, li, lk);
+    else if (wave == 1) deep_row_tile<3>(Lm, bv, Wg, cc, li, lk);
+    else if (wave == 2) {
+      deep_row_tile<2>(Lm, bv, Wg, cc, li, lk);
+      deep_row_tile<0>(Lm, bv, Wg, cc, li, lk);
+    } else deep_row_tile<1>(Lm, bv, Wg, cc, li, lk);
+  }
+  if (g == 0) {
+    if (tid < 3 * BS) {                                                  // y = U^T b in three partial sums per row
+      const int row = tid % BS, part = tid / BS;
+      double yy = 0.0;
+      const int c1 = min(27 * part + 27, row + 1);
+      for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
+      ysc[tid] = yy;
+    }
+    store_mat(ch.D + i * MB, Lm, tid);
+    __syncthreads();
+    if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+  }
+}
+
 // Half-height (40-row) staging of an 80x80 matrix: rows [r0, r0+40) -> dst[40][LD].
 __device__ __forceinline__ void load_half(double* dst, const double* __restrict__ src, int r0, int tid) {
   const double2* s2 = reinterpret_cast<const double2*>(src + (size_t)r0 * BS);
@@ -992,9 +1060,11 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
     lv.elim_off = (int)elim.size() / 3;
     lv.remain_off = (int)remain.size() / 4;
     lv.n_elim = n_pick;
+    lv.adjacent = false;
     std::vector<int> next;
     for (int p = 0; p < R; ++p) {
       if (pick[p]) {
+        if ((p > 0 && act[p - 1] == act[p] - 1) || (p + 1 < R && act[p + 1] == act[p] + 1)) lv.adjacent = true;
         elim.push_back(act[p]);
         elim.push_back(p > 0 ? act[p - 1] : -1);
         elim.push_back(p + 1 < R ? act[p + 1] : -1);
@@ -1023,6 +1093,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
 }
 
 static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(double);
+static constexpr size_t kElimDeepLds = (MAT + BS + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
@@ -1032,6 +1103,8 @@ static constexpr size_t kBacksub0Lds = (MAT + 3 * BS + 18 * NP) * sizeof(double)
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kElimLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim_deep),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kElimDeepLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update_deep),
@@ -1051,8 +1124,14 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
   for (const BcrLevel& lv : sch.levels) {
     {
       ProfSpan sp(prof, PC_ELIM, s);
-      hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
-                         d_c, d_numeric_err, d_status, level);
+      const bool fused0 = level == 0 && ch.st != nullptr;
+      if (!fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64) {   // narrow level: T workgroups per node
+        const int T = std::min(10, 256 / lv.n_elim);   // <= one workgroup per CU
+        hipLaunchKernelGGL(k_bcr_elim_deep, dim3(lv.n_elim * T), dim3(256), kElimDeepLds, s, ch,
+                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T);
+      } else
+        hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
+                           d_c, d_numeric_err, d_status, level);
     }
     ACINO_LAUNCH_CHECK();
     if (lv.n_remain > 0) {

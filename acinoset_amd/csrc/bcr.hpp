@@ -9,6 +9,7 @@ namespace acino {
 struct BcrLevel {
   int n_elim, n_remain;
   int elim_off, remain_off;  // offsets (in entries) into the device schedule arrays
+  bool adjacent;             // some eliminated node still has a neighbour at original distance 1 (implicit coupling)
 };
 
 // Host-side elimination schedule for a chain of n nodes; pinned ends are never eliminated.
