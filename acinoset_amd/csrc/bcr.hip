@@ -640,7 +640,68 @@ __device__ __forceinline__ void load_half(double* dst, const double* __restrict_
 
 // role 0: D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+), b_j -= W^T y ; role 1: block(jn, j) = -W_r(i+)^T W_l(i+).
 // Both roles stream through ONE 80x81 LDS buffer (52 KB) so three workgroups share a CU and the staging of
-// one overlaps the matrix-core phase of another.
+// one overlaps the matrix-core phase of another.  The matrix-core phase is LDS-bandwidth bound when every MFMA
+// fetches its own A and B operand, so tiles are assigned to waves BY ROW and the k loop is outermost: the operand
+// of a k-step depends only on (k, column block), one LDS read feeds every tile of the row that uses the block
+// (role 0: 14 reads per k-step for 15 tiles instead of 30; role 1: 28 for 25 tiles instead of 50).
+//
+// role 0 tiles (ib, jb), jb <= ib:  wave 0: row 4 | wave 1: row 3 | wave 2: row 2 and (0,0) | wave 3: row 1
+template <int WAVE>
+struct SyrkTiles {
+  static constexpr int nb = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 3 : 2));   // column blocks 0 .. nb-1
+  static constexpr int nt = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 4 : 2));
+  static constexpr int ib(int q) { return WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1)); }
+  static constexpr int jb(int q) { return WAVE == 2 ? (q < 3 ? q : 0) : q; }
+};
+template <int WAVE, int KSTEPS>
+__device__ __forceinline__ void syrk_rows(const double* Wb, d4 (&acc)[5], int li, int lk) {
+  using T = SyrkTiles<WAVE>;
+  const double* p = Wb + lk * LD + li;
+  double v0[T::nb], v1[T::nb];
+#pragma unroll
+  for (int c = 0; c < T::nb; ++c) v0[c] = p[c * 16];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; s += 2) {
+#pragma unroll
+    for (int c = 0; c < T::nb; ++c) v1[c] = p[(4 * (s + 1)) * LD + c * 16];
+#pragma unroll
+    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v0[T::ib(q)], v0[T::jb(q)], acc[q]);
+    if (s + 2 < KSTEPS) {
+#pragma unroll
+      for (int c = 0; c < T::nb; ++c) v0[c] = p[(4 * (s + 2)) * LD + c * 16];
+    }
+#pragma unroll
+    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v1[T::ib(q)], v1[T::jb(q)], acc[q]);
+  }
+}
+template <int WAVE, class F>
+__device__ __forceinline__ void syrk_tiles_foreach(F&& f) {
+  using T = SyrkTiles<WAVE>;
+#pragma unroll
+  for (int q = 0; q < T::nt; ++q) f(q, T::ib(q), T::jb(q));
+}
+// role 1 tiles (ib, jb), all 25:  wave w: row w (5 tiles) + from row 4: (4,0) | (4,1) | (4,2) | (4,3),(4,4)
+template <int WAVE>
+struct GemmTiles {
+  static constexpr int nt = WAVE == 3 ? 7 : 6;
+  static constexpr int ib(int q) { return q < 5 ? WAVE : 4; }
+  static constexpr int jb(int q) { return q < 5 ? q : (WAVE == 3 ? 3 + (q - 5) : WAVE); }
+};
+template <int WAVE, int KSTEPS>
+__device__ __forceinline__ void gemm_rows(const double* Ha, const double* Hb, d4 (&acc)[7], int li, int lk) {
+  using T = GemmTiles<WAVE>;
+  const double* pa = Ha + lk * LD + li;
+  const double* pb = Hb + lk * LD + li;
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    double a0 = pa[(4 * s) * LD + WAVE * 16], a4 = pa[(4 * s) * LD + 4 * 16], bq[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) bq[c] = pb[(4 * s) * LD + c * 16];
+#pragma unroll
+    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(q < 5 ? -a0 : -a4, bq[T::jb(q)], acc[q]);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __restrict__ cst,
              const int* __restrict__ status, int level) {
@@ -648,36 +709,30 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
   if (status && *status != 0) return;
   double* Wb = reinterpret_cast<double*>(smem_raw);
   double* yv = Wb + MAT;
-  double* red = yv + BS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ent = blockIdx.x >> 1, role = blockIdx.x & 1;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
   if (role == 0) {
-    const bool fused = ch.st != nullptr && level == 0;
-    if (im < 0 && ip < 0 && !fused) return;    // (fused level 0 still has to build and store D_j, b_j)
+    if (im < 0 && ip < 0) return;
     double* Dj = ch.D + j * MB;
-    d4 acc[4];
-    double bs = 0.0;
-    if (fused) {                    // level 0: D_j and b_j are built here, never read from HBM
-      double gmax = build_node(Wb, yv, ch, *cst, j, tid);
-      publish_gmax(gmax, red, ch.gn_part, j, tid);   // (contains a barrier: the block is complete in LDS)
-      if (tid < BS) bs = yv[tid];
-    } else if (tid < BS) {
-      bs = ch.b[(size_t)j * BS + tid];
-    }
+    d4 acc[5];
+    double bs = (tid < BS) ? ch.b[(size_t)j * BS + tid] : 0.0;
+    auto load_tiles = [&](int q, int ib, int jb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {   // this wave's (<= 4) output tiles of D_j (C layout)
-      const int t = wave + 4 * q;
-      if (t < 15) {
-        const int ib = c_tri_i[t], jb = c_tri_j[t];
+      for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+    };
+    auto store_tiles = [&](int q, int ib, int jb) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          acc[q][rr] = fused ? Wb[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li]
-                             : Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+      for (int rr = 0; rr < 4; ++rr) {
+        Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
+        if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[q][rr];
       }
-    }
-    if (fused) __syncthreads();     // tiles are in registers before the buffer is reused for W
+    };
+    if (wave == 0) syrk_tiles_foreach<0>(load_tiles);
+    else if (wave == 1) syrk_tiles_foreach<1>(load_tiles);
+    else if (wave == 2) syrk_tiles_foreach<2>(load_tiles);
+    else syrk_tiles_foreach<3>(load_tiles);
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int nb = side == 0 ? im : ip;
@@ -686,30 +741,17 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
       load_mat(Wb, (side == 0 ? ch.Wr : ch.Wl) + nb * MB, tid);   // W_r of the left / W_l of the right neighbour
       if (tid < BS) yv[tid] = ch.b[(size_t)nb * BS + tid];
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = wave + 4 * q;
-        if (t < 15) {
-          const int ib = c_tri_i[t], jb = c_tri_j[t];
-          acc[q] = mma_seq<BS / 4, true>(acc[q], Wb + lk * LD + ib * 16 + li, 4 * LD, Wb + lk * LD + jb * 16 + li,
-                                         4 * LD);
-        }
-      }
+      if (wave == 0) syrk_rows<0, BS / 4>(Wb, acc, li, lk);
+      else if (wave == 1) syrk_rows<1, BS / 4>(Wb, acc, li, lk);
+      else if (wave == 2) syrk_rows<2, BS / 4>(Wb, acc, li, lk);
+      else syrk_rows<3, BS / 4>(Wb, acc, li, lk);
       if (tid < BS)
         for (int k = 0; k < BS; ++k) bs -= Wb[k * LD + tid] * yv[k];
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = wave + 4 * q;
-      if (t < 15) {
-        const int ib = c_tri_i[t], jb = c_tri_j[t];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
-          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[q][rr];
-        }
-      }
-    }
+    if (wave == 0) syrk_tiles_foreach<0>(store_tiles);
+    else if (wave == 1) syrk_tiles_foreach<1>(store_tiles);
+    else if (wave == 2) syrk_tiles_foreach<2>(store_tiles);
+    else syrk_tiles_foreach<3>(store_tiles);
     if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
   } else {
     if (ip < 0 || jn < 0) return;
@@ -724,24 +766,22 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
       load_half(Ha, ch.Wr + ip * MB, 40 * h, tid);
       load_half(Hb, ch.Wl + ip * MB, 40 * h, tid);
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        const int t = wave + 4 * q;
-        if (t < NT * NT) {
-          const int ib = t / NT, jb = t % NT;
-          acc[q] = mma_seq<10, true>(acc[q], Ha + lk * LD + ib * 16 + li, 4 * LD, Hb + lk * LD + jb * 16 + li, 4 * LD);
-        }
-      }
+      if (wave == 0) gemm_rows<0, 10>(Ha, Hb, acc, li, lk);
+      else if (wave == 1) gemm_rows<1, 10>(Ha, Hb, acc, li, lk);
+      else if (wave == 2) gemm_rows<2, 10>(Ha, Hb, acc, li, lk);
+      else gemm_rows<3, 10>(Ha, Hb, acc, li, lk);
     }
     double* Cj = ch.Cpl + j * MB;     // block(jn, j): rows jn, cols j
+    auto store_c = [&](int q, int ib, int jb) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
+    };
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-      const int t = wave + 4 * q;
-      if (t < NT * NT) {
-        const int ib = t / NT, jb = t % NT;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Cj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
-      }
+      if (wave == 0 && q < GemmTiles<0>::nt) store_c(q, GemmTiles<0>::ib(q), GemmTiles<0>::jb(q));
+      if (wave == 1 && q < GemmTiles<1>::nt) store_c(q, GemmTiles<1>::ib(q), GemmTiles<1>::jb(q));
+      if (wave == 2 && q < GemmTiles<2>::nt) store_c(q, GemmTiles<2>::ib(q), GemmTiles<2>::jb(q));
+      if (wave == 3 && q < GemmTiles<3>::nt) store_c(q, GemmTiles<3>::ib(q), GemmTiles<3>::jb(q));
     }
   }
 }
