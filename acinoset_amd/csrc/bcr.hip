@@ -702,7 +702,7 @@ __device__ __forceinline__ void gemm_rows(const double* Ha, const double* Hb, d4
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __restrict__ cst,
              const int* __restrict__ status, int level) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
