@@ -120,7 +120,7 @@ SIGNATURES = {
     "acino_fte_export_edges": (_I, [_P, _I, _P, _P]),
     "acino_fte_profile_begin": (_I, [_P]),
     "acino_fte_debug_stamps": (_I, [_P, _P]),
-    "acino_fte_profile_end": (_I, [_P, _P, _P, _P]),
+    "acino_fte_profile_end": (_I, [_P, _P, _P, _P, _P]),
     "acino_sizeof_sba_params": (_Z, []),
     "acino_sizeof_sba_info": (_Z, []),
     "acino_sba_workspace_bytes": (_Z, [_I, _L, _L]),

@@ -1163,9 +1163,10 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
   int level = 0;
   for (const BcrLevel& lv : sch.levels) {
     {
-      ProfSpan sp(prof, PC_ELIM, s);
       const bool fused0 = level == 0 && ch.st != nullptr;
-      if (!fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64) {   // narrow level: T workgroups per node
+      const bool deep = !fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64;
+      ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
+      if (deep) {   // narrow level: T workgroups per node
         const int T = std::min(10, 256 / lv.n_elim);   // <= one workgroup per CU
         hipLaunchKernelGGL(k_bcr_elim_deep, dim3(lv.n_elim * T), dim3(256), kElimDeepLds, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T);
@@ -1176,8 +1177,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     ACINO_LAUNCH_CHECK();
     if (lv.n_remain > 0) {
       {
-        ProfSpan sp(prof, PC_UPDATE, s);
-        if (level == 0 && ch.st != nullptr)
+        const bool up0 = level == 0 && ch.st != nullptr;
+        ProfSpan sp(prof, up0 ? PC_UPDATE0 : (lv.n_remain <= 128 ? PC_UPDATE_DEEP : PC_UPDATE), s, lv.n_remain);
+        if (up0)
           hipLaunchKernelGGL(k_bcr_update0, dim3(lv.n_remain), dim3(256), kUpdate0Lds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status);
         else if (lv.n_remain <= 128) {     // narrow level: <= 512 workgroups after the 2 S-way split
@@ -1200,7 +1202,7 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
   for (int k = (int)sch.levels.size() - 1; k >= 0; --k) {
     const BcrLevel& lv = sch.levels[k];
     {
-      ProfSpan sp(prof, PC_BACKSUB, s);
+      ProfSpan sp(prof, (k == 0 && ch.st != nullptr) ? PC_BACKSUB0 : PC_BACKSUB, s, lv.n_elim);
       if (k == 0 && ch.st != nullptr)
         hipLaunchKernelGGL(k_bcr_backsub0, dim3(lv.n_elim), dim3(256), kBacksub0Lds, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_c, d_status);

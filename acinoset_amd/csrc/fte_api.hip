@@ -417,7 +417,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
   const Buffers& b = ctx->b;
   int rc;
   {
-    ProfSpan sp(&ctx->prof, PC_ASSEMBLE, s);
+    ProfSpan sp(&ctx->prof, PC_ASSEMBLE, s, ctx->h.n_frames);
     rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.cost_part, b.nbehind,
                          need_jac, respect_status, s);
   }
@@ -674,7 +674,7 @@ int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   const Buffers& b = ctx->b;
   {
-    ProfSpan sp(&ctx->prof, PC_TRIAL, (hipStream_t)stream);
+    ProfSpan sp(&ctx->prof, PC_TRIAL, (hipStream_t)stream, ctx->h.n_frames);
     hipLaunchKernelGGL(k_trial, dim3(ctx->n_blk_trial), dim3(256), 0, (hipStream_t)stream, b.cst, b.state, b.x[0],
                        b.x[1], b.g[0], b.g[1], b.H[0], b.H[1], ctx->chain.b, b.pred_part, b.step_part);
   }
@@ -836,19 +836,22 @@ int acino_fte_profile_begin(acino_fte_ctx* ctx) {
 
 // Stops profiling, synchronises `stream` and returns per kernel class the summed HIP-event time (ms) and
 // the number of launches.  Class order: setup, elim, update, backsub, trial, assemble, totals, control.
-int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, void* stream) {
+int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, int64_t* units_by_class,
+                          void* stream) {
   ACINO_REQUIRE(ctx && ms_by_class && launches_by_class, "null");
   ctx->prof.on = false;
   ACINO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   for (int c = 0; c < PC_COUNT; ++c) {
     ms_by_class[c] = 0.0;
     launches_by_class[c] = 0;
+    if (units_by_class) units_by_class[c] = 0;
   }
   for (const Profiler::Span& sp : ctx->prof.spans) {
     float ms = 0.f;
     ACINO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->prof.pool[sp.a], ctx->prof.pool[sp.b]));
     ms_by_class[sp.cls] += ms;
     launches_by_class[sp.cls] += 1;
+    if (units_by_class) units_by_class[sp.cls] += sp.units;
   }
   ctx->prof.spans.clear();
   ctx->prof.used = 0;

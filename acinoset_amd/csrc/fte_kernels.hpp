@@ -44,12 +44,16 @@ __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
 
 // Per-kernel-class HIP-event profiler (bench.py's live roofline measurement).  Events are recorded on
 // the stream the kernels are launched on; nothing is recorded unless enabled.
-enum ProfClass { PC_SETUP = 0, PC_ELIM, PC_UPDATE, PC_BACKSUB, PC_TRIAL, PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_COUNT };
+// one class per kernel: {elim, elim_deep, update0, update, update_deep, backsub0, backsub, trial, assemble, totals,
+// control, spare}; `units` = chain nodes (BCR kernels) or frames (trial / assemble) the launch processed
+enum ProfClass { PC_ELIM = 0, PC_ELIM_DEEP, PC_UPDATE0, PC_UPDATE, PC_UPDATE_DEEP, PC_BACKSUB0, PC_BACKSUB, PC_TRIAL,
+                 PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_SPARE, PC_COUNT };
+static_assert(PC_COUNT == ACINO_PROF_CLASSES, "profiler classes");
 struct Profiler {
   bool on = false;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  struct Span { int cls; size_t a, b; };
+  struct Span { int cls; size_t a, b; long long units; };
   std::vector<Span> spans;
   hipEvent_t next() {
     if (used == pool.size()) {
@@ -68,7 +72,9 @@ struct ProfSpan {
   hipStream_t s;
   size_t a = 0;
   int cls;
-  ProfSpan(Profiler* prof, int c, hipStream_t st) : p(prof && prof->on ? prof : nullptr), s(st), cls(c) {
+  long long units;
+  ProfSpan(Profiler* prof, int c, hipStream_t st, long long n_units = 0)
+      : p(prof && prof->on ? prof : nullptr), s(st), cls(c), units(n_units) {
     if (p) {
       a = p->used;
       hipEvent_t e = p->next();
@@ -81,7 +87,7 @@ struct ProfSpan {
       hipEvent_t e = p->next();
       if (e) {
         (void)hipEventRecord(e, s);
-        p->spans.push_back({cls, a, b});
+        p->spans.push_back({cls, a, b, units});
       }
     }
   }

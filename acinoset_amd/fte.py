@@ -144,16 +144,23 @@ class FTEContext:
         check(lib().acino_fte_get_result(self._h, self.Ts, ptr(x), ptr(pos), ptr(dx), ptr(ddx), stream_ptr()))
         return x, pos, dx, ddx
 
-    PROF_CLASSES = ("setup", "elim", "update", "backsub", "trial", "assemble", "totals", "control")
+    PROF_CLASSES = ("elim", "elim_deep", "update0", "update", "update_deep", "backsub0", "backsub", "trial", "assemble",
+                    "totals", "control", "spare")
+    PROF_KERNELS = dict(elim="k_bcr_elim", elim_deep="k_bcr_elim_deep", update0="k_bcr_update0", update="k_bcr_update",
+                        update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
+                        trial="k_trial", assemble="k_fte_assemble<true>", totals="k_totals", control="k_control")
 
     def profile_begin(self):
         check(lib().acino_fte_profile_begin(self._h))
 
     def profile_end(self):
-        ms = (C.c_double * 8)()
-        n = (C.c_int * 8)()
-        check(lib().acino_fte_profile_end(self._h, ms, n, stream_ptr()))
-        return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(self.PROF_CLASSES)}
+        """Per kernel class: summed HIP-event time (ms), launches, work units (chain nodes / frames)."""
+        n = len(self.PROF_CLASSES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int * n)()
+        units = (C.c_int64 * n)()
+        check(lib().acino_fte_profile_end(self._h, ms, cnt, units, stream_ptr()))
+        return {k: dict(ms=ms[i], launches=cnt[i], units=units[i]) for i, k in enumerate(self.PROF_CLASSES)}
 
     def cost(self, x_active):
         x = calib._to_dev(x_active, self.device)

@@ -25,11 +25,15 @@ if ROOT not in sys.path:
 
 N_FRAMES = 10000
 N_CAMS = 6
-# Algorithmic flops per frame per LM iteration (dense accounting), by kernel class.
+# Algorithmic flops per frame per LM iteration (dense accounting), by PHASE of the iteration.
 ALG_FLOPS = {"assemble": 218.0e3,   # FK 1.1k + projection 7.8k + Jacobians 14.4k + chain 16.7k + weights 10k + J^T W J 156k + J^T r 12k
              "elim": 52.0e3,        # block Cholesky 25^3/3 + three 25x25 triangular solves
              "update": 187.5e3,     # six 2*25^3 trailing GEMM updates of the banded factorisation
              "backsub": 10.0e3}     # forward/backward substitution
+# every phase of the block-cyclic reduction is carried by several kernels (level 0 has its own sparse-coupling forms, the
+# narrow levels their own latency-oriented kernels); a kernel's share of the phase = the chain nodes it processed
+PHASE_OF = {"elim": "elim", "elim_deep": "elim", "update0": "update", "update": "update", "update_deep": "update",
+            "backsub0": "backsub", "backsub": "backsub", "assemble": "assemble"}
 ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
@@ -244,21 +248,27 @@ def main():
         n_loc = n1 - n0
         ms_step = 1e3 * dt / args.steps
         value = args.frames * args.steps / dt
-        dom = max(ALG_FLOPS, key=lambda k: prof[k]["ms"])
+        dom = max(PHASE_OF, key=lambda k: prof[k]["ms"])            # the kernel with the largest summed launch time
         launches = max(prof[dom]["launches"], 1)
         avg_ms = prof[dom]["ms"] / launches
-        flops_per_launch = ALG_FLOPS[dom] * n_loc * args.steps / launches
+        phase = PHASE_OF[dom]
+        phase_units = sum(prof[k]["units"] for k in PHASE_OF if PHASE_OF[k] == phase)
+        share = prof[dom]["units"] / max(phase_units, 1)             # of the phase's nodes (frames for assemble)
+        flops_per_launch = ALG_FLOPS[phase] * n_loc * args.steps * share / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
-        kname = {"elim": "k_bcr_elim", "update": "k_bcr_update", "assemble": "k_fte_assemble<true>",
-                 "backsub": "k_bcr_backsub"}[dom]
+        kname = fte.FTEContext.PROF_KERNELS[dom]
         traffic = None     # HBM bytes / launch of the dominant kernel from the committed PMC passes (profiles/)
+        mfma = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_final", "pmc_traffic.json")))
+            pdir = os.path.join(ROOT, "profiles", "round1_final")
             if args.frames == N_FRAMES and world == 1:
-                traffic = pmc["kernels"]["acino::" + kname]["bytes_per_launch"]
+                traffic = json.load(open(os.path.join(pdir, "pmc_traffic.json")))["kernels"]["acino::" + kname]["bytes_per_launch"]
+                mk = json.load(open(os.path.join(pdir, "pmc_mfma_lds.json")))["kernels"]["acino::" + kname]
+                mfma = dict(mfma_f64_flops_executed_per_launch=mk["mfma_f64_flops_per_launch"],
+                            mfma_util_percent=mk["mfma_util_percent"], lds_bank_conflict_rate=mk["lds_bank_conflict_rate"])
         except Exception:
-            traffic = None
+            pass
         out = {
             "metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,6 +283,8 @@ def main():
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "launches_per_step": launches / args.steps, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
+                         "share_of_phase": {"phase": phase, "nodes_or_frames": share},
+                         "pmc": mfma,
                          "step": {"achieved_tflops": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12,
                                   "frac_fp64": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,

@@ -171,13 +171,15 @@ int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* 
  * CURRENT iterate, for parity checks.  Either may be NULL. */
 int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
 /* Live per-kernel timing for bench.py: HIP events recorded on the launch stream around every kernel between
- * begin and end.  end synchronises and returns, per class {setup, elim, update, backsub, trial, assemble,
- * totals, control}, the summed event time in ms and the launch count. */
-#define ACINO_PROF_CLASSES 8
+ * begin and end.  end synchronises and returns, per class {elim, elim_deep, update0, update, update_deep, backsub0,
+ * backsub, trial, assemble, totals, control, spare} (one class per kernel), the summed event time in ms, the launch
+ * count and the work units (chain nodes for the block-reduction kernels, frames for trial/assemble; may be NULL). */
+#define ACINO_PROF_CLASSES 12
 int acino_fte_profile_begin(acino_fte_ctx* ctx);
 /* Debug aid: phase timestamps (wall_clock64 ticks) of workgroup 0 of the elimination kernel -> d_dbg[16]; NULL disables. */
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);
-int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, void* stream);
+int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, int64_t* units_by_class,
+                          void* stream);
 /* Stand-alone helpers: dx/ddx of a trajectory d_x[N][25]; FK of active states d_xa[N][25] -> d_pos[N][20][3]. */
 int acino_fte_derivatives(const double* d_x, int64_t n_frames, double ts, double* d_dx, double* d_ddx, void* stream);
 int acino_fk_active(const double* d_xa, int64_t n_frames, double* d_pos, void* stream);

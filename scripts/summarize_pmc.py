@@ -5,7 +5,8 @@
 
 HBM traffic: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is
 doubled (MI355X_MICROARCH.md, HBM section).  MFMA: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = fp64 matrix flops executed;
-MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs).  LDS bank-conflict rate =
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), GRBM_GUI_ACTIVE taken per XCD (rocprofv3 reports
+the sum over the 8 XCDs).  LDS bank-conflict rate =
 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles)."""
 import csv
 import glob
@@ -57,7 +58,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in acc:
         if not k.startswith("acino::"):
             continue
         g = lambda c: acc.get(c, {}).get(k, [1, 0.0])[1]
-        gui = g("GRBM_GUI_ACTIVE")
+        gui = g("GRBM_GUI_ACTIVE") / 8.0     # the CSV value is the SUM over the 8 XCDs; the formulas use the per-die count
         out["kernels"][k] = dict(
             launches=n,
             mfma_f64_flops_per_launch=g("SQ_INSTS_VALU_MFMA_MOPS_F64") * 512.0 / n,
