@@ -118,6 +118,11 @@ SIGNATURES = {
     "acino_fte_backsub_local": (_I, [_P, _P, _I, _I, _P]),
     "acino_fte_trial": (_I, [_P, _P]),
     "acino_fte_export_edges": (_I, [_P, _I, _P, _P]),
+    "acino_fte_graphs_active": (_I, [_P]),
+    "acino_fte_shard_reduce": (_I, [_P, _P, _I, _I, _P]),
+    "acino_fte_shard_solve": (_I, [_P, _P, _P, _P, _Z, _P, _I, _I, _P]),
+    "acino_fte_shard_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "acino_fte_shard_control": (_I, [_P, _P, _I, _I, _P]),
     "acino_fte_profile_begin": (_I, [_P]),
     "acino_fte_debug_stamps": (_I, [_P, _P]),
     "acino_fte_profile_end": (_I, [_P, _P, _P, _P, _P]),

@@ -39,6 +39,12 @@ struct acino_fte_ctx {
   bool graph_on = false;            // replay the LM step as a hipGraph (single-shard contexts, non-null stream)
   hipGraphExec_t gexec = nullptr;
   hipStream_t gstream = nullptr;
+  // the four phases of a SHARDED iteration (between the collectives), each captured once per buffer set
+  struct SegGraph {
+    hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;
+    uintptr_t key[6] = {0, 0, 0, 0, 0, 0};
+  } seg[4];
 };
 
 namespace acino {
@@ -256,6 +262,24 @@ __global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st,
                           const int* __restrict__ numeric_err, int init) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   lm_control(*cst, st, totals, numeric_err, init);
+}
+
+// Sharded solve: every rank combines the gathered per-rank sums {cost, pred, step_inf, gnorm_inf, n_behind} in rank
+// order (identical on all ranks) and takes the accept/reject decision on its own device.
+__global__ void k_control_gathered(const FteConst* __restrict__ cst, acino_fte_state* st,
+                                   const double* __restrict__ all_partials, int world,
+                                   const int* __restrict__ numeric_err, int init) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int g = 0; g < world; ++g) {
+    const double* p = all_partials + 8 * g;
+    tot[0] += p[0];
+    tot[1] += p[1];
+    tot[2] = fmax(tot[2], p[2]);
+    tot[3] = fmax(tot[3], p[3]);
+    tot[4] += p[4];
+  }
+  lm_control(*cst, st, tot, numeric_err, init);
 }
 
 __global__ void k_copy_x_in(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
@@ -512,8 +536,18 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
 
 int acino_fte_destroy(acino_fte_ctx* ctx) {
   if (ctx && ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
+  if (ctx)
+    for (auto& g : ctx->seg)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
   delete ctx;
   return ACINO_OK;
+}
+
+int acino_fte_graphs_active(acino_fte_ctx* ctx) {
+  if (!ctx) return 0;
+  int m = ctx->gexec ? 16 : 0;
+  for (int i = 0; i < 4; ++i) m |= ctx->seg[i].exec ? (1 << i) : 0;
+  return m;
 }
 
 int acino_fte_enable_graph(acino_fte_ctx* ctx, int on) {
@@ -606,13 +640,8 @@ size_t acino_sep_scratch_bytes(int n_sep) {
   return 5 * align_up((size_t)n_sep * BS * BS * sizeof(double)) + align_up(ints * sizeof(int)) + 1024;
 }
 
-int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
-                           void* stream) {
-  ACINO_REQUIRE(d_sep && d_sep_x && d_scratch, "null");
-  ACINO_REQUIRE(n_sep >= 1 && n_sep <= 1024, "n_sep");
-  ACINO_REQUIRE(scratch_bytes >= acino_sep_scratch_bytes(n_sep), "separator scratch too small");
-  ACINO_REQUIRE(((uintptr_t)d_scratch & 255) == 0, "scratch must be 256-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
+namespace acino {
+static const BcrSchedule& sep_schedule(int n_sep) {
   static thread_local std::map<int, BcrSchedule> cache;   // schedules are immutable once built
   auto it = cache.find(n_sep);
   if (it == cache.end()) {
@@ -620,7 +649,9 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
     sch.build(n_sep, false, false);
     it = cache.emplace(n_sep, std::move(sch)).first;
   }
-  const BcrSchedule& sch = it->second;
+  return it->second;
+}
+static BcrChain sep_chain(void* d_scratch, int n_sep, const BcrSchedule& sch) {
   Carver c{(char*)d_scratch, 0};
   BcrChain ch;
   ch.n_nodes = n_sep;
@@ -637,11 +668,38 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
   ch.st = nullptr;
   ch.x0 = ch.x1 = ch.g0 = ch.g1 = ch.H0 = ch.H1 = nullptr;
   ch.gn_part = nullptr;
-  if (int rc = bcr_set_func_attributes()) return rc;
+  return ch;
+}
+// The (static) schedule is written into the caller's scratch by a kernel that carries it as an argument: no
+// host-to-device copy, so the write is stream-ordered, capturable and never synchronises (chains of <= 128 separators;
+// longer ones fall back to a copy and are not graph-captured).
+struct SchedArg {
+  int n;
+  int v[960];
+};
+__global__ void k_write_schedule(SchedArg a, int* __restrict__ dst) {
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) dst[i] = a.v[i];
+}
+static bool sep_schedule_fits_arg(const BcrSchedule& sch) { return sch.elim.size() + sch.remain.size() <= 960; }
+static int sep_upload_schedule(const BcrChain& ch, const BcrSchedule& sch, hipStream_t s) {
+  int* d_sched = const_cast<int*>(ch.d_elim);
+  if (sep_schedule_fits_arg(sch)) {
+    SchedArg a;
+    a.n = (int)(sch.elim.size() + sch.remain.size());
+    std::copy(sch.elim.begin(), sch.elim.end(), a.v);
+    std::copy(sch.remain.begin(), sch.remain.end(), a.v + sch.elim.size());
+    hipLaunchKernelGGL(k_write_schedule, dim3(1), dim3(256), 0, s, a, d_sched);
+    ACINO_LAUNCH_CHECK();
+    return ACINO_OK;
+  }
   ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, sch.elim.data(), sizeof(int) * sch.elim.size(), hipMemcpyHostToDevice, s));
   if (!sch.remain.empty())
     ACINO_HIP_CHECK(hipMemcpyAsync(d_sched + sch.elim.size(), sch.remain.data(), sizeof(int) * sch.remain.size(),
                                    hipMemcpyHostToDevice, s));
+  return ACINO_OK;
+}
+static int sep_launch(const BcrChain& ch, const BcrSchedule& sch, const double* d_sep, int n_sep, double* d_sep_x,
+                      hipStream_t s) {
   hipLaunchKernelGGL(k_import_sep, dim3(8, n_sep), dim3(256), 0, s, d_sep, n_sep, ch);
   ACINO_LAUNCH_CHECK();
   int rc = bcr_reduce(ch, sch, nullptr, nullptr, nullptr, s);
@@ -651,6 +709,21 @@ int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void
   hipLaunchKernelGGL(k_copy_vec, dim3((n_sep * BS + 255) / 256), dim3(256), 0, s, ch.b, d_sep_x, n_sep * BS);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
+}
+}  // namespace acino
+
+int acino_solve_separators(const double* d_sep, int n_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
+                           void* stream) {
+  ACINO_REQUIRE(d_sep && d_sep_x && d_scratch, "null");
+  ACINO_REQUIRE(n_sep >= 1 && n_sep <= 1024, "n_sep");
+  ACINO_REQUIRE(scratch_bytes >= acino_sep_scratch_bytes(n_sep), "separator scratch too small");
+  ACINO_REQUIRE(((uintptr_t)d_scratch & 255) == 0, "scratch must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const BcrSchedule& sch = sep_schedule(n_sep);
+  BcrChain ch = sep_chain(d_scratch, n_sep, sch);
+  if (int rc = bcr_set_func_attributes()) return rc;
+  if (int rc = sep_upload_schedule(ch, sch, s)) return rc;
+  return sep_launch(ch, sch, d_sep, n_sep, d_sep_x, s);
 }
 
 int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank, int world, void* stream) {
@@ -689,6 +762,106 @@ int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* 
                      ctx->b.x[1], ctx->h.n_frames, d_edge);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
+}
+
+// ---- the four phases of a sharded iteration ------------------------------------------------
+// A phase is a fixed launch sequence on caller-owned buffers; with graphs enabled it is captured once per buffer set
+// and replayed, so a rank issues 4 graph launches + 3 collectives per iteration instead of ~50 kernel launches.
+extern "C++" {
+template <class F>
+static int run_phase(acino_fte_ctx* ctx, int id, const uintptr_t (&key)[6], hipStream_t s, F&& body) {
+  if (!(ctx->graph_on && !ctx->prof.on && s != nullptr)) return body();
+  acino_fte_ctx::SegGraph& g = ctx->seg[id];
+  if (!g.exec || g.stream != s || memcmp(g.key, key, sizeof(key)) != 0) {
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+    // capture; if anything about it fails (another thread of the process touching the runtime, an unsupported
+    // call) the phase simply runs eagerly from now on - nothing captured has executed
+    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int rc = body();
+      hipGraph_t graph = nullptr;
+      const hipError_t e = hipStreamEndCapture(s, &graph);
+      ok = rc == ACINO_OK && e == hipSuccess && graph != nullptr;
+      if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      g.exec = nullptr;
+      ctx->graph_on = false;
+      return body();
+    }
+    g.stream = s;
+    memcpy(g.key, key, sizeof(key));
+  }
+  ACINO_HIP_CHECK(hipGraphLaunch(g.exec, s));
+  return ACINO_OK;
+}
+}  // extern "C++"
+
+int acino_fte_shard_reduce(acino_fte_ctx* ctx, double* d_sep, int rank, int world, void* stream) {
+  ACINO_REQUIRE(ctx && d_sep && world >= 2, "args");
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t key[6] = {(uintptr_t)d_sep, (uintptr_t)rank, (uintptr_t)world, 0, 0, 0};
+  return run_phase(ctx, 0, key, s, [&]() -> int {
+    ACINO_HIP_CHECK(hipMemsetAsync(d_sep, 0, sizeof(double) * (size_t)(world - 1) * ACINO_SEP_DOUBLES, s));
+    if (int rc = acino_fte_reduce_local(ctx, stream)) return rc;
+    return acino_fte_export_separators(ctx, d_sep, rank, world, stream);
+  });
+}
+
+int acino_fte_shard_solve(acino_fte_ctx* ctx, const double* d_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
+                          double* d_edge_out, int rank, int world, void* stream) {
+  ACINO_REQUIRE(ctx && d_sep && d_sep_x && d_scratch && d_edge_out && world >= 2, "args");
+  const int n_sep = world - 1;
+  ACINO_REQUIRE(scratch_bytes >= acino_sep_scratch_bytes(n_sep), "separator scratch too small");
+  ACINO_REQUIRE(((uintptr_t)d_scratch & 255) == 0, "scratch must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const BcrSchedule& sch = sep_schedule(n_sep);
+  const BcrChain ch = sep_chain(d_scratch, n_sep, sch);
+  const uintptr_t key[6] = {(uintptr_t)d_sep, (uintptr_t)d_sep_x, (uintptr_t)d_scratch, (uintptr_t)d_edge_out,
+                            (uintptr_t)rank, (uintptr_t)world};
+  auto body = [&]() -> int {
+    if (int rc = sep_upload_schedule(ch, sch, s)) return rc;
+    if (int rc = sep_launch(ch, sch, d_sep, n_sep, d_sep_x, s)) return rc;
+    if (int rc = acino_fte_backsub_local(ctx, d_sep_x, rank, world, stream)) return rc;
+    if (int rc = acino_fte_trial(ctx, stream)) return rc;
+    return acino_fte_export_edges(ctx, 1, d_edge_out, stream);
+  };
+  if (!sep_schedule_fits_arg(sch)) return body();     // (host copy inside: run eagerly)
+  return run_phase(ctx, 1, key, s, body);
+}
+
+int acino_fte_shard_eval(acino_fte_ctx* ctx, int which, const double* d_all_edges, int rank, int world,
+                         double* d_partial_out, void* stream) {
+  ACINO_REQUIRE(ctx && d_all_edges && d_partial_out && world >= 2 && rank >= 0 && rank < world, "args");
+  ACINO_REQUIRE(which == 0 || which == 1, "which");
+  hipStream_t s = (hipStream_t)stream;
+  const double* hl = rank > 0 ? d_all_edges + (size_t)(rank - 1) * 6 * NP + 3 * NP : nullptr;   // left rank's last 3 frames
+  const double* hr = rank + 1 < world ? d_all_edges + (size_t)(rank + 1) * 6 * NP : nullptr;     // right rank's first 3
+  const uintptr_t key[6] = {(uintptr_t)d_all_edges, (uintptr_t)d_partial_out, (uintptr_t)rank, (uintptr_t)world,
+                            (uintptr_t)which, 0};
+  return run_phase(ctx, 2, key, s, [&]() -> int {
+    if (int rc = acino_fte_set_halo(ctx, which, hl, hr, stream)) return rc;
+    if (int rc = acino_fte_eval(ctx, which, stream)) return rc;
+    return acino_fte_export_partials(ctx, d_partial_out, stream);
+  });
+}
+
+int acino_fte_shard_control(acino_fte_ctx* ctx, const double* d_all_partials, int world, int init, void* stream) {
+  ACINO_REQUIRE(ctx && d_all_partials && world >= 1, "args");
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t key[6] = {(uintptr_t)d_all_partials, (uintptr_t)world, (uintptr_t)init, 0, 0, 0};
+  return run_phase(ctx, 3, key, s, [&]() -> int {
+    ProfSpan sp(&ctx->prof, PC_CONTROL, s);
+    hipLaunchKernelGGL(k_control_gathered, dim3(1), dim3(64), 0, s, ctx->b.cst, ctx->b.state, d_all_partials, world,
+                       ctx->b.numeric_err, init);
+    ACINO_LAUNCH_CHECK();
+    return ACINO_OK;
+  });
 }
 
 static int step_eager(acino_fte_ctx* ctx, void* stream) {

@@ -96,6 +96,26 @@ class HipBackend:
     def result_x(self):
         return self.ctx.result()[0]
 
+    # sharded iteration as four fused phases (each one C-ABI call = one hipGraph replay when graphs are enabled)
+    fused_phases = True
+
+    def phase_reduce(self, sep):
+        check(lib().acino_fte_shard_reduce(self.ctx._h, ptr(sep), self.rank, self.world, stream_ptr()))
+
+    def phase_solve(self, sep, sep_x, edges_out):
+        check(lib().acino_fte_shard_solve(self.ctx._h, ptr(sep), ptr(sep_x), C.c_void_p(self._scratch_ptr),
+                                          self._scratch_bytes, ptr(edges_out), self.rank, self.world, stream_ptr()))
+
+    def phase_eval(self, which, all_edges, partial_out):
+        check(lib().acino_fte_shard_eval(self.ctx._h, which, ptr(all_edges), self.rank, self.world, ptr(partial_out),
+                                         stream_ptr()))
+
+    def phase_control(self, all_partials, init):
+        check(lib().acino_fte_shard_control(self.ctx._h, ptr(all_partials), self.world, int(init), stream_ptr()))
+
+    def enable_graph(self, on=True):
+        self.ctx.enable_graph(on)
+
     # unsharded fast path: the whole iteration is one C-ABI call (and one hipGraph replay when enabled)
     def set_x_single(self, x_local):
         self.ctx.set_x(x_local)
@@ -183,6 +203,14 @@ class ShardedFTE:
         if self.world == 1 and hasattr(self.b, "set_x_single"):
             self.b.set_x_single(x_local)
             return
+        if self.world > 1 and getattr(self.b, "fused_phases", False):
+            self.b.load_x(x_local)
+            self.b.export_edges(0, self._edges)
+            self.comm.all_gather(self._all_edges, self._edges)
+            self.b.phase_eval(0, self._all_edges, self._partial)
+            self.comm.all_gather(self._all_partials, self._partial)
+            self.b.phase_control(self._all_partials, True)
+            return
         self.b.load_x(x_local)
         self._exchange_halo(0)
         self.b.eval(0)
@@ -191,6 +219,16 @@ class ShardedFTE:
     def step(self):
         if self.world == 1 and hasattr(self.b, "step_single"):
             self.b.step_single()
+            return
+        if self.world > 1 and getattr(self.b, "fused_phases", False):
+            # 4 launches + 3 collectives per iteration; every buffer is persistent, so the phases replay as graphs
+            self.b.phase_reduce(self._sep)
+            self.comm.all_reduce_sum(self._sep)
+            self.b.phase_solve(self._sep, self._sep_x, self._edges)
+            self.comm.all_gather(self._all_edges, self._edges)
+            self.b.phase_eval(1, self._all_edges, self._partial)
+            self.comm.all_gather(self._all_partials, self._partial)
+            self.b.phase_control(self._all_partials, False)
             return
         self.b.reduce_local()
         if self.world > 1:

@@ -122,6 +122,10 @@ class FTEContext:
         """Replay the LM step as a hipGraph (takes effect on a non-default stream)."""
         check(lib().acino_fte_enable_graph(self._h, int(bool(on))))
 
+    def graphs_active(self):
+        """Bit mask: bits 0..3 the four sharded phases, bit 4 the whole single-shard step."""
+        return int(lib().acino_fte_graphs_active(self._h))
+
     def step(self):
         check(lib().acino_fte_step(self._h, stream_ptr()))
 

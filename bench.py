@@ -213,8 +213,8 @@ def main():
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        if use_graph:
-            ctx.enable_graph(True)        # the step has no host sync: capture once, replay (single GPU)
+        if not args.no_graph:
+            ctx.enable_graph(True)        # no host sync inside a step: capture once, replay (N > 1: the 4 phases between the collectives)
         solver.set_x(x0_local)
         for _ in range(args.warmup):
             solver.step()
@@ -290,7 +290,7 @@ def main():
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
                                   "frac_hbm": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "gpu_kernel_ms_per_step": gpu_ms_step,
-                                  "launch": "hipGraph replay" if use_graph else "eager",
+                                  "launch": "eager" if args.no_graph else ("hipGraph replay" if world == 1 else "4 hipGraph phases + 3 collectives"),
                                   "ms_per_step_eager_with_events": 1e3 * dt_eager / args.steps},
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name")},

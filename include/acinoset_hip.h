@@ -287,6 +287,23 @@ size_t acino_ekf_workspace_bytes(int64_t n_frames, int n_seq);
 int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double* d_cams24, const double* d_states0,
                   void* d_ws, size_t ws_bytes, double* d_est, double* d_smooth, int32_t* d_outliers, void* stream);
 
+/* The same sharded iteration as FOUR fused phases with the three collectives between them; each phase is a fixed
+ * launch sequence on caller-owned buffers and is captured into a hipGraph (acino_fte_enable_graph) per buffer set:
+ *   reduce  : zero d_sep, local reduction, export separators            -> all_reduce(d_sep)
+ *   solve   : separator solve, local back-substitution, trial iterate,
+ *             export its 3+3 edge frames to d_edge_out[6][25]           -> all_gather -> d_all_edges[world][6][25]
+ *   eval    : halo from the neighbours' rows of d_all_edges, residuals + Jacobians + assembly of iterate `which`,
+ *             local sums to d_partial_out[8]                            -> all_gather -> d_all_partials[world][8]
+ *   control : sums combined in rank order, accept/reject + lambda update (init=1: record the loaded iterate). */
+/* Bit mask of instantiated graphs: bits 0..3 = the four sharded phases, bit 4 = the whole single-shard step. */
+int acino_fte_graphs_active(acino_fte_ctx* ctx);
+int acino_fte_shard_reduce(acino_fte_ctx* ctx, double* d_sep, int rank, int world, void* stream);
+int acino_fte_shard_solve(acino_fte_ctx* ctx, const double* d_sep, double* d_sep_x, void* d_scratch, size_t scratch_bytes,
+                          double* d_edge_out, int rank, int world, void* stream);
+int acino_fte_shard_eval(acino_fte_ctx* ctx, int which, const double* d_all_edges, int rank, int world,
+                         double* d_partial_out, void* stream);
+int acino_fte_shard_control(acino_fte_ctx* ctx, const double* d_all_partials, int world, int init, void* stream);
+
 /* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
 

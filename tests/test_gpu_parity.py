@@ -245,10 +245,11 @@ class ThreadComm:
         self.barrier.wait()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_hip_path_equals_single_shard(mods, world):
+@pytest.mark.parametrize("world,graphs", [(2, False), (3, False), (4, False)])
+def test_sharded_hip_path_equals_single_shard(mods, world, graphs):
     """The multi-GPU code path (pinned separators, separator export/all-reduce/solve, halos, global control)
-    run by `world` threads on one GPU must reproduce the single-shard HIP solve."""
+    run by `world` threads on one GPU must reproduce the single-shard HIP solve (phases launched eagerly: stream
+    capture is a per-process affair, the multi-PROCESS test below replays them as hipGraphs)."""
     calib, fte, synth = mods
     from acinoset_amd import dist as adist
     n, steps = 63, 8
@@ -273,6 +274,8 @@ def test_sharded_hip_path_equals_single_shard(mods, world):
             with torch.cuda.stream(torch.cuda.Stream()):
                 drv, (n0, n1) = adist.make_sharded(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world, comm=comm,
                                                    ftol=0.0, xtol=0.0, gtol=0.0)
+                if graphs:
+                    drv.b.enable_graph(True)
                 drv.set_x(torch.as_tensor(x0[n0:n1]))
                 for _ in range(steps):
                     drv.step()
@@ -343,3 +346,55 @@ def test_batched_sequences_equal_individual_solves(mods):
         for k in ("x", "positions", "dx", "ddx"):
             assert res[k].shape == one[k].shape and np.abs(res[k] - one[k]).max() < 1e-7 * max(1.0, np.abs(one[k]).max())
     assert fte.fte_solve_batch([], *rig, seqs[0]["Ts"]) == []
+
+
+def _mp_shard_worker(rank, world, port, n, steps, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acinoset_amd import dist as adist
+        from acinoset_amd import fte, synth
+        torch.cuda.set_device(0)
+        seq = synth.make_sequence(n, "sprint")
+        rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+        x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(4).normal(0, 0.03, (n, 25))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            drv, (n0, n1) = adist.make_sharded(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world,
+                                               ftol=0.0, xtol=0.0, gtol=0.0)
+            drv.b.enable_graph(True)                      # the four phases between the collectives replay as hipGraphs
+            drv.set_x(torch.as_tensor(x0[n0:n1]))
+            for _ in range(steps):
+                drv.step()
+            x = drv.b.result_x().cpu().numpy()
+            st = drv.b.state()
+            graphs = drv.b.ctx.graphs_active()
+        np.savez(out_path + f".{rank}.npz", x=x, cost=st["cost"], accepted=st["accepted"], it=st["iter"], graphs=graphs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
+    """One PROCESS per shard (torch.distributed, gloo, every rank on this GPU), hipGraph phases: the driver's
+    multi-GPU launch minus RCCL.  Must reproduce the single-shard solve."""
+    import torch.multiprocessing as mp
+    calib, fte, synth = mods
+    n, steps = 96, 8
+    seq = synth.make_sequence(n, "sprint")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(4).normal(0, 0.03, (n, 25))
+    ref = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
+    ref.set_x(x0)
+    for _ in range(steps):
+        ref.step()
+    x_ref, st_ref = ref.result()[0].cpu().numpy(), ref.state()
+    out = str(tmp_path / "shard")
+    mp.spawn(_mp_shard_worker, args=(world, 29730 + world, n, steps, out), nprocs=world, join=True)
+    parts = [np.load(out + f".{r}.npz") for r in range(world)]
+    assert all(int(p["accepted"]) == st_ref["accepted"] and int(p["it"]) == steps for p in parts)
+    assert all(int(p["graphs"]) == 0b1111 for p in parts)          # every phase really was a graph replay
+    assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-9 * abs(st_ref["cost"])
+    assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 1e-8
