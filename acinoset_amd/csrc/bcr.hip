@@ -462,7 +462,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     double gmax = build_node(Lm, yv, ch, *cst, i, tid);
     publish_gmax(gmax, red, ch.gn_part, i, tid);
   } else {
-    load_mat(Lm, ch.D + i * MB, tid);
+    load_mat(Lm, ch.D + i * MB, tid);      // (only the lower tiles are meaningful: the update kernels write no others)
     if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
   }
   __syncthreads();
@@ -724,10 +724,7 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
     };
     auto store_tiles = [&](int q, int ib, int jb) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];
-        if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[q][rr];
-      }
+      for (int rr = 0; rr < 4; ++rr) Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[q][rr];   // lower tiles only
     };
     if (wave == 0) syrk_tiles_foreach<0>(load_tiles);
     else if (wave == 1) syrk_tiles_foreach<1>(load_tiles);
@@ -835,9 +832,7 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
         if (both) a = mma_seq<BS / 4, true>(a, Wb2 + lk * LD + ib * 16 + li, 4 * LD, Wb2 + lk * LD + jb * 16 + li, 4 * LD);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const double v = dt[q][rr] + a[rr];
-          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = v;
-          if (ib != jb) Dj[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = v;
+          Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = dt[q][rr] + a[rr];          // lower tiles only
         }
       }
     }
