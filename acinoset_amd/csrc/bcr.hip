@@ -906,6 +906,85 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
   }
 }
 
+// The deepest levels of the back-substitution as ONE launch.  Per node the three matrices do not depend on anything
+// computed here, only the two neighbour solutions do - so every (level, node) gets its own workgroup, requests
+// W_l, W_r and U at once (three LDS buffers), and only then waits for the deeper levels: a chain of
+// (acquire, 160 doubles, two short mat-vecs, release) per level instead of a kernel launch with three HBM round
+// trips.  Entries are ordered deepest level first and a workgroup only ever waits for entries with a LOWER index, so
+// progress does not depend on how many workgroups are resident.  done[0] counts finished entries (zeroed before
+// the launch); visibility between CUs / XCDs: agent-scope release after the solution is written, agent-scope
+// acquire by one lane + barrier before it is read.
+__global__ void __launch_bounds__(256)
+k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Ml = reinterpret_cast<double*>(smem_raw);
+  double* Mr = Ml + MAT;
+  double* Mu = Mr + MAT;
+  double* xl = Mu + MAT;          // [80] each
+  double* xr = xl + BS;
+  double* tv = xr + BS;
+  double* part = tv + BS;         // [3][80]
+  const int tid = threadIdx.x;
+  const int* en = ch.d_tail + 4 * blockIdx.x;
+  const int i = en[0], l = en[1], r = en[2], need = en[3];
+  const size_t MB = (size_t)BS * BS;
+  {  // all three matrices in flight before the first LDS write
+    const double2* s0 = reinterpret_cast<const double2*>(ch.Wl + i * MB);
+    const double2* s1 = reinterpret_cast<const double2*>(ch.Wr + i * MB);
+    const double2* s2 = reinterpret_cast<const double2*>(ch.D + i * MB);
+    double2 v0[13], v1[13], v2[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < BS * BS / 2) {
+        v0[k] = l >= 0 ? s0[idx] : make_double2(0.0, 0.0);
+        v1[k] = r >= 0 ? s1[idx] : make_double2(0.0, 0.0);
+        v2[k] = s2[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < BS * BS / 2) {
+        const int e = 2 * idx, rr = e / BS, c = e % BS;
+        Ml[rr * LD + c] = v0[k].x;  Ml[rr * LD + c + 1] = v0[k].y;
+        Mr[rr * LD + c] = v1[k].x;  Mr[rr * LD + c + 1] = v1[k].y;
+        Mu[rr * LD + c] = v2[k].x;  Mu[rr * LD + c + 1] = v2[k].y;
+      }
+    }
+  }
+  const double yi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;     // y_i: written by the reduction, long ago
+  if (tid == 0) {   // cheap relaxed polls, ONE acquire (cache invalidation) once the deeper levels are done
+    while (__hip_atomic_load(ch.d_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (tid < BS) {
+    xl[tid] = l >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)l * BS + tid) : 0.0;
+    xr[tid] = r >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)r * BS + tid) : 0.0;
+  }
+  __syncthreads();
+  const int row = tid % BS, pr = tid / BS, k0 = 27 * pr, k1 = min(k0 + 27, BS);
+  if (tid < 3 * BS) {
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s += Ml[row * LD + k] * xl[k] + Mr[row * LD + k] * xr[k];
+    part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < BS) tv[tid] = yi - ((part[tid] + part[BS + tid]) + part[2 * BS + tid]);
+  __syncthreads();
+  if (tid < 3 * BS) {                                                  // x = U t, U upper triangular
+    double s = 0.0;
+    for (int k = max(k0, row); k < k1; ++k) s += Mu[row * LD + k] * tv[k];
+    part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];
+  __syncthreads();                // the workgroup's stores are ordered before lane 0's agent-scope release
+  if (tid == 0) __hip_atomic_fetch_add(ch.d_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- level 0 of an FTE chain: stencil forms --------------------------------------------------
 // coefficient tables (fill_coupling_coef): cL/cR[(ii*3 + jj)*NP + p], ii <= jj.
 //   E_l(n) = block(n, n-1): rows (ii,p) of n, cols (jj,p) of n-1, value cL_n[(ii*3+jj)*NP+p]
@@ -1125,6 +1204,26 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
     act.swap(next);
     if (act.empty()) break;
   }
+  tail.clear();
+  tail_levels = 0;
+  int total = 0;
+  for (int k = (int)levels.size() - 1; k >= 1; --k) {     // (level 0 of an FTE chain has its own kernel)
+    const BcrLevel& lv = levels[k];
+    if (total + lv.n_elim > 128) break;
+    for (int e = 0; e < lv.n_elim; ++e) {
+      const int* en = &elim[3 * (lv.elim_off + e)];
+      tail.push_back(en[0]);
+      tail.push_back(en[1]);
+      tail.push_back(en[2]);
+      tail.push_back(total);                              // every entry of the deeper levels comes first
+    }
+    total += lv.n_elim;
+    ++tail_levels;
+  }
+  if (tail_levels < 2) {                                   // nothing to fuse
+    tail.clear();
+    tail_levels = 0;
+  }
 }
 
 static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(double);
@@ -1132,6 +1231,7 @@ static constexpr size_t kElimDeepLds = (MAT + BS + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(double);
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
+static constexpr size_t kBacksubTailLds = (3 * MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
 static constexpr size_t kBacksub0Lds = (MAT + 3 * BS + 18 * NP) * sizeof(double);
 
@@ -1144,6 +1244,8 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update_deep),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateDeepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub_tail),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
@@ -1194,7 +1296,18 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof) {
-  for (int k = (int)sch.levels.size() - 1; k >= 0; --k) {
+  int top = (int)sch.levels.size() - 1;
+  if (ch.d_tail && sch.tail_levels > 0) {
+    const int n_tail = (int)sch.tail.size() / 4;
+    ACINO_HIP_CHECK(hipMemsetAsync(ch.d_done, 0, sizeof(int), s));
+    {
+      ProfSpan sp(prof, PC_BACKSUB_TAIL, s, n_tail);
+      hipLaunchKernelGGL(k_bcr_backsub_tail, dim3(n_tail), dim3(256), kBacksubTailLds, s, ch, d_status);
+    }
+    ACINO_LAUNCH_CHECK();
+    top -= sch.tail_levels;
+  }
+  for (int k = top; k >= 0; --k) {
     const BcrLevel& lv = sch.levels[k];
     {
       ProfSpan sp(prof, (k == 0 && ch.st != nullptr) ? PC_BACKSUB0 : PC_BACKSUB, s, lv.n_elim);

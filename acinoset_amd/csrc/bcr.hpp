@@ -17,6 +17,11 @@ struct BcrSchedule {
   std::vector<BcrLevel> levels;
   std::vector<int> elim;    // 3 ints per entry: node, left, right        (-1 = none)
   std::vector<int> remain;  // 4 ints per entry: node, elim-left, elim-right, new right neighbour
+  // back-substitution "tail": the deepest tail_levels levels (<= 128 nodes together) as ONE launch, deepest first;
+  // 4 ints per entry: node, left, right, number of entries that must be finished before this one may start
+  std::vector<int> tail;
+  int tail_levels = 0;
+  size_t ints() const { return elim.size() + remain.size() + tail.size() + 4; }   // (+ the tail's progress counter)
   void build(int n, bool pin_left, bool pin_right);
 };
 
@@ -30,6 +35,8 @@ struct BcrChain {
   double* b;     // [n][80] rhs -> y -> solution
   const int* d_elim;
   const int* d_remain;
+  const int* d_tail;         // device copy of BcrSchedule::tail (null: no fused tail)
+  int* d_done;               // progress counter of the tail kernel
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
   long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
   // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build

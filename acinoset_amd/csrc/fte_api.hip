@@ -80,7 +80,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.totals = c.take<double>(8);
   b.nbehind = c.take<int>(4);
   b.numeric_err = b.nbehind + 1;
-  b.sched = c.take<int>(sched_ints + 4);
+  b.sched = c.take<int>(sched_ints);
   BcrChain chn;
   chn.n_nodes = (int)T;
   chn.D = c.take<double>(T * BS * BS);
@@ -90,6 +90,8 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.b = c.take<double>(T * BS);
   chn.d_elim = nullptr;
   chn.d_remain = nullptr;
+  chn.d_tail = nullptr;
+  chn.d_done = nullptr;
   chn.implicit_couplings = 1;
   chn.dbg = nullptr;
   chn.st = b.state;
@@ -462,7 +464,7 @@ size_t acino_fte_workspace_bytes(const acino_fte_params* p) {
   if (!p || p->n_frames < 1) return 0;
   BcrSchedule sch;
   sch.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
-  return carve(p, nullptr, nullptr, nullptr, sch.elim.size() + sch.remain.size()) + 256;
+  return carve(p, nullptr, nullptr, nullptr, sch.ints()) + 256;
 }
 
 int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det, const double* d_cams24,
@@ -481,7 +483,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   }
   ctx->lam0 = p->lam0;
   ctx->sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
-  const size_t sched_ints = ctx->sched.elim.size() + ctx->sched.remain.size();
+  const size_t sched_ints = ctx->sched.ints();
   const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, sched_ints);
   if (need > workspace_bytes) {
     set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -515,6 +517,9 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   if (e == hipSuccess && !ctx->sched.remain.empty())
     e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size(), ctx->sched.remain.data(),
                        sizeof(int) * ctx->sched.remain.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !ctx->sched.tail.empty())
+    e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size(), ctx->sched.tail.data(),
+                       sizeof(int) * ctx->sched.tail.size(), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     set_error("context upload failed: %s", hipGetErrorString(e));
@@ -523,6 +528,10 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   }
   ctx->chain.d_elim = ctx->b.sched;
   ctx->chain.d_remain = ctx->b.sched + ctx->sched.elim.size();
+  if (!ctx->sched.tail.empty()) {
+    ctx->chain.d_tail = ctx->chain.d_remain + ctx->sched.remain.size();
+    ctx->chain.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
+  }
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
   rc = bcr_set_func_attributes();
@@ -663,6 +672,8 @@ static BcrChain sep_chain(void* d_scratch, int n_sep, const BcrSchedule& sch) {
   int* d_sched = c.take<int>(sch.elim.size() + sch.remain.size() + 8);
   ch.d_elim = d_sched;
   ch.d_remain = d_sched + sch.elim.size();
+  ch.d_tail = nullptr;            // (the separator chain keeps the per-level kernels)
+  ch.d_done = nullptr;
   ch.implicit_couplings = 0;
   ch.dbg = nullptr;
   ch.st = nullptr;

@@ -45,9 +45,9 @@ __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
 // Per-kernel-class HIP-event profiler (bench.py's live roofline measurement).  Events are recorded on
 // the stream the kernels are launched on; nothing is recorded unless enabled.
 // one class per kernel: {elim, elim_deep, update0, update, update_deep, backsub0, backsub, trial, assemble, totals,
-// control, spare}; `units` = chain nodes (BCR kernels) or frames (trial / assemble) the launch processed
+// control, backsub_tail}; `units` = chain nodes (BCR kernels) or frames (trial / assemble) the launch processed
 enum ProfClass { PC_ELIM = 0, PC_ELIM_DEEP, PC_UPDATE0, PC_UPDATE, PC_UPDATE_DEEP, PC_BACKSUB0, PC_BACKSUB, PC_TRIAL,
-                 PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_SPARE, PC_COUNT };
+                 PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_BACKSUB_TAIL, PC_COUNT };
 static_assert(PC_COUNT == ACINO_PROF_CLASSES, "profiler classes");
 struct Profiler {
   bool on = false;

@@ -149,10 +149,10 @@ class FTEContext:
         return x, pos, dx, ddx
 
     PROF_CLASSES = ("elim", "elim_deep", "update0", "update", "update_deep", "backsub0", "backsub", "trial", "assemble",
-                    "totals", "control", "spare")
+                    "totals", "control", "backsub_tail")
     PROF_KERNELS = dict(elim="k_bcr_elim", elim_deep="k_bcr_elim_deep", update0="k_bcr_update0", update="k_bcr_update",
                         update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
-                        trial="k_trial", assemble="k_fte_assemble<true>", totals="k_totals", control="k_control")
+                        backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true>", totals="k_totals", control="k_control")
 
     def profile_begin(self):
         check(lib().acino_fte_profile_begin(self._h))

@@ -33,7 +33,7 @@ ALG_FLOPS = {"assemble": 218.0e3,   # FK 1.1k + projection 7.8k + Jacobians 14.4
 # every phase of the block-cyclic reduction is carried by several kernels (level 0 has its own sparse-coupling forms, the
 # narrow levels their own latency-oriented kernels); a kernel's share of the phase = the chain nodes it processed
 PHASE_OF = {"elim": "elim", "elim_deep": "elim", "update0": "update", "update": "update", "update_deep": "update",
-            "backsub0": "backsub", "backsub": "backsub", "assemble": "assemble"}
+            "backsub0": "backsub", "backsub": "backsub", "backsub_tail": "backsub", "assemble": "assemble"}
 ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)

@@ -172,7 +172,7 @@ int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* 
 int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
 /* Live per-kernel timing for bench.py: HIP events recorded on the launch stream around every kernel between
  * begin and end.  end synchronises and returns, per class {elim, elim_deep, update0, update, update_deep, backsub0,
- * backsub, trial, assemble, totals, control, spare} (one class per kernel), the summed event time in ms, the launch
+ * backsub, trial, assemble, totals, control, backsub_tail} (one class per kernel), the summed event time in ms, the launch
  * count and the work units (chain nodes for the block-reduction kernels, frames for trial/assemble; may be NULL). */
 #define ACINO_PROF_CLASSES 12
 int acino_fte_profile_begin(acino_fte_ctx* ctx);
