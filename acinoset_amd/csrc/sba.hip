@@ -13,8 +13,10 @@ namespace acino {
 constexpr int SBA_MAXC = ACINO_MAX_CAMS;
 
 struct SbaIntr {
-  double fx, fy, cx, cy, k1, k2, k3, k4;
+  double fx, fy, cx, cy;
+  double d[12];   // fisheye: k1..k4 ; pinhole (cv2.projectPoints): k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
 };
+constexpr int SBA_INTR = 16;
 
 // cv2.fisheye projection of a camera-frame point and d(uv)/d(Xc)
 template <bool JAC>
@@ -23,7 +25,7 @@ __device__ __forceinline__ void fisheye_cam(const SbaIntr& c, const double Xc[3]
   const double a = Xc[0] * iz, b = Xc[1] * iz;
   const double r = sqrt(a * a + b * b);
   const double th = atan(r), th2 = th * th;
-  const double thd = th * (1 + th2 * (c.k1 + th2 * (c.k2 + th2 * (c.k3 + th2 * c.k4))));
+  const double thd = th * (1 + th2 * (c.d[0] + th2 * (c.d[1] + th2 * (c.d[2] + th2 * c.d[3]))));
   const bool small = !(r > 1e-8);
   const double m = small ? 1.0 : thd / r;
   uv[0] = c.fx * a * m + c.cx;
@@ -31,7 +33,7 @@ __device__ __forceinline__ void fisheye_cam(const SbaIntr& c, const double Xc[3]
   if (JAC) {
     double dm_da = 0.0, dm_db = 0.0;
     if (!small) {
-      const double dthd = 1 + th2 * (3 * c.k1 + th2 * (5 * c.k2 + th2 * (7 * c.k3 + th2 * 9 * c.k4)));
+      const double dthd = 1 + th2 * (3 * c.d[0] + th2 * (5 * c.d[1] + th2 * (7 * c.d[2] + th2 * 9 * c.d[3])));
       const double dm_dr = (dthd / (1 + r * r) * r - thd) / (r * r);
       dm_da = dm_dr * a / r;
       dm_db = dm_dr * b / r;
@@ -47,10 +49,43 @@ __device__ __forceinline__ void fisheye_cam(const SbaIntr& c, const double Xc[3]
   }
 }
 
+// cv2.projectPoints (rational + tangential + thin-prism model; the skew entry of K is ignored, as OpenCV does)
+template <bool JAC>
+__device__ __forceinline__ void pinhole_cam(const SbaIntr& c, const double Xc[3], double uv[2], double J[2][3]) {
+  const double* k = c.d;
+  const double iz = 1.0 / Xc[2];
+  const double a = Xc[0] * iz, b = Xc[1] * iz;
+  const double r2 = a * a + b * b, r4 = r2 * r2, r6 = r4 * r2;
+  const double num = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+  const double iden = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+  const double rad = num * iden;
+  const double xd = a * rad + 2 * k[2] * a * b + k[3] * (r2 + 2 * a * a) + k[8] * r2 + k[9] * r4;
+  const double yd = b * rad + k[2] * (r2 + 2 * b * b) + 2 * k[3] * a * b + k[10] * r2 + k[11] * r4;
+  uv[0] = c.fx * xd + c.cx;
+  uv[1] = c.fy * yd + c.cy;
+  if (JAC) {
+    const double dnum = k[0] + 2 * k[1] * r2 + 3 * k[4] * r4, dden = k[5] + 2 * k[6] * r2 + 3 * k[7] * r4;
+    const double drad = (dnum - rad * dden) * iden;                  // d rad / d r2
+    const double sx = k[8] + 2 * k[9] * r2, sy = k[10] + 2 * k[11] * r2;
+    const double dx_da = rad + 2 * a * a * drad + 2 * k[2] * b + 6 * k[3] * a + 2 * a * sx;
+    const double dx_db = 2 * a * b * drad + 2 * k[2] * a + 2 * k[3] * b + 2 * b * sx;
+    const double dy_da = 2 * a * b * drad + 2 * k[2] * a + 2 * k[3] * b + 2 * a * sy;
+    const double dy_db = rad + 2 * b * b * drad + 6 * k[2] * b + 2 * k[3] * a + 2 * b * sy;
+    const double du_da = c.fx * dx_da, du_db = c.fx * dx_db, dv_da = c.fy * dy_da, dv_db = c.fy * dy_db;
+    J[0][0] = du_da * iz;
+    J[0][1] = du_db * iz;
+    J[0][2] = -(du_da * a + du_db * b) * iz;
+    J[1][0] = dv_da * iz;
+    J[1][1] = dv_db * iz;
+    J[1][2] = -(dv_da * a + dv_db * b) * iz;
+  }
+}
+
 struct SbaBuf {
   int C, P, M, opt_cams;
+  int model, pad;        // 0 fisheye, 1 pinhole
   double fs;
-  const double* intr;    // [C][8]
+  const double* intr;    // [C][16]
   const double* uv;      // [M][2]
   const int* cam_idx;    // [M]
   const int* pt_start;   // [P+1]
@@ -87,12 +122,13 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
     for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
       const int k = B.pt_obs[o], c = B.cam_idx[k];
       const double* R = Rt + 12 * c;
-      const SbaIntr& in = *reinterpret_cast<const SbaIntr*>(B.intr + 8 * c);
+      const SbaIntr& in = *reinterpret_cast<const SbaIntr*>(B.intr + SBA_INTR * c);
       const double RX[3] = {R[0] * X[0] + R[1] * X[1] + R[2] * X[2], R[3] * X[0] + R[4] * X[1] + R[5] * X[2],
                             R[6] * X[0] + R[7] * X[1] + R[8] * X[2]};
       const double Xc[3] = {RX[0] + R[9], RX[1] + R[10], RX[2] + R[11]};
       double uvp[2], Jpi[2][3];
-      fisheye_cam<JAC>(in, Xc, uvp, Jpi);
+      if (B.model == 0) fisheye_cam<JAC>(in, Xc, uvp, Jpi);
+      else pinhole_cam<JAC>(in, Xc, uvp, Jpi);
       const double r0 = uvp[0] - B.uv[2 * k], r1 = uvp[1] - B.uv[2 * k + 1];
       if (res_out) {
         res_out[2 * k] = r0;
@@ -382,6 +418,7 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
   ACINO_REQUIRE(prm->n_cams >= 1 && prm->n_cams <= SBA_MAXC, "n_cams in 1..16");
   ACINO_REQUIRE(prm->n_points >= 1 && prm->n_obs >= 1, "sizes");
   ACINO_REQUIRE(prm->f_scale > 0 && prm->lam0 > 0 && prm->max_iter >= 0, "f_scale, lam0, max_iter");
+  ACINO_REQUIRE(prm->camera_model == 0 || prm->camera_model == 1, "camera_model: 0 fisheye, 1 pinhole");
   ACINO_REQUIRE(d_intr && d_Rt && d_pts && d_uv && d_cam_idx && d_pt_start && d_pt_obs && d_ws, "null buffer");
   ACINO_REQUIRE(((uintptr_t)d_ws & 255) == 0, "workspace must be 256-byte aligned");
   ACINO_REQUIRE(ws_bytes >= acino_sba_workspace_bytes(prm->n_cams, prm->n_points, prm->n_obs), "workspace too small");
@@ -399,6 +436,8 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
   B.P = (int)P;
   B.M = (int)M;
   B.opt_cams = prm->optimize_cameras ? 1 : 0;
+  B.model = prm->camera_model;
+  B.pad = 0;
   B.fs = prm->f_scale;
   B.intr = d_intr;
   B.uv = d_uv;

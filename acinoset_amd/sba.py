@@ -8,9 +8,9 @@
     bundle_adjust_board_points_and_extrinsics(...)                 calib.py:362-366
 
 Same argument order and return values (``obj_pts[, r_arr, t_arr], residuals`` with ``residuals = dict(before=,
-after=)`` flat ``(reprojected - points_2d).ravel()`` vectors).  ``project_func`` is accepted for signature
-compatibility and must be the fisheye projection (the only camera model the reference's SBA call sites inject,
-app.py:215-223); the arithmetic is the analytic-Jacobian Levenberg-Marquardt solver in csrc/sba.hip, which
+after=)`` flat ``(reprojected - points_2d).ravel()`` vectors).  ``project_func`` selects the camera model exactly as
+the reference's two call sites do (app.py:215-223): ``project_points_fisheye`` -> cv2.fisheye, ``project_points`` ->
+cv2.projectPoints (rational / tangential / thin-prism pinhole); the arithmetic is the analytic-Jacobian Levenberg-Marquardt solver in csrc/sba.hip, which
 minimises the SAME robust cost as scipy's ``least_squares(loss='cauchy', f_scale=...)``.  The last solve's
 summary (costs, iterations, status) is kept in ``last_info``.
 """
@@ -25,11 +25,15 @@ from ._lib import SbaInfo, SbaParams, check, lib, ptr, stream_ptr
 last_info = None
 
 
-def _check_project_func(project_func):
+def _camera_model(project_func):
+    """0 = cv2.fisheye model (the reference's sba_board_points_fisheye, app.py:220-223), 1 = cv2.projectPoints pinhole
+    model (sba_board_points, app.py:215-218); decided by the injected projection function's name."""
     name = getattr(project_func, "__name__", "")
-    if project_func is not None and name and "fisheye" not in name:
-        raise NotImplementedError("GPU bundle adjustment implements the fisheye camera model only "
-                                  f"(got project_func={name})")
+    if project_func is None or "fisheye" in name:
+        return 0
+    if name == "project_points":
+        return 1
+    raise NotImplementedError(f"GPU bundle adjustment knows the reference's two camera models (got project_func={name})")
 
 
 def _csr_by_point(point_3d_indices, n_points):
@@ -43,7 +47,7 @@ def _csr_by_point(point_3d_indices, n_points):
 
 
 def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, optimize_cameras,
-           f_scale, max_iter, ftol, gtol, lam0=1e-3):
+           f_scale, max_iter, ftol, gtol, lam0=1e-3, model=0):
     global last_info
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -56,14 +60,21 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
         raise ValueError("points_2d, point_3d_indices and camera_indices must have one entry per observation")
     if n_obs and (cam_idx.min() < 0 or cam_idx.max() >= n_cams):
         raise ValueError("camera_indices out of range")
-    intr = np.zeros((n_cams, 8))
+    intr = np.zeros((n_cams, 16))
     Rt = np.zeros((n_cams, 12))
     for c in range(n_cams):
         k = np.asarray(k_arr[c], dtype=np.float64)
-        if abs(k[0, 1]) > 1e-12 * abs(k[0, 0]):
-            raise NotImplementedError("skewed intrinsics are not supported by the GPU bundle adjustment "
-                                      "(calib.py:78 calibrates with CALIB_FIX_SKEW)")
-        intr[c] = [k[0, 0], k[1, 1], k[0, 2], k[1, 2], *np.asarray(d_arr[c], dtype=np.float64).reshape(-1)[:4]]
+        dist = np.asarray(d_arr[c], dtype=np.float64).reshape(-1)
+        if model == 0:
+            if abs(k[0, 1]) > 1e-12 * abs(k[0, 0]):
+                raise NotImplementedError("skewed fisheye intrinsics are not supported by the GPU bundle adjustment "
+                                          "(calib.py:78 calibrates with CALIB_FIX_SKEW)")
+            if dist.size != 4:
+                raise ValueError("fisheye cameras have 4 distortion coefficients")
+        elif dist.size not in (4, 5, 8, 12):
+            raise ValueError("pinhole distortion vector must have 4, 5, 8 or 12 entries (cv2.projectPoints)")
+        intr[c, :4] = [k[0, 0], k[1, 1], k[0, 2], k[1, 2]]
+        intr[c, 4:4 + dist.size] = dist
         r = np.asarray(r_arr[c], dtype=np.float64)
         r = calib._rodrigues(r) if r.size == 3 else r
         if optimize_cameras:                      # calib.py:373 passes every rotation through cv2.Rodrigues, which
@@ -74,7 +85,8 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
     start, order = _csr_by_point(point_3d_indices, n_points)
 
     prm = SbaParams(n_cams=n_cams, optimize_cameras=int(bool(optimize_cameras)), n_points=n_points, n_obs=n_obs,
-                    f_scale=float(f_scale), lam0=float(lam0), ftol=float(ftol), gtol=float(gtol), max_iter=int(max_iter))
+                    f_scale=float(f_scale), lam0=float(lam0), ftol=float(ftol), gtol=float(gtol), max_iter=int(max_iter),
+                    camera_model=int(model))
     nbytes = lib().acino_sba_workspace_bytes(n_cams, n_points, n_obs)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (ws.data_ptr() + 255) // 256 * 256
@@ -97,18 +109,16 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
 def bundle_adjust_points_only(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr,
                               project_func=None, f_scale=50, max_iter=200, ftol=1e-15, gtol=1e-10):
     """calib.py:327-341: refine the 3-D points, cameras fixed; Cauchy loss with scale ``f_scale`` px."""
-    _check_project_func(project_func)
     pts, _r, _t, residuals = _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr,
-                                    False, f_scale, max_iter, ftol, gtol)
+                                    False, f_scale, max_iter, ftol, gtol, model=_camera_model(project_func))
     return pts, residuals
 
 
 def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr,
                                         t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10):
     """calib.py:369-390: refine the 3-D points and every camera's rotation + translation (Cauchy loss, scale 1)."""
-    _check_project_func(project_func)
     return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
-                  max_iter, ftol, gtol)
+                  max_iter, ftol, gtol, model=_camera_model(project_func))
 
 
 def prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,

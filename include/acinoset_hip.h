@@ -236,7 +236,7 @@ typedef struct acino_sba_params {
   double ftol;                /* stop when an accepted step lowers the cost by <= ftol * cost */
   double gtol;                /* stop when ||J^T W r||_inf <= gtol */
   int32_t max_iter;
-  int32_t pad0;
+  int32_t camera_model;       /* 0 = cv2.fisheye (app.py:220-223), 1 = cv2.projectPoints pinhole (app.py:215-218) */
 } acino_sba_params;
 typedef struct acino_sba_info {
   double cost_initial, cost_final, gnorm_inf, lam;
@@ -247,7 +247,8 @@ typedef struct acino_sba_info {
 size_t acino_sizeof_sba_params(void);
 size_t acino_sizeof_sba_info(void);
 size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs);
-/* d_intr[C][8] = fx fy cx cy k1..k4; d_res_before / d_res_after [M][2] (projected - observed, as calib.py:316,359) or NULL. */
+/* d_intr[C][16] = fx fy cx cy | 12 distortion coefficients (fisheye: k1..k4, rest 0; pinhole: k1 k2 p1 p2 k3 k4 k5 k6
+ * s1..s4); d_res_before / d_res_after [M][2] (projected - observed, as calib.py:316,359) or NULL. */
 int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,
                     const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start, const int32_t* d_pt_obs,
                     void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,

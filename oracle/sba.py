@@ -59,14 +59,15 @@ def prepare_calib_board_data(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr,
             np.array(point_3d_indices, dtype=int), np.array(camera_indices, dtype=int))
 
 
-def residuals(obj_pts, r_mats, t_arr, k_arr, d_arr, point_3d_indices, camera_indices, points_2d):
-    """(reprojected - points_2d).ravel(), vectorised per camera (calib.py:357-359)."""
+def residuals(obj_pts, r_mats, t_arr, k_arr, d_arr, point_3d_indices, camera_indices, points_2d, project_func=None):
+    """(reprojected - points_2d).ravel(), vectorised per camera (calib.py:357-359); project_func = the injected
+    projection (default: the fisheye model, app.py:220-223)."""
+    project_func = project_func or camera.project_points_fisheye
     out = np.empty((len(points_2d), 2))
     for c in range(len(k_arr)):
         sel = camera_indices == c
         if sel.any():
-            out[sel] = camera.project_points_fisheye(obj_pts[point_3d_indices[sel]], k_arr[c], d_arr[c], r_mats[c],
-                                                     t_arr[c])
+            out[sel] = project_func(obj_pts[point_3d_indices[sel]], k_arr[c], d_arr[c], r_mats[c], t_arr[c])
     return (out - points_2d).ravel()
 
 
@@ -91,7 +92,7 @@ def cauchy_cost(res, f_scale=1.0):
 
 
 def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr,
-                                        t_arr, max_nfev=1000, ftol=1e-10, verbose=0):
+                                        t_arr, max_nfev=1000, ftol=1e-10, verbose=0, project_func=None):
     """calib.py:369-390 with the reference's least_squares settings."""
     n_points, n_cameras = len(points_3d), len(k_arr)
     r_vecs = np.array([rodrigues_to_vec(r) for r in r_arr]).flatten()
@@ -105,7 +106,7 @@ def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, 
 
     def fun(params):
         pts, rm, tt = unpack(params)
-        return residuals(pts, rm, tt, k_arr, d_arr, point_3d_indices, camera_indices, points_2d)
+        return residuals(pts, rm, tt, k_arr, d_arr, point_3d_indices, camera_indices, points_2d, project_func)
 
     f0 = fun(x0)
     A = sparsity(n_cameras, 6, camera_indices, n_points, point_3d_indices)
