@@ -528,7 +528,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   }
   ctx->chain.d_elim = ctx->b.sched;
   ctx->chain.d_remain = ctx->b.sched + ctx->sched.elim.size();
-  if (!ctx->sched.tail.empty()) {
+  if (!ctx->sched.tail.empty() && !p->shared_gpu) {
     ctx->chain.d_tail = ctx->chain.d_remain + ctx->sched.remain.size();
     ctx->chain.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
   }

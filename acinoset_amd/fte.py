@@ -50,7 +50,7 @@ def bounds45():
 
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
-                lam_max=1e16, clamp_lambda=False):
+                lam_max=1e16, clamp_lambda=False, shared_gpu=False):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -72,6 +72,7 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
         p.hi[i] = hi[ACTIVE[i]]
     p.lam0, p.ftol, p.xtol, p.gtol = float(lam0), float(ftol), float(xtol), float(gtol)
     p.lam_max, p.clamp_lambda = float(lam_max), int(bool(clamp_lambda))
+    p.shared_gpu = int(bool(shared_gpu))
     return p
 
 
@@ -307,7 +308,7 @@ def fte_solve_batch(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0
             s = streams[b % len(streams)]
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+                ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, shared_gpu=True, **kw)
                 ctxs.append(ctx)
                 ctx.enable_graph(True)
                 ctx.set_x(x0[:, ACTIVE])

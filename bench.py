@@ -128,7 +128,7 @@ def secondary_metrics(det, rig, Ts):
     ctxs = []
     for b in range(8):
         with torch.cuda.stream(streams[b % 8]):
-            c = fte.FTEContext(det3, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+            c = fte.FTEContext(det3, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, shared_gpu=True)
             c.enable_graph(True)
             c.set_x(x3)
             for _ in range(3):
@@ -200,7 +200,8 @@ def main():
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     x0_full = fte.triangulation_init(det, *rig, 0.5)
     solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world,
-                                          ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)   # never stops: every step is full work
+                                          ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,    # never stops: every step is full work
+                                          shared_gpu="ACINO_FORCE_DEVICE" in os.environ)      # (ranks sharing one GPU: functional runs only)
     x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
 
     def sync():

@@ -119,7 +119,9 @@ typedef struct acino_fte_params {
   double ftol, xtol, gtol; /* stopping tolerances (0 disables a test)                       */
   double lam_max;          /* damping ceiling (0 = 1e16)                                    */
   int32_t clamp_lambda;    /* 0: stop with status 4 when lam exceeds lam_max; 1: clamp and keep iterating */
-  int32_t pad0;
+  int32_t shared_gpu;      /* 1: other solver contexts run on this GPU at the same time (batched clips, several ranks on one
+                            * device): kernels that spin-wait on other workgroups (the fused back-substitution tail) are
+                            * replaced by their per-level forms - concurrent spin-waiting kernels could fill the CUs */
 } acino_fte_params;
 
 /* LM state mirrored in device memory (read back with acino_fte_get_state). */

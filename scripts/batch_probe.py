@@ -24,7 +24,7 @@ for B in (1, 2, 4, 8, 16):
     ctxs = []
     for s in streams:
         with torch.cuda.stream(s):
-            c = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+            c = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, shared_gpu=B > 1)
             c.enable_graph(True)
             c.set_x(x0)
             for _ in range(3):

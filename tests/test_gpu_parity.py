@@ -273,7 +273,7 @@ def test_sharded_hip_path_equals_single_shard(mods, world, graphs):
             comm.bind(rank)
             with torch.cuda.stream(torch.cuda.Stream()):
                 drv, (n0, n1) = adist.make_sharded(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world, comm=comm,
-                                                   ftol=0.0, xtol=0.0, gtol=0.0)
+                                                   ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=True)
                 if graphs:
                     drv.b.enable_graph(True)
                 drv.set_x(torch.as_tensor(x0[n0:n1]))
@@ -363,7 +363,7 @@ def _mp_shard_worker(rank, world, port, n, steps, out_path):
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             drv, (n0, n1) = adist.make_sharded(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world,
-                                               ftol=0.0, xtol=0.0, gtol=0.0)
+                                               ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=True)   # the ranks share this GPU
             drv.b.enable_graph(True)                      # the four phases between the collectives replay as hipGraphs
             drv.set_x(torch.as_tensor(x0[n0:n1]))
             for _ in range(steps):
