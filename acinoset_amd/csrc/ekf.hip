@@ -46,6 +46,61 @@ struct EkfK {
   double sT, dlc_thresh, max_pixel_err, eps;
 };
 
+__device__ __forceinline__ double ekf_readlane(double x, int lane) {
+  long long b = __builtin_bit_cast(long long, x);
+  int lo = __builtin_amdgcn_readlane((int)b, lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// Cholesky of the 25 x 25 SPD matrix A (LDS, leading dimension SLD) by ONE wave, in registers: lane i holds row i;
+// pivots and multipliers are wave-uniform SGPR broadcasts (v_readlane), no barriers.  With NRHS > 0 the same wave
+// then solves L Z = Rhs for the NRHS (<= 26) columns of Rhs (LDS, leading dimension SLD; lane c owns column c, the
+// entries of L are broadcast from the lane that holds their row) and overwrites Rhs with Z.  The lower triangle of
+// A is overwritten by L.  Returns false on a non-positive pivot.  Call from one wave; other waves wait at a barrier.
+template <int NRHS>
+__device__ bool wave_chol25(double* A, double* Rhs, int lane) {
+  double row[EP];
+#pragma unroll
+  for (int j = 0; j < EP; ++j) row[j] = (lane < EP && j <= lane) ? A[lane * SLD + j] : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < EP; ++k) {
+    const double piv0 = ekf_readlane(row[k], k);
+    ok = ok && (piv0 > 0.0);
+    const double piv = fmax(piv0, 1e-300);
+    double y = __builtin_amdgcn_rsq(piv);
+    const double e = fma(-(piv * y), y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    const double lik = row[k] * y;                      // L[i][k] for lanes i >= k
+    row[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < EP; ++j) row[j] -= lik * ekf_readlane(lik, j);
+  }
+  if (lane < EP) {
+#pragma unroll
+    for (int j = 0; j < EP; ++j)
+      if (j <= lane) A[lane * SLD + j] = row[j];
+  }
+  if (NRHS > 0) {
+    double z[EP];
+#pragma unroll
+    for (int k = 0; k < EP; ++k) z[k] = lane < NRHS ? Rhs[k * SLD + lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < EP; ++k) {
+      double sacc = z[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) sacc -= ekf_readlane(row[j], k) * z[j];     // L[k][j] lives in lane k
+      z[k] = sacc / ekf_readlane(row[k], k);
+    }
+    if (lane < NRHS) {
+#pragma unroll
+      for (int k = 0; k < EP; ++k) Rhs[k * SLD + lane] = z[k];
+    }
+  }
+  return ok;
+}
+
 // In-place lower Cholesky of the n x n SPD matrix A (LDS, leading dimension ld); all threads of the block.
 // The strictly-upper triangle is left untouched.  Returns false (to every thread) on a non-positive pivot.
 __device__ bool lds_chol(double* A, int n, int ld, int tid, int nthreads) {
@@ -235,12 +290,17 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       const int ti = wave >> 1, tj = wave & 1;
       const int arow = 16 * ti + li, bcol = 16 * tj + li;
       d4 acc = {0, 0, 0, 0};
-      for (int s = 0; s < rows / 4; ++s) {
-        const int kr = 4 * s + lk;
-        const double a = arow < EP ? Hq[kr * HLD + arow] : 0.0;
-        const double w = ri[kr];
-        const double b = bcol < EP ? w * Hq[kr * HLD + bcol] : (bcol == EP ? w * rs[kr] : 0.0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      const bool a_on = arow < EP, b_h = bcol < EP, b_r = bcol == EP;
+      const double* pa = Hq + (a_on ? arow : 0);
+      const double* pb = b_h ? Hq + bcol : rs;            // column of Hq, or the residual as the 26th column
+      const int sb = b_h ? HLD : 1;
+      for (int s = 0; s < rows / 4; s += 2) {             // rows / 4 = 10 C is even; operands of two steps first
+        const int k0 = 4 * s + lk, k1 = k0 + 4;
+        const double a0 = pa[k0 * HLD], a1 = pa[k1 * HLD];
+        const double w0 = ri[k0], w1 = ri[k1];
+        const double b0 = pb[k0 * sb], b1 = pb[k1 * sb];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_on ? a0 : 0.0, (b_h || b_r) ? w0 * b0 : 0.0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_on ? a1 : 0.0, (b_h || b_r) ? w1 * b1 : 0.0, acc, 0, 0, 0);
       }
       __syncthreads();      // every wave is done with the FK frames' memory (scr is reused from here on)
 #pragma unroll
@@ -251,7 +311,8 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
     }
     for (int e = tid; e < EP * EP; e += 256) Lc[(e / EP) * SLD + e % EP] = P[(e / EP) * PLD + e % EP];
     __syncthreads();
-    if (!lds_chol(Lc, EP, SLD, tid, 256) && !bad) { bad = true; bad_code = 2 * f + 1; }
+    if (wave == 0 && !wave_chol25<0>(Lc, nullptr, lane) && !bad) { bad = true; bad_code = 2 * f + 1; }
+    __syncthreads();
     // N1 = Lc^T M ;  u = Lc^T g in column 25
     for (int e = tid; e < EP * (EP + 1); e += 256) {
       const int a = e / (EP + 1), b = e % (EP + 1);
@@ -267,14 +328,8 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       Bm[a * SLD + b] = s;
     }
     __syncthreads();
-    if (!lds_chol(Bm, EP, SLD, tid, 256) && !bad) { bad = true; bad_code = 2 * f + 2; }
-    if (tid <= EP) {   // Z = Lb^-1 [N1 | u], one column per thread
-      for (int a = 0; a < EP; ++a) {
-        double s = N1[a * SLD + tid];
-        for (int k = 0; k < a; ++k) s -= Bm[a * SLD + k] * N1[k * SLD + tid];
-        N1[a * SLD + tid] = s / Bm[a * SLD + a];
-      }
-    }
+    // B = Lb Lb^T and Z = Lb^-1 [N1 | u] in one wave's registers
+    if (wave == 0 && !wave_chol25<EP + 1>(Bm, N1, lane) && !bad) { bad = true; bad_code = 2 * f + 2; }
     __syncthreads();
     // A = M - Z^T Z ;  w = g - Z^T zu
     for (int e = tid; e < EP * (EP + 1); e += 256) {
@@ -299,12 +354,30 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
     }
     for (int e = tid; e < EP * ES; e += 256) Pt[(e / ES) * PLD + e % ES] = P[(e / ES) * PLD + e % ES];
     __syncthreads();
-    for (int e = tid; e < ES * ES; e += 256) {
-      const int r = e / ES, c = e % ES;
-      double s = P[r * PLD + c];
-#pragma unroll 5
-      for (int b = 0; b < EP; ++b) s -= V[r * HLD + b] * Pt[b * PLD + c];
-      P[r * PLD + c] = s;
+    // P -= V Ptop on the matrix cores: 5 x 5 tiles of the 75 x 75 matrix (padded to 80), K = 25 padded to 28
+    for (int t = wave; t < 25; t += 4) {
+      const int ti = t / 5, tj = t % 5;
+      const int rowA = 16 * ti + li, colB = 16 * tj + li;
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + lk + 4 * r;
+        acc[r] = (row < ES && colB < ES) ? P[row * PLD + colB] : 0.0;
+      }
+      double av[7], bv[7];
+#pragma unroll
+      for (int s7 = 0; s7 < 7; ++s7) {
+        const int kk = 4 * s7 + lk;
+        av[s7] = (rowA < ES && kk < EP) ? V[rowA * HLD + kk] : 0.0;
+        bv[s7] = (colB < ES && kk < EP) ? Pt[kk * PLD + colB] : 0.0;
+      }
+#pragma unroll
+      for (int s7 = 0; s7 < 7; ++s7) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s7], bv[s7], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + lk + 4 * r;
+        if (row < ES && colB < ES) P[row * PLD + colB] = acc[r];
+      }
     }
     __syncthreads();
     if (tid < ES) x_est[(size_t)f * ES + tid] = xs[tid];
