@@ -101,27 +101,6 @@ __device__ bool wave_chol25(double* A, double* Rhs, int lane) {
   return ok;
 }
 
-// In-place lower Cholesky of the n x n SPD matrix A (LDS, leading dimension ld); all threads of the block.
-// The strictly-upper triangle is left untouched.  Returns false (to every thread) on a non-positive pivot.
-__device__ bool lds_chol(double* A, int n, int ld, int tid, int nthreads) {
-  bool ok = true;
-  for (int k = 0; k < n; ++k) {
-    const double d = A[k * ld + k];
-    __syncthreads();
-    if (!(d > 0.0)) ok = false;
-    const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-    for (int i = k + tid; i < n; i += nthreads) A[i * ld + k] *= inv;       // row k becomes sqrt(d)
-    __syncthreads();
-    const int m = n - k - 1;
-    for (int e = tid; e < m * m; e += nthreads) {
-      const int i = k + 1 + e / m, j = k + 1 + e % m;
-      if (j <= i) A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
-    }
-    __syncthreads();
-  }
-  return ok;
-}
-
 __global__ void __launch_bounds__(256)
 k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restrict__ cams,
               const double* __restrict__ states0_all, double* __restrict__ x_pred_all, double* __restrict__ x_est_all,
