@@ -152,33 +152,6 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
   }
 }
 
-__device__ double block_sum(const double* v, int n, double* sh) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-    __syncthreads();
-  }
-  double r = sh[0];
-  __syncthreads();
-  return r;
-}
-__device__ double block_max(const double* v, int n, double* sh) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s = fmax(s, v[i]);
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
-    __syncthreads();
-  }
-  double r = sh[0];
-  __syncthreads();
-  return r;
-}
-
 // totals = {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}   (fixed summation order)
 __device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
                            int init);
@@ -189,12 +162,37 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
          const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
          int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control) {
   if (st->status != 0) return;
-  __shared__ double sh[256];
-  double c = block_sum(cost_part, n_cost, sh);
-  double p = with_step ? block_sum(pred_part, n_trial, sh) : 0.0;
-  double s = with_step ? block_max(step_part, n_trial, sh) : 0.0;
-  double g = with_step ? block_max(gn_part, n_nodes, sh) : 0.0;
+  // the four reductions run together: strided per-thread partials (all loads in flight), one shuffle tree per wave,
+  // four waves combined in order - a fixed summation order, one barrier
+  __shared__ double sh[4][4];
+  double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
+  for (int i = threadIdx.x; i < n_cost; i += 256) c += cost_part[i];
+  if (with_step) {
+    for (int i = threadIdx.x; i < n_trial; i += 256) {
+      p += pred_part[i];
+      s = fmax(s, step_part[i]);
+    }
+    for (int i = threadIdx.x; i < n_nodes; i += 256) g = fmax(g, gn_part[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    c += __shfl_down(c, off, 64);
+    p += __shfl_down(p, off, 64);
+    s = fmax(s, __shfl_down(s, off, 64));
+    g = fmax(g, __shfl_down(g, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    double* w = sh[threadIdx.x >> 6];
+    w[0] = c;
+    w[1] = p;
+    w[2] = s;
+    w[3] = g;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    c = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    p = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+    s = fmax(fmax(sh[0][2], sh[1][2]), fmax(sh[2][2], sh[3][2]));
+    g = fmax(fmax(sh[0][3], sh[1][3]), fmax(sh[2][3], sh[3][3]));
     totals[0] = c;
     totals[1] = p;
     totals[2] = s;
