@@ -77,22 +77,31 @@ __device__ __forceinline__ void chol16_inv_acc(double* T, d4 acc, int lane, int*
       col[kk] = __shfl(acc[s], i + 16 * kk, 64);
       ucol[kk] = __shfl(uacc[s], i + 16 * kk, 64);
     }
+    // The pivot chain inside the panel is kept as short as the arithmetic allows: the multipliers and the next
+    // diagonal entry are broadcast RAW (before this pivot's 1/sqrt is known, i.e. beside its rsq chain), and the next
+    // pivot a'(c+1,c+1) - (a(c+1,c) y)^2 is formed directly from them: rsq -> Newton -> mul -> fma -> next rsq.
+    double piv0 = readlane_d(col[0], 4 * s);
 #pragma unroll
     for (int k0 = 0; k0 < 4; ++k0) {
-      const int c = 4 * s + k0;
-      const double piv0 = readlane_d(col[k0], c);
+      double mraw[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = k0 + 1; kk < 4; ++kk) mraw[kk] = readlane_d(col[k0], 4 * s + kk);    // a[4s+kk][c], unscaled
+      const double dnext = k0 < 3 ? readlane_d(col[k0 + 1], 4 * s + k0 + 1) : 0.0;       // a[c+1][c+1] so far
       bad |= !(piv0 > 0.0);                                   // flagged off the dependency chain
       const double piv = fmax(piv0, 1e-300);
-      // 1/sqrt(piv): hardware estimate + one coupled Newton step (4 fp64 ops on the chain, no range fix-ups:
-      // piv is a positive normal number here)
+      // 1/sqrt(piv): hardware estimate + one coupled Newton step (no range fix-ups: piv is a positive normal number)
       double y = __builtin_amdgcn_rsq(piv);
       const double e = fma(-(piv * y), y, 1.0);
       y = fma(y * e, fma(e, 0.375, 0.5), y);
+      if (k0 < 3) {
+        const double t = mraw[k0 + 1] * y;                    // L[c+1][c]
+        piv0 = fma(-t, t, dnext);
+      }
       col[k0] *= y;                                           // row c becomes sqrt(piv); rows < c hold don't-cares
       ucol[k0] *= y;
 #pragma unroll
       for (int kk = k0 + 1; kk < 4; ++kk) {
-        const double m = readlane_d(col[k0], 4 * s + kk);     // L[4s+kk][c]
+        const double m = mraw[kk] * y;                        // L[4s+kk][c]
         col[kk] -= col[k0] * m;
         ucol[kk] -= ucol[k0] * m;
       }
