@@ -398,3 +398,35 @@ def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
     assert all(int(p["graphs"]) == 0b1111 for p in parts)          # every phase really was a graph replay
     assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-9 * abs(st_ref["cost"])
     assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 1e-8
+
+
+@pytest.mark.parametrize("n,cams", [(5, 6), (8, 2), (47, 4), (64, 6), (95, 3), (193, 6), (385, 6), (1537, 6), (9998, 6)])
+def test_size_sweep_schedules(mods, n, cams):
+    """Chain lengths around the kernel-selection thresholds (wide / narrow / fused-tail levels, odd node counts, frame
+    counts that are not multiples of 3, fewer cameras): every LM step must lower or keep the cost, stay finite, and -
+    where the oracle is affordable - end at the oracle's cost."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(n, "sprint" if n < 400 else "loop")
+    det = seq["det"][:, :cams].copy()
+    rig = tuple(a[:cams] for a in (seq["K"], seq["D"], seq["R"], seq["t"]))
+    x0 = np.zeros((n, 45))
+    x0[:, fte.ACTIVE] = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(n).normal(0, 0.02, (n, 25))
+    lo, hi = fte.bounds45()
+    x0 = np.clip(x0, lo, hi)
+    ctx = fte.FTEContext(det, *rig, seq["Ts"], ftol=1e-12)
+    ctx.set_x(x0[:, fte.ACTIVE])
+    costs = [ctx.state()["cost"]]
+    for _ in range(12):
+        ctx.step()
+        st = ctx.state()
+        costs.append(st["cost"])
+        if st["status"] != 0:
+            break
+    assert st["status"] != 5 and np.all(np.isfinite(costs)) and np.all(np.diff(costs) <= 1e-9 * np.abs(costs[0]))
+    x = ctx.result()[0].cpu().numpy()
+    assert np.isfinite(x).all()
+    ctx.close()
+    if n <= 95:
+        prob = ofte.FTEProblem(det[..., :2], det[..., 2], *rig, seq["Ts"])
+        xo, oinfo = ofte.lm_solve(prob, x0[:, ofk.ACTIVE], max_iter=len(costs) - 1, ftol=1e-12)
+        assert abs(costs[-1] - oinfo["cost"]) < 1e-6 * abs(oinfo["cost"])
