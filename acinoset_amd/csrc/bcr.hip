@@ -120,7 +120,7 @@ __device__ __forceinline__ void chol16_inv_acc(double* T, d4 acc, int lane, int*
   }
   if (bad && err && lane == 0) atomicExch(err, 1);
 }
-__device__ void chol16_inv(double* T, int lane, int* err) {
+__device__ __forceinline__ void chol16_inv(double* T, int lane, int* err) {
   const int i = lane & 15, k = lane >> 4;
   d4 acc;
 #pragma unroll
@@ -148,7 +148,7 @@ __constant__ uint8_t c_trail[4][13] = {
 // panel: row tile taken by wave w at block column kb (wave 0 always takes the tile the look-ahead needs next)
 __constant__ uint8_t c_panel[5][4] = {{1, 2, 3, 4}, {2, 0, 3, 4}, {3, 0, 1, 4}, {4, 0, 1, 2}, {0, 1, 2, 3}};
 
-__device__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
+__device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   if (wave == 0) chol16_inv(Lm, lane, err);
   __syncthreads();
