@@ -33,6 +33,26 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
   return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
+// All-gather across the four 16-lane rows of a wave: lane (i, k) holds x_k(i); afterwards every lane (i, *) holds
+// c[j] = x_j(i), j = 0..3.  Two gfx950 row-swap instructions per 32-bit half (v_permlane16_swap: odd rows of the first
+// operand <-> even rows of the second; v_permlane32_swap: upper half of the first <-> lower half of the second) -
+// plain VALU latency instead of four trips through the LDS crossbar (ds_bpermute).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_allgather(double x, double (&c)[4]) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  const u2v l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0]: x0 x0 x2 x2   [1]: x1 x1 x3 x3
+  const u2v h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const u2v la = __builtin_amdgcn_permlane32_swap(l1[0], l1[0], false, false);   // [0]: x0 everywhere, [1]: x2
+  const u2v lb = __builtin_amdgcn_permlane32_swap(l1[1], l1[1], false, false);   // [0]: x1,            [1]: x3
+  const u2v ha = __builtin_amdgcn_permlane32_swap(h1[0], h1[0], false, false);
+  const u2v hb = __builtin_amdgcn_permlane32_swap(h1[1], h1[1], false, false);
+  c[0] = __builtin_bit_cast(double, ((unsigned long long)ha[0] << 32) | la[0]);
+  c[1] = __builtin_bit_cast(double, ((unsigned long long)hb[0] << 32) | lb[0]);
+  c[2] = __builtin_bit_cast(double, ((unsigned long long)ha[1] << 32) | la[1]);
+  c[3] = __builtin_bit_cast(double, ((unsigned long long)hb[1] << 32) | lb[1]);
+}
+
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -72,11 +92,8 @@ __device__ __forceinline__ void chol16_inv_acc(double* T, d4 acc, int lane, int*
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     double col[4], ucol[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      col[kk] = __shfl(acc[s], i + 16 * kk, 64);
-      ucol[kk] = __shfl(uacc[s], i + 16 * kk, 64);
-    }
+    row_allgather(acc[s], col);
+    row_allgather(uacc[s], ucol);
     // The pivot chain inside the panel is kept as short as the arithmetic allows: the multipliers and the next
     // diagonal entry are broadcast RAW (before this pivot's 1/sqrt is known, i.e. beside its rsq chain), and the next
     // pivot a'(c+1,c+1) - (a(c+1,c) y)^2 is formed directly from them: rsq -> Newton -> mul -> fma -> next rsq.
