@@ -4,14 +4,15 @@
 // of 16 with identity rows, so every block operation is a 5x5 grid of 16x16 fp64 tiles executed on
 // the matrix cores (v_mfma_f64_16x16x4_f64).  One level = two launches:
 //   elim   (one workgroup per eliminated node i with neighbours l, r):
-//            D_i = L L^T (blocked Cholesky in LDS), U = L^-T by blocked inversion on the matrix cores,
+//            D_i = L L^T (blocked Cholesky in LDS) with U = L^-T built alongside ([A; I] L^-T = [L; L^-T]),
 //            W_l = U^T A_il, W_r = U^T A_ir (plain tile GEMMs), y = U^T b_i         -> HBM
 //   update (two workgroups per remaining node j):
 //            D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+),  b_j -= W^T y,
 //            new coupling block(j', j) = -W_r(i+)^T W_l(i+)
 // and back-substitution x_i = U (y - W_l x_l - W_r x_r) (three mat-vecs) walks the levels in reverse.
 // Level-0 couplings are the constant third-difference blocks and are generated in LDS, never stored.
-// LDS: ONE 80x81 fp64 matrix per workgroup (52 KB -> three workgroups per CU); leading dimension 81 makes both
+// LDS: ONE 80x81 fp64 matrix per workgroup (52 KB; 2 workgroups per CU in the elimination - 255 VGPRs -, 3 in the
+// update); narrow levels have their own latency-oriented kernels (*_deep, backsub_tail); leading dimension 81 makes both
 // the row-pattern and the column-pattern MFMA operand reads bank-conflict free.  The damped system itself is
 // built inside the level-0 kernels from the assembly's H/g (no separate set-up pass through HBM).
 #include "bcr.hpp"
@@ -301,7 +302,7 @@ __device__ __forceinline__ void load_mat2(double* dst0, const double* __restrict
 }
 
 // Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
-// assembly's H/g (what k_setup used to write to HBM): D = H_gn + lam*diag(H_gn), bound-active variables
+// assembly's H/g (no set-up pass through HBM): D = H_gn + lam*diag(H_gn), bound-active variables
 // pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).
 // Returns this thread's max |projected gradient| contribution.  All 256 threads; one barrier inside (the
 // caller's publish_gmax barrier completes the block).  (Two barriers inside.)
@@ -463,7 +464,7 @@ __device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __r
 }
 
 // Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the D
-// slot), W_l, W_r and y.  LDS holds ONE 80x81 matrix (the factor), so three workgroups share a CU: the serial
+// slot), W_l, W_r and y.  LDS holds ONE 80x81 matrix (the factor), so two workgroups share a CU: the serial
 // pivot chains of one overlap the matrix-core / memory phases of the others.
 __global__ void __launch_bounds__(256, 2)   // <= 256 VGPR+AGPR: two workgroups per CU overlap each other's pivot chains
 k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst, int* numeric_err,
