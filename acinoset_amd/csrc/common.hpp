@@ -212,7 +212,10 @@ template <bool DERIV>
 __device__ __forceinline__ void redescending(const LossC& L, double err, double& rho, double& drho, double& h) {
   double e = fabs(err);
   double u = exp(-e);                       // one exp: sigma(s, e) = 1 / (1 + exp(s) * exp(-e))
-  double sa = 1.0 / (1.0 + L.ea * u), sb = 1.0 / (1.0 + L.eb * u), sc = 1.0 / (1.0 + L.ec * u);
+  // ... and one division for the three logistic steps (the product stays below 1e15 for e >= 0)
+  const double da = 1.0 + L.ea * u, db = 1.0 + L.eb * u, dc = 1.0 + L.ec * u;
+  const double inv = 1.0 / (da * db * dc);
+  double sa = inv * (db * dc), sb = inv * (da * dc), sc = inv * (da * db);
   double cb = L.c - L.b;
   double t2 = L.a * e - L.a * L.a / 2;
   double ce = (L.c - e) / cb;

@@ -127,12 +127,14 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       }
       double iz = 1.0 / zc;
       double a = xc * iz, b = yc * iz;
-      double r = sqrt(a * a + b * b + 1e-12);
+      const double r2 = a * a + b * b + 1e-12;
+      const double ir = rsqrt(r2);                 // every later "/ r" is a multiplication
+      double r = r2 * ir;
       double th = atan(r);
       double th2 = th * th;
       double poly = 1 + th2 * (cam.k1 + th2 * (cam.k2 + th2 * (cam.k3 + th2 * cam.k4)));
       double thD = th * poly;
-      double m = thD / r;
+      double m = thD * ir;
       double su = w * (cam.fx * a * m + cam.cx - um);
       double sv = w * (cam.fy * b * m + cam.cy - vm);
       double rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0;
@@ -141,8 +143,8 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       my_cost += rho_u + rho_v;
       if (JAC) {
         double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
-        double dm_dr = (dthD / (1 + r * r) * r - thD) / (r * r);
-        double dm_da = dm_dr * a / r, dm_db = dm_dr * b / r;
+        double dm_dr = (dthD / (1 + r2) * r - thD) * (ir * ir);
+        double dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
         double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
         double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
         double uc0 = du_da * iz, uc1 = du_db * iz, uc2 = -(du_da * a + du_db * b) * iz;
