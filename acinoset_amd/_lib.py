@@ -29,7 +29,8 @@ class FteParams(C.Structure):
                 ("inv_r_meas", C.c_double), ("redesc_a", C.c_double), ("redesc_b", C.c_double),
                 ("redesc_c", C.c_double), ("q_w", C.c_double * N_ACTIVE), ("lo", C.c_double * N_ACTIVE),
                 ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
-                ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32)]
+                ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32),
+                ("clip_len", C.c_int64)]
 
 
 class FteState(C.Structure):

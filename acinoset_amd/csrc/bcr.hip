@@ -347,7 +347,7 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
       const int q = tid - BS, pr = q / NP, p = q % NP;          // frame pairs (0,1), (0,2), (1,2)
       const int ii = pr == 2 ? 1 : 0, jj = pr == 0 ? 1 : 2;
       if (fbase + jj < K.n_frames) {
-        const double v = 2.0 * K.q_w[p] * band_coef(K.n_offset + fbase + ii, jj - ii, K.n_global);
+        const double v = 2.0 * K.q_w[p] * band_coef_clip(K.n_offset + fbase + ii, jj - ii, K.n_global, K.clip_len);
         Dm[(ii * NP + p) * LD + jj * NP + p] = v;
         Dm[(jj * NP + p) * LD + ii * NP + p] = v;
       }
@@ -403,7 +403,8 @@ __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst&
     double v = 0.0;
     if (ii <= jj) {
       const int k = 3 + ii - jj;
-      v = 2.0 * K.q_w[p] * (side == 0 ? band_coef(f_i - 3 + jj, k, K.n_global) : band_coef(f_i + jj, k, K.n_global));
+      v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
+                                            : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
     }
     (side == 0 ? coefL : coefR)[q] = v;
   }

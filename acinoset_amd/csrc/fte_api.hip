@@ -398,6 +398,7 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->n_cams = p->n_cams;
   c->n_global = p->n_global;
   c->n_offset = p->n_offset;
+  c->clip_len = p->clip_len;
   c->pin_left = p->pin_left ? 1 : 0;
   c->pin_right = p->pin_right ? 1 : 0;
   c->n_nodes = chain_nodes(p);
@@ -425,6 +426,10 @@ static int validate(const acino_fte_params* p) {
   ACINO_REQUIRE(p->n_global >= p->n_frames && p->n_offset >= 0 && p->n_offset + p->n_frames <= p->n_global,
                 "shard range inside the sequence");
   ACINO_REQUIRE(!p->pin_left || (p->n_offset >= 3 && p->n_offset % 3 == 0), "pinned-left shard must start at a multiple of 3");
+  ACINO_REQUIRE(p->clip_len >= 0, "clip_len");
+  ACINO_REQUIRE(p->clip_len == 0 || (!p->pin_left && !p->pin_right && p->n_offset == 0 && p->n_global == p->n_frames &&
+                                     p->n_frames % p->clip_len == 0),
+                "clips: single-GPU context whose n_frames is a multiple of clip_len");
   ACINO_REQUIRE(!p->pin_right || (p->n_frames % 3 == 0), "pinned-right shard must hold a multiple of 3 frames");
   ACINO_REQUIRE(!(p->pin_left || p->pin_right) || p->n_frames >= 6, "sharded ranks need >= 6 frames");
   ACINO_REQUIRE(p->redesc_c > p->redesc_b && p->redesc_b > p->redesc_a && p->redesc_a > 0, "redescending a<b<c");

@@ -233,7 +233,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     const double q = K.q_w[bq];
     const double* xc = xh + (int64_t)(n + HALO) * NP + bq;   // x[n][bq]; neighbours at +-k*NP
     // smoothness cost: rows whose last frame is this one
-    if (ng >= 3) {
+    if ((K.clip_len > 0 ? ng % K.clip_len : ng) >= 3) {
       double d3 = xc[0] - 3.0 * xc[-NP] + 3.0 * xc[-2 * NP] - xc[-3 * NP];
       my_cost += q * d3 * d3;
     }
@@ -241,10 +241,10 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       double gs = 0.0;
 #pragma unroll
       for (int k = -3; k <= 3; ++k) {
-        double bc = k >= 0 ? band_coef(ng, k, K.n_global) : band_coef(ng + k, -k, K.n_global);
+        double bc = k >= 0 ? band_coef_clip(ng, k, K.n_global, K.clip_len) : band_coef_clip(ng + k, -k, K.n_global, K.clip_len);
         if (bc != 0.0) gs += bc * xc[k * NP];
       }
-      const double b0 = band_coef(ng, 0, K.n_global);
+      const double b0 = band_coef_clip(ng, 0, K.n_global, K.clip_len);
       const int g = c_state_grp[bq];
       const double* S = F[f].sub[g < 0 ? 0 : g];
       double xb[6];

@@ -27,6 +27,7 @@ struct FteConst {
   double ftol, xtol, gtol;
   double lam_max;
   int32_t clamp_lambda, pad1;
+  int64_t clip_len;        // > 0: independent clips of this many frames laid end to end (no coupling across clips)
   Cam cams[ACINO_MAX_CAMS];
 };
 
@@ -40,6 +41,15 @@ __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
   double tot = 0.0;
   for (int64_t j = jlo; j <= jhi; ++j) tot += c[n - j] * c[n + k - j];
   return tot;
+}
+
+// The same coefficient when the frame axis holds several independent clips of `clip` frames each (0 = one sequence).
+__host__ __device__ inline double band_coef_clip(int64_t n, int k, int64_t ng, int64_t clip) {
+  if (clip <= 0) return band_coef(n, k, ng);
+  if (n < 0 || n + k >= ng) return 0.0;
+  const int64_t c0 = n / clip;
+  if ((n + k) / clip != c0) return 0.0;
+  return band_coef(n - c0 * clip, k, clip);
 }
 
 // Per-kernel-class HIP-event profiler (bench.py's live roofline measurement).  Events are recorded on

@@ -50,7 +50,7 @@ def bounds45():
 
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
-                lam_max=1e16, clamp_lambda=False, shared_gpu=False):
+                lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -73,6 +73,7 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
     p.lam0, p.ftol, p.xtol, p.gtol = float(lam0), float(ftol), float(xtol), float(gtol)
     p.lam_max, p.clamp_lambda = float(lam_max), int(bool(clamp_lambda))
     p.shared_gpu = int(bool(shared_gpu))
+    p.clip_len = int(clip_len)
     return p
 
 
@@ -269,6 +270,66 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
     results = dict(positions=conv(pos), x=conv(x), dx=conv(dx), ddx=conv(ddx), start_frame=start_frame)
     return results, info
+
+
+def _derivatives(x_clip, Ts):
+    dx, ddx = torch.empty_like(x_clip), torch.empty_like(x_clip)
+    check(lib().acino_fte_derivatives(ptr(x_clip), x_clip.shape[0], float(Ts), ptr(dx), ptr(ddx), stream_ptr()))
+    return dx, ddx
+
+
+def fte_solve_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0.5, start_frames=None, max_iter=100,
+                    init="nose_line", return_numpy=True, **kw):
+    """Equal-length clips of one rig solved as ONE problem (BASELINE config 5's batched FTE at full width): the clips
+    are laid end to end on the frame axis, the smoothness prior is cut at the clip boundaries (``clip_len``), and the
+    block-cyclic reduction runs over the whole chain - every launch is as wide as all clips together, so the narrow
+    levels that dominate a single short clip almost vanish.  One Levenberg-Marquardt controller acts on the SUM of the
+    clips' costs (the problem is block diagonal: each clip converges to its own optimum, but damping and accept/reject
+    are shared, so iterates differ from per-clip solves until convergence).  Returns a list of (results, info)."""
+    B = len(dets)
+    if B == 0:
+        return []
+    dets_t = [d if isinstance(d, torch.Tensor) else torch.as_tensor(np.asarray(d, dtype=np.float64)) for d in dets]
+    S = int(dets_t[0].shape[0])
+    if any(int(d.shape[0]) != S for d in dets_t):
+        raise ValueError("fte_solve_clips needs clips of equal length (use fte_solve_batch otherwise)")
+    start_frames = list(start_frames) if start_frames is not None else [0] * B
+    inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
+    x0_all = np.zeros((B * S, N_STATES))
+    for b, det in enumerate(dets_t):
+        if x0s is not None and x0s[b] is not None:
+            x0 = x0s[b]
+        elif init == "nose_line":
+            x0 = nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, start_frame=start_frames[b])
+        elif init == "triangulation":
+            x0 = triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh)
+        else:
+            raise ValueError("init must be 'nose_line' or 'triangulation'")
+        x0 = np.asarray(x0.cpu().numpy() if isinstance(x0, torch.Tensor) else x0, dtype=np.float64)
+        if x0.shape != (S, N_STATES):
+            raise ValueError(f"x0 of clip {b} must be [{S}, 45]")
+        if np.any(x0[:, inactive] != 0):
+            raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
+        x0_all[b * S:(b + 1) * S] = x0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    det_all = torch.cat([d.to(device=dev, dtype=torch.float64) for d in dets_t], dim=0)
+    ctx = FTEContext(det_all, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, clip_len=S, **kw)
+    try:
+        ctx.set_x(x0_all[:, ACTIVE])
+        info = ctx.solve(max_iter)
+        x, pos, _dx, _ddx = ctx.result()
+        if info["status"] == 5:
+            raise RuntimeError("FTE: block factorisation hit a non-positive pivot")
+        conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
+        out = []
+        for b in range(B):
+            xb = x[b * S:(b + 1) * S].contiguous()
+            dxb, ddxb = _derivatives(xb, Ts)                     # per clip: no differences across a clip boundary
+            out.append((dict(positions=conv(pos[b * S:(b + 1) * S]), x=conv(xb), dx=conv(dxb), ddx=conv(ddxb),
+                             start_frame=start_frames[b]), dict(info, clips=B, cost_is_sum_over_clips=True)))
+        return out
+    finally:
+        ctx.close()
 
 
 def fte_solve_batch(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0.5, start_frames=None, max_iter=100,

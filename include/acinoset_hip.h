@@ -122,6 +122,10 @@ typedef struct acino_fte_params {
   int32_t shared_gpu;      /* 1: other solver contexts run on this GPU at the same time (batched clips, several ranks on one
                             * device): kernels that spin-wait on other workgroups (the fused back-substitution tail) are
                             * replaced by their per-level forms - concurrent spin-waiting kernels could fill the CUs */
+  int64_t clip_len;        /* 0: the frames are ONE sequence.  > 0: the frames are n_frames / clip_len independent clips of
+                            * this many frames laid end to end (BASELINE config 5): the smoothness prior does not couple
+                            * frames of different clips, everything else - kernels, schedule, one LM controller over the
+                            * sum of the clips' costs - is unchanged.  Single-GPU contexts only. */
 } acino_fte_params;
 
 /* LM state mirrored in device memory (read back with acino_fte_get_state). */
