@@ -432,16 +432,17 @@ def test_size_sweep_schedules(mods, n, cams):
         assert abs(costs[-1] - oinfo["cost"]) < 1e-6 * abs(oinfo["cost"])
 
 
-def test_clips_solved_as_one_chain(mods):
+@pytest.mark.parametrize("clip", [45, 40])           # 40: clip boundaries fall inside 3-frame nodes
+def test_clips_solved_as_one_chain(mods, clip):
     """fte_solve_clips: equal-length clips laid end to end with the smoothness prior cut at the clip boundaries.  The
     problem is block diagonal, so every clip must converge to the optimum of its own solve (shared damping: compared
     after convergence, 1e-3 m as everywhere), and no derivative may be taken across a clip boundary."""
     calib, fte, synth = mods
-    seqs = [synth.make_sequence(45, "sprint", seed=20210313 + i) for i in range(4)]
+    seqs = [synth.make_sequence(clip, "sprint", seed=20210313 + i) for i in range(4)]
     rig = (seqs[0]["K"], seqs[0]["D"], seqs[0]["R"], seqs[0]["t"])
     x0s = []
     for s in seqs:
-        x0 = np.zeros((45, 45))
+        x0 = np.zeros((clip, 45))
         x0[:, fte.ACTIVE] = s["q_true"][:, fte.ACTIVE]
         x0s.append(x0)
     fused = fte.fte_solve_clips([s["det"] for s in seqs], *rig, seqs[0]["Ts"], x0s=x0s, max_iter=120, ftol=1e-13)
@@ -453,7 +454,7 @@ def test_clips_solved_as_one_chain(mods):
         assert np.abs(res["positions"] - one["positions"]).max() < 1e-3
         Ts = s["Ts"]
         assert np.allclose(res["x"][1:], res["x"][:-1] + Ts * res["dx"][1:], atol=1e-12)      # within the clip only
-        assert res["x"].shape == (45, 25) and res["ddx"].shape == (45, 25)
+        assert res["x"].shape == (clip, 25) and res["ddx"].shape == (clip, 25)
     assert abs(fused[0][1]["cost"] - total) < 1e-6 * abs(total)                              # sum of the clips' optima
     with pytest.raises(ValueError):
-        fte.fte_solve_clips([seqs[0]["det"], seqs[1]["det"][:40]], *rig, seqs[0]["Ts"])
+        fte.fte_solve_clips([seqs[0]["det"], seqs[1]["det"][:30]], *rig, seqs[0]["Ts"])
