@@ -458,3 +458,27 @@ def test_clips_solved_as_one_chain(mods, clip):
     assert abs(fused[0][1]["cost"] - total) < 1e-6 * abs(total)                              # sum of the clips' optima
     with pytest.raises(ValueError):
         fte.fte_solve_clips([seqs[0]["det"], seqs[1]["det"][:30]], *rig, seqs[0]["Ts"])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_randomised_solves_match_oracle(mods, seed):
+    """Random clip length / camera subset / extra dropouts / start perturbation: converged GPU solve vs oracle LM."""
+    calib, fte, synth = mods
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(20, 70))
+    cams = np.sort(rng.choice(6, size=int(rng.integers(3, 7)), replace=False))
+    seq = synth.make_sequence(n, "sprint", seed=seed)
+    det = seq["det"][:, cams].copy()
+    det[rng.random(det.shape[:3]) < 0.1, 2] = 0.0                       # 10 % more dropouts
+    rig = tuple(a[cams] for a in (seq["K"], seq["D"], seq["R"], seq["t"]))
+    x0 = np.zeros((n, 45))
+    x0[:, fte.ACTIVE] = seq["q_true"][:, fte.ACTIVE] + rng.normal(0, 0.03, (n, 25))
+    lo, hi = fte.bounds45()
+    x0 = np.clip(x0, lo, hi)
+    res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x0, max_iter=100, ftol=1e-13)
+    prob = ofte.FTEProblem(det[..., :2], det[..., 2], *rig, seq["Ts"])
+    xo, oinfo = ofte.lm_solve(prob, x0[:, ofk.ACTIVE], max_iter=100, ftol=1e-13)
+    out = ofte.fte_outputs(prob, xo, x0)
+    assert info["status_name"] in ("ftol", "xtol", "gtol")
+    assert abs(info["cost"] - oinfo["cost"]) < 1e-5 * abs(oinfo["cost"])
+    assert np.abs(res["positions"] - out["positions"]).max() < 1e-3            # north_star tolerance, metres
