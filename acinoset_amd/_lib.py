@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
 SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
-HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
+HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
 N_ACTIVE = 25
 N_STATES = 45
@@ -48,7 +48,8 @@ class FteState(C.Structure):
 
 class EkfParams(C.Structure):
     _fields_ = [("n_frames", C.c_int64), ("n_seq", C.c_int32), ("n_cams", C.c_int32), ("fps", C.c_double),
-                ("dlc_thresh", C.c_double), ("cam_width", C.c_double)]
+                ("dlc_thresh", C.c_double), ("cam_width", C.c_double), ("smoother_pivoting", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class SkelOp(C.Structure):

@@ -1,0 +1,301 @@
+// Dense 80 x 80 fp64 block machinery shared by the block cyclic reduction (bcr.hip) and the Kalman smoother
+// (ekf.hip): 16 x 16 tiles on the matrix cores (v_mfma_f64_16x16x4_f64), the register-resident 16 x 16 Cholesky with
+// its inverse factor, the blocked 80 x 80 Cholesky built on it, and the HBM <-> LDS block moves.  LDS leading dimension
+// 81 makes both the row-pattern and the column-pattern MFMA operand reads bank-conflict free.  256 threads (four waves).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "fte_kernels.hpp"
+
+namespace acino {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int LD = 81;
+constexpr int MAT = BS * LD;
+constexpr int NT = 5;
+
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  long long b = __builtin_bit_cast(long long, x);
+  int lo = __builtin_amdgcn_readlane((int)b, lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// All-gather across the four 16-lane rows of a wave: lane (i, k) holds x_k(i); afterwards every lane (i, *) holds
+// c[j] = x_j(i), j = 0..3.  Two gfx950 row-swap instructions per 32-bit half (v_permlane16_swap: odd rows of the first
+// operand <-> even rows of the second; v_permlane32_swap: upper half of the first <-> lower half of the second) -
+// plain VALU latency instead of four trips through the LDS crossbar (ds_bpermute).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_allgather(double x, double (&c)[4]) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  const u2v l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0]: x0 x0 x2 x2   [1]: x1 x1 x3 x3
+  const u2v h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const u2v la = __builtin_amdgcn_permlane32_swap(l1[0], l1[0], false, false);   // [0]: x0 everywhere, [1]: x2
+  const u2v lb = __builtin_amdgcn_permlane32_swap(l1[1], l1[1], false, false);   // [0]: x1,            [1]: x3
+  const u2v ha = __builtin_amdgcn_permlane32_swap(h1[0], h1[0], false, false);
+  const u2v hb = __builtin_amdgcn_permlane32_swap(h1[1], h1[1], false, false);
+  c[0] = __builtin_bit_cast(double, ((unsigned long long)ha[0] << 32) | la[0]);
+  c[1] = __builtin_bit_cast(double, ((unsigned long long)hb[0] << 32) | lb[0]);
+  c[2] = __builtin_bit_cast(double, ((unsigned long long)ha[1] << 32) | la[1]);
+  c[3] = __builtin_bit_cast(double, ((unsigned long long)hb[1] << 32) | lb[1]);
+}
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// NS back-to-back MFMAs on one accumulator with ALL operand reads issued first (software pipelining:
+// an LDS read costs ~100+ cycles of latency, an fp64 MFMA 64 cycles of issue).  pa/pb are this lane's
+// operand pointers for k-step 0; k-step s reads pa[s*sa], pb[s*sb].
+template <int NS, bool NEG>
+__device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const double* pb, int sb) {
+  double av[NS], bv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    av[s] = pa[s * sa];
+    bv[s] = pb[s * sb];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc = mfma(NEG ? -av[s] : av[s], bv[s], acc);
+  return acc;
+}
+
+// One wave (all 64 lanes): Cholesky of the symmetric 16x16 tile T (LDS, leading dim LD) and the inverse of
+// its factor, entirely in registers.  Lane (i = lane & 15, k = lane >> 4) holds row i, columns {k, k+4, k+8,
+// k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  The right-looking column
+// operations that turn C into L are applied at the same time to an identity tile (uacc), which they turn into
+// U = L^-T: no separate triangular inversion.  Columns go in four panels of four: every lane gathers its row's
+// four panel entries (one cross-lane exchange per PANEL), the pivots and multipliers L[4s+k'][c] are
+// wave-uniform and travel through SGPRs (v_readlane), so the 16-pivot dependency chain is readlane -> rsq ->
+// Newton -> mul -> readlane -> fma; ONE v_mfma_f64_16x16x4 per tile then applies the rank-4 update to the
+// remaining columns (the finished panel register is already both the A and the B operand).  The tile is
+// OVERWRITTEN by U_kk (upper triangular); L_kk is not kept.
+// LDT: leading dimension of T (and of Lout).  With KEEP_L the factor itself goes to Lout (lower triangle, zeros above).
+// Returns true when every pivot was positive (wave-uniform).
+template <int LDT = LD, bool KEEP_L = false>
+__device__ __forceinline__ bool chol16_inv_acc(double* T, d4 acc, int lane, int* err, double* Lout = nullptr) {
+  const int i = lane & 15, k = lane >> 4;
+  d4 uacc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double col[4], ucol[4];
+    row_allgather(acc[s], col);
+    row_allgather(uacc[s], ucol);
+    // The pivot chain inside the panel is kept as short as the arithmetic allows: the multipliers and the next
+    // diagonal entry are broadcast RAW (before this pivot's 1/sqrt is known, i.e. beside its rsq chain), and the next
+    // pivot a'(c+1,c+1) - (a(c+1,c) y)^2 is formed directly from them: rsq -> Newton -> mul -> fma -> next rsq.
+    double piv0 = readlane_d(col[0], 4 * s);
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) {
+      double mraw[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = k0 + 1; kk < 4; ++kk) mraw[kk] = readlane_d(col[k0], 4 * s + kk);    // a[4s+kk][c], unscaled
+      const double dnext = k0 < 3 ? readlane_d(col[k0 + 1], 4 * s + k0 + 1) : 0.0;       // a[c+1][c+1] so far
+      bad |= !(piv0 > 0.0);                                   // flagged off the dependency chain
+      const double piv = fmax(piv0, 1e-300);
+      // 1/sqrt(piv): hardware estimate + one coupled Newton step (no range fix-ups: piv is a positive normal number)
+      double y = __builtin_amdgcn_rsq(piv);
+      const double e = fma(-(piv * y), y, 1.0);
+      y = fma(y * e, fma(e, 0.375, 0.5), y);
+      if (k0 < 3) {
+        const double t = mraw[k0 + 1] * y;                    // L[c+1][c]
+        piv0 = fma(-t, t, dnext);
+      }
+      col[k0] *= y;                                           // row c becomes sqrt(piv); rows < c hold don't-cares
+      ucol[k0] *= y;
+#pragma unroll
+      for (int kk = k0 + 1; kk < 4; ++kk) {
+        const double m = mraw[kk] * y;                        // L[4s+kk][c]
+        col[kk] -= col[k0] * m;
+        ucol[kk] -= ucol[k0] * m;
+      }
+    }
+    if (k == 0) {                                             // U[i][4s .. 4s+3] is final
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) T[i * LDT + 4 * s + kk] = ucol[kk];
+    }
+    if (KEEP_L && k == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) Lout[i * LDT + 4 * s + kk] = (i >= 4 * s + kk) ? col[kk] : 0.0;
+    }
+    if (s < 3) {
+      const double pk = k == 0 ? col[0] : (k == 1 ? col[1] : (k == 2 ? col[2] : col[3]));
+      const double p = (i >= 4 * s + k) ? pk : 0.0;           // strictly-upper entries are discarded here, once
+      const double pu = k == 0 ? ucol[0] : (k == 1 ? ucol[1] : (k == 2 ? ucol[2] : ucol[3]));
+      acc = mfma(-p, p, acc);
+      uacc = mfma(-p, pu, uacc);     // register r of lane (i,k) is result[4r+k][i] = -(P PU^T)[4r+k][i] = dU[i][4r+k]
+    }
+  }
+  if (bad && err && lane == 0) atomicExch(err, 1);
+  return !bad;
+}
+__device__ __forceinline__ void chol16_inv(double* T, int lane, int* err) {
+  const int i = lane & 15, k = lane >> 4;
+  d4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T[(k + 4 * r) * LD + i];
+  chol16_inv_acc(T, acc, lane, err);
+}
+
+// Blocked Cholesky of the 80x80 matrix in LDS, with the inverse factor built alongside.  On exit: strictly-lower
+// tiles hold L(ib,jb), diagonal tiles U_kk = L_kk^-T and strictly-upper tiles (j,c) hold U(j,c), U = L^-T
+// (80x80 upper triangular).  The column operations that reduce A to L are applied at block level to the identity as
+// well ([A; I] L^-T = [L; L^-T]); the work tiles of that second matrix live in the (otherwise unused) strictly-upper
+// tiles, so nothing is zero-filled: tile (j,c) is first WRITTEN at step kb = j and accumulated afterwards.
+// Per block column kb:  panel  tile(t,kb) <- tile(t,kb) U_kk for every t != kb (4 tiles, one per wave);
+//                       trailing tile(t,c) -= tile(t,kb) L(c,kb)^T for c > kb, t in {0..kb} u {c..4}.
+// LOOK-AHEAD: in the trailing phase wave 0 takes only the next diagonal tile, keeps the result in registers (the
+// MFMA C layout is the factorisation's layout) and goes straight into its 16-pivot chain, while waves 1..3 do all
+// other trailing tiles (<= 5 each) - the inverse costs no time on the critical path.
+// task tables for waves 1..3: [kb][n] = 16*ti + tj ; ti <= kb marks a tile of U (overwrite when ti == kb)
+static __constant__ uint8_t c_trail_n[4] = {13, 11, 8, 4};
+static __constant__ uint8_t c_trail[4][13] = {
+    {0x21, 0x22, 0x31, 0x32, 0x33, 0x41, 0x42, 0x43, 0x44, 0x01, 0x02, 0x03, 0x04},
+    {0x32, 0x33, 0x42, 0x43, 0x44, 0x02, 0x03, 0x04, 0x12, 0x13, 0x14, 0, 0},
+    {0x43, 0x44, 0x03, 0x04, 0x13, 0x14, 0x23, 0x24, 0, 0, 0, 0, 0},
+    {0x04, 0x14, 0x24, 0x34, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// panel: row tile taken by wave w at block column kb (wave 0 always takes the tile the look-ahead needs next)
+static __constant__ uint8_t c_panel[5][4] = {{1, 2, 3, 4}, {2, 0, 3, 4}, {3, 0, 1, 4}, {4, 0, 1, 2}, {0, 1, 2, 3}};
+
+__device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  if (wave == 0) chol16_inv(Lm, lane, err);
+  __syncthreads();
+  for (int kb = 0; kb < NT; ++kb) {
+    const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+    {  // panel: tile(t,kb) <- tile(t,kb) * U_kk   (L(ib,kb) = A(ib,kb) L_kk^-T below, U(j,kb) above the diagonal)
+      double* A = Lm + (c_panel[kb][wave] * 16) * LD + kb * 16;
+      double av[4], bv[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        av[s] = A[li * LD + 4 * s + lk];
+        bv[s] = Ukk[(4 * s + lk) * LD + li];
+      }
+      d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+    }
+    __syncthreads();
+    if (kb == NT - 1) break;
+    if (wave == 0) {
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      if (dbg && kb == 0 && tid == 0) dbg[16] = (long long)wall_clock64();
+      chol16_inv_acc(Cc, a, lane, err);
+      if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
+    } else {
+      const int ntask = c_trail_n[kb];
+      for (int t = wave - 1; t < ntask; t += 3) {
+        const int code = c_trail[kb][t], ti = code >> 4, tj = code & 15;
+        double* Cc = Lm + (ti * 16) * LD + tj * 16;
+        const double* A = Lm + (ti * 16) * LD + kb * 16;
+        const double* B = Lm + (tj * 16) * LD + kb * 16;
+        d4 a = {0, 0, 0, 0};
+        double av[4], bv[4];
+        if (ti != kb) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          av[s] = A[li * LD + 4 * s + lk];
+          bv[s] = B[li * LD + 4 * s + lk];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[rr];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// 80x80 fp64 matrix HBM <-> LDS with all loads of a thread in flight before the first use (13 x 16 B).
+template <bool TRANSPOSE>
+__device__ __forceinline__ void load_mat_any(double* dst, const double* __restrict__ src, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2 v[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) v[k] = s2[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      if (TRANSPOSE) {
+        dst[c * LD + r] = v[k].x;
+        dst[(c + 1) * LD + r] = v[k].y;
+      } else {
+        dst[r * LD + c] = v[k].x;
+        dst[r * LD + c + 1] = v[k].y;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void load_mat(double* dst, const double* __restrict__ src, int tid) {
+  load_mat_any<false>(dst, src, tid);
+}
+__device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict__ src, int tid) {
+  load_mat_any<true>(dst, src, tid);
+}
+__device__ __forceinline__ void store_mat(double* __restrict__ dst, const double* src, int tid) {
+  double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      d2[idx] = make_double2(src[r * LD + c], src[r * LD + c + 1]);
+    }
+  }
+}
+
+// Two 80x80 matrices HBM -> LDS with ALL loads of both in flight before the first LDS write (the narrow levels
+// of the reduction are latency-bound: one HBM round trip instead of two).
+__device__ __forceinline__ void load_mat2(double* dst0, const double* __restrict__ src0, double* dst1,
+                                          const double* __restrict__ src1, int tid) {
+  const double2* s0 = reinterpret_cast<const double2*>(src0);
+  const double2* s1 = reinterpret_cast<const double2*>(src1);
+  double2 v0[13], v1[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      v0[k] = s0[idx];
+      v1[k] = s1[idx];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      dst0[r * LD + c] = v0[k].x;
+      dst0[r * LD + c + 1] = v0[k].y;
+      dst1[r * LD + c] = v1[k].x;
+      dst1[r * LD + c + 1] = v1[k].y;
+    }
+  }
+}
+
+}  // namespace acino

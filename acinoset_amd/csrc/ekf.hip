@@ -5,16 +5,23 @@
 // differences with eps = 1e-3 (:631-646), 3-sigma gating (:815-819), K = P H^T inv(S) with S 240x240 (:822),
 // P <- (I - K H) P (:829), smoother (:836-841).  The filter is sequential in frames, so ONE workgroup runs a whole
 // sequence (grid = sequences) with the 75x75 covariance, the 240x25 Jacobian and every intermediate in LDS:
-//   * FK of the 26 forward-difference variants column-parallel (78 threads), 26 x C x 20 projections on all threads;
+//   * FK of the 26 forward-difference variants column-parallel (78 threads); projections only of the (variant,
+//     marker) pairs in which the marker moves with the perturbed parameter (about half; found once per launch by
+//     probing the chain at a generic pose - the other forward differences are exactly 0 at every pose);
 //   * H has 25 non-zero columns and R is diagonal, so with M = Hq^T R^-1 Hq, g = Hq^T R^-1 r (fp64 MFMA, g rides
 //     along as a 26th column) the 240x240 inverse collapses to 25x25 algebra:
 //       K r = P[:, :25] (I + M Pq)^-1 g,   P <- P - P[:, :25] (I + M Pq)^-1 M P[:25, :],   Pq = P[:25, :25],
 //     evaluated through Pq = Lc Lc^T and the SPD matrix B = I + Lc^T M Lc (push-through identity) - identical
-//     to the reference's formulas in exact arithmetic;  diag(S) for the gate is the row-wise form Hq Pq Hq^T + R.
-// The smoother gains A_i = P_est[i] F^T inv(P_pred[i+1]) are independent across frames (one workgroup each); only
-// the 75x75 mat-vec recursion is sequential (one workgroup per sequence).  The smoothed covariances are not computed:
-// the reference never saves them (:850-857).
+//     to the reference's formulas in exact arithmetic;  diag(S) for the gate is the row norms of Hq Lc, + R;
+//   * every product is 16 x 16 fp64 MFMA tiles (tile_gemm); the two 25 x 25 Cholesky factorisations run in ONE wave's
+//     registers (wave_chol32: the 16 x 16 register factorisation of dense80.hpp twice + MFMA glue), chol(Pq) in
+//     wave 3 while waves 0-2 evaluate the 572 sines / cosines; triangular solves are products with U = L^-T.
+// The smoother gains A_i = P_est[i] F^T inv(P_pred[i+1]) are independent across frames (one workgroup each, P_pred
+// rebuilt from P_est, blocked Cholesky + two triangular products, pivoting fallback); only the 75x75 mat-vec
+// recursion is sequential (one workgroup per sequence).  The smoothed covariances are not computed: the reference
+// never saves them (:850-857).
 #include "cheetah_fk.hpp"
+#include "dense80.hpp"
 
 namespace acino {
 
@@ -22,12 +29,13 @@ constexpr int EP = 25;            // pose parameters (qb_list order)
 constexpr int ES = 75;            // states: pose, velocity, acceleration
 constexpr int EKF_MAXC = 6;
 constexpr int EROWS = EKF_MAXC * 2 * NL;   // 240
-constexpr int PLD = 76;           // leading dimension of 75 x 75 matrices in LDS
+constexpr int PLD = 81;           // leading dimension of the covariance in LDS: 80 x 81, zero beyond 75 (no masks on tiles)
+constexpr int PR = 80;            // its padded row count
+constexpr int VLD = 28;           // leading dimension of V = P[:, :25] A (80 x 28, zero beyond 75 x 25)
 constexpr int HLD = 27;           // leading dimension of Hq
 constexpr int SLD = 27;           // leading dimension of the 25 x 25 (+1) work matrices
 constexpr int NVAR = EP + 1;      // base pose + one forward-difference variant per parameter
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct FkLite {
   static constexpr bool kHasOm = false;
@@ -42,7 +50,7 @@ __device__ const double c_qb_list[EP] = {5.0,  5.0,  5.0,   10.0,  10.0,  10.0, 
                                          100.0, 30.0, 140.0, 40.0, 350.0, 200.0, 350.0, 200.0, 450.0, 400.0, 450.0, 400.0};
 
 struct EkfK {
-  int n_frames, n_cams;
+  int n_frames, n_cams, pivoting;
   double sT, dlc_thresh, max_pixel_err, eps;
 };
 
@@ -53,62 +61,131 @@ __device__ __forceinline__ double ekf_readlane(double x, int lane) {
   return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-// Cholesky of the 25 x 25 SPD matrix A (LDS, leading dimension SLD) by ONE wave, in registers: lane i holds row i;
-// pivots and multipliers are wave-uniform SGPR broadcasts (v_readlane), no barriers.  With NRHS > 0 the same wave
-// then solves L Z = Rhs for the NRHS (<= 26) columns of Rhs (LDS, leading dimension SLD; lane c owns column c, the
-// entries of L are broadcast from the lane that holds their row) and overwrites Rhs with Z.  The lower triangle of
-// A is overwritten by L.  Returns false on a non-positive pivot.  Call from one wave; other waves wait at a barrier.
-template <int NRHS>
-__device__ bool wave_chol25(double* A, double* Rhs, int lane) {
-  double row[EP];
+// Cholesky of the 25 x 25 SPD matrix A (LDS, leading dimension lda, lower triangle read) by ONE wave, blocked 16 + 9
+// (the second tile padded with identity): the register-resident 16 x 16 factorisation of dense80.hpp twice, the panel
+// L10 = A10 U00 and the Schur complement A11 - L10 L10^T on the matrix cores in between.  Lw (32 x 33) receives L
+// (tiles (0,0), (1,0), (1,1)); Uw (32 x 33) the diagonal inverse factors U00 = L00^-T, U11 = L11^-T and, with WITH_U,
+// the whole U = L^-T = [[U00, -U00 L10^T U11], [0, U11]] - a triangular solve then is a product with U^T.
+// Everything a lane reads back was written by its own wave (LDS operations of one wave complete in order).
+constexpr int WLD = 33;
+template <bool WITH_U>
+__device__ bool wave_chol32(const double* A, int lda, double* Lw, double* Uw, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  d4 acc;
 #pragma unroll
-  for (int j = 0; j < EP; ++j) row[j] = (lane < EP && j <= lane) ? A[lane * SLD + j] : 0.0;
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < EP; ++k) {
-    const double piv0 = ekf_readlane(row[k], k);
-    ok = ok && (piv0 > 0.0);
-    const double piv = fmax(piv0, 1e-300);
-    double y = __builtin_amdgcn_rsq(piv);
-    const double e = fma(-(piv * y), y, 1.0);
-    y = fma(y * e, fma(e, 0.375, 0.5), y);
-    const double lik = row[k] * y;                      // L[i][k] for lanes i >= k
-    row[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < EP; ++j) row[j] -= lik * ekf_readlane(lik, j);
+  for (int r = 0; r < 4; ++r) {
+    const int i = lk + 4 * r;
+    acc[r] = A[(i > li ? i : li) * lda + (i > li ? li : i)];
   }
-  if (lane < EP) {
+  bool ok = chol16_inv_acc<WLD, true>(Uw, acc, lane, nullptr, Lw);
+  double av[4], bv[4];
 #pragma unroll
-    for (int j = 0; j < EP; ++j)
-      if (j <= lane) A[lane * SLD + j] = row[j];
+  for (int s = 0; s < 4; ++s) {                 // panel L10 = A10 U00
+    av[s] = (16 + li < EP) ? A[(16 + li) * lda + 4 * s + lk] : 0.0;
+    bv[s] = Uw[(4 * s + lk) * WLD + li];
   }
-  if (NRHS > 0) {
-    double z[EP];
+  d4 l10 = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < EP; ++k) z[k] = lane < NRHS ? Rhs[k * SLD + lane] : 0.0;
+  for (int s = 0; s < 4; ++s) l10 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], l10, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < EP; ++k) {
-      double sacc = z[k];
+  for (int r = 0; r < 4; ++r) Lw[(16 + lk + 4 * r) * WLD + li] = l10[r];
 #pragma unroll
-      for (int j = 0; j < k; ++j) sacc -= ekf_readlane(row[j], k) * z[j];     // L[k][j] lives in lane k
-      z[k] = sacc / ekf_readlane(row[k], k);
+  for (int r = 0; r < 4; ++r) {                 // A11 (identity on the padding)
+    const int i = 16 + lk + 4 * r, j = 16 + li;
+    acc[r] = (i < EP && j < EP) ? A[(i > j ? i : j) * lda + (i > j ? j : i)] : (i == j ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) av[s] = Lw[(16 + li) * WLD + 4 * s + lk];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s], av[s], acc, 0, 0, 0);
+  ok = chol16_inv_acc<WLD, true>(Uw + 16 * WLD + 16, acc, lane, nullptr, Lw + 16 * WLD + 16) && ok;
+  if (WITH_U) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {               // Y = L10^T U11
+      av[s] = Lw[(16 + 4 * s + lk) * WLD + li];
+      bv[s] = Uw[(16 + 4 * s + lk) * WLD + 16 + li];
     }
-    if (lane < NRHS) {
+    d4 y = {0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < EP; ++k) Rhs[k * SLD + lane] = z[k];
+    for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], y, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Uw[(lk + 4 * r) * WLD + 16 + li] = y[r];
+      Uw[(16 + lk + 4 * r) * WLD + li] = 0.0;
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {               // U01 = -U00 Y
+      av[s] = Uw[li * WLD + 4 * s + lk];
+      bv[s] = Uw[(4 * s + lk) * WLD + 16 + li];
+    }
+    d4 u01 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u01 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s], bv[s], u01, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Uw[(lk + 4 * r) * WLD + 16 + li] = u01[r];
   }
   return ok;
+}
+
+// C = A B on the matrix cores with 16 x 16 output tiles dealt to the four waves; KS k-steps of 4.  The operands and
+// the result go through accessors (a_at(row, k), b_at(k, col), c_out(row, col, value)) that mask the padding.
+template <int KS, class FA, class FB, class FC>
+__device__ __forceinline__ void tile_gemm(int tiles_m, int tiles_n, int wave, int li, int lk, FA a_at, FB b_at, FC c_out) {
+  for (int t = wave; t < tiles_m * tiles_n; t += 4) {
+    const int ti = t / tiles_n, tj = t % tiles_n;
+    double av[KS], bv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      av[s] = a_at(16 * ti + li, 4 * s + lk);
+      bv[s] = b_at(4 * s + lk, 16 * tj + li);
+    }
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_out(16 * ti + lk + 4 * r, 16 * tj + li, acc[r]);
+  }
+}
+
+// Entry (i, j) of each of the nine 25 x 25 blocks of F P F^T + Q (:761-766, :733-757), F = [[I, a1 I, a2 I], [0, I, a1 I],
+// [0, 0, I]].  Reads and writes the same nine positions, so src == dst is fine with one thread per (i, j).  The
+// smoother's gain kernel rebuilds P_pred[i+1] from P_est[i] with this same code - the filter does not store it.
+__device__ __forceinline__ void predict_cov_entry(const double* src, int lds, double* dst, int ldd, int i, int j, double sT) {
+  const double a1 = sT, a2 = sT * sT / 2;
+  double p[3][3], r[3][3];
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 3; ++bj) p[bi][bj] = src[(bi * EP + i) * lds + bj * EP + j];
+#pragma unroll
+  for (int bj = 0; bj < 3; ++bj) {
+    r[0][bj] = p[0][bj] + a1 * p[1][bj] + a2 * p[2][bj];
+    r[1][bj] = p[1][bj] + a1 * p[2][bj];
+    r[2][bj] = p[2][bj];
+  }
+  double qd = 0.0;
+  if (i == j) {
+    const double h = c_qb_list[i] / 2;
+    qd = h * h;
+  }
+  const double s2 = sT * sT;
+  const double qc[3][3] = {{s2 * s2 / 4, s2 * sT / 2, s2 / 2}, {s2 * sT / 2, s2, sT}, {s2 / 2, sT, 1.0}};
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) {
+    dst[(bi * EP + i) * ldd + j] = r[bi][0] + a1 * r[bi][1] + a2 * r[bi][2] + qc[bi][0] * qd;
+    dst[(bi * EP + i) * ldd + EP + j] = r[bi][1] + a1 * r[bi][2] + qc[bi][1] * qd;
+    dst[(bi * EP + i) * ldd + 2 * EP + j] = r[bi][2] + qc[bi][2] * qd;
+  }
 }
 
 __global__ void __launch_bounds__(256)
 k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restrict__ cams,
               const double* __restrict__ states0_all, double* __restrict__ x_pred_all, double* __restrict__ x_est_all,
-              double* __restrict__ P_pred_all, double* __restrict__ P_est_all, int* __restrict__ outliers,
+              double* __restrict__ P_est_all, int* __restrict__ outliers,
               int* __restrict__ numeric_err) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* P = sm;                       // [75][76]
-  double* Hq = P + ES * PLD;            // [240][27]   later: V [75][27] and Ptop [25][76]
+  double* Hq = P + PR * PLD;            // [240][27]   later: V [80][28] and Ptop [28][81]
   double* hv = Hq + EROWS * HLD;        // [240] h(x)
   double* rs = hv + EROWS;              // [240] residual
   double* ri = rs + EROWS;              // [240] 1 / R
@@ -117,27 +194,30 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
   double* gv = xs + 80;                 // [32]
   double* tv = gv + 32;                 // [32]
   double* scr = tv + 32;                // FK frames, then the 25 x 27 work matrices
-  Cam* cm = reinterpret_cast<Cam*>(scr + 6 * EP * SLD);
+  Cam* cm = reinterpret_cast<Cam*>(scr + 2800 + 2 * 32 * WLD);
+  unsigned* dep = reinterpret_cast<unsigned*>(cm + EKF_MAXC);          // [20]
+  int* n_pairs = reinterpret_cast<int*>(dep + NL);
+  unsigned short* pairs = reinterpret_cast<unsigned short*>(n_pairs + 4);    // [<= 20 + 25 * 20]
   FkLite* fr = reinterpret_cast<FkLite*>(scr);
   double* Mm = scr;                     // M (25 x 26: column 25 = g)
-  double* Lc = Mm + EP * SLD;
-  double* N1 = Lc + EP * SLD;           // Lc^T M, then Z = Lb^-1 [N1 | u]
-  double* Bm = N1 + EP * SLD;           // B -> Lb
-  double* Am = Bm + EP * SLD;
+  double* N1 = Mm + EP * SLD;           // Lc^T [M | g]
+  double* Bm = N1 + EP * SLD;           // B -> Lb, then Z = Lb^-1 N1
+  double* Am = Bm + EP * SLD;           // A
+  double* Lc = scr + 2800;              // chol(Pq) [32][33]; beyond the FK frames (26 x 107 doubles): built early
+  double* Ub = Lc + 32 * WLD;           // [32][33] inverse factors: scratch of chol(Pq), then U = Lb^-T
   double* V = Hq;                       // [75][27]
-  double* Pt = Hq + ES * HLD;           // [25][76]
+  double* Pt = Hq + PR * VLD;           // [28][81]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int seq = blockIdx.x, N = K.n_frames, C = K.n_cams, rows = C * 2 * NL;
   const double* det = det_all + (size_t)seq * N * C * NL * 3;
   double* x_pred = x_pred_all + (size_t)seq * N * ES;
   double* x_est = x_est_all + (size_t)seq * N * ES;
-  double* P_pred = P_pred_all + (size_t)seq * N * ES * ES;
   double* P_est = P_est_all + (size_t)seq * N * ES * ES;
   const double sT = K.sT, a1 = sT, a2 = sT * sT / 2;
 
   for (int e = tid; e < C * ACINO_CAM_STRIDE; e += 256) reinterpret_cast<double*>(cm)[e] = cams[e];
-  for (int e = tid; e < ES * PLD; e += 256) P[e] = 0.0;
+  for (int e = tid; e < PR * PLD; e += 256) P[e] = 0.0;
   if (tid < ES) xs[tid] = states0_all[(size_t)seq * ES + tid];
   __syncthreads();
   if (tid < ES) {   // P0 (:713-730)
@@ -153,6 +233,57 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
   int bad_code = 0;
   __syncthreads();
 
+  // sines / cosines and head positions of the 26 pose variants of ``pose`` (threads tid < nthr, stride nthr)
+  auto fill_frames = [&](const double* pose, int nthr) {
+    for (int task = tid; task < NVAR * 22; task += nthr) {
+      const int v = task / 22, a = task % 22;               // active angle a + 3
+      int p = 0;
+#pragma unroll
+      for (int q = 3; q < EP; ++q) p = (c_ekf2act[q] == a + 3) ? q : p;
+      const double ang = pose[p] + ((v - 1 == p) ? K.eps : 0.0);
+      double s, c;
+      sincos(ang, &s, &c);
+      fr[v].sc[a][0] = s;
+      fr[v].sc[a][1] = c;
+    }
+    for (int task = tid; task < NVAR * 3; task += nthr) {
+      const int v = task / 3, c = task % 3;
+      fr[v].pos[20][c] = pose[c] + ((v - 1 == c) ? K.eps : 0.0);
+    }
+  };
+  // Which marker moves with which parameter is a property of the kinematic chain: probe it once at a generic pose
+  // (a marker whose position is bit-identical in the perturbed frame gives a forward difference of exactly 0 at every
+  // pose - those projections are skipped and the Jacobian entry is written as 0).  pairs[] = the base variant's 20
+  // markers followed by the dependent (variant, marker) pairs; dep[l] = bit mask over the parameters.
+  {
+    if (tid < EP) hv[tid] = 0.3 + 0.17 * tid;
+    __syncthreads();
+    fill_frames(hv, 256);
+    __syncthreads();
+    if (tid < NVAR * 3) fk_columns(fr[tid / 3], tid % 3);
+    __syncthreads();
+    unsigned char* flag = reinterpret_cast<unsigned char*>(Hq);
+    for (int e = tid; e < EP * NL; e += 256) {
+      const int v = 1 + e / NL, l = e % NL;
+      flag[e] = fr[v].pos[l][0] != fr[0].pos[l][0] || fr[v].pos[l][1] != fr[0].pos[l][1] || fr[v].pos[l][2] != fr[0].pos[l][2];
+    }
+    __syncthreads();
+    if (tid < NL) {
+      unsigned m = 0;
+      for (int p = 0; p < EP; ++p) m |= flag[p * NL + tid] ? (1u << p) : 0u;
+      dep[tid] = m;
+      pairs[tid] = (unsigned short)tid;
+    }
+    if (tid == 0) {
+      int n = NL;
+      for (int e = 0; e < EP * NL; ++e)
+        if (flag[e]) pairs[n++] = (unsigned short)(((1 + e / NL) << 5) | (e % NL));
+      *n_pairs = n;
+    }
+    __syncthreads();
+  }
+  const int np = *n_pairs;
+
   for (int f = 0; f < N; ++f) {
     // ---- predict (:622-628; the reference rounds the predicted state to float32) ----
     if (tid < EP) {
@@ -164,58 +295,23 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       xs[2 * EP + tid] = (double)(float)acc;
     }
     // P <- F P F^T + Q, block-wise: F = [[I, a1 I, a2 I], [0, I, a1 I], [0, 0, I]]
-    for (int e = tid; e < EP * EP; e += 256) {
-      const int i = e / EP, j = e % EP;
-      double p[3][3], r[3][3];
-#pragma unroll
-      for (int bi = 0; bi < 3; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < 3; ++bj) p[bi][bj] = P[(bi * EP + i) * PLD + bj * EP + j];
-#pragma unroll
-      for (int bj = 0; bj < 3; ++bj) {
-        r[0][bj] = p[0][bj] + a1 * p[1][bj] + a2 * p[2][bj];
-        r[1][bj] = p[1][bj] + a1 * p[2][bj];
-        r[2][bj] = p[2][bj];
-      }
-      double qd = 0.0;
-      if (i == j) {
-        const double h = c_qb_list[i] / 2;
-        qd = h * h;
-      }
-      const double s2 = sT * sT;
-      const double qc[3][3] = {{s2 * s2 / 4, s2 * sT / 2, s2 / 2}, {s2 * sT / 2, s2, sT}, {s2 / 2, sT, 1.0}};
-#pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        P[(bi * EP + i) * PLD + j] = r[bi][0] + a1 * r[bi][1] + a2 * r[bi][2] + qc[bi][0] * qd;
-        P[(bi * EP + i) * PLD + EP + j] = r[bi][1] + a1 * r[bi][2] + qc[bi][1] * qd;
-        P[(bi * EP + i) * PLD + 2 * EP + j] = r[bi][2] + qc[bi][2] * qd;
-      }
-    }
+    for (int e = tid; e < EP * EP; e += 256) predict_cov_entry(P, PLD, P, PLD, e / EP, e % EP, sT);
     __syncthreads();
     if (tid < ES) x_pred[(size_t)f * ES + tid] = xs[tid];
-    for (int e = tid; e < ES * ES; e += 256) P_pred[(size_t)f * ES * ES + e] = P[(e / ES) * PLD + e % ES];
 
     // ---- measurement model: 26 pose variants (base + eps on each parameter) ----
-    for (int task = tid; task < NVAR * 22; task += 256) {
-      const int v = task / 22, a = task % 22;               // active angle a + 3
-      int p = 0;
-#pragma unroll
-      for (int q = 3; q < EP; ++q) p = (c_ekf2act[q] == a + 3) ? q : p;
-      const double ang = xs[p] + ((v - 1 == p) ? K.eps : 0.0);
-      double s, c;
-      sincos(ang, &s, &c);
-      fr[v].sc[a][0] = s;
-      fr[v].sc[a][1] = c;
-    }
-    for (int task = tid; task < NVAR * 3; task += 256) {
-      const int v = task / 3, c = task % 3;
-      fr[v].pos[20][c] = xs[c] + ((v - 1 == c) ? K.eps : 0.0);
+    // waves 0-2 build the kinematic frames; wave 3 meanwhile factors Pq = Lc Lc^T in its registers
+    if (wave < 3) {
+      fill_frames(xs, 192);
+      for (int e = tid; e < rows * EP; e += 192) Hq[(e / EP) * HLD + e % EP] = 0.0;     // entries of markers that do not move
+    } else {
+      if (!wave_chol32<false>(P, PLD, Lc, Ub, lane) && !bad) { bad = true; bad_code = 2 * f + 1; }
     }
     __syncthreads();
     if (tid < NVAR * 3) fk_columns(fr[tid / 3], tid % 3);
     __syncthreads();
-    for (int task = tid; task < NVAR * C * NL; task += 256) {
-      const int v = task / (C * NL), rem = task % (C * NL), c = rem / NL, l = rem % NL;
+    for (int task = tid; task < np * C; task += 256) {
+      const int pr = pairs[task / C], c = task % C, v = pr >> 5, l = pr & 31;
       double u, w;
       project_fisheye_pt(cm[c], fr[v].pos[l][0], fr[v].pos[l][1], fr[v].pos[l][2], u, w);
       const int row = c * 2 * NL + 2 * l;
@@ -228,9 +324,10 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       }
     }
     __syncthreads();
-    for (int e = tid; e < rows * EP; e += 256) {
-      const int row = e / EP, p = e % EP;
-      Hq[row * HLD + p] = (Hq[row * HLD + p] - hv[row]) / K.eps;       // (:643)
+    for (int task = tid; task < (np - NL) * C * 2; task += 256) {
+      const int pr = pairs[NL + task / (2 * C)], c = (task >> 1) % C, row = c * 2 * NL + 2 * (pr & 31) + (task & 1);
+      double* h = Hq + row * HLD + (pr >> 5) - 1;
+      *h = (*h - hv[row]) / K.eps;       // (:643)
     }
     if (tid < rows) {
       const int c = tid / (2 * NL), l = (tid % (2 * NL)) / 2, d = tid & 1;
@@ -240,19 +337,30 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       ri[tid] = 1.0 / (sdv * sdv);
     }
     __syncthreads();
-    // diag S = Hq Pq Hq^T + R, row-wise
-    if (tid < rows) {
-      double h[EP];
+    // diag S = Hq Pq Hq^T + R = row norms of Hq Lc, + R: G^T = Lc^T Hq^T on the matrix cores, 16 measurement rows per
+    // tile column (lane li = row, the 25 entries of a row spread over 2 tiles x 4 registers x 4 lane groups)
+    for (int tr = wave; tr < rows / 16; tr += 4) {
+      const int row = 16 * tr + li;
+      double hq[7], lc0[7], lc1[7];
 #pragma unroll
-      for (int a = 0; a < EP; ++a) h[a] = Hq[tid * HLD + a];
-      double s = 0.0;
-      for (int a = 0; a < EP; ++a) {
-        double in = 0.0;
-#pragma unroll
-        for (int b = 0; b < EP; ++b) in += P[a * PLD + b] * h[b];
-        s += h[a] * in;
+      for (int s7 = 0; s7 < 7; ++s7) {
+        const int kk = 4 * s7 + lk;
+        hq[s7] = kk < EP ? Hq[row * HLD + kk] : 0.0;
+        lc0[s7] = (kk < EP && kk >= li) ? Lc[kk * WLD + li] : 0.0;
+        lc1[s7] = (kk < EP && li + 16 < EP && kk >= li + 16) ? Lc[kk * WLD + li + 16] : 0.0;
       }
-      sd[tid] = s + 1.0 / ri[tid];
+      d4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s7 = 0; s7 < 7; ++s7) {
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lc0[s7], hq[s7], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lc1[s7], hq[s7], g1, 0, 0, 0);
+      }
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ss += g0[r] * g0[r] + g1[r] * g1[r];
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lk == 0) sd[row] = ss + 1.0 / ri[row];
     }
     __syncthreads();
     if (tid < rows / 2) {   // 3-sigma gate per pixel pair (:813-819)
@@ -273,51 +381,55 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       const double* pa = Hq + (a_on ? arow : 0);
       const double* pb = b_h ? Hq + bcol : rs;            // column of Hq, or the residual as the 26th column
       const int sb = b_h ? HLD : 1;
-      for (int s = 0; s < rows / 4; s += 2) {             // rows / 4 = 10 C is even; operands of two steps first
-        const int k0 = 4 * s + lk, k1 = k0 + 4;
-        const double a0 = pa[k0 * HLD], a1 = pa[k1 * HLD];
-        const double w0 = ri[k0], w1 = ri[k1];
-        const double b0 = pb[k0 * sb], b1 = pb[k1 * sb];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_on ? a0 : 0.0, (b_h || b_r) ? w0 * b0 : 0.0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_on ? a1 : 0.0, (b_h || b_r) ? w1 * b1 : 0.0, acc, 0, 0, 0);
+      for (int s = 0; s < rows / 4; s += 5) {             // rows / 4 = 10 C; the operands of five steps in flight
+        double av[5], bw[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int k0 = 4 * (s + u) + lk;
+          av[u] = pa[k0 * HLD];
+          bw[u] = ri[k0] * pb[k0 * sb];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_on ? av[u] : 0.0, (b_h || b_r) ? bw[u] : 0.0, acc, 0, 0, 0);
       }
-      __syncthreads();      // every wave is done with the FK frames' memory (scr is reused from here on)
+      // (the FK frames that share scr were last read by the projections, several barriers ago)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
         if (row < EP && col <= EP) Mm[row * SLD + col] = acc[r];
       }
     }
-    for (int e = tid; e < EP * EP; e += 256) Lc[(e / EP) * SLD + e % EP] = P[(e / EP) * PLD + e % EP];
     __syncthreads();
-    if (wave == 0 && !wave_chol25<0>(Lc, nullptr, lane) && !bad) { bad = true; bad_code = 2 * f + 1; }
+    // N1 = Lc^T [M | g]
+    tile_gemm<7>(2, 2, wave, li, lk,
+                 [&](int a_, int k) { return (a_ < EP && k < EP && k >= a_) ? Lc[k * WLD + a_] : 0.0; },
+                 [&](int k, int b_) { return (k < EP && b_ <= EP) ? Mm[k * SLD + b_] : 0.0; },
+                 [&](int a_, int b_, double v) { if (a_ < EP && b_ <= EP) N1[a_ * SLD + b_] = v; });
     __syncthreads();
-    // N1 = Lc^T M ;  u = Lc^T g in column 25
-    for (int e = tid; e < EP * (EP + 1); e += 256) {
-      const int a = e / (EP + 1), b = e % (EP + 1);
-      double s = 0.0;
-      for (int k = a; k < EP; ++k) s += Lc[k * SLD + a] * Mm[k * SLD + b];
-      N1[a * SLD + b] = s;
-    }
+    // B = I + N1 Lc
+    tile_gemm<7>(2, 2, wave, li, lk,
+                 [&](int a_, int k) { return (a_ < EP && k < EP) ? N1[a_ * SLD + k] : 0.0; },
+                 [&](int k, int b_) { return (k < EP && b_ < EP && k >= b_) ? Lc[k * WLD + b_] : 0.0; },
+                 [&](int a_, int b_, double v) { if (a_ < EP && b_ < EP) Bm[a_ * SLD + b_] = v + (a_ == b_ ? 1.0 : 0.0); });
     __syncthreads();
-    for (int e = tid; e < EP * EP; e += 256) {   // B = I + N1 Lc
-      const int a = e / EP, b = e % EP;
-      double s = a == b ? 1.0 : 0.0;
-      for (int k = b; k < EP; ++k) s += N1[a * SLD + k] * Lc[k * SLD + b];
-      Bm[a * SLD + b] = s;
-    }
+    // B = Lb Lb^T with U = Lb^-T alongside, in one wave's registers
+    if (wave == 0 && !wave_chol32<true>(Bm, SLD, Lc, Ub, lane) && !bad) { bad = true; bad_code = 2 * f + 2; }   // (Lc is done with)
     __syncthreads();
-    // B = Lb Lb^T and Z = Lb^-1 [N1 | u] in one wave's registers
-    if (wave == 0 && !wave_chol25<EP + 1>(Bm, N1, lane) && !bad) { bad = true; bad_code = 2 * f + 2; }
+    // Z = Lb^-1 [N1 | u] = U^T [N1 | u]   (into Bm: Lb itself is not needed again)
+    tile_gemm<7>(2, 2, wave, li, lk,
+                 [&](int a_, int k) { return (a_ < EP && k <= a_) ? Ub[k * WLD + a_] : 0.0; },
+                 [&](int k, int b_) { return (k < EP && b_ <= EP) ? N1[k * SLD + b_] : 0.0; },
+                 [&](int a_, int b_, double v) { if (a_ < EP && b_ <= EP) Bm[a_ * SLD + b_] = v; });
     __syncthreads();
     // A = M - Z^T Z ;  w = g - Z^T zu
-    for (int e = tid; e < EP * (EP + 1); e += 256) {
-      const int a = e / (EP + 1), b = e % (EP + 1);
-      double s = Mm[a * SLD + b];
-      for (int k = 0; k < EP; ++k) s -= N1[k * SLD + a] * N1[k * SLD + b];
-      if (b < EP) Am[a * SLD + b] = s;
-      else gv[a] = s;
-    }
+    tile_gemm<7>(2, 2, wave, li, lk,
+                 [&](int a_, int k) { return (a_ < EP && k < EP) ? Bm[k * SLD + a_] : 0.0; },
+                 [&](int k, int b_) { return (k < EP && b_ <= EP) ? Bm[k * SLD + b_] : 0.0; },
+                 [&](int a_, int b_, double v) {
+                   if (a_ < EP && b_ < EP) Am[a_ * SLD + b_] = Mm[a_ * SLD + b_] - v;
+                   else if (a_ < EP && b_ == EP) gv[a_] = Mm[a_ * SLD + EP] - v;
+                 });
     __syncthreads();
     // state correction x += P[:, :25] w ; V = P[:, :25] A ; Ptop = P[:25, :]
     if (tid < ES) {
@@ -325,37 +437,48 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       for (int a = 0; a < EP; ++a) s += P[tid * PLD + a] * gv[a];
       xs[tid] += s;
     }
-    for (int e = tid; e < ES * EP; e += 256) {
-      const int r = e / EP, b = e % EP;
-      double s = 0.0;
-      for (int a = 0; a < EP; ++a) s += P[r * PLD + a] * Am[a * SLD + b];
-      V[r * HLD + b] = s;
-    }
-    for (int e = tid; e < EP * ES; e += 256) Pt[(e / ES) * PLD + e % ES] = P[(e / ES) * PLD + e % ES];
+    tile_gemm<7>(5, 2, wave, li, lk,
+                 [&](int r_, int k) { return k < EP ? P[r_ * PLD + k] : 0.0; },
+                 [&](int k, int b_) { return (k < EP && b_ < EP) ? Am[k * SLD + b_] : 0.0; },
+                 [&](int r_, int b_, double v) { if (b_ < VLD) V[r_ * VLD + b_] = v; });     // zero beyond 75 x 25
+    for (int e = tid; e < 28 * PLD; e += 256) Pt[e] = e < EP * PLD ? P[e] : 0.0;
     __syncthreads();
     // P -= V Ptop on the matrix cores: 5 x 5 tiles of the 75 x 75 matrix (padded to 80), K = 25 padded to 28
-    for (int t = wave; t < 25; t += 4) {
-      const int ti = t / 5, tj = t % 5;
-      const int rowA = 16 * ti + li, colB = 16 * tj + li;
-      d4 acc;
+    for (int q0 = 0; q0 < 7; q0 += 2) {      // two tiles' operands in flight per wave
+      d4 acc[2];
+      double av[2][7], bv[2][7];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + lk + 4 * r;
-        acc[r] = (row < ES && colB < ES) ? P[row * PLD + colB] : 0.0;
+      for (int q = 0; q < 2; ++q) {
+        const int t = wave + 4 * (q0 + q);
+        if (t < 25) {
+          const int ti = t / 5, tj = t % 5;
+          const int rowA = 16 * ti + li, colB = 16 * tj + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + lk + 4 * r;
+            acc[q][r] = P[row * PLD + colB];
+          }
+#pragma unroll
+          for (int s7 = 0; s7 < 7; ++s7) {
+            const int kk = 4 * s7 + lk;
+            av[q][s7] = V[rowA * VLD + kk];
+            bv[q][s7] = Pt[kk * PLD + colB];
+          }
+        }
       }
-      double av[7], bv[7];
 #pragma unroll
-      for (int s7 = 0; s7 < 7; ++s7) {
-        const int kk = 4 * s7 + lk;
-        av[s7] = (rowA < ES && kk < EP) ? V[rowA * HLD + kk] : 0.0;
-        bv[s7] = (colB < ES && kk < EP) ? Pt[kk * PLD + colB] : 0.0;
-      }
+      for (int q = 0; q < 2; ++q) {
+        const int t = wave + 4 * (q0 + q);
+        if (t < 25) {
 #pragma unroll
-      for (int s7 = 0; s7 < 7; ++s7) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s7], bv[s7], acc, 0, 0, 0);
+          for (int s7 = 0; s7 < 7; ++s7) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q][s7], bv[q][s7], acc[q], 0, 0, 0);
+          const int ti = t / 5, tj = t % 5, colB = 16 * tj + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + lk + 4 * r;
-        if (row < ES && colB < ES) P[row * PLD + colB] = acc[r];
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + lk + 4 * r;
+            P[row * PLD + colB] = acc[q][r];
+          }
+        }
       }
     }
     __syncthreads();
@@ -366,44 +489,96 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
   // outlier count: one pair per thread per frame
   for (int off = 32; off > 0; off >>= 1) n_out += __shfl_down(n_out, off, 64);
   if (lane == 0 && n_out) atomicAdd(&outliers[seq], n_out);
-  if (bad && tid == 0) atomicCAS(numeric_err, 0, bad_code);   // first failure: 2 f + 1 (P) or 2 f + 2 (B)
+  if (bad && lane == 0) atomicCAS(numeric_err, 0, bad_code);   // first failure: 2 f + 1 (P) or 2 f + 2 (B)
 }
 
-// A_i = P_est[i] F^T inv(P_pred[i+1]) for i = 1 .. N-2 (one workgroup per (sequence, frame)); A_i^T = inv(P_pred[i+1]) (F P_est[i]^T).
+// A_i = P_est[i] F^T inv(P_pred[i+1]) for i = 1 .. N-2 (one workgroup per (sequence, frame)), P_pred[i+1] = F P_est[i] F^T + Q
+// rebuilt here;  A_i^T = inv(P_pred[i+1]) G, G = F P_est[i]^T.  P_pred is symmetric positive definite while the filter
+// is healthy: blocked Cholesky with the inverse factor U = L^-T (dense80.hpp), then A_i = (U^T G)^T U^T - two
+// triangular 80 x 80 products on the matrix cores.  If a pivot is not positive ((I - K H) P does not keep positive
+// definiteness to round-off when a filter has lost its target), the workgroup falls back to Gauss-Jordan elimination
+// with partial pivoting on [P_pred | G] - like the reference's np.linalg.inv (:840), no definiteness requirement.
+__device__ void rts_build(double* Lp, double* G, const double* E, double sT, int tid) {
+  const double a1 = sT, a2 = sT * sT / 2;
+  for (int e = tid; e < EP * EP; e += 256) predict_cov_entry(E, LD, Lp, LD, e / EP, e % EP, sT);
+  for (int e = tid; e < BS * BS; e += 256) {
+    const int r = e / BS, c = e % BS;
+    double g = 0.0;
+    if (r < ES && c < ES) {     // G[r][c] = (F P_est^T)[r][c] = sum_k F[r][k] P_est[c][k]
+      g = E[c * LD + r];
+      if (r < 2 * EP) g += a1 * E[c * LD + r + EP];
+      if (r < EP) g += a2 * E[c * LD + r + 2 * EP];
+    } else {
+      Lp[r * LD + c] = (r == c) ? 1.0 : 0.0;
+    }
+    G[r * LD + c] = g;
+  }
+}
+
 __global__ void __launch_bounds__(256)
-k_rts_gain(EkfK K, const double* __restrict__ P_pred_all, const double* __restrict__ P_est_all, double* __restrict__ A_all,
-           int* __restrict__ numeric_err) {
+k_rts_gain(EkfK K, const double* __restrict__ P_est_all, double* __restrict__ A_all, int* __restrict__ numeric_err) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* Lp = sm;                 // [75][76]
-  double* G = Lp + ES * PLD;       // [75][76]
-  const int tid = threadIdx.x;
+  double* Lp = sm;                 // [80][81] P_pred -> L / U
+  double* G = Lp + MAT;            // [80][81] F P_est^T -> U^T G
+  double* E = G + MAT;             // [80][81] P_est
+  __shared__ int s_err, s_piv;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int N = K.n_frames, per = N - 2;
   const int seq = blockIdx.x / per, i = 1 + blockIdx.x % per;
-  const double* Pp = P_pred_all + ((size_t)seq * N + i + 1) * ES * ES;
   const double* Pe = P_est_all + ((size_t)seq * N + i) * ES * ES;
   double* A = A_all + ((size_t)seq * N + i) * ES * ES;
-  const double a1 = K.sT, a2 = K.sT * K.sT / 2;
-  for (int e = tid; e < ES * ES; e += 256) {
-    const int r = e / ES, c = e % ES;
-    Lp[r * PLD + c] = Pp[e];
-    // G[r][c] = (F P_est^T)[r][c] = sum_k F[r][k] P_est[c][k]
-    double g = Pe[c * ES + r];
-    if (r < 2 * EP) g += a1 * Pe[c * ES + r + EP];
-    if (r < EP) g += a2 * Pe[c * ES + r + 2 * EP];
-    G[r * PLD + c] = g;
+  for (int e = tid; e < ES * ES; e += 256) E[(e / ES) * LD + e % ES] = Pe[e];
+  if (tid == 0) s_err = 0;
+  __syncthreads();
+  rts_build(Lp, G, E, K.sT, tid);
+  __syncthreads();
+  if (!K.pivoting) chol80(Lp, tid, &s_err);
+  if (!K.pivoting && !s_err) {
+    d4 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {          // T = U^T G : tile (ti, tj) = sum_{k <= ti} U(k, ti)^T G(k, tj)
+      const int t = wave + 4 * q;
+      acc[q] = d4{0, 0, 0, 0};
+      if (t < 25) {
+        const int ti = t / 5, tj = t % 5;
+        for (int k = 0; k <= ti; ++k)
+          acc[q] = mma_seq<4, false>(acc[q], Lp + (16 * k + lk) * LD + 16 * ti + li, 4 * LD, G + (16 * k + lk) * LD + 16 * tj + li,
+                                     4 * LD);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int t = wave + 4 * q;
+      if (t < 25) {
+        const int ti = t / 5, tj = t % 5;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[(16 * ti + lk + 4 * r) * LD + 16 * tj + li] = acc[q][r];
+      }
+    }
+    __syncthreads();
+    for (int t = wave; t < 25; t += 4) {   // A = T^T U^T : tile (tj, ti) = sum_{k >= ti} T(k, tj)^T U(ti, k)^T
+      const int tj = t / 5, ti = t % 5;
+      d4 a = {0, 0, 0, 0};
+      for (int k = ti; k < 5; ++k)
+        a = mma_seq<4, false>(a, G + (16 * k + lk) * LD + 16 * tj + li, 4 * LD, Lp + (16 * ti + li) * LD + 16 * k + lk, 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tj + lk + 4 * r, col = 16 * ti + li;
+        if (row < ES && col < ES) A[row * ES + col] = a[r];
+      }
+    }
+    return;
   }
   __syncthreads();
-  // X = inv(P_pred) G by Gauss-Jordan elimination with partial pivoting on [P_pred | G] (the reference uses
-  // np.linalg.inv, :840: LU with pivoting - no positive-definiteness requirement, which (I - K H) P does not keep
-  // to round-off over thousands of frames)
-  __shared__ int s_piv;
-  const int lane = tid & 63;
+  rts_build(Lp, G, E, K.sT, tid);
+  __syncthreads();
   for (int k = 0; k < ES; ++k) {
     if (tid < 64) {
       double best = -1.0;
       int bi = k;
       for (int r = k + lane; r < ES; r += 64) {
-        const double v = fabs(Lp[r * PLD + k]);
+        const double v = fabs(Lp[r * LD + k]);
         if (v > best) {
           best = v;
           bi = r;
@@ -427,30 +602,30 @@ k_rts_gain(EkfK K, const double* __restrict__ P_pred_all, const double* __restri
     if (pr != k && tid < 2 * ES) {
       double* M2 = tid < ES ? Lp : G;
       const int c = tid % ES;
-      const double t = M2[k * PLD + c];
-      M2[k * PLD + c] = M2[pr * PLD + c];
-      M2[pr * PLD + c] = t;
+      const double t = M2[k * LD + c];
+      M2[k * LD + c] = M2[pr * LD + c];
+      M2[pr * LD + c] = t;
     }
     __syncthreads();
-    const double d = Lp[k * PLD + k];
+    const double d = Lp[k * LD + k];
     __syncthreads();
     const double inv = 1.0 / (d != 0.0 ? d : 1.0);
     if (tid < 2 * ES) {
       double* M2 = tid < ES ? Lp : G;
-      M2[k * PLD + tid % ES] *= inv;
+      M2[k * LD + tid % ES] *= inv;
     }
     __syncthreads();
     const int nc = (ES - k - 1) + ES;          // columns k+1.. of P_pred, all of G
     for (int e = tid; e < ES * nc; e += 256) {
       const int r = e / nc, cc = e % nc;
       if (r == k) continue;
-      const double fct = Lp[r * PLD + k];
-      if (cc < ES - k - 1) Lp[r * PLD + k + 1 + cc] -= fct * Lp[k * PLD + k + 1 + cc];
-      else G[r * PLD + cc - (ES - k - 1)] -= fct * G[k * PLD + cc - (ES - k - 1)];
+      const double fct = Lp[r * LD + k];
+      if (cc < ES - k - 1) Lp[r * LD + k + 1 + cc] -= fct * Lp[k * LD + k + 1 + cc];
+      else G[r * LD + cc - (ES - k - 1)] -= fct * G[k * LD + cc - (ES - k - 1)];
     }
     __syncthreads();
   }
-  for (int e = tid; e < ES * ES; e += 256) A[e] = G[(e % ES) * PLD + e / ES];     // A = X^T
+  for (int e = tid; e < ES * ES; e += 256) A[e] = G[(e % ES) * LD + e / ES];     // A = X^T
 }
 
 // smooth[i] = x_est[i] + A_i (smooth[i+1] - x_pred[i+1]), i = N-2 .. 1; frames 0 and N-1 keep the filtered state (:836-839).
@@ -496,11 +671,12 @@ k_rts_recurse(EkfK K, const double* __restrict__ x_pred_all, const double* __res
   }
 }
 
+constexpr size_t kRtsLds = 3 * MAT * sizeof(double);
 static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
-constexpr size_t kEkfLds = (size_t)(ES * PLD + EROWS * HLD + 4 * EROWS + 80 + 32 + 32 + 6 * EP * SLD) * sizeof(double) +
-                           EKF_MAXC * sizeof(Cam);
+constexpr size_t kEkfLds = (size_t)(PR * PLD + EROWS * HLD + 4 * EROWS + 80 + 32 + 32 + 2800 + 2 * 32 * 33) * sizeof(double) +
+                           EKF_MAXC * sizeof(Cam) + (NL + 4) * 4 + (NL + EP * NL) * 2 + 8;
 static_assert(sizeof(FkLite) * NVAR <= 6 * EP * SLD * sizeof(double), "FK frames must fit the scratch region");
-static_assert((ES * HLD + EP * PLD) <= EROWS * HLD, "V and Ptop alias the Jacobian storage");
+static_assert((PR * VLD + 28 * PLD) <= EROWS * HLD, "V and Ptop alias the Jacobian storage");
 static_assert(kEkfLds <= 160 * 1024, "EKF workgroup state must fit the 160 KB LDS");
 
 }  // namespace acino
@@ -514,7 +690,7 @@ size_t acino_sizeof_ekf_params(void) { return sizeof(acino_ekf_params); }
 size_t acino_ekf_workspace_bytes(int64_t n_frames, int n_seq) {
   if (n_frames < 1 || n_seq < 1) return 0;
   const size_t N = (size_t)n_frames * n_seq;
-  return 3 * a256(N * ES * ES * 8) + 2 * a256(N * ES * 8) + 1024;
+  return 2 * a256(N * ES * ES * 8) + 2 * a256(N * ES * 8) + 1024;
 }
 
 int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double* d_cams24, const double* d_states0,
@@ -529,7 +705,6 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
   hipStream_t s = (hipStream_t)stream;
   const size_t N = (size_t)prm->n_frames * prm->n_seq;
   char* w = (char*)d_ws;
-  double* P_pred = (double*)w;  w += a256(N * ES * ES * 8);
   double* P_est = (double*)w;   w += a256(N * ES * ES * 8);
   double* A = (double*)w;       w += a256(N * ES * ES * 8);
   double* x_pred = (double*)w;  w += a256(N * ES * 8);
@@ -537,6 +712,7 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
   EkfK K;
   K.n_frames = (int)prm->n_frames;
   K.n_cams = prm->n_cams;
+  K.pivoting = prm->smoother_pivoting;
   K.sT = 1.0 / prm->fps;
   K.dlc_thresh = prm->dlc_thresh;
   K.max_pixel_err = prm->cam_width;
@@ -546,17 +722,16 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ekf_forward),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEkfLds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rts_gain),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ES * PLD * 8)));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRtsLds));
     attr_done = true;
   }
   ACINO_HIP_CHECK(hipMemsetAsync(d_outliers, 0, sizeof(int32_t) * prm->n_seq, s));
   ACINO_HIP_CHECK(hipMemsetAsync(nerr, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_ekf_forward, dim3(prm->n_seq), dim3(256), kEkfLds, s, K, d_det, d_cams24, d_states0, x_pred, d_est,
-                     P_pred, P_est, d_outliers, nerr);
+                     P_est, d_outliers, nerr);
   ACINO_LAUNCH_CHECK();
   if (prm->n_frames >= 3) {
-    hipLaunchKernelGGL(k_rts_gain, dim3((unsigned)(prm->n_seq * (prm->n_frames - 2))), dim3(256), 2 * ES * PLD * 8, s, K,
-                       P_pred, P_est, A, nerr);
+    hipLaunchKernelGGL(k_rts_gain, dim3((unsigned)(prm->n_seq * (prm->n_frames - 2))), dim3(256), kRtsLds, s, K, P_est, A, nerr);
     ACINO_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_rts_recurse, dim3(prm->n_seq), dim3(256), 0, s, K, x_pred, d_est, A, d_smooth);
@@ -569,7 +744,7 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
       set_error("EKF: %s lost positive definiteness at frame %d", (h_err & 1) ? "the pose covariance" : "I + Lc^T M Lc",
                 (h_err - 1) / 2);
     else
-      set_error("EKF smoother: the predicted covariance of frame %d is not positive definite", -h_err);
+      set_error("EKF smoother: the predicted covariance of frame %d is singular", -h_err);
     return ACINO_ERR_NUMERIC;
   }
   return ACINO_OK;

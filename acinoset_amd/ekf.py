@@ -57,7 +57,7 @@ def initial_state(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, start_frame=
 
 
 def ekf_batch(dets, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, camera_resolution, start_frames=None, states0=None,
-              with_positions=True):
+              with_positions=True, smoother_pivoting=False):
     """Filter + smooth several clips of the same rig.  ``dets``: list of det[N_b, C, 20, 3] (x, y, likelihood);
     clips of equal length share one launch.  Returns one result dictionary per clip."""
     _lib.require_gpu()
@@ -93,7 +93,7 @@ def ekf_batch(dets, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, camera_resoluti
         det = torch.stack([dets_d[b] for b in members]).contiguous()
         st0 = torch.as_tensor(np.stack([s0[b] for b in members]), device=dev)
         prm = EkfParams(n_frames=n_frames, n_seq=len(members), n_cams=n_cams, fps=float(fps), dlc_thresh=float(dlc_thresh),
-                        cam_width=float(camera_resolution[0]))
+                        cam_width=float(camera_resolution[0]), smoother_pivoting=int(bool(smoother_pivoting)))
         nbytes = lib().acino_ekf_workspace_bytes(n_frames, len(members))
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
@@ -115,7 +115,7 @@ def ekf_batch(dets, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, camera_resoluti
 
 
 def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, camera_resolution, start_frame=0, states0=None,
-        with_positions=True):
+        with_positions=True, smoother_pivoting=False):
     """One clip: det[N, C, 20, 3] for the frames start_frame .. start_frame + N - 1."""
     return ekf_batch([det], k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, camera_resolution, [start_frame],
-                     None if states0 is None else [states0], with_positions)[0]
+                     None if states0 is None else [states0], with_positions, smoother_pivoting)[0]

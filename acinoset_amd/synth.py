@@ -39,8 +39,10 @@ def trajectory(n_frames, kind="loop", seed_phase=0.0):
     PHI, THETA, PSI = fte.PHI, fte.THETA, fte.PSI
     tt = np.arange(n_frames) / FPS
     q = np.zeros((n_frames, 45))
-    if kind == "loop":
-        radius, speed = 2.5, 10.0
+    if kind in ("loop", "walk"):
+        # "walk": the same circle at 2 m/s - slow enough for the EKF's constant-acceleration model (5 m/s^2 process
+        # noise on x, y) to follow the centripetal acceleration, which it cannot at 10 m/s
+        radius, speed = 2.5, (10.0 if kind == "loop" else 2.0)
         ang = speed / radius * tt + seed_phase
         q[:, 0] = LOOK_AT[0] + radius * np.cos(ang)
         q[:, 1] = LOOK_AT[1] + radius * np.sin(ang)

@@ -280,7 +280,8 @@ int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_p
  * [n_seq][n_frames][n_cams][20][3] (x, y, likelihood), d_states0 [n_seq][75] the state BEFORE the first prediction
  * (:700-711), d_est / d_smooth [n_seq][n_frames][75] the filtered and the smoothed states (:848-856 slices them into
  * x, dx, ddx), d_outliers [n_seq] the gated pixel pairs (:818).  Model constants (P0, Q, R, the 3-sigma gate, the
- * forward-difference step 1e-3) are the reference's literals. */
+ * forward-difference step 1e-3) are the reference's literals.  The predicted covariances are not stored: the smoother
+ * rebuilds P_pred[i+1] = F P_est[i] F^T + Q from the filtered one with the filter's own arithmetic. */
 typedef struct acino_ekf_params {
   int64_t n_frames;
   int32_t n_seq;
@@ -288,6 +289,10 @@ typedef struct acino_ekf_params {
   double fps;
   double dlc_thresh;          /* likelihood < thresh -> measurement sigma = cam_width (:805-808) */
   double cam_width;           /* camera_resolution[0], the reference's max_pixel_err (:611) */
+  int32_t smoother_pivoting;  /* 0: Cholesky of P_pred, Gauss-Jordan with partial pivoting only where a pivot fails;
+                                 1: always the pivoting solver (the reference's np.linalg.inv makes no definiteness
+                                 assumption, :840) */
+  int32_t reserved;
 } acino_ekf_params;
 size_t acino_sizeof_ekf_params(void);
 size_t acino_ekf_workspace_bytes(int64_t n_frames, int n_seq);
