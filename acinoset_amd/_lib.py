@@ -80,6 +80,9 @@ _L = C.c_int64
 _D = C.c_double
 _Z = C.c_size_t
 
+# acino_reduce_fn: int (*)(void* user, double* d_buf, int64_t n, int op, void* stream)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
 # name -> (restype, argtypes); every symbol include/acinoset_hip.h declares
 SIGNATURES = {
     "acino_last_error_string": (C.c_char_p, []),
@@ -132,6 +135,8 @@ SIGNATURES = {
     "acino_sizeof_sba_info": (_Z, []),
     "acino_sba_workspace_bytes": (_Z, [_I, _L, _L]),
     "acino_sba_solve": (_I, [C.POINTER(SbaParams), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P, C.POINTER(SbaInfo), _P]),
+    "acino_sba_solve_sharded": (_I, [C.POINTER(SbaParams), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P, C.POINTER(SbaInfo),
+                                     REDUCE_FN, _P, _P]),
     "acino_sizeof_ekf_params": (_Z, []),
     "acino_ekf_workspace_bytes": (_Z, [_L, _I]),
     "acino_ekf_run": (_I, [C.POINTER(EkfParams), _P, _P, _P, _P, _Z, _P, _P, _P, _P]),

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_sba_cam_solve(SbaBuf B, double lam) {
       const int cam = i / 6, a = i % 6, q = a * 6 - (a * (a - 1)) / 2;
       pred += 0.5 * sb[i] * (lam * B.U[21 * cam + q] * sb[i] - B.gc[i]);
     }
-    atomicAdd(&B.scal[1], pred);
+    B.scal[4] = pred;
   }
 }
 
@@ -414,9 +414,18 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
                     const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start, const int32_t* d_pt_obs,
                     void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,
                     void* stream) {
+  return acino_sba_solve_sharded(prm, d_intr, d_Rt, d_pts, d_uv, d_cam_idx, d_pt_start, d_pt_obs, d_ws, ws_bytes,
+                                 d_res_before, d_res_after, info, nullptr, nullptr, stream);
+}
+
+int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,
+                            const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start,
+                            const int32_t* d_pt_obs, void* d_ws, size_t ws_bytes, double* d_res_before,
+                            double* d_res_after, acino_sba_info* info, acino_reduce_fn reduce, void* reduce_user,
+                            void* stream) {
   ACINO_REQUIRE(prm && info, "params/info");
   ACINO_REQUIRE(prm->n_cams >= 1 && prm->n_cams <= SBA_MAXC, "n_cams in 1..16");
-  ACINO_REQUIRE(prm->n_points >= 1 && prm->n_obs >= 1, "sizes");
+  ACINO_REQUIRE(prm->n_points >= 1 && prm->n_obs >= 1, "sizes (a rank without points cannot take part)");
   ACINO_REQUIRE(prm->f_scale > 0 && prm->lam0 > 0 && prm->max_iter >= 0, "f_scale, lam0, max_iter");
   ACINO_REQUIRE(prm->camera_model == 0 || prm->camera_model == 1, "camera_model: 0 fisheye, 1 pinhole");
   ACINO_REQUIRE(d_intr && d_Rt && d_pts && d_uv && d_cam_idx && d_pt_start && d_pt_obs && d_ws, "null buffer");
@@ -450,13 +459,24 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
   B.dp = (double*)take(P * 3 * 8);
   double* pts_t = (double*)take(P * 3 * 8);
   B.Wpc = (double*)take(M * 18 * 8);
-  B.U = (double*)take(C * 21 * 8);
-  B.gc = (double*)take(n * 8);
-  B.rhs = (double*)take(n * 8);
+  B.U = (double*)take((C * 21 + n) * 8);      // [U | gc] contiguous: one reduction
+  B.gc = B.U + C * 21;
   B.dc = (double*)take(n * 8);
-  B.S = (double*)take(n * n * 8);
+  B.S = (double*)take((n * n + n) * 8);        // [S | rhs] contiguous: one reduction
+  B.rhs = B.S + n * n;
   double* Rt_t = (double*)take(C * 12 * 8);
-  B.scal = (double*)take(64);
+  B.scal = (double*)take(64);                  // 0 cost, 1 predicted reduction (points), 2 max |g_point|, 3 not-PD flag,
+                                               // 4 predicted reduction (cameras; identical on every rank)
+  // global sums / maxima over the ranks that share the cameras (no-op for a single process)
+  auto greduce = [&](double* d_buf, size_t cnt, int op) -> int {
+    if (!reduce) return ACINO_OK;
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    if (reduce(reduce_user, d_buf, (int64_t)cnt, op, stream) != 0) {
+      set_error("SBA: the reduction callback failed");
+      return ACINO_ERR_CALLBACK;
+    }
+    return ACINO_OK;
+  };
   const int nblk = (int)((P + 255) / 256);
   const size_t lds_s = (n * n + n) * 8, lds_c = (n * (n + 1) + n) * 8;
 
@@ -470,6 +490,12 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
       hipLaunchKernelGGL(k_sba_point<false>, dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
     }
     ACINO_LAUNCH_CHECK();
+    if (int e = greduce(B.scal, 1, 0)) return e;
+    if (jac) {
+      if (int e = greduce(B.scal + 2, 1, 1)) return e;
+      if (B.opt_cams)
+        if (int e = greduce(B.U, C * 21 + n, 0)) return e;
+    }
     ACINO_HIP_CHECK(hipMemcpyAsync(h, B.scal, 32, hipMemcpyDeviceToHost, s));
     ACINO_HIP_CHECK(hipStreamSynchronize(s));
     return ACINO_OK;
@@ -497,13 +523,11 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
     }
     info->iterations = it + 1;
     ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
-    if (B.opt_cams) {
-      ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, n * n * 8, s));
-      ACINO_HIP_CHECK(hipMemsetAsync(B.rhs, 0, n * 8, s));
-    }
+    if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
     hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
     ACINO_LAUNCH_CHECK();
     if (B.opt_cams) {
+      if (int e = greduce(B.S, n * n + n, 0)) return e;
       hipLaunchKernelGGL(k_sba_cam_solve, dim3(1), dim3(256), lds_c, s, B, lam);
       ACINO_LAUNCH_CHECK();
     }
@@ -511,10 +535,11 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
     ACINO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sba_apply_cams, dim3(1), dim3(64), 0, s, B, d_Rt, Rt_t);
     ACINO_LAUNCH_CHECK();
-    double hp[4];
-    ACINO_HIP_CHECK(hipMemcpyAsync(hp, B.scal, 32, hipMemcpyDeviceToHost, s));
+    if (int e = greduce(B.scal + 1, 1, 0)) return e;
+    double hp[5];
+    ACINO_HIP_CHECK(hipMemcpyAsync(hp, B.scal, 40, hipMemcpyDeviceToHost, s));
     ACINO_HIP_CHECK(hipStreamSynchronize(s));
-    const double pred = hp[1];
+    const double pred = hp[1] + hp[4];
     double ht[4] = {INFINITY, 0, 0, 0};
     if (hp[3] == 0.0) {   // else: the damped reduced camera system lost definiteness to round-off along the free
       rc = eval(Rt_t, pts_t, false, nullptr, ht);   // gauge (7 DoF when every camera moves) - a rejected step

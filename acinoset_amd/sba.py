@@ -46,8 +46,43 @@ def _csr_by_point(point_3d_indices, n_points):
     return start, order
 
 
+class ReduceHook:
+    """The callback of ``acino_sba_solve_sharded``: combines ``n`` doubles at an address inside the workspace tensor
+    ``ws`` over all ranks, in place (op 0 sum, 1 max).  ``comm`` offers ``all_reduce(tensor, op)`` - by default
+    torch.distributed (backend "nccl" = RCCL on the GPU node; with "gloo" device memory is staged through the host,
+    which is how several ranks can share one GPU in the tests)."""
+
+    def __init__(self, ws, group=None):
+        self.ws, self.group, self.calls, self.error = ws, group, 0, None
+        self.fn = _lib.REDUCE_FN(self._call)
+
+    def all_reduce(self, t, op):
+        import torch.distributed as dist
+        rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=rop, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=rop, group=self.group)
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+
+    def _call(self, _user, buf, n, op, _stream):
+        try:
+            off = int(buf) - self.ws.data_ptr()
+            if off < 0 or off % 8 or off + 8 * n > self.ws.numel():
+                raise ValueError("reduction buffer outside the workspace")
+            self.all_reduce(self.ws[off:off + 8 * n].view(torch.float64), op)
+            self.calls += 1
+            return 0
+        except Exception as e:      # an exception must not unwind through the C frames
+            self.error = e
+            return 1
+
+
 def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, optimize_cameras,
-           f_scale, max_iter, ftol, gtol, lam0=1e-3, model=0):
+           f_scale, max_iter, ftol, gtol, lam0=1e-3, model=0, group=None, sharded=False):
     global last_info
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -96,9 +131,18 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
     res_b = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
     res_a = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
     info = SbaInfo()
-    check(lib().acino_sba_solve(C.byref(prm), ptr(d_intr), ptr(d_Rt), ptr(d_pts), ptr(d_uv), ptr(d_cam), ptr(d_start),
-                                ptr(d_order), C.c_void_p(ws_ptr), nbytes, ptr(res_b), ptr(res_a), C.byref(info),
-                                stream_ptr()))
+    if sharded:
+        hook = ReduceHook(ws, group)
+        status = lib().acino_sba_solve_sharded(C.byref(prm), ptr(d_intr), ptr(d_Rt), ptr(d_pts), ptr(d_uv), ptr(d_cam),
+                                               ptr(d_start), ptr(d_order), C.c_void_p(ws_ptr), nbytes, ptr(res_b),
+                                               ptr(res_a), C.byref(info), hook.fn, None, stream_ptr())
+        if hook.error is not None:
+            raise hook.error
+        check(status)
+    else:
+        check(lib().acino_sba_solve(C.byref(prm), ptr(d_intr), ptr(d_Rt), ptr(d_pts), ptr(d_uv), ptr(d_cam),
+                                    ptr(d_start), ptr(d_order), C.c_void_p(ws_ptr), nbytes, ptr(res_b), ptr(res_a),
+                                    C.byref(info), stream_ptr()))
     torch.cuda.current_stream().synchronize()
     last_info = info.as_dict()
     Rt_o = d_Rt.cpu().numpy()
@@ -119,6 +163,18 @@ def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, 
     """calib.py:369-390: refine the 3-D points and every camera's rotation + translation (Cauchy loss, scale 1)."""
     return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
                   max_iter, ftol, gtol, model=_camera_model(project_func))
+
+
+def bundle_adjust_points_and_extrinsics_sharded(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
+                                                r_arr, t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10,
+                                                group=None):
+    """The same refinement with the POINTS spread over the ranks of a torch.distributed group (one process per GPU)
+    and the cameras shared: every rank passes its own points / observations (``point_3d_indices`` local, 0-based) and
+    the same initial poses; the reduced camera system is summed over the ranks each iteration (a 6C x 6C block + 6C
+    vector - BASELINE config 5's extrinsic refinement over all sequences).  Returns this rank's refined points, the
+    common poses and this rank's residuals; ``last_info`` carries the GLOBAL costs."""
+    return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
+                  max_iter, ftol, gtol, model=_camera_model(project_func), group=group, sharded=True)
 
 
 def prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,

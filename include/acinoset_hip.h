@@ -44,7 +44,8 @@ typedef enum acino_status {
   ACINO_ERR_WORKSPACE = -3,      /* workspace too small / misaligned                 */
   ACINO_ERR_NO_DEVICE = -4,
   ACINO_ERR_UNSUPPORTED = -5,
-  ACINO_ERR_NUMERIC = -6         /* non-positive pivot in the block factorisation    */
+  ACINO_ERR_NUMERIC = -6,        /* non-positive pivot in the block factorisation    */
+  ACINO_ERR_CALLBACK = -7        /* a caller-supplied reduction callback failed      */
 } acino_status;
 
 /* ---- camera records -------------------------------------------------------------------------
@@ -259,6 +260,19 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
                     const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start, const int32_t* d_pt_obs,
                     void* d_ws, size_t ws_bytes, double* d_res_before, double* d_res_after, acino_sba_info* info,
                     void* stream);
+/* The same solve with the POINTS sharded over several processes / GPUs and the cameras replicated (BASELINE config 5,
+ * "the SBA extrinsic refinement adds a 36x36 camera-block + 36-vector all-reduce per
+ * iteration").  Every rank passes its own points and observations and identical camera poses; `reduce` must combine
+ * n doubles at d_buf (device memory inside d_ws) over all ranks in place - op 0: sum, op 1: max - and return 0; it is
+ * called after the stream has been synchronised, four times per LM iteration (cost + camera blocks + camera gradient;
+ * the Schur complement and its right-hand side; the predicted reduction; the trial cost).  All ranks take identical
+ * decisions and leave with identical poses.  reduce == NULL is acino_sba_solve. */
+typedef int (*acino_reduce_fn)(void* user, double* d_buf, int64_t n, int op, void* stream);
+int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,
+                            const double* d_uv, const int32_t* d_cam_idx, const int32_t* d_pt_start,
+                            const int32_t* d_pt_obs, void* d_ws, size_t ws_bytes, double* d_res_before,
+                            double* d_res_after, acino_sba_info* info, acino_reduce_fn reduce, void* reduce_user,
+                            void* stream);
 
 /* ---- generic-skeleton forward kinematics (src/build.py:28-86) ---------------------------
  * The host compiles a skeleton dictionary into <= ACINO_SKEL_MAX_OPS link operations, evaluated in order for every

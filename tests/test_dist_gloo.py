@@ -77,3 +77,39 @@ def test_shard_plan():
         assert all(b - a >= 6 for a, b in plan) or w == 1
     with pytest.raises(ValueError):
         shard_plan(9, 2)
+
+
+def _hook_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from acinoset_amd import sba
+    ws = torch.zeros(4096, dtype=torch.uint8)
+    hook = sba.ReduceHook(ws)
+    vals = ws[256:256 + 8 * 5].view(torch.float64)
+    vals.copy_(torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], dtype=torch.float64) * (rank + 1))
+    base = ws.data_ptr()
+    rc_sum = hook._call(None, base + 256, 3, 0, None)          # sum over ranks of the first three
+    rc_max = hook._call(None, base + 256 + 32, 1, 1, None)     # max over ranks of the last one
+    rc_bad = hook._call(None, base + 4090, 4, 0, None)         # beyond the workspace: refused, no collective issued
+    # through the C function pointer the library would call
+    cfn_rc = hook.fn(None, base + 256 + 24, 1, 0, None)
+    np.save(out_path + f".{rank}.npy", np.array(list(vals.numpy()) + [rc_sum, rc_max, rc_bad, cfn_rc, hook.calls]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sba_reduce_hook_sums_workspace_slices_over_ranks(tmp_path, world):
+    """The callback acino_sba_solve_sharded calls (acinoset_amd.sba.ReduceHook): in-place sum / max of a slice of
+    the workspace tensor over the ranks, addressed by raw pointer."""
+    out = str(tmp_path / "hook")
+    mp.spawn(_hook_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    tri = world * (world + 1) / 2
+    for r in range(world):
+        got = np.load(out + f".{r}.npy")
+        assert list(got[:3]) == [tri, 2 * tri, 3 * tri]          # summed
+        assert got[3] == 4.0 * tri                                 # summed through the C function pointer
+        assert got[4] == 5.0 * world                               # max
+        assert list(got[5:]) == [0, 0, 1, 0, 3]                    # return codes; three collectives completed

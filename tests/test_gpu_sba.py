@@ -184,3 +184,58 @@ def test_trajectory_pipelines_tri_and_sba_points(gsba):
     e_sba = np.linalg.norm(p_sba - seq["pos_true"], axis=-1)[ok]
     assert np.median(e_sba) <= np.median(e_tri) * 1.02 and np.median(e_sba) < 0.03
     assert osba.cauchy_cost(res["after"], 50) <= osba.cauchy_cost(res["before"], 50)
+
+
+def _rig_problem(seed=5, n_pts=400):
+    from acinoset_amd import synth
+    rng = np.random.default_rng(seed)
+    K, D, R, t = synth.make_rig()
+    X = np.array([2.0, 6.5, 0.7]) + rng.normal(0, 1.0, (n_pts, 3))
+    p2, pi, ci = [], [], []
+    for p in range(n_pts):
+        for c in np.sort(rng.choice(6, size=rng.integers(2, 7), replace=False)):
+            p2.append(ocam.project_points_fisheye(X[p:p + 1], K[c], D[c], R[c], t[c])[0] + rng.normal(0, 0.3, 2))
+            pi.append(p)
+            ci.append(c)
+    Rp = np.array([ocam.rodrigues(rng.normal(0, 0.015, 3)) @ R[c] for c in range(6)])
+    tp = t.reshape(6, 3, 1) + rng.normal(0, 0.02, (6, 3, 1))
+    return np.array(p2), X + rng.normal(0, 0.05, X.shape), np.array(pi), np.array(ci), K, D, Rp, tp
+
+
+def _mp_sba_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acinoset_amd import sba
+        torch.cuda.set_device(0)
+        p2, X0, pi, ci, K, D, Rp, tp = _rig_problem()
+        lo, hi = rank * len(X0) // world, (rank + 1) * len(X0) // world        # this rank's points
+        m = (pi >= lo) & (pi < hi)
+        pts, rm, tt, res = sba.bundle_adjust_points_and_extrinsics_sharded(p2[m], X0[lo:hi], pi[m] - lo, ci[m], K, D, Rp, tp)
+        np.savez(out_path + f".{rank}.npz", pts=pts, r=rm, t=tt, after=res["after"], cost=sba.last_info["cost_final"],
+                 cost0=sba.last_info["cost_initial"], it=sba.last_info["iterations"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_points_sharded_over_processes_equal_single_solve(gsba, world, tmp_path):
+    """BASELINE config 5's extrinsic refinement: points sharded over processes (gloo here, every rank on this GPU; RCCL
+    on a node), cameras shared through the all-reduced camera system.  Must reproduce the single-process solve."""
+    import torch.multiprocessing as mp
+    sba, _ = gsba
+    p2, X0, pi, ci, K, D, Rp, tp = _rig_problem()
+    pts1, r1, t1, res1 = sba.bundle_adjust_points_and_extrinsics(p2, X0, pi, ci, K, D, Rp, tp)
+    one = dict(sba.last_info)
+    out = str(tmp_path / "sba")
+    mp.spawn(_mp_sba_worker, args=(world, 29760 + world, out), nprocs=world, join=True)
+    parts = [np.load(out + f".{r}.npz") for r in range(world)]
+    for p in parts:                                   # every rank: the same global cost, iteration count and poses
+        assert abs(float(p["cost0"]) - one["cost_initial"]) < 1e-9 * one["cost_initial"]
+        assert abs(float(p["cost"]) - one["cost_final"]) < 1e-6 * one["cost_final"], (float(p["cost"]), one)
+        assert np.array_equal(p["r"], parts[0]["r"]) and np.array_equal(p["t"], parts[0]["t"])
+        assert np.abs(p["r"] - r1).max() < 1e-6 and np.abs(p["t"] - t1).max() < 1e-6
+    assert np.abs(np.concatenate([p["pts"] for p in parts]) - pts1).max() < 1e-5
