@@ -339,7 +339,7 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
     __syncthreads();
     // diag S = Hq Pq Hq^T + R = row norms of Hq Lc, + R: G^T = Lc^T Hq^T on the matrix cores, 16 measurement rows per
     // tile column (lane li = row, the 25 entries of a row spread over 2 tiles x 4 registers x 4 lane groups)
-    for (int tr = wave; tr < rows / 16; tr += 4) {
+    for (int tr = wave; tr < (rows + 15) / 16; tr += 4) {     // (rows = 40 C: the last tile is half empty for odd C)
       const int row = 16 * tr + li;
       double hq[7], lc0[7], lc1[7];
 #pragma unroll
@@ -360,7 +360,7 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       for (int r = 0; r < 4; ++r) ss += g0[r] * g0[r] + g1[r] * g1[r];
       ss += __shfl_xor(ss, 16, 64);
       ss += __shfl_xor(ss, 32, 64);
-      if (lk == 0) sd[row] = ss + 1.0 / ri[row];
+      if (lk == 0 && row < rows) sd[row] = ss + 1.0 / ri[row];
     }
     __syncthreads();
     if (tid < rows / 2) {   // 3-sigma gate per pixel pair (:813-819)

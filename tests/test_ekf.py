@@ -41,10 +41,13 @@ def test_oracle_tracks_a_synthetic_sprint():
 @pytest.mark.gpu
 def test_hip_ekf_matches_oracle(gpu_lib):
     from acinoset_amd import ekf, synth
-    for n, kind, seed in ((30, "sprint", 1), (20, "loop", 2)):
+    for n, kind, seed, cams in ((30, "sprint", 1, slice(None)), (20, "loop", 2, slice(None)), (16, "sprint", 3, [0, 2, 5]),
+                                (12, "sprint", 4, [1])):
         seq = synth.make_sequence(n, kind, seed=20210313 + seed)
-        rig = (seq["K"], seq["D"], seq["R"], seq["t"])
-        s0 = ekf.initial_state(seq["det"], *rig, 120.0, 0.5)
+        seq["det"] = seq["det"][:, cams]
+        rig = (seq["K"][cams], seq["D"][cams], seq["R"][cams], seq["t"][cams])       # 6, 3 and 1 cameras
+        s0 = ekf.initial_state(synth.make_sequence(n, kind, seed=20210313 + seed)["det"], seq["K"], seq["D"], seq["R"],
+                               seq["t"], 120.0, 0.5)
         want = oekf.ekf(seq["det"], *rig, 120.0, 0.5, 2704, s0)
         got = ekf.ekf(seq["det"], *rig, 120.0, 0.5, (2704, 1520), states0=s0)
         assert got["outliers_ignored"] == want["outliers_ignored"]
