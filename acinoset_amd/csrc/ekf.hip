@@ -526,7 +526,7 @@ k_rts_gain(EkfK K, const double* __restrict__ P_est_all, double* __restrict__ A_
   const int N = K.n_frames, per = N - 2;
   const int seq = blockIdx.x / per, i = 1 + blockIdx.x % per;
   const double* Pe = P_est_all + ((size_t)seq * N + i) * ES * ES;
-  double* A = A_all + ((size_t)seq * N + i) * ES * ES;
+  double* At = A_all + ((size_t)seq * N + i) * ES * ES;     // stored TRANSPOSED: the recursion reads columns
   for (int e = tid; e < ES * ES; e += 256) E[(e / ES) * LD + e % ES] = Pe[e];
   if (tid == 0) s_err = 0;
   __syncthreads();
@@ -557,15 +557,15 @@ k_rts_gain(EkfK K, const double* __restrict__ P_est_all, double* __restrict__ A_
       }
     }
     __syncthreads();
-    for (int t = wave; t < 25; t += 4) {   // A = T^T U^T : tile (tj, ti) = sum_{k >= ti} T(k, tj)^T U(ti, k)^T
-      const int tj = t / 5, ti = t % 5;
+    for (int t = wave; t < 25; t += 4) {   // A^T = U T : tile (ti, tj) = sum_{k >= ti} U(ti, k) T(k, tj)
+      const int ti = t / 5, tj = t % 5;
       d4 a = {0, 0, 0, 0};
       for (int k = ti; k < 5; ++k)
-        a = mma_seq<4, false>(a, G + (16 * k + lk) * LD + 16 * tj + li, 4 * LD, Lp + (16 * ti + li) * LD + 16 * k + lk, 4);
+        a = mma_seq<4, false>(a, Lp + (16 * ti + li) * LD + 16 * k + lk, 4, G + (16 * k + lk) * LD + 16 * tj + li, 4 * LD);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * tj + lk + 4 * r, col = 16 * ti + li;
-        if (row < ES && col < ES) A[row * ES + col] = a[r];
+        const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+        if (row < ES && col < ES) At[row * ES + col] = a[r];
       }
     }
     return;
@@ -625,54 +625,69 @@ k_rts_gain(EkfK K, const double* __restrict__ P_est_all, double* __restrict__ A_
     }
     __syncthreads();
   }
-  for (int e = tid; e < ES * ES; e += 256) A[e] = G[(e % ES) * LD + e / ES];     // A = X^T
+  for (int e = tid; e < ES * ES; e += 256) At[e] = G[(e / ES) * LD + e % ES];     // A^T = X
 }
 
 // smooth[i] = x_est[i] + A_i (smooth[i+1] - x_pred[i+1]), i = N-2 .. 1; frames 0 and N-1 keep the filtered state (:836-839).
-__global__ void __launch_bounds__(256)
+// The recursion is a chain of 75 x 75 mat-vecs: one thread per row keeps its row of A_i in registers (the next
+// frame's row is already in flight), the difference vector is double-buffered in LDS - ONE barrier per frame.
+__global__ void __launch_bounds__(128)
 k_rts_recurse(EkfK K, const double* __restrict__ x_pred_all, const double* __restrict__ x_est_all,
               const double* __restrict__ A_all, double* __restrict__ smooth_all) {
-  __shared__ double v[ES], part[3][ES];
+  __shared__ __attribute__((aligned(16))) double v[2][ES + 1];
   const int tid = threadIdx.x, N = K.n_frames, seq = blockIdx.x;
   const double* x_pred = x_pred_all + (size_t)seq * N * ES;
   const double* x_est = x_est_all + (size_t)seq * N * ES;
   const double* A = A_all + (size_t)seq * N * ES * ES;
   double* smooth = smooth_all + (size_t)seq * N * ES;
-  const int r = tid % ES, p = tid / ES;      // 3 threads per row, 25 columns each
-  if (tid < ES) {
+  const bool on = tid < ES;
+  if (on) {
     smooth[tid] = x_est[tid];
     if (N > 1) smooth[(size_t)(N - 1) * ES + tid] = x_est[(size_t)(N - 1) * ES + tid];
   }
   if (N < 3) return;
-  double cur = (tid < ES) ? x_est[(size_t)(N - 1) * ES + tid] : 0.0;       // smooth[i+1][tid]
-  double a[EP];
-  if (tid < 3 * ES) {
+  double a[ES], an[ES];
+  double xe = 0.0, xp_next = 0.0;
+  if (on) {
+    v[0][tid] = x_est[(size_t)(N - 1) * ES + tid] - x_pred[(size_t)(N - 1) * ES + tid];
+    xe = x_est[(size_t)(N - 2) * ES + tid];
+    xp_next = x_pred[(size_t)(N - 2) * ES + tid];
 #pragma unroll
-    for (int c = 0; c < EP; ++c) a[c] = A[(size_t)(N - 2) * ES * ES + r * ES + p * EP + c];
+    for (int c = 0; c < ES; ++c) a[c] = A[(size_t)(N - 2) * ES * ES + c * ES + tid];     // A is stored transposed
   }
+  __syncthreads();
+  int buf = 0;
   for (int i = N - 2; i >= 1; --i) {
-    if (tid < ES) v[tid] = cur - x_pred[(size_t)(i + 1) * ES + tid];
-    __syncthreads();
-    double s = 0.0;
-    if (tid < 3 * ES) {
+    double xe_n = 0.0, xp_n = 0.0;
+    if (on && i > 1) {                 // the next frame's operands: in flight during this frame's dot product
+      xe_n = x_est[(size_t)(i - 1) * ES + tid];
+      xp_n = x_pred[(size_t)(i - 1) * ES + tid];
 #pragma unroll
-      for (int c = 0; c < EP; ++c) s += a[c] * v[p * EP + c];
-      part[p][r] = s;
-      if (i > 1) {   // prefetch the next gain rows while the partial sums are combined
+      for (int c = 0; c < ES; ++c) an[c] = A[(size_t)(i - 1) * ES * ES + c * ES + tid];
+    }
+    if (on) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int c = 0; c < EP; ++c) a[c] = A[(size_t)(i - 1) * ES * ES + r * ES + p * EP + c];
+      for (int c = 0; c < ES; c += 3) {
+        s0 += a[c] * v[buf][c];
+        s1 += a[c + 1] * v[buf][c + 1];
+        s2 += a[c + 2] * v[buf][c + 2];
       }
-    }
-    __syncthreads();
-    if (tid < ES) {
-      cur = x_est[(size_t)i * ES + tid] + ((part[0][tid] + part[1][tid]) + part[2][tid]);
+      const double cur = xe + ((s0 + s1) + s2);
       smooth[(size_t)i * ES + tid] = cur;
+      v[buf ^ 1][tid] = cur - xp_next;       // smooth[i] - x_pred[i]: the next frame's right-hand side
+#pragma unroll
+      for (int c = 0; c < ES; ++c) a[c] = an[c];
+      xe = xe_n;
+      xp_next = xp_n;
     }
+    buf ^= 1;
+    __syncthreads();
   }
 }
 
-constexpr size_t kRtsLds = 3 * MAT * sizeof(double);
 static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
+constexpr size_t kRtsLds = 3 * MAT * sizeof(double);
 constexpr size_t kEkfLds = (size_t)(PR * PLD + EROWS * HLD + 4 * EROWS + 80 + 32 + 32 + 2800 + 2 * 32 * 33) * sizeof(double) +
                            EKF_MAXC * sizeof(Cam) + (NL + 4) * 4 + (NL + EP * NL) * 2 + 8;
 static_assert(sizeof(FkLite) * NVAR <= 6 * EP * SLD * sizeof(double), "FK frames must fit the scratch region");
@@ -734,7 +749,7 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
     hipLaunchKernelGGL(k_rts_gain, dim3((unsigned)(prm->n_seq * (prm->n_frames - 2))), dim3(256), kRtsLds, s, K, P_est, A, nerr);
     ACINO_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_rts_recurse, dim3(prm->n_seq), dim3(256), 0, s, K, x_pred, d_est, A, d_smooth);
+  hipLaunchKernelGGL(k_rts_recurse, dim3(prm->n_seq), dim3(128), 0, s, K, x_pred, d_est, A, d_smooth);
   ACINO_LAUNCH_CHECK();
   int h_err = 0;
   ACINO_HIP_CHECK(hipMemcpyAsync(&h_err, nerr, sizeof(int), hipMemcpyDeviceToHost, s));
