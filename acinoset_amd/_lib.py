@@ -95,6 +95,7 @@ SIGNATURES = {
     "acino_project_pinhole": (_I, [_P, _L, _P, _P, _P]),
     "acino_triangulate_pairs": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P]),
     "acino_reproject_residuals": (_I, [_P, _P, _L, _I, _I, _D, _P, _P, _P, _P]),
+    "acino_triangulate_reproject": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
     "acino_cheetah_fk": (_I, [_P, _L, _P, _P]),
     "acino_fk_active": (_I, [_P, _L, _P, _P]),
     "acino_sizeof_fte_params": (_Z, []),

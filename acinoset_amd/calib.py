@@ -184,6 +184,27 @@ def reproject_residuals(pts3, det, thresh, k_arr, d_arr, r_arr, t_arr):
     return _ret(res, det), _ret(sums, det)
 
 
+def triangulate_reproject_dense(det, thresh, k_arr, d_arr, r_arr, t_arr):
+    """``triangulate_pairs_dense`` followed by ``reproject_residuals`` of the triangulated points, in ONE pass over
+    the detections (BASELINE config 2): returns tri[N,L,3], npairs, pairmask, residuals[N,C,L,2], sums[4]."""
+    dev = _dev()
+    d = _to_dev(det, dev)
+    if d.dim() != 4 or d.shape[-1] != 3:
+        raise ValueError("det must be [N, C, L, 3]")
+    N, Cn, L, _ = d.shape
+    cams = torch.as_tensor(fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
+    if cams.shape[0] != Cn:
+        raise ValueError("camera count mismatch")
+    tri = torch.empty((N, L, 3), dtype=torch.float64, device=dev)
+    npairs = torch.empty((N, L), dtype=torch.uint8, device=dev)
+    mask = torch.empty((N, L), dtype=torch.uint8, device=dev)
+    res = torch.empty((N, Cn, L, 2), dtype=torch.float64, device=dev)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+    check(lib().acino_triangulate_reproject(ptr(d), N, Cn, L, float(thresh), ptr(cams), ptr(tri), ptr(npairs), ptr(mask),
+                                            ptr(res), ptr(sums), stream_ptr()))
+    return _ret(tri, det), _ret(npairs, det), _ret(mask, det), _ret(res, det), _ret(sums, det)
+
+
 def dataframe_to_dense(points_2d_df, n_cameras):
     """Long DataFrame [frame, camera, marker, x, y, (likelihood)] -> dense det[N,C,L,3] plus the sorted
     frame and marker keys.  Rows absent from the frame get likelihood -inf (never valid)."""

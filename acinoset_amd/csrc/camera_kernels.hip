@@ -149,64 +149,121 @@ __global__ void __launch_bounds__(256) k_project_pinhole(const double* __restric
 }
 
 // ---- dense adjacent-pair triangulation ------------------------------------------------------
-// One thread per (frame, marker).  Camera records are staged in LDS once per workgroup; detections
-// are read as 24-byte (x, y, likelihood) records, consecutive lanes = consecutive markers, so a wave
-// reads one contiguous 1.5 KB span per camera.  Undistortion of camera c is reused for pairs (c-1,c)
-// and (c,c+1).  Mean = Kahan sum in pair order / count (pandas group_mean), NaN when no pair.
+// One thread per (frame, marker), 256 consecutive (frame, marker) items per workgroup pass.  The detections those
+// items need are ONE contiguous span of d_det (whole frames: C x L records of 24 bytes each), so the workgroup copies
+// the span into LDS with fully coalesced 8-byte loads and the per-thread 24-byte record reads (x, y, likelihood of
+// camera c) come from LDS - HBM sees each byte once, in order.  Camera records are staged once per workgroup.
+// Undistortion of camera c is reused for pairs (c-1,c) and (c,c+1).  Mean = Kahan sum in pair order / count (pandas
+// group_mean), NaN when no pair.  REPROJECT fuses k_reproject_residuals: the mean point is projected into every
+// camera with a valid detection while the detections are still in LDS (BASELINE config 2 in one pass).
+template <bool REPROJECT>
 __global__ void __launch_bounds__(256)
 k_triangulate_pairs(const double* __restrict__ det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                     const double* __restrict__ cams, double* __restrict__ tri, uint8_t* __restrict__ npairs,
-                    uint8_t* __restrict__ pairmask) {
+                    uint8_t* __restrict__ pairmask, double* __restrict__ res, double* __restrict__ sums,
+                    int stage_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double stage[];
   __shared__ Cam c[ACINO_MAX_CAMS];
+  __shared__ double red[4][4];
   for (int i = threadIdx.x; i < n_cams * ACINO_CAM_STRIDE; i += blockDim.x)
     reinterpret_cast<double*>(c)[i] = cams[i];
-  __syncthreads();
   const int64_t total = n_frames * n_markers;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = idx / n_markers;
-    const int l = (int)(idx - n * n_markers);
-    const double* base = det + ((n * n_cams) * n_markers + l) * 3;
-    double sum[3] = {0, 0, 0}, comp[3] = {0, 0, 0};
-    int cnt = 0;
-    unsigned mask = 0;
-    bool pv = false;
-    double px = 0, py = 0;
-    for (int ci = 0; ci < n_cams; ++ci) {
-      const double* d = base + (int64_t)ci * n_markers * 3;
-      double u = d[0], v = d[1], lik = d[2];
-      bool valid = lik > thresh;
-      double x = 0, y = 0;
-      if (valid) {
-        if (!undistort_fisheye_pt(c[ci], u, v, 10, 1e-8, x, y)) x = y = -1000000.0;
-      }
-      if (valid && pv) {
-        double X[3];
-        triangulate_two_view(c[ci - 1], c[ci], px, py, x, y, X);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {  // Kahan step
-          double yk = X[k] - comp[k];
-          double t = sum[k] + yk;
-          comp[k] = (t - sum[k]) - yk;
-          sum[k] = t;
+  const int64_t frame_doubles = (int64_t)n_cams * n_markers * 3;
+  double s_cnt = 0, s_r = 0, s_r2 = 0, s_c = 0;
+  for (int64_t idx0 = blockIdx.x * (int64_t)256; idx0 < total; idx0 += (int64_t)gridDim.x * 256) {
+    const int64_t nf0 = idx0 / n_markers;
+    int64_t nf1 = (idx0 + 255) / n_markers;
+    if (nf1 > n_frames - 1) nf1 = n_frames - 1;
+    const int64_t span = (nf1 - nf0 + 1) * frame_doubles;
+    const bool staged = span <= stage_doubles;
+    __syncthreads();                              // the previous pass is done with the stage (and c[] is complete)
+    if (staged) {
+      const double* src = det + nf0 * frame_doubles;
+      for (int64_t e = threadIdx.x; e < span; e += 256) stage[e] = src[e];
+    }
+    __syncthreads();
+    const int64_t idx = idx0 + threadIdx.x;
+    if (idx < total) {
+      const int64_t n = idx / n_markers;
+      const int l = (int)(idx - n * n_markers);
+      const double* base = staged ? stage + (n - nf0) * frame_doubles + (int64_t)l * 3
+                                  : det + n * frame_doubles + (int64_t)l * 3;
+      double sum[3] = {0, 0, 0}, comp[3] = {0, 0, 0};
+      int cnt = 0;
+      unsigned mask = 0;
+      bool pv = false;
+      double px = 0, py = 0;
+      for (int ci = 0; ci < n_cams; ++ci) {
+        const double* d = base + (int64_t)ci * n_markers * 3;
+        double u = d[0], v = d[1], lik = d[2];
+        bool valid = lik > thresh;
+        double x = 0, y = 0;
+        if (valid) {
+          if (!undistort_fisheye_pt(c[ci], u, v, 10, 1e-8, x, y)) x = y = -1000000.0;
         }
-        ++cnt;
-        mask |= 1u << (ci - 1);
+        if (valid && pv) {
+          double X[3];
+          triangulate_two_view(c[ci - 1], c[ci], px, py, x, y, X);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {  // Kahan step
+            double yk = X[k] - comp[k];
+            double t = sum[k] + yk;
+            comp[k] = (t - sum[k]) - yk;
+            sum[k] = t;
+          }
+          ++cnt;
+          mask |= 1u << (ci - 1);
+        }
+        pv = valid;
+        px = x;
+        py = y;
       }
-      pv = valid;
-      px = x;
-      py = y;
+      double X = __builtin_nan(""), Y = X, Z = X;
+      if (cnt > 0) {
+        X = sum[0] / cnt;
+        Y = sum[1] / cnt;
+        Z = sum[2] / cnt;
+      }
+      double* o = tri + idx * 3;
+      o[0] = X;
+      o[1] = Y;
+      o[2] = Z;
+      if (npairs) npairs[idx] = (uint8_t)cnt;
+      if (pairmask) pairmask[idx] = (uint8_t)mask;
+      if (REPROJECT) {
+        const bool fin = isfinite(X) && isfinite(Y) && isfinite(Z);
+        for (int ci = 0; ci < n_cams; ++ci) {
+          const double* d = base + (int64_t)ci * n_markers * 3;
+          double ru = __builtin_nan(""), rv = __builtin_nan("");
+          if (fin && d[2] > thresh) {
+            double u, v;
+            project_fisheye_pt(c[ci], X, Y, Z, u, v);
+            ru = u - d[0];
+            rv = v - d[1];
+            s_cnt += 2;
+            s_r += ru + rv;
+            s_r2 += ru * ru + rv * rv;
+            s_c += 0.5 * (log1p(ru * ru) + log1p(rv * rv));
+          }
+          reinterpret_cast<double2*>(res)[(n * n_cams + ci) * n_markers + l] = make_double2(ru, rv);
+        }
+      }
     }
-    double* o = tri + idx * 3;
-    if (cnt > 0) {
-      o[0] = sum[0] / cnt;
-      o[1] = sum[1] / cnt;
-      o[2] = sum[2] / cnt;
-    } else {
-      o[0] = o[1] = o[2] = __builtin_nan("");
+  }
+  if (REPROJECT && sums) {
+    double v[4] = {s_cnt, s_r, s_r2, s_c};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+      for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0;
+      for (int w = 0; w < 4; ++w) t += red[w][threadIdx.x];
+      atomicAdd(&sums[threadIdx.x], t);
     }
-    if (npairs) npairs[idx] = (uint8_t)cnt;
-    if (pairmask) pairmask[idx] = (uint8_t)mask;
   }
 }
 
@@ -347,6 +404,24 @@ int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32,
   return ACINO_OK;
 }
 
+static int launch_pairs(bool reproject, const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                        const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask, double* d_res,
+                        double* d_sums, void* stream) {
+  // whole frames covering 256 consecutive (frame, marker) items; larger rigs than 64 KB read HBM directly
+  const int64_t frames = 256 / n_markers + 2;
+  int64_t stage = frames * n_cams * n_markers * 3;
+  if (stage * 8 > 64 * 1024) stage = 0;
+  const int grid = grid_for(n_frames * n_markers, 256);
+  if (reproject)
+    hipLaunchKernelGGL(k_triangulate_pairs<true>, dim3(grid), dim3(256), (size_t)stage * 8, (hipStream_t)stream, d_det,
+                       n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, d_res, d_sums, (int)stage);
+  else
+    hipLaunchKernelGGL(k_triangulate_pairs<false>, dim3(grid), dim3(256), (size_t)stage * 8, (hipStream_t)stream, d_det,
+                       n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, d_res, d_sums, (int)stage);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
 int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                             const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                             void* stream) {
@@ -354,11 +429,19 @@ int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, i
   ACINO_REQUIRE(n_cams >= 1 && n_cams <= 8, "n_cams must be 1..8 (pair mask is one byte)");
   if (n_frames == 0 || n_markers == 0) return ACINO_OK;
   ACINO_REQUIRE(d_det && d_cams24 && d_tri, "null buffer");
-  hipLaunchKernelGGL(k_triangulate_pairs, dim3(grid_for(n_frames * n_markers, 256)), dim3(256), 0,
-                     (hipStream_t)stream, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs,
-                     d_pairmask);
-  ACINO_LAUNCH_CHECK();
-  return ACINO_OK;
+  return launch_pairs(false, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, nullptr,
+                      nullptr, stream);
+}
+
+int acino_triangulate_reproject(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                                const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                                double* d_res, double* d_sums, void* stream) {
+  ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= 8, "n_cams must be 1..8 (pair mask is one byte)");
+  if (n_frames == 0 || n_markers == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_det && d_cams24 && d_tri && d_res, "null buffer");
+  return launch_pairs(true, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, d_res,
+                      d_sums, stream);
 }
 
 int acino_reproject_residuals(const double* d_pts3, const double* d_det, int64_t n_frames, int n_cams,

@@ -100,10 +100,75 @@ __device__ __forceinline__ void project_fisheye_pt(const Cam& c, double X, doubl
   v = yd * c.fy + c.cy;
 }
 
+__device__ __forceinline__ bool m_finite(double v) { return fabs(v) <= 1.79769313486231570e308; }   // false for NaN too
+
+// Right-singular vector of the smallest singular value of the 4x4 DLT matrix by INVERSE ITERATION on B = A^T A
+// (LDL^T of the 4x4, start e4 - the homogeneous solution (X, Y, Z, 1) / |.| always has a w component).  For a
+// triangulation the three large singular values are O(1) and the smallest is the noise (sigma4 / sigma3 ~ 1e-3), so
+// each step gains (sigma3 / sigma4)^2 ~ 1e5..1e6 and two or three steps reach 1e-16; squaring the matrix costs
+// eps * lambda1 / (lambda3 - lambda4) ~ 1e-13 of accuracy on the unit vector, far inside the parity tolerance, because
+// the wanted vector is separated from the rest by the GAP, not by the size of sigma4.  About 300 instructions
+// against ~4 000 for the Jacobi SVD.  Returns false when six steps have not converged (a pair of rays that do not
+// come close to meeting: the caller then falls back to the SVD, which is what the reference computes).
+__device__ __forceinline__ bool dlt_null_vector_invit(const double A[4][4], double out[3]) {
+  double B[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) B[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j] + A[3][i] * A[3][j];
+  const double floor_ = 1e-30 * (B[0][0] + B[1][1] + B[2][2] + B[3][3]) + 1e-300;
+  // B = L D L^T, unit lower L stored in l[][], reciprocal pivots in id[]
+  double l10, l20, l30, l21, l31, l32, id[4];
+  double d0 = fmax(B[0][0], floor_);
+  id[0] = 1.0 / d0;
+  l10 = B[0][1] * id[0];
+  l20 = B[0][2] * id[0];
+  l30 = B[0][3] * id[0];
+  double d1 = fmax(B[1][1] - l10 * B[0][1], floor_);
+  id[1] = 1.0 / d1;
+  const double b21 = B[1][2] - l20 * B[0][1], b31 = B[1][3] - l30 * B[0][1];
+  l21 = b21 * id[1];
+  l31 = b31 * id[1];
+  double d2 = fmax(B[2][2] - l20 * B[0][2] - l21 * b21, floor_);
+  id[2] = 1.0 / d2;
+  const double b32 = B[2][3] - l30 * B[0][2] - l31 * b21;
+  l32 = b32 * id[2];
+  double d3 = fmax(B[3][3] - l30 * B[0][3] - l31 * b31 - l32 * b32, floor_);
+  id[3] = 1.0 / d3;
+  double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
+  bool conv = false;
+#pragma unroll 1
+  for (int it = 0; it < 6 && !conv; ++it) {
+    // forward L z = x, scale by D^-1, backward L^T y = z
+    const double z0 = x0, z1 = x1 - l10 * z0, z2 = x2 - l20 * z0 - l21 * z1, z3 = x3 - l30 * z0 - l31 * z1 - l32 * z2;
+    const double y3 = z3 * id[3];
+    const double y2 = z2 * id[2] - l32 * y3;
+    const double y1 = z1 * id[1] - l21 * y2 - l31 * y3;
+    const double y0 = z0 * id[0] - l10 * y1 - l20 * y2 - l30 * y3;
+    // scale-safe normalisation (1 / d3 can be 1e30 for noise-free data)
+    const double m = fmax(fmax(fabs(y0), fabs(y1)), fmax(fabs(y2), fabs(y3)));
+    const double im = 1.0 / m;
+    const double s0 = y0 * im, s1 = y1 * im, s2 = y2 * im, s3 = y3 * im;
+    const double rn = rsqrt(s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3);
+    const double n0 = s0 * rn, n1 = s1 * rn, n2 = s2 * rn, n3 = s3 * rn;
+    const double diff = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
+    conv = diff < 1e-13;      // the step just taken shrank the error by another (sigma4 / sigma3)^2
+    x0 = n0;
+    x1 = n1;
+    x2 = n2;
+    x3 = n3;
+  }
+  out[0] = x0 / x3;
+  out[1] = x1 / x3;
+  out[2] = x2 / x3;
+  return conv && m_finite(out[0]) && m_finite(out[1]) && m_finite(out[2]);
+}
+
 // Null vector of the 4x4 DLT matrix by one-sided Jacobi (Hestenes) on its columns: on exit the
 // columns of A*V are orthogonal; the right-singular vector of the smallest singular value is the
 // column of V whose A*V column has the smallest norm.  Returns X/W (dehomogenised).
 __device__ __forceinline__ void dlt_null_vector(double A[4][4], double out[3]) {
+  if (dlt_null_vector_invit(A, out)) return;
   double V[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)

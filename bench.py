@@ -92,9 +92,9 @@ def secondary_metrics(det, rig, Ts):
     res = torch.empty((N, Cn, L, 2), dtype=torch.float64, device=dev)
     sums = torch.zeros(4, dtype=torch.float64, device=dev)
 
-    def once():
-        check(lib().acino_triangulate_pairs(ptr(d), N, Cn, L, 0.5, ptr(cams), ptr(tri), ptr(npairs), ptr(mask), stream_ptr()))
-        check(lib().acino_reproject_residuals(ptr(tri), ptr(d), N, Cn, L, 0.5, ptr(cams), ptr(res), ptr(sums), stream_ptr()))
+    def once():     # triangulation + reprojection residual of the triangulated points, one pass over the detections
+        check(lib().acino_triangulate_reproject(ptr(d), N, Cn, L, 0.5, ptr(cams), ptr(tri), ptr(npairs), ptr(mask), ptr(res),
+                                                ptr(sums), stream_ptr()))
     for _ in range(3):
         once()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -105,7 +105,7 @@ def secondary_metrics(det, rig, Ts):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    bytes_per_frame = Cn * L * 3 * 8 + L * 3 * 8 + 2 * L + (L * 3 * 8 + Cn * L * 3 * 8 + Cn * L * 2 * 8)   # both kernels, in + out
+    bytes_per_frame = Cn * L * 3 * 8 + L * 3 * 8 + 2 * L + Cn * L * 2 * 8      # detections in; points, pair counts/masks, residuals out
     out["config2_triangulate_reproject"] = dict(frames=N, ms=ms, frames_per_s=N / (ms * 1e-3),
                                                 hbm_gbs=N * bytes_per_frame / (ms * 1e-3) / 1e9,
                                                 frac_hbm=N * bytes_per_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

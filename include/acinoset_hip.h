@@ -12,6 +12,7 @@
  *   acino_project_pinhole            project_points                   src/calib/calib.py:64-66
  *   acino_triangulate_pairs          get_pairwise_3d_points_from_df   src/calib/calib.py:394-423
  *   acino_reproject_residuals        project(triangulate(.)) - pts    src/calib/calib.py:312-316 (cost_func_points_only)
+ *   acino_triangulate_reproject      the two above fused (one pass over the detections)
  *   acino_cheetah_fk                 pose_to_3d                       src/all_optimizations.py:66-190
  *   acino_fte_*                      the Pyomo model + opt.solve()    src/all_optimizations.py:283-556
  *
@@ -88,6 +89,12 @@ int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32,
 int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                             const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                             void* stream);
+/* The two calls below in one pass over d_det (BASELINE configs[1]: triangulation + reprojection residual of the
+ * triangulated points in every camera): d_tri / d_npairs / d_pairmask as acino_triangulate_pairs, d_res / d_sums as
+ * acino_reproject_residuals applied to d_tri. */
+int acino_triangulate_reproject(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                                const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                                double* d_res, double* d_sums, void* stream);
 /* Reprojection residual of d_pts3[N][L][3] in every camera against d_det:
  * d_res[N][C][L][2] = project(pts3) - det.xy where det valid and pts3 finite, else NaN.
  * d_sums[4] (may be NULL) += {count, sum r, sum r^2, 0.5*sum log1p(r^2)} over valid residual components. */

@@ -116,6 +116,18 @@ def test_pair_index_path_bit_exact(mods, seq60, golden_dir):
     assert np.array_equal(cnt, cno) and np.array_equal(mask, mko)                  # index path: bit-exact
     assert np.array_equal(np.isnan(tri), np.isnan(tro)) and np.isnan(tri[5]).all() and np.isnan(tri[7, 3]).all()
     assert np.nanmax(np.abs(tri - tro)) < 1e-10
+    for n_f, cams_, marks in ((60, slice(None), slice(None)), (37, [0, 1, 3], slice(0, 7)), (1, [2, 3], slice(0, 1)),
+                              (14, slice(None), np.r_[0:20, 0:20, 0:20, 0:20, 0:20, 0:20, 0:20])):    # 140 markers: 1.8 frames / pass
+        dd = np.ascontiguousarray(det[:n_f][:, cams_][:, :, marks])
+        rg = tuple(a[cams_] for a in rig)
+        t2, c2, m2, r2, s2 = calib.triangulate_reproject_dense(dd, 0.5, *rg)
+        t1, c1, m1 = calib.triangulate_pairs_dense(dd, 0.5, *rg)
+        r1, s1 = calib.reproject_residuals(t1, dd, 0.5, *rg)
+        to_, co_, mo_ = oidx.pairwise_dense(dd, 0.5, *rg, ocam.triangulate_points_fisheye)
+        assert np.array_equal(c2, co_) and np.array_equal(m2, mo_) and np.array_equal(t2, t1, equal_nan=True)
+        assert np.array_equal(r2, r1, equal_nan=True) and s2[0] == s1[0]
+        if np.isfinite(to_).any():
+            assert np.nanmax(np.abs(t2 - to_)) < 1e-10
     # DataFrame form against the reference's own output conventions (golden from calib.py itself)
     import pandas as pd
     rows = [dict(frame=n, camera=c, marker=f"m{l:02d}", x=det[n, c, l, 0], y=det[n, c, l, 1], likelihood=det[n, c, l, 2])
@@ -313,6 +325,11 @@ def test_full_size_properties(mods):
     res, sums = calib.reproject_residuals(tri, det, 0.5, *rig)
     assert sums[0] == 2 * (valid & np.isfinite(tri).all(-1)[:, None, :]).sum()
     assert np.isnan(res[~valid]).all()
+    # the fused single-pass form is the two calls above, bit for bit (sums: same terms, different summation order)
+    tri2, cnt2, mask2, res2, sums2 = calib.triangulate_reproject_dense(det, 0.5, *rig)
+    assert np.array_equal(tri2, tri, equal_nan=True) and np.array_equal(cnt2, cnt) and np.array_equal(mask2, mask)
+    assert np.array_equal(res2, res, equal_nan=True)
+    assert sums2[0] == sums[0] and np.allclose(sums2[1:], sums[1:], rtol=1e-11, atol=1e-6)
     # config 3/4 shape: LM from the triangulation init; cost monotone, trajectory near the truth
     x0 = fte.triangulation_init(det, *rig, 0.5)
     ctx = fte.FTEContext(det, *rig, seq["Ts"])
