@@ -64,6 +64,21 @@ def test_pointwise_camera_kernels(mods):
     tg = calib.triangulate_points_fisheye(p1, p2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
     to = ocam.triangulate_points_fisheye(p1, p2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
     assert np.abs(tg - to).max() < 1e-10                                                                # metres
+    # the null vector comes from inverse iteration on A^T A with the Jacobi SVD as fallback: exact data (A singular to
+    # round-off), grossly inconsistent pairs (no gap between the two smallest singular values: fallback) and the
+    # reference's -1e6 marker for failed undistortions must all agree with the SVD oracle
+    e1, e2 = (ocam.project_points_fisheye(X, K[c], D[c], R[c], t[c]) for c in (0, 1))
+    front = np.isfinite(e1).all(1) & np.isfinite(e2).all(1) & ((X @ R[0][2] + t[0].ravel()[2]) > 0.5) & ((X @ R[1][2] + t[1].ravel()[2]) > 0.5)
+    e1, e2 = e1[front], e2[front]
+    assert front.sum() > 500
+    te = calib.triangulate_points_fisheye(e1, e2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
+    oe = ocam.triangulate_points_fisheye(e1, e2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
+    assert np.abs(te - oe).max() < 1e-10 and np.median(np.abs(te - X[front]).max(1)) < 1e-12
+    b1, b2 = e1 + rng.normal(0, 60, e1.shape), e2 + rng.normal(0, 60, e2.shape)
+    tb = calib.triangulate_points_fisheye(b1, b2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
+    ob = ocam.triangulate_points_fisheye(b1, b2, K[0], D[0], R[0], t[0], K[1], D[1], R[1], t[1])
+    rel = np.abs(tb - ob).max(1) / np.maximum(1.0, np.abs(ob).max(1))
+    assert np.isfinite(tb).all() and np.median(rel) < 1e-12 and rel.max() < 1e-7, (np.median(rel), rel.max())
     # pinhole: keep to the field of view where OpenCV's 5-step fixed-point undistortion contracts
     # (outside it the iteration is chaotic and amplifies 1-ulp differences; not a property of the kernel)
     def _r2(c):
