@@ -248,6 +248,19 @@ __device__ __forceinline__ void triangulate_two_view(const Cam& ca, const Cam& c
   dlt_null_vector(A, out);
 }
 
+// The opt-in to more than 64 KB of dynamic LDS (hipFuncSetAttribute) is a per-DEVICE property of a kernel: remember it
+// per device, not per process (a process may drive more than one GPU).
+struct PerDeviceOnce {
+  unsigned char seen[64] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (seen[dev]) return false;
+    seen[dev] = 1;
+    return true;
+  }
+};
+
 // ---- redescending loss (build.py:382-395) ---------------------------------------------------
 struct LossC {
   double a, b, c;

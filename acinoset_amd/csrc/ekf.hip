@@ -732,13 +732,12 @@ int acino_ekf_run(const acino_ekf_params* prm, const double* d_det, const double
   K.dlc_thresh = prm->dlc_thresh;
   K.max_pixel_err = prm->cam_width;
   K.eps = 1e-3;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ekf_forward),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEkfLds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rts_gain),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRtsLds));
-    attr_done = true;
   }
   ACINO_HIP_CHECK(hipMemsetAsync(d_outliers, 0, sizeof(int32_t) * prm->n_seq, s));
   ACINO_HIP_CHECK(hipMemsetAsync(nerr, 0, sizeof(int), s));

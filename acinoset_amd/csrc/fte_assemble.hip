@@ -342,15 +342,14 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
   const int nb = n_assemble_blocks(h_c.n_frames);
   if (nb == 0) return ACINO_OK;
   const size_t lds = sizeof(FrameLds) * FPB + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
-    attr_done = true;
   }
   if (need_jac)
     hipLaunchKernelGGL(k_fte_assemble<true>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
@@ -363,12 +362,10 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
 }
 
 static int fk_attr() {
-  static bool done = false;
-  if (!done) {
+  static PerDeviceOnce attr;
+  if (attr.first())
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
-    done = true;
-  }
   return ACINO_OK;
 }
 
