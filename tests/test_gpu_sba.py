@@ -239,3 +239,16 @@ def test_points_sharded_over_processes_equal_single_solve(gsba, world, tmp_path)
         assert np.array_equal(p["r"], parts[0]["r"]) and np.array_equal(p["t"], parts[0]["t"])
         assert np.abs(p["r"] - r1).max() < 1e-6 and np.abs(p["t"] - t1).max() < 1e-6
     assert np.abs(np.concatenate([p["pts"] for p in parts]) - pts1).max() < 1e-5
+
+
+def test_sharded_solve_reports_a_failing_reduction(gsba):
+    """No process group: the reduction callback fails inside the C solve, which must stop with ACINO_ERR_CALLBACK and
+    hand the Python exception back (no exception may unwind through the C frames)."""
+    sba, _ = gsba
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    p2, X0, pi, ci, K, D, Rp, tp = _rig_problem(n_pts=40)
+    with pytest.raises((RuntimeError, ValueError)):
+        sba.bundle_adjust_points_and_extrinsics_sharded(p2, X0, pi, ci, K, D, Rp, tp)
+    pts, _r, _t, _res = sba.bundle_adjust_points_and_extrinsics(p2, X0, pi, ci, K, D, Rp, tp)     # the library is still usable
+    assert np.isfinite(pts).all()
