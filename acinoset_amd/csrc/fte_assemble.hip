@@ -125,7 +125,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
         my_cost += 2.0 * rho0;
         continue;
       }
-      double iz = 1.0 / zc;
+      double iz = rcp64(zc);
       double a = xc * iz, b = yc * iz;
       const double r2 = a * a + b * b + 1e-12;
       const double ir = rsqrt(r2);                 // every later "/ r" is a multiplication
@@ -143,7 +143,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       my_cost += rho_u + rho_v;
       if (JAC) {
         double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
-        double dm_dr = (dthD / (1 + r2) * r - thD) * (ir * ir);
+        double dm_dr = (dthD * rcp64(1 + r2) * r - thD) * (ir * ir);
         double dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
         double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
         double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
