@@ -237,7 +237,7 @@ k_triangulate_pairs(const double* __restrict__ det, int64_t n_frames, int n_cams
           double ru = __builtin_nan(""), rv = __builtin_nan("");
           if (fin && d[2] > thresh) {
             double u, v;
-            project_fisheye_pt(c[ci], X, Y, Z, u, v);
+            project_fisheye_pt<true>(c[ci], X, Y, Z, u, v);
             ru = u - d[0];
             rv = v - d[1];
             s_cnt += 2;
@@ -291,7 +291,7 @@ k_reproject_residuals(const double* __restrict__ pts3, const double* __restrict_
       double ru = __builtin_nan(""), rv = __builtin_nan("");
       if (fin && d[2] > thresh) {
         double u, v;
-        project_fisheye_pt(c[ci], X, Y, Z, u, v);
+        project_fisheye_pt<true>(c[ci], X, Y, Z, u, v);
         ru = u - d[0];
         rv = v - d[1];
         s_cnt += 2;

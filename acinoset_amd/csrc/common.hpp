@@ -50,12 +50,23 @@ struct Cam {
 };
 static_assert(sizeof(Cam) == ACINO_CAM_STRIDE * sizeof(double), "camera record layout");
 
+// 1 / x for a finite non-zero x: hardware estimate + two Newton steps (5 instructions, error within an ulp, against
+// ~30 for the correctly rounded IEEE quotient).  The per-point camera arithmetic (undistortion, DLT, projection,
+// robust loss) is bound by fp64 VALU issue and was one third divisions.
+__device__ __forceinline__ double rcp64(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
 // Kannala-Brandt inverse (OpenCV fisheye::undistortPoints, no R/P).  Returns false when OpenCV would
 // flag the point (not converged / theta sign flipped) - caller writes -1e6.
 __device__ __forceinline__ bool undistort_fisheye_pt(const Cam& c, double u, double v, int max_iter, double eps,
                                                     double& xn, double& yn) {
-  double pwy = (v - c.cy) / c.fy;
-  double pwx = (u - c.cx) / c.fx - c.alpha * pwy;
+  double pwy = (v - c.cy) * rcp64(c.fy);
+  double pwx = (u - c.cx) * rcp64(c.fx) - c.alpha * pwy;
   double theta_d = sqrt(pwx * pwx + pwy * pwy);
   theta_d = fmin(fmax(-M_PI / 2.0, theta_d), M_PI / 2.0);
   bool converged = false;
@@ -65,15 +76,15 @@ __device__ __forceinline__ bool undistort_fisheye_pt(const Cam& c, double u, dou
     for (int j = 0; j < max_iter; ++j) {
       double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
       double k0t2 = c.k1 * t2, k1t4 = c.k2 * t4, k2t6 = c.k3 * t6, k3t8 = c.k4 * t8;
-      double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) /
-                   (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+      double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) *
+                   rcp64(1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
       theta = theta - fix;
       if (fabs(fix) < eps) {
         converged = true;
         break;
       }
     }
-    scale = tan(theta) / theta_d;
+    scale = tan(theta) * rcp64(theta_d);
   } else {
     converged = true;
   }
@@ -84,17 +95,20 @@ __device__ __forceinline__ bool undistort_fisheye_pt(const Cam& c, double u, dou
 }
 
 // cv2.fisheye.projectPoints for one point (r > 1e-8 branch as OpenCV).
+// FAST: reciprocals instead of the three IEEE quotients (the bulk residual kernels; within an ulp per operation).
+template <bool FAST = false>
 __device__ __forceinline__ void project_fisheye_pt(const Cam& c, double X, double Y, double Z, double& u,
                                                   double& v) {
   double xc = c.R[0] * X + c.R[1] * Y + c.R[2] * Z + c.t[0];
   double yc = c.R[3] * X + c.R[4] * Y + c.R[5] * Z + c.t[1];
   double zc = c.R[6] * X + c.R[7] * Y + c.R[8] * Z + c.t[2];
-  double a = xc / zc, b = yc / zc;
+  const double iz = FAST ? rcp64(zc) : 1.0 / zc;
+  double a = FAST ? xc * iz : xc / zc, b = FAST ? yc * iz : yc / zc;
   double r = sqrt(a * a + b * b);
   double th = atan(r);
   double th2 = th * th;
   double thd = th * (1 + th2 * (c.k1 + th2 * (c.k2 + th2 * (c.k3 + th2 * c.k4))));
-  double cdist = r > 1e-8 ? thd / r : 1.0;
+  double cdist = r > 1e-8 ? (FAST ? thd * rcp64(r) : thd / r) : 1.0;
   double xd = a * cdist, yd = b * cdist;
   u = (xd + c.alpha * yd) * c.fx + c.cx;
   v = yd * c.fy + c.cy;
@@ -120,21 +134,21 @@ __device__ __forceinline__ bool dlt_null_vector_invit(const double A[4][4], doub
   // B = L D L^T, unit lower L stored in l[][], reciprocal pivots in id[]
   double l10, l20, l30, l21, l31, l32, id[4];
   double d0 = fmax(B[0][0], floor_);
-  id[0] = 1.0 / d0;
+  id[0] = rcp64(d0);
   l10 = B[0][1] * id[0];
   l20 = B[0][2] * id[0];
   l30 = B[0][3] * id[0];
   double d1 = fmax(B[1][1] - l10 * B[0][1], floor_);
-  id[1] = 1.0 / d1;
+  id[1] = rcp64(d1);
   const double b21 = B[1][2] - l20 * B[0][1], b31 = B[1][3] - l30 * B[0][1];
   l21 = b21 * id[1];
   l31 = b31 * id[1];
   double d2 = fmax(B[2][2] - l20 * B[0][2] - l21 * b21, floor_);
-  id[2] = 1.0 / d2;
+  id[2] = rcp64(d2);
   const double b32 = B[2][3] - l30 * B[0][2] - l31 * b21;
   l32 = b32 * id[2];
   double d3 = fmax(B[3][3] - l30 * B[0][3] - l31 * b31 - l32 * b32, floor_);
-  id[3] = 1.0 / d3;
+  id[3] = rcp64(d3);
   double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 1.0;
   bool conv = false;
 #pragma unroll 1
@@ -147,7 +161,7 @@ __device__ __forceinline__ bool dlt_null_vector_invit(const double A[4][4], doub
     const double y0 = z0 * id[0] - l10 * y1 - l20 * y2 - l30 * y3;
     // scale-safe normalisation (1 / d3 can be 1e30 for noise-free data)
     const double m = fmax(fmax(fabs(y0), fabs(y1)), fmax(fabs(y2), fabs(y3)));
-    const double im = 1.0 / m;
+    const double im = rcp64(m);
     const double s0 = y0 * im, s1 = y1 * im, s2 = y2 * im, s3 = y3 * im;
     const double rn = rsqrt(s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3);
     const double n0 = s0 * rn, n1 = s1 * rn, n2 = s2 * rn, n3 = s3 * rn;
@@ -158,9 +172,10 @@ __device__ __forceinline__ bool dlt_null_vector_invit(const double A[4][4], doub
     x2 = n2;
     x3 = n3;
   }
-  out[0] = x0 / x3;
-  out[1] = x1 / x3;
-  out[2] = x2 / x3;
+  const double iw = rcp64(x3);      // x3 == 0 (a point at infinity) gives NaN here: not finite, the caller falls back
+  out[0] = x0 * iw;
+  out[1] = x1 * iw;
+  out[2] = x2 * iw;
   return conv && m_finite(out[0]) && m_finite(out[1]) && m_finite(out[2]);
 }
 
@@ -285,17 +300,6 @@ inline LossC make_loss(double a, double b, double c) {
   L.icb = 1.0 / cb;
   L.d0 = (dsa - dsb) * t2 + (sa - sb) * a + (dsb - dsc) * t3 + (sb - sc) * (a * c / cb) + dsc * L.t4;
   return L;
-}
-
-// 1 / x for a positive normal x: hardware estimate + two Newton steps (5 instructions, error within an ulp, against
-// ~30 for the correctly rounded IEEE quotient - the assembly kernel is bound by fp64 VALU issue and its camera
-// evaluation had seven divisions).
-__device__ __forceinline__ double rcp64(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
 }
 
 // rho(e), rho'(e) and the Gauss-Newton curvature weight h = clip((rho'(e) - rho'(0+))/e, 0, 1); e = |err|.
