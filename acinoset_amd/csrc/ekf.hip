@@ -414,7 +414,12 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
                  [&](int a_, int b_, double v) { if (a_ < EP && b_ < EP) Bm[a_ * SLD + b_] = v + (a_ == b_ ? 1.0 : 0.0); });
     __syncthreads();
     // B = Lb Lb^T with U = Lb^-T alongside, in one wave's registers
-    if (wave == 0 && !wave_chol32<true>(Bm, SLD, Lc, Ub, lane) && !bad) { bad = true; bad_code = 2 * f + 2; }   // (Lc is done with)
+    // (waves 1-3 meanwhile copy the top rows of P for the covariance update: the Jacobian storage they go to is free)
+    if (wave == 0) {
+      if (!wave_chol32<true>(Bm, SLD, Lc, Ub, lane) && !bad) { bad = true; bad_code = 2 * f + 2; }   // (Lc is done with)
+    } else {
+      for (int e = tid - 64; e < 28 * PLD; e += 192) Pt[e] = e < EP * PLD ? P[e] : 0.0;
+    }
     __syncthreads();
     // Z = Lb^-1 [N1 | u] = U^T [N1 | u]   (into Bm: Lb itself is not needed again)
     tile_gemm<7>(2, 2, wave, li, lk,
@@ -441,7 +446,6 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
                  [&](int r_, int k) { return k < EP ? P[r_ * PLD + k] : 0.0; },
                  [&](int k, int b_) { return (k < EP && b_ < EP) ? Am[k * SLD + b_] : 0.0; },
                  [&](int r_, int b_, double v) { if (b_ < VLD) V[r_ * VLD + b_] = v; });     // zero beyond 75 x 25
-    for (int e = tid; e < 28 * PLD; e += 256) Pt[e] = e < EP * PLD ? P[e] : 0.0;
     __syncthreads();
     // P -= V Ptop on the matrix cores: 5 x 5 tiles of the 75 x 75 matrix (padded to 80), K = 25 padded to 28
     for (int q0 = 0; q0 < 7; q0 += 2) {      // two tiles' operands in flight per wave
@@ -477,13 +481,12 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * ti + lk + 4 * r;
             P[row * PLD + colB] = acc[q][r];
+            if (row < ES && colB < ES) P_est[(size_t)f * ES * ES + row * ES + colB] = acc[q][r];   // the smoother's input
           }
         }
       }
     }
-    __syncthreads();
     if (tid < ES) x_est[(size_t)f * ES + tid] = xs[tid];
-    for (int e = tid; e < ES * ES; e += 256) P_est[(size_t)f * ES * ES + e] = P[(e / ES) * PLD + e % ES];
     __syncthreads();
   }
   // outlier count: one pair per thread per frame
