@@ -407,10 +407,10 @@ int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32,
 static int launch_pairs(bool reproject, const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                         const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask, double* d_res,
                         double* d_sums, void* stream) {
-  // whole frames covering 256 consecutive (frame, marker) items; larger rigs than 64 KB read HBM directly
+  // whole frames covering 256 consecutive (frame, marker) items; rigs whose span exceeds 60 KB read HBM directly
   const int64_t frames = 256 / n_markers + 2;
   int64_t stage = frames * n_cams * n_markers * 3;
-  if (stage * 8 > 64 * 1024) stage = 0;
+  if (stage * 8 > 60 * 1024) stage = 0;      // (static LDS - camera records - shares the 64 KB that need no opt-in)
   const int grid = grid_for(n_frames * n_markers, 256);
   if (reproject)
     hipLaunchKernelGGL(k_triangulate_pairs<true>, dim3(grid), dim3(256), (size_t)stage * 8, (hipStream_t)stream, d_det,
