@@ -14,6 +14,7 @@ struct Buffers {
   double* x[2];       // [(N+6)][25] with 3 halo frames each side
   double* g[2];       // [N][25]
   double* H[2];       // [N][25][25] Gauss-Newton blocks (measurement + smoothness diagonal)
+  double* hd[2];      // [N][25] their diagonals, contiguous (the trial kernel would otherwise touch all of H for them)
   double* cost_part;  // [nblk]
   double* pred_part;  // [nblk_t]
   double* step_part;  // [nblk_t]
@@ -73,6 +74,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   for (int k = 0; k < 2; ++k) b.x[k] = c.take<double>((N + 2 * HALO) * NP);
   for (int k = 0; k < 2; ++k) b.g[k] = c.take<double>(N * NP);
   for (int k = 0; k < 2; ++k) b.H[k] = c.take<double>(N * NP * NP);
+  for (int k = 0; k < 2; ++k) b.hd[k] = c.take<double>(N * NP);
   b.cost_part = c.take<double>(n_assemble_blocks((int)N) + 1);
   b.pred_part = c.take<double>((N * NP + 255) / 256 + 1);
   b.step_part = c.take<double>((N * NP + 255) / 256 + 1);
@@ -110,7 +112,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
 __global__ void __launch_bounds__(256)
 k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, double* __restrict__ x0,
         double* __restrict__ x1, const double* __restrict__ g0, const double* __restrict__ g1,
-        const double* __restrict__ H0, const double* __restrict__ H1, const double* __restrict__ delta_nodes,
+        const double* __restrict__ hd0, const double* __restrict__ hd1, const double* __restrict__ delta_nodes,
         double* __restrict__ pred_part, double* __restrict__ step_part) {
   if (st->status != 0) return;
   const FteConst& K = *cst;
@@ -118,7 +120,7 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
   const double* x = cur ? x1 : x0;
   double* xt = cur ? x0 : x1;
   const double* g = cur ? g1 : g0;
-  const double* H = cur ? H1 : H0;
+  const double* hd = cur ? hd1 : hd0;     // diag of the Gauss-Newton blocks, written by the assembly
   const double lam = st->lam;
   const int tid = threadIdx.x;
   const int64_t e = (int64_t)blockIdx.x * 256 + tid;
@@ -130,7 +132,7 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
     const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[e];
     const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
     const double pg = fixed ? 0.0 : gv;
-    const double d0 = H[((size_t)n * NP + p) * NP + p];
+    const double d0 = hd[e];
     const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
     xt[(size_t)(n + HALO) * NP + p] = xn;
     pred = 0.5 * d * (lam * d0 * d - pg);
@@ -447,7 +449,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
   int rc;
   {
     ProfSpan sp(&ctx->prof, PC_ASSEMBLE, s, ctx->h.n_frames);
-    rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.cost_part, b.nbehind,
+    rc = launch_assemble(b.cst, ctx->h, b.state, which, ctx->d_det, b.x, b.H, b.g, b.hd, b.cost_part, b.nbehind,
                          need_jac, respect_status, s);
   }
   if (rc) return rc;
@@ -763,7 +765,7 @@ int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
   {
     ProfSpan sp(&ctx->prof, PC_TRIAL, (hipStream_t)stream, ctx->h.n_frames);
     hipLaunchKernelGGL(k_trial, dim3(ctx->n_blk_trial), dim3(256), 0, (hipStream_t)stream, b.cst, b.state, b.x[0],
-                       b.x[1], b.g[0], b.g[1], b.H[0], b.H[1], ctx->chain.b, b.pred_part, b.step_part);
+                       b.x[1], b.g[0], b.g[1], b.hd[0], b.hd[1], ctx->chain.b, b.pred_part, b.step_part);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;

@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(256)
 k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
                const double* __restrict__ det, const double* __restrict__ x0, const double* __restrict__ x1,
                double* __restrict__ H0, double* __restrict__ H1, double* __restrict__ g0, double* __restrict__ g1,
-               double* __restrict__ cost_partials, int* __restrict__ nbehind, int respect_status) {
+               double* __restrict__ hd0, double* __restrict__ hd1, double* __restrict__ cost_partials,
+               int* __restrict__ nbehind, int respect_status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FrameLds* F = reinterpret_cast<FrameLds*>(smem_raw);
   double* red = reinterpret_cast<double*>(smem_raw + sizeof(FrameLds) * FPB);
@@ -47,6 +48,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
   const double* __restrict__ xh = buf ? x1 : x0;
   double* __restrict__ D0 = buf ? H1 : H0;
   double* __restrict__ gout = buf ? g1 : g0;
+  double* __restrict__ hdout = buf ? hd1 : hd0;      // diag(H), contiguous, for the trial kernel's predicted reduction
   const FteConst& K = *cst;
   const int N = K.n_frames;
   const int f0 = blockIdx.x * FPB;
@@ -284,7 +286,10 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
             const double* xa = F[f].xi[a - 3];
             val = xa[0] * Y[0] + xa[1] * Y[1] + xa[2] * Y[2] + xa[3] * Y[3] + xa[4] * Y[4] + xa[5] * Y[5];
           }
-          if (a == bq) val += 2.0 * q * b0;
+          if (a == bq) {
+            val += 2.0 * q * b0;
+            hdout[(int64_t)n * NP + bq] = val;
+          }
           Dn[a * NP + bq] = val;
           if (!b_anc_a) Dn[bq * NP + a] = val;   // strict ancestor: mirror
         } else if (!b_anc_a) {
@@ -338,7 +343,7 @@ int n_assemble_blocks(int n_frames) { return (n_frames + FPB - 1) / FPB; }
 
 int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_state* d_st, int which,
                     const double* d_det, double* const x[2], double* const H[2], double* const g[2],
-                    double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s) {
+                    double* const hd[2], double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s) {
   const int nb = n_assemble_blocks(h_c.n_frames);
   if (nb == 0) return ACINO_OK;
   const size_t lds = sizeof(FrameLds) * FPB + 64;
@@ -353,10 +358,10 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
   }
   if (need_jac)
     hipLaunchKernelGGL(k_fte_assemble<true>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
-                       H[1], g[0], g[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
+                       H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
   else
     hipLaunchKernelGGL(k_fte_assemble<false>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
-                       H[1], g[0], g[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
+                       H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }

@@ -108,7 +108,7 @@ constexpr int HALO = 3;
 
 int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_state* d_st, int which,
                     const double* d_det, double* const x[2], double* const H[2], double* const g[2],
-                    double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s);
+                    double* const hd[2], double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s);
 int n_assemble_blocks(int n_frames);
 int launch_fk(const double* d_q, int64_t n, double* d_pos, hipStream_t s);
 int launch_fk_active(const double* d_xa_halo, int64_t n, double* d_pos, hipStream_t s);
