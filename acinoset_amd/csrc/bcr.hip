@@ -461,7 +461,8 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
   double* Wb = reinterpret_cast<double*>(smem_raw);
   double* yv = Wb + MAT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ent = blockIdx.x >> 1, role = blockIdx.x & 1;
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // both roles of a node and its neighbours: one L2
+  const int ent = blk >> 1, role = blk & 1;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
   if (role == 0) {
@@ -759,8 +760,8 @@ k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __res
   double* cLp = cRm + 9 * NP;
   double* cRp = cLp + 9 * NP;
   const int tid = threadIdx.x;
-  const int j = remain[4 * blockIdx.x], im = remain[4 * blockIdx.x + 1], ip = remain[4 * blockIdx.x + 2],
-            jn = remain[4 * blockIdx.x + 3];
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // neighbouring nodes share G(i) through one L2
+  const int j = remain[4 * blk], im = remain[4 * blk + 1], ip = remain[4 * blk + 2], jn = remain[4 * blk + 3];
   const size_t MB = (size_t)BS * BS;
   const FteConst& K = *cst;
   if (im >= 0) fill_coupling_coef(cLm, cRm, K, im, tid);

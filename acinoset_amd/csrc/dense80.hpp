@@ -16,6 +16,15 @@ constexpr int LD = 81;
 constexpr int MAT = BS * LD;
 constexpr int NT = 5;
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup k runs on XCD k % 8) and every XCD has its own L2.  Kernels
+// whose NEIGHBOURING work items read the same 51 KB operand (the two remaining neighbours of an eliminated node, the
+// two roles of an update) map the hardware index to a logical index such that each XCD works on one contiguous range:
+// the second reader then finds the operand in its L2 instead of fetching it again through the fabric.
+__device__ __forceinline__ int xcd_contiguous(int k, int n) {
+  const int x = k & 7, q = k >> 3, base = n >> 3, rem = n & 7;
+  return x * base + (x < rem ? x : rem) + q;
+}
+
 __device__ __forceinline__ double readlane_d(double x, int lane) {
   long long b = __builtin_bit_cast(long long, x);
   int lo = __builtin_amdgcn_readlane((int)b, lane);
