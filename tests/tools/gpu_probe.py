@@ -1,6 +1,6 @@
 """Ad-hoc GPU diagnostics (not a test): prints parity numbers of every kernel against the oracle."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import ctypes as C
 from acinoset_amd import _lib, calib, fte, synth
@@ -37,7 +37,7 @@ tg = calib.triangulate_points(q1, q2, K_[0], dpin, R_[0], t_[0], K_[1], dpin, R_
 to = ocam.triangulate_points(q1, q2, K_[0], dpin, R_[0], t_[0], K_[1], dpin, R_[1], t_[1])
 print("triangulate pinhole err", np.nanmax(np.abs(tg - to)))
 # 3. FK
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "cheetah_fk.npz"))
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", "cheetah_fk.npz"))
 pos = fte.cheetah_fk(g["q"])
 print("fk err vs golden", np.abs(pos - g["positions"]).max())
 # 4. sequence + pairs
