@@ -202,7 +202,8 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   double* coefR = coefL + 9 * NP;
   double* ysc = coefR + 9 * NP;   // [3][80] partial sums of the triangular mat-vecs
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // one contiguous range of the chain per XCD
+  const int i = elim[3 * blk], l = elim[3 * blk + 1], r = elim[3 * blk + 2];
   const size_t MB = (size_t)BS * BS;
   const bool fused = ch.st != nullptr && level == 0;
   const bool impl_l = ch.implicit_couplings && l >= 0 && l == i - 1, impl_r = ch.implicit_couplings && r >= 0 && r == i + 1;
@@ -760,7 +761,7 @@ k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __res
   double* cLp = cRm + 9 * NP;
   double* cRp = cLp + 9 * NP;
   const int tid = threadIdx.x;
-  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // neighbouring nodes share G(i) through one L2
+  const int blk = xcd_contiguous_rev((int)blockIdx.x, (int)gridDim.x);   // neighbouring nodes share G(i) through one L2; backwards: the G written last by the elimination first
   const int j = remain[4 * blk], im = remain[4 * blk + 1], ip = remain[4 * blk + 2], jn = remain[4 * blk + 3];
   const size_t MB = (size_t)BS * BS;
   const FteConst& K = *cst;

@@ -25,6 +25,14 @@ __device__ __forceinline__ int xcd_contiguous(int k, int n) {
   return x * base + (x < rem ? x : rem) + q;
 }
 
+// The same contiguous ranges walked BACKWARDS: a consumer kernel that starts with the work items whose operands the
+// producer kernel (same mapping, forwards) wrote last finds them still in the XCD's L2.
+__device__ __forceinline__ int xcd_contiguous_rev(int k, int n) {
+  const int x = k & 7, q = k >> 3, base = n >> 3, rem = n & 7;
+  const int cnt = base + (x < rem ? 1 : 0);
+  return x * base + (x < rem ? x : rem) + (cnt - 1 - q);
+}
+
 __device__ __forceinline__ double readlane_d(double x, int lane) {
   long long b = __builtin_bit_cast(long long, x);
   int lo = __builtin_amdgcn_readlane((int)b, lane);
