@@ -866,27 +866,30 @@ k_bcr_update0(BcrChain ch, const int* __restrict__ remain, const FteConst* __res
   if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
 }
 
-// Level-0 back-substitution: x_i = z_i - G_i (E_l x_l + E_r x_r).
+// Level-0 back-substitution: x_i = z_i - G_i (E_l x_l + E_r x_r).  G is read straight from HBM into registers - no LDS
+// staging, so every workgroup of the level is resident at once and all of its loads are in flight together.  G is
+// symmetric: thread (r, part) accumulates over ROWS c of COLUMN r, so the lanes of a wave read consecutive addresses.
 __global__ void __launch_bounds__(256)
 k_bcr_backsub0(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict__ cst,
                const int* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
-  double* Gb = reinterpret_cast<double*>(smem_raw);
-  double* xl = Gb + MAT;
-  double* xr = xl + BS;
-  double* vv = xr + BS;
-  double* cL = vv + BS;
-  double* cR = cL + 9 * NP;
+  __shared__ double xl[BS], xr[BS], vv[BS], ysc[3 * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
+  const int col = tid % BS, part = tid / BS, c0 = 27 * part, nc = part < 2 ? 27 : 26;
+  double g[27];
+  if (tid < 3 * BS) {
+    const double* G = ch.D + i * MB;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) g[k] = k < nc ? G[(size_t)(c0 + k) * BS + col] : 0.0;
+  }
   fill_coupling_coef(cL, cR, *cst, i, tid);
-  load_mat(Gb, ch.D + i * MB, tid);
   if (tid < BS) {
     xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
     xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
   }
+  const double zi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;
   __syncthreads();
   if (tid < BS) {
     double v = 0.0;
@@ -898,14 +901,18 @@ k_bcr_backsub0(BcrChain ch, const int* __restrict__ elim, const FteConst* __rest
     vv[tid] = v;
   }
   __syncthreads();
-  if (tid < BS) {
+  if (tid < 3 * BS) {
     double s0 = 0.0, s1 = 0.0;
-    for (int c = 0; c < BS; c += 2) {
-      s0 += Gb[tid * LD + c] * vv[c];
-      s1 += Gb[tid * LD + c + 1] * vv[c + 1];
+#pragma unroll
+    for (int k = 0; k < 26; k += 2) {
+      s0 += g[k] * vv[c0 + k];
+      s1 += g[k + 1] * vv[c0 + k + 1];
     }
-    ch.b[(size_t)i * BS + tid] = ch.b[(size_t)i * BS + tid] - (s0 + s1);
+    if (nc == 27) s0 += g[26] * vv[c0 + 26];
+    ysc[tid] = s0 + s1;
   }
+  __syncthreads();
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = zi - ((ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid]);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -989,7 +996,6 @@ static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(do
 static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
 static constexpr size_t kBacksubTailLds = (3 * MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
-static constexpr size_t kBacksub0Lds = (MAT + 3 * BS + 18 * NP) * sizeof(double);
 
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
@@ -1006,8 +1012,6 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdate0Lds));
-  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub0),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksub0Lds));
   return ACINO_OK;
 }
 
@@ -1068,7 +1072,7 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     {
       ProfSpan sp(prof, (k == 0 && ch.st != nullptr) ? PC_BACKSUB0 : PC_BACKSUB, s, lv.n_elim);
       if (k == 0 && ch.st != nullptr)
-        hipLaunchKernelGGL(k_bcr_backsub0, dim3(lv.n_elim), dim3(256), kBacksub0Lds, s, ch,
+        hipLaunchKernelGGL(k_bcr_backsub0, dim3(lv.n_elim), dim3(256), 0, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_c, d_status);
       else
         hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,

@@ -275,6 +275,35 @@ __device__ __forceinline__ void load_mat(double* dst, const double* __restrict__
 __device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict__ src, int tid) {
   load_mat_any<true>(dst, src, tid);
 }
+// A SYMMETRIC 80x80 matrix HBM -> LDS reading only its lower triangle (rows are fetched up to the diagonal: 55 % of the
+// cache lines) and mirroring it in LDS.  For consumers that are bound by HBM, not by LDS.
+__device__ __forceinline__ void load_mat_sym(double* dst, const double* __restrict__ src, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2 v[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      if (c <= r) v[k] = s2[idx];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < BS * BS / 2) {
+      const int e = 2 * idx, r = e / BS, c = e % BS;
+      if (c <= r) {
+        dst[r * LD + c] = v[k].x;
+        dst[c * LD + r] = v[k].x;
+        if (c + 1 <= r) {
+          dst[r * LD + c + 1] = v[k].y;
+          dst[(c + 1) * LD + r] = v[k].y;
+        }
+      }
+    }
+  }
+}
 __device__ __forceinline__ void store_mat(double* __restrict__ dst, const double* src, int tid) {
   double2* d2 = reinterpret_cast<double2*>(dst);
 #pragma unroll
