@@ -620,43 +620,59 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   }
 }
 
-// x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T ; the three matrices stream through one LDS buffer.
+// x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T.  All three matrices are requested at once (into registers: ONE HBM round
+// trip instead of three) and take their turn in the single LDS buffer; the mat-vecs use 240 threads (three partial
+// sums per row).
 __global__ void __launch_bounds__(256)
 k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Mb = reinterpret_cast<double*>(smem_raw);
-  double* xv = Mb + MAT;
-  double* tv = xv + BS;
+  double* xv = Mb + MAT;       // [2][80] x_l, x_r
+  double* tv = xv + 2 * BS;    // [80]
+  double* ysc = tv + BS;       // [3][80]
   const int tid = threadIdx.x;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
+  double2 vl[13], vr[13], vu[13];
+  if (l >= 0) fetch_mat(vl, ch.Wl + i * MB, tid);
+  if (r >= 0) fetch_mat(vr, ch.Wr + i * MB, tid);
+  fetch_mat(vu, ch.D + i * MB, tid);
   double t = (tid < BS) ? ch.b[(size_t)i * BS + tid] : 0.0;
+  if (tid < BS) {
+    xv[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
+    xv[BS + tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
+  }
+  const int row = tid % BS, part = tid / BS, c0 = 27 * part, c1 = part < 2 ? c0 + 27 : BS;
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
-    const int nb = side == 0 ? l : r;
-    if (nb < 0) continue;
-    load_mat(Mb, (side == 0 ? ch.Wl : ch.Wr) + i * MB, tid);
-    if (tid < BS) xv[tid] = ch.b[(size_t)nb * BS + tid];
+    if ((side == 0 ? l : r) < 0) continue;
+    stage_mat(Mb, side == 0 ? vl : vr, tid);
     __syncthreads();
-    if (tid < BS) {                         // row tid of W (stride-81 rows: conflict free)
+    if (tid < 3 * BS) {                     // row `row` of W, columns [c0, c1) (stride-81 rows: conflict free)
+      const double* x = xv + side * BS;
       double s0 = 0.0, s1 = 0.0;
-      for (int c = 0; c < BS; c += 2) {
-        s0 += Mb[tid * LD + c] * xv[c];
-        s1 += Mb[tid * LD + c + 1] * xv[c + 1];
+      int c = c0;
+      for (; c + 1 < c1; c += 2) {
+        s0 += Mb[row * LD + c] * x[c];
+        s1 += Mb[row * LD + c + 1] * x[c + 1];
       }
-      t -= s0 + s1;
+      if (c < c1) s0 += Mb[row * LD + c] * x[c];
+      ysc[tid] = s0 + s1;
     }
     __syncthreads();
+    if (tid < BS) t -= (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];
   }
-  load_mat(Mb, ch.D + i * MB, tid);
+  stage_mat(Mb, vu, tid);
   if (tid < BS) tv[tid] = t;
   __syncthreads();
-  if (tid < BS) {                           // x = U t (U upper triangular)
-    double s = 0.0;
-    for (int c = tid; c < BS; ++c) s += Mb[tid * LD + c] * tv[c];
-    ch.b[(size_t)i * BS + tid] = s;
+  if (tid < 3 * BS) {                       // x = U t (U upper triangular): columns >= row only
+    double s0 = 0.0;
+    for (int c = max(c0, row); c < c1; ++c) s0 += Mb[row * LD + c] * tv[c];
+    ysc[tid] = s0;
   }
+  __syncthreads();
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];
 }
 
 // The deepest levels of the back-substitution as ONE launch.  Per node the three matrices do not depend on anything
@@ -993,7 +1009,7 @@ static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(do
 static constexpr size_t kElimDeepLds = (MAT + BS + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(double);
-static constexpr size_t kBacksubLds = (MAT + 2 * BS) * sizeof(double);
+static constexpr size_t kBacksubLds = (MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kBacksubTailLds = (3 * MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
 

@@ -275,32 +275,24 @@ __device__ __forceinline__ void load_mat(double* dst, const double* __restrict__
 __device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict__ src, int tid) {
   load_mat_any<true>(dst, src, tid);
 }
-// A SYMMETRIC 80x80 matrix HBM -> LDS reading only its lower triangle (rows are fetched up to the diagonal: 55 % of the
-// cache lines) and mirroring it in LDS.  For consumers that are bound by HBM, not by LDS.
-__device__ __forceinline__ void load_mat_sym(double* dst, const double* __restrict__ src, int tid) {
+// The two halves of load_mat, for kernels that want several matrices in flight but only ONE LDS buffer: request a
+// matrix into registers now (13 x 16 B per thread), stage it into LDS when its turn comes.
+__device__ __forceinline__ void fetch_mat(double2 (&v)[13], const double* __restrict__ src, int tid) {
   const double2* s2 = reinterpret_cast<const double2*>(src);
-  double2 v[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) {
     const int idx = tid + 256 * k;
-    if (idx < BS * BS / 2) {
-      const int e = 2 * idx, r = e / BS, c = e % BS;
-      if (c <= r) v[k] = s2[idx];
-    }
+    if (idx < BS * BS / 2) v[k] = s2[idx];
   }
+}
+__device__ __forceinline__ void stage_mat(double* dst, const double2 (&v)[13], int tid) {
 #pragma unroll
   for (int k = 0; k < 13; ++k) {
     const int idx = tid + 256 * k;
     if (idx < BS * BS / 2) {
       const int e = 2 * idx, r = e / BS, c = e % BS;
-      if (c <= r) {
-        dst[r * LD + c] = v[k].x;
-        dst[c * LD + r] = v[k].x;
-        if (c + 1 <= r) {
-          dst[r * LD + c + 1] = v[k].y;
-          dst[(c + 1) * LD + r] = v[k].y;
-        }
-      }
+      dst[r * LD + c] = v[k].x;
+      dst[r * LD + c + 1] = v[k].y;
     }
   }
 }
