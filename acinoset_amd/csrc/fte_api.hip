@@ -155,26 +155,43 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
 }
 
 // totals = {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}   (fixed summation order)
+struct LmTol {
+  double gtol, ftol, xtol, lam_max;
+  int clamp_lambda;
+};
+__device__ void lm_control_local(const LmTol& K, acino_fte_state& S, const double* totals, int numeric_err, int init);
 __device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
                            int init);
 
 // fused_control: -1 none (sharded: the decision needs the cross-rank sums), 0 LM step, 1 initial evaluation
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double* pred_part,
          const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
          int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control) {
   if (st->status != 0) return;
-  // the four reductions run together: strided per-thread partials (all loads in flight), one shuffle tree per wave,
-  // four waves combined in order - a fixed summation order, one barrier
-  __shared__ double sh[4][4];
+  // the four reductions run together: strided per-thread partials, one shuffle tree per wave, the sixteen waves
+  // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
+  // HBM round trips (one per stride), so the stride count is what it costs - 4 instead of 14 for 10 000 frames
+  constexpr int NW = 16;
+  __shared__ double sh[NW][4];
+  // thread 0 will run the controller: its operands are requested now, beside the reductions
+  acino_fte_state S;
+  LmTol T{0, 0, 0, 0, 0};
+  int ne = 0, nb = 0;
+  if (threadIdx.x == 0) {
+    S = *st;
+    T = LmTol{cst->gtol, cst->ftol, cst->xtol, cst->lam_max, cst->clamp_lambda};
+    ne = *numeric_err;
+    nb = *nbehind;
+  }
   double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
-  for (int i = threadIdx.x; i < n_cost; i += 256) c += cost_part[i];
+  for (int i = threadIdx.x; i < n_cost; i += 64 * NW) c += cost_part[i];
   if (with_step) {
-    for (int i = threadIdx.x; i < n_trial; i += 256) {
+    for (int i = threadIdx.x; i < n_trial; i += 64 * NW) {
       p += pred_part[i];
       s = fmax(s, step_part[i]);
     }
-    for (int i = threadIdx.x; i < n_nodes; i += 256) g = fmax(g, gn_part[i]);
+    for (int i = threadIdx.x; i < n_nodes; i += 64 * NW) g = fmax(g, gn_part[i]);
   }
   for (int off = 32; off > 0; off >>= 1) {
     c += __shfl_down(c, off, 64);
@@ -191,73 +208,88 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    c = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
-    p = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
-    s = fmax(fmax(sh[0][2], sh[1][2]), fmax(sh[2][2], sh[3][2]));
-    g = fmax(fmax(sh[0][3], sh[1][3]), fmax(sh[2][3], sh[3][3]));
-    totals[0] = c;
-    totals[1] = p;
-    totals[2] = s;
-    totals[3] = g;
-    totals[4] = (double)*nbehind;
-    totals[5] = totals[6] = totals[7] = 0.0;
+    c = 0.0;
+    p = 0.0;
+    s = 0.0;
+    g = 0.0;
+    for (int w = 0; w < NW; ++w) {
+      c += sh[w][0];
+      p += sh[w][1];
+      s = fmax(s, sh[w][2]);
+      g = fmax(g, sh[w][3]);
+    }
+    const double tot[8] = {c, p, s, g, (double)nb, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) totals[q] = tot[q];
     *nbehind = 0;
-    if (fused_control >= 0) lm_control(*cst, st, totals, numeric_err, fused_control);
+    if (fused_control >= 0) {
+      lm_control_local(T, S, tot, ne, fused_control);
+      *st = S;
+    }
   }
 }
 
 // Accept / reject + Nielsen lambda update; mirrors oracle/fte.py:lm_solve step for step.
-__device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
-                           int init) {
-  if (st->status != 0) return;
+// The controller on a LOCAL copy of the state (the caller loads the state and the tolerances early and stores the state
+// back once: on one thread every access to global memory is a dependent round trip).
+__device__ void lm_control_local(const LmTol& K, acino_fte_state& S, const double* totals, int numeric_err, int init) {
+  if (S.status != 0) return;
   if (init) {
-    st->cost = totals[0];
-    st->cost_trial = totals[0];
-    st->n_behind = (int)totals[4];
+    S.cost = totals[0];
+    S.cost_trial = totals[0];
+    S.n_behind = (int)totals[4];
     return;
   }
-  const double F = st->cost, Ft = totals[0], pred = totals[1], step = totals[2], gnorm = totals[3];
-  st->cost_trial = Ft;
-  st->pred = pred;
-  st->step_inf = step;
-  st->gnorm_inf = gnorm;
-  st->iter += 1;
-  if (*numeric_err) {
-    st->status = 5;
+  const double F = S.cost, Ft = totals[0], pred = totals[1], step = totals[2], gnorm = totals[3];
+  S.cost_trial = Ft;
+  S.pred = pred;
+  S.step_inf = step;
+  S.gnorm_inf = gnorm;
+  S.iter += 1;
+  if (numeric_err) {
+    S.status = 5;
     return;
   }
   if (gnorm <= K.gtol) {   // the iterate the step started from was already stationary: keep it
-    st->status = 3;
-    st->last_accept = 0;
+    S.status = 3;
+    S.last_accept = 0;
     return;
   }
   const double gain = pred > 0.0 ? (F - Ft) / pred : -1.0;
-  st->gain = gain;
+  S.gain = gain;
   if (Ft < F) {
     const double dF = F - Ft;
-    st->cur ^= 1;
-    st->cost = Ft;
-    st->accepted += 1;
-    st->last_accept = 1;
-    st->n_behind = (int)totals[4];
+    S.cur ^= 1;
+    S.cost = Ft;
+    S.accepted += 1;
+    S.last_accept = 1;
+    S.n_behind = (int)totals[4];
     const double t = 2.0 * gain - 1.0;
-    st->lam = st->lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
-    st->nu = 2.0;
-    if (dF <= K.ftol * fabs(Ft)) st->status = 1;
-    else if (step <= K.xtol) st->status = 2;
+    S.lam = S.lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+    S.nu = 2.0;
+    if (dF <= K.ftol * fabs(Ft)) S.status = 1;
+    else if (step <= K.xtol) S.status = 2;
   } else {
-    st->last_accept = 0;
-    st->lam *= st->nu;
-    st->nu *= 2.0;
-    if (st->lam > K.lam_max) {
+    S.last_accept = 0;
+    S.lam *= S.nu;
+    S.nu *= 2.0;
+    if (S.lam > K.lam_max) {
       if (K.clamp_lambda) {
-        st->lam = K.lam_max;
-        st->nu = 2.0;
+        S.lam = K.lam_max;
+        S.nu = 2.0;
       } else {
-        st->status = 4;
+        S.status = 4;
       }
     }
   }
+}
+
+__device__ void lm_control(const FteConst& K, acino_fte_state* st, const double* totals, const int* numeric_err,
+                           int init) {
+  acino_fte_state S = *st;
+  const LmTol T{K.gtol, K.ftol, K.xtol, K.lam_max, K.clamp_lambda};
+  lm_control_local(T, S, totals, *numeric_err, init);
+  *st = S;
 }
 
 __global__ void k_control(const FteConst* __restrict__ cst, acino_fte_state* st, const double* __restrict__ totals,
@@ -455,7 +487,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
   if (rc) return rc;
   {
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1024), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
                        b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
                        with_step ? 1 : 0, b.cst, b.numeric_err, fused_control);
   }
