@@ -326,14 +326,17 @@ __device__ __forceinline__ void deep_row_tile(const double* Lm, const double (&b
   strip_row_r<IB>(Lm, bv, Wg, cc, li, lk);
 }
 __global__ void __launch_bounds__(256, 2)
-k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T) {
+k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T,
+                int one_xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Lm = reinterpret_cast<double*>(smem_raw);
   double* yv = Lm + MAT;       // [80] rhs
   double* ysc = yv + BS;       // [3][80]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ent = blockIdx.x / T, g = blockIdx.x % T;
+  if (one_xcd && (blockIdx.x & 7)) return;       // the whole level on XCD 0 (workgroup k runs on XCD k % 8)
+  const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ent = bx / T, g = bx % T;
   const int i = elim[3 * ent], l = elim[3 * ent + 1], r = elim[3 * ent + 2];
   const size_t MB = (size_t)BS * BS;
   double bv[20];
@@ -542,7 +545,7 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
 // seven (that phase is LDS-bandwidth bound inside one CU); both neighbour matrices are requested at once into two
 // LDS buffers, the D_j tile is requested with them and only added at the end.  grid = n_remain * 2 * S.
 __global__ void __launch_bounds__(256)
-k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S) {
+k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S, int one_xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Wb = reinterpret_cast<double*>(smem_raw);
@@ -551,7 +554,9 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   double* yv2 = yv + BS;
   double* ysc = yv2 + BS;            // [3][80]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ent = blockIdx.x / (2 * S), role = (blockIdx.x / S) & 1, sub = blockIdx.x % S;
+  if (one_xcd && (blockIdx.x & 7)) return;
+  const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ent = bx / (2 * S), role = (bx / S) & 1, sub = bx % S;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
   if (role == 0) {
@@ -1041,8 +1046,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
         const int T = std::min(10, 256 / lv.n_elim);   // <= one workgroup per CU
-        hipLaunchKernelGGL(k_bcr_elim_deep, dim3(lv.n_elim * T), dim3(256), kElimDeepLds, s, ch,
-                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T);
+        const int one = lv.n_elim * T <= 32 ? 1 : 0;
+        hipLaunchKernelGGL(k_bcr_elim_deep, dim3(lv.n_elim * T * (one ? 8 : 1)), dim3(256), kElimDeepLds, s, ch,
+                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, one);
       } else
         hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
                            d_c, d_numeric_err, d_status, level);
@@ -1057,8 +1063,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status);
         else if (lv.n_remain <= 128) {     // narrow level: <= 512 workgroups after the 2 S-way split
           const int S = lv.n_remain <= 32 ? 4 : (lv.n_remain <= 64 ? 2 : 1);
-          hipLaunchKernelGGL(k_bcr_update_deep, dim3(2 * S * lv.n_remain), dim3(256), kUpdateDeepLds, s, ch,
-                             ch.d_remain + 4 * lv.remain_off, d_status, S);
+          const int one = 2 * S * lv.n_remain <= 32 ? 1 : 0;
+          hipLaunchKernelGGL(k_bcr_update_deep, dim3(2 * S * lv.n_remain * (one ? 8 : 1)), dim3(256), kUpdateDeepLds, s, ch,
+                             ch.d_remain + 4 * lv.remain_off, d_status, S, one);
         } else
           hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
