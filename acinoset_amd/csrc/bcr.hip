@@ -327,15 +327,17 @@ __device__ __forceinline__ void deep_row_tile(const double* Lm, const double (&b
 }
 __global__ void __launch_bounds__(256, 2)
 k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T,
-                int one_xcd) {
+                int nx, int per, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Lm = reinterpret_cast<double*>(smem_raw);
   double* yv = Lm + MAT;       // [80] rhs
   double* ysc = yv + BS;       // [3][80]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  if (one_xcd && (blockIdx.x & 7)) return;       // the whole level on XCD 0 (workgroup k runs on XCD k % 8)
-  const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // narrow level on nx XCDs (workgroup k runs on XCD k % 8), each a contiguous range of `per` logical workgroups:
+  // the workgroups of a node and of its neighbours share one L2, and so do this kernel and its consumers' kernels
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bx = xcd * per + slot;
+  if (xcd >= nx || slot >= per || bx >= total) return;
   const int ent = bx / T, g = bx % T;
   const int i = elim[3 * ent], l = elim[3 * ent + 1], r = elim[3 * ent + 2];
   const size_t MB = (size_t)BS * BS;
@@ -545,7 +547,8 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
 // seven (that phase is LDS-bandwidth bound inside one CU); both neighbour matrices are requested at once into two
 // LDS buffers, the D_j tile is requested with them and only added at the end.  grid = n_remain * 2 * S.
 __global__ void __launch_bounds__(256)
-k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S, int one_xcd) {
+k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S, int nx, int per,
+                  int total) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Wb = reinterpret_cast<double*>(smem_raw);
@@ -554,8 +557,8 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   double* yv2 = yv + BS;
   double* ysc = yv2 + BS;            // [3][80]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  if (one_xcd && (blockIdx.x & 7)) return;
-  const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bx = xcd * per + slot;     // (as in k_bcr_elim_deep)
+  if (xcd >= nx || slot >= per || bx >= total) return;
   const int ent = bx / (2 * S), role = (bx / S) & 1, sub = bx % S;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
@@ -1046,9 +1049,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
         const int T = std::min(10, 256 / lv.n_elim);   // <= one workgroup per CU
-        const int one = lv.n_elim * T <= 32 ? 1 : 0;
-        hipLaunchKernelGGL(k_bcr_elim_deep, dim3(lv.n_elim * T * (one ? 8 : 1)), dim3(256), kElimDeepLds, s, ch,
-                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, one);
+        const int total = lv.n_elim * T, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
+        hipLaunchKernelGGL(k_bcr_elim_deep, dim3(8 * per), dim3(256), kElimDeepLds, s, ch,
+                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, nx, per, total);
       } else
         hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
                            d_c, d_numeric_err, d_status, level);
@@ -1063,9 +1066,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status);
         else if (lv.n_remain <= 128) {     // narrow level: <= 512 workgroups after the 2 S-way split
           const int S = lv.n_remain <= 32 ? 4 : (lv.n_remain <= 64 ? 2 : 1);
-          const int one = 2 * S * lv.n_remain <= 32 ? 1 : 0;
-          hipLaunchKernelGGL(k_bcr_update_deep, dim3(2 * S * lv.n_remain * (one ? 8 : 1)), dim3(256), kUpdateDeepLds, s, ch,
-                             ch.d_remain + 4 * lv.remain_off, d_status, S, one);
+          const int total = 2 * S * lv.n_remain, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
+          hipLaunchKernelGGL(k_bcr_update_deep, dim3(8 * per), dim3(256), kUpdateDeepLds, s, ch,
+                             ch.d_remain + 4 * lv.remain_off, d_status, S, nx, per, total);
         } else
           hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
