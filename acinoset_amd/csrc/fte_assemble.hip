@@ -15,6 +15,7 @@
 // where xi = (pivot x omega, omega) is the joint twist: dp_l/dq_a = omega_a x (p_l - pivot_a).
 // J (240x25 per frame) is never materialised; only H_n (25x25) and g_n leave the workgroup.
 #include "cheetah_fk.hpp"
+#include "dense80.hpp"
 
 namespace acino {
 
@@ -51,7 +52,10 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
   double* __restrict__ hdout = buf ? hd1 : hd0;      // diag(H), contiguous, for the trial kernel's predicted reduction
   const FteConst& K = *cst;
   const int N = K.n_frames;
-  const int f0 = blockIdx.x * FPB;
+  // frames dealt to the XCDs in contiguous ranges, walked backwards: the level-0 elimination (same ranges, forwards)
+  // starts with the H blocks written last
+  const int blk = xcd_contiguous_rev((int)blockIdx.x, (int)gridDim.x);
+  const int f0 = blk * FPB;
   const int nf = min(FPB, N - f0);
   double my_cost = 0.0;
 
@@ -305,7 +309,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
   if (tid == 0) {
     double t = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    cost_partials[blockIdx.x] = t;
+    cost_partials[blk] = t;
   }
 }
 
