@@ -559,9 +559,40 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bx = xcd * per + slot;     // (as in k_bcr_elim_deep)
   if (xcd >= nx || slot >= per || bx >= total) return;
-  const int ent = bx / (2 * S), role = (bx / S) & 1, sub = bx % S;
+  // 2 S + 1 workgroups per node: S for role 0 (D_j tiles), S for role 1 (coupling block), one for b_j
+  const int ent = bx / (2 * S + 1), rb = bx % (2 * S + 1), role = rb == 2 * S ? 2 : rb / S, sub = rb % S;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
+  if (role == 2) {   // b_j -= W_r(im)^T y(im) + W_l(ip)^T y(ip), straight from HBM: thread (column, third of the rows),
+                     // lanes along a row of W (coalesced); keeps this mat-vec off the tile workgroups' critical path
+    if (im < 0 && ip < 0) return;
+    if (tid < BS) {
+      yv[tid] = im >= 0 ? ch.b[(size_t)im * BS + tid] : 0.0;
+      yv2[tid] = ip >= 0 ? ch.b[(size_t)ip * BS + tid] : 0.0;
+    }
+    const int col = tid % BS, part = tid / BS, k0 = 27 * part, nk = part < 2 ? 27 : 26;
+    double wa[27], wc[27];
+    if (tid < 3 * BS) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        wa[k] = (im >= 0 && k < nk) ? ch.Wr[im * MB + (size_t)(k0 + k) * BS + col] : 0.0;
+        wc[k] = (ip >= 0 && k < nk) ? ch.Wl[ip * MB + (size_t)(k0 + k) * BS + col] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (tid < 3 * BS) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        s0 += wa[k] * yv[k0 + (k < nk ? k : 0)];
+        s1 += wc[k] * yv2[k0 + (k < nk ? k : 0)];
+      }
+      ysc[tid] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < BS) ch.b[(size_t)j * BS + tid] -= ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    return;
+  }
   if (role == 0) {
     if (im < 0 && ip < 0) return;
     double* Dj = ch.D + j * MB;
@@ -578,10 +609,6 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
     const bool both = im >= 0 && ip >= 0;
     if (both) load_mat2(Wb, ch.Wr + im * MB, Wb2, ch.Wl + ip * MB, tid);
     else load_mat(Wb, im >= 0 ? ch.Wr + im * MB : ch.Wl + ip * MB, tid);
-    if (tid < BS) {
-      yv[tid] = ch.b[(size_t)(im >= 0 ? im : ip) * BS + tid];
-      if (both) yv2[tid] = ch.b[(size_t)ip * BS + tid];
-    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -596,18 +623,6 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
           Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = dt[q][rr] + a[rr];          // lower tiles only
         }
       }
-    }
-    if (sub == 0) {                  // b_j -= W^T y, three partial sums per row
-      if (tid < 3 * BS) {
-        const int col = tid % BS, k0 = 27 * (tid / BS), k1 = min(k0 + 27, BS);
-        double sp = 0.0;
-        for (int k = k0; k < k1; ++k) sp += Wb[k * LD + col] * yv[k];
-        if (both)
-          for (int k = k0; k < k1; ++k) sp += Wb2[k * LD + col] * yv2[k];
-        ysc[tid] = sp;
-      }
-      __syncthreads();
-      if (tid < BS) ch.b[(size_t)j * BS + tid] -= ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
     }
   } else {
     if (ip < 0 || jn < 0) return;
@@ -1066,7 +1081,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status);
         else if (lv.n_remain <= 128) {     // narrow level: <= 512 workgroups after the 2 S-way split
           const int S = lv.n_remain <= 32 ? 4 : (lv.n_remain <= 64 ? 2 : 1);
-          const int total = 2 * S * lv.n_remain, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
+          const int total = (2 * S + 1) * lv.n_remain, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
           hipLaunchKernelGGL(k_bcr_update_deep, dim3(8 * per), dim3(256), kUpdateDeepLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_status, S, nx, per, total);
         } else
