@@ -467,15 +467,46 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
   double* Wb = reinterpret_cast<double*>(smem_raw);
   double* yv = Wb + MAT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // both roles of a node and its neighbours: one L2
-  const int ent = blk >> 1, role = blk & 1;
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // the roles of a node and its neighbours: one L2
+  const int ent = blk / 3, role = blk % 3;
   const int j = remain[4 * ent], im = remain[4 * ent + 1], ip = remain[4 * ent + 2], jn = remain[4 * ent + 3];
   const size_t MB = (size_t)BS * BS;
+  if (role == 2) {   // b_j -= W_r(im)^T y(im) + W_l(ip)^T y(ip), straight from HBM (see k_bcr_update_deep)
+    if (im < 0 && ip < 0) return;
+    double* ya = Wb;            // [80] y(im), [80] y(ip), [3][80] partial sums
+    double* yb = ya + BS;
+    double* ysc = yb + BS;
+    if (tid < BS) {
+      ya[tid] = im >= 0 ? ch.b[(size_t)im * BS + tid] : 0.0;
+      yb[tid] = ip >= 0 ? ch.b[(size_t)ip * BS + tid] : 0.0;
+    }
+    const int col = tid % BS, part = tid / BS, k0 = 27 * part, nk = part < 2 ? 27 : 26;
+    double wa[27], wc[27];
+    if (tid < 3 * BS) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        wa[k] = (im >= 0 && k < nk) ? ch.Wr[im * MB + (size_t)(k0 + k) * BS + col] : 0.0;
+        wc[k] = (ip >= 0 && k < nk) ? ch.Wl[ip * MB + (size_t)(k0 + k) * BS + col] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (tid < 3 * BS) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        s0 += wa[k] * ya[k0 + (k < nk ? k : 0)];
+        s1 += wc[k] * yb[k0 + (k < nk ? k : 0)];
+      }
+      ysc[tid] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < BS) ch.b[(size_t)j * BS + tid] -= ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    return;
+  }
   if (role == 0) {
     if (im < 0 && ip < 0) return;
     double* Dj = ch.D + j * MB;
     d4 acc[5];
-    double bs = (tid < BS) ? ch.b[(size_t)j * BS + tid] : 0.0;
     auto load_tiles = [&](int q, int ib, int jb) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
@@ -494,20 +525,16 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
       if (nb < 0) continue;
       if (side == 1 && im >= 0) __syncthreads();               // everyone done with the previous W
       load_mat(Wb, (side == 0 ? ch.Wr : ch.Wl) + nb * MB, tid);   // W_r of the left / W_l of the right neighbour
-      if (tid < BS) yv[tid] = ch.b[(size_t)nb * BS + tid];
       __syncthreads();
       if (wave == 0) syrk_rows<0, BS / 4>(Wb, acc, li, lk);
       else if (wave == 1) syrk_rows<1, BS / 4>(Wb, acc, li, lk);
       else if (wave == 2) syrk_rows<2, BS / 4>(Wb, acc, li, lk);
       else syrk_rows<3, BS / 4>(Wb, acc, li, lk);
-      if (tid < BS)
-        for (int k = 0; k < BS; ++k) bs -= Wb[k * LD + tid] * yv[k];
     }
     if (wave == 0) syrk_tiles_foreach<0>(store_tiles);
     else if (wave == 1) syrk_tiles_foreach<1>(store_tiles);
     else if (wave == 2) syrk_tiles_foreach<2>(store_tiles);
     else syrk_tiles_foreach<3>(store_tiles);
-    if (tid < BS) ch.b[(size_t)j * BS + tid] = bs;
   } else {
     if (ip < 0 || jn < 0) return;
     double* Ha = Wb;                  // rows [h*40, h*40+40) of W_r(ip)   (cols = jn)
@@ -1085,7 +1112,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
           hipLaunchKernelGGL(k_bcr_update_deep, dim3(8 * per), dim3(256), kUpdateDeepLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_status, S, nx, per, total);
         } else
-          hipLaunchKernelGGL(k_bcr_update, dim3(2 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
+          hipLaunchKernelGGL(k_bcr_update, dim3(3 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
       }
       ACINO_LAUNCH_CHECK();
