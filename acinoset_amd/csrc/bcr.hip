@@ -327,7 +327,7 @@ __device__ __forceinline__ void deep_row_tile(const double* Lm, const double (&b
 }
 __global__ void __launch_bounds__(256, 2)
 k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T,
-                int nx, int per, int total) {
+                int extra, int nx, int per, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Lm = reinterpret_cast<double*>(smem_raw);
@@ -338,16 +338,18 @@ k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, con
   // the workgroups of a node and of its neighbours share one L2, and so do this kernel and its consumers' kernels
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bx = xcd * per + slot;
   if (xcd >= nx || slot >= per || bx >= total) return;
-  const int ent = bx / T, g = bx % T;
+  // T (+ 1) workgroups per node: T share the ten strips of W_l / W_r; where the level leaves CUs free (extra), one more
+  // stores the factor and y, so that no workgroup has a strip AND the 51 KB store behind its factorisation
+  const int ent = bx / (T + extra), g = bx % (T + extra), g_store = extra ? T : 0;
   const int i = elim[3 * ent], l = elim[3 * ent + 1], r = elim[3 * ent + 2];
   const size_t MB = (size_t)BS * BS;
   double bv[20];
-  deep_strip_operands(ch, i, l, r, g, bv, li, lk);       // first strip: in flight during the factorisation
+  if (g < T) deep_strip_operands(ch, i, l, r, g, bv, li, lk);       // first strip: in flight during the factorisation
   load_mat(Lm, ch.D + i * MB, tid);
   if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
   __syncthreads();
-  chol80(Lm, tid, g == 0 ? numeric_err : nullptr);
-  for (int sidx = g; sidx < 10; sidx += T) {
+  chol80(Lm, tid, g == g_store ? numeric_err : nullptr);
+  for (int sidx = g; sidx < 10 && g < T; sidx += T) {
     if (sidx != g) deep_strip_operands(ch, i, l, r, sidx, bv, li, lk);
     const bool left = sidx < 5;
     if ((left ? l : r) < 0) continue;
@@ -361,7 +363,7 @@ k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, con
       deep_row_tile<0>(Lm, bv, Wg, cc, li, lk);
     } else deep_row_tile<1>(Lm, bv, Wg, cc, li, lk);
   }
-  if (g == 0) {
+  if (g == g_store) {
     if (tid < 3 * BS) {                                                  // y = U^T b in three partial sums per row
       const int row = tid % BS, part = tid / BS;
       double yy = 0.0;
@@ -1090,10 +1092,11 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       const bool deep = !fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64;
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
-        const int T = std::min(10, 256 / lv.n_elim);   // <= one workgroup per CU
-        const int total = lv.n_elim * T, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
+        const int T = std::min(10, 256 / lv.n_elim);   // strip workgroups per node (+ 1 that stores the factor)
+        const int extra = lv.n_elim * (T + 1) <= 256 ? 1 : 0;
+        const int total = lv.n_elim * (T + extra), nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
         hipLaunchKernelGGL(k_bcr_elim_deep, dim3(8 * per), dim3(256), kElimDeepLds, s, ch,
-                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, nx, per, total);
+                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, extra, nx, per, total);
       } else
         hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
                            d_c, d_numeric_err, d_status, level);
