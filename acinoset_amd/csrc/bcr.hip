@@ -6,9 +6,10 @@
 //   elim   (one workgroup per eliminated node i with neighbours l, r):
 //            D_i = L L^T (blocked Cholesky in LDS) with U = L^-T built alongside ([A; I] L^-T = [L; L^-T]),
 //            W_l = U^T A_il, W_r = U^T A_ir (plain tile GEMMs), y = U^T b_i         -> HBM
-//   update (two workgroups per remaining node j):
-//            D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+),  b_j -= W^T y,
+//   update (three workgroups per remaining node j, one per line):
+//            D_j -= W_r(i-)^T W_r(i-) + W_l(i+)^T W_l(i+)
 //            new coupling block(j', j) = -W_r(i+)^T W_l(i+)
+//            b_j -= W_r(i-)^T y(i-) + W_l(i+)^T y(i+)          (a mat-vec straight from HBM, no LDS staging)
 // and back-substitution x_i = U (y - W_l x_l - W_r x_r) (three mat-vecs) walks the levels in reverse.
 // Level-0 couplings are the constant third-difference blocks and are generated in LDS, never stored.
 // LDS: ONE 80x81 fp64 matrix per workgroup (52 KB; 2 workgroups per CU in the elimination - 255 VGPRs -, 3 in the
