@@ -240,7 +240,9 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
       int p = 0;
 #pragma unroll
       for (int q = 3; q < EP; ++q) p = (c_ekf2act[q] == a + 3) ? q : p;
-      const double ang = pose[p] + ((v - 1 == p) ? K.eps : 0.0);
+      // the reference perturbs its FLOAT32 state array (:628, :640): fl32(x_p) + fl32(eps), a float32 sum, while the
+      // difference quotient divides by the float64 eps (:643) - the filter's output carries that ~1e-4 column scaling
+      const double ang = (v - 1 == p) ? (double)((float)pose[p] + (float)K.eps) : pose[p];
       double s, c;
       sincos(ang, &s, &c);
       fr[v].sc[a][0] = s;
@@ -248,7 +250,7 @@ k_ekf_forward(EkfK K, const double* __restrict__ det_all, const double* __restri
     }
     for (int task = tid; task < NVAR * 3; task += nthr) {
       const int v = task / 3, c = task % 3;
-      fr[v].pos[20][c] = pose[c] + ((v - 1 == c) ? K.eps : 0.0);
+      fr[v].pos[20][c] = (v - 1 == c) ? (double)((float)pose[c] + (float)K.eps) : pose[c];
     }
   };
   // Which marker moves with which parameter is a property of the kinematic chain: probe it once at a generic pose

@@ -123,10 +123,11 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       double xc = cam.R[0] * px + cam.R[1] * py + cam.R[2] * pz + cam.t[0];
       double yc = cam.R[3] * px + cam.R[4] * py + cam.R[5] * pz + cam.t[1];
       double zc = cam.R[6] * px + cam.R[7] * py + cam.R[8] * pz + cam.t[2];
-      if (zc < 1e-6) {
-        if (w > 0) ++behind;
-        w = 0.0;
-      }
+      // the reference's pt3d_to_2d (all_optimizations.py:193-209) has no cut at z_cam <= 0: a marker behind a camera
+      // keeps its mirrored projection and pays (typically the saturated) loss.  Only the singular plane itself is
+      // dropped; n_behind counts weighted detections with z_cam < 1e-6 (diagnostic).
+      if (zc < 1e-6 && w > 0) ++behind;
+      if (fabs(zc) < 1e-9) w = 0.0;
       if (w == 0.0) {
         my_cost += 2.0 * rho0;
         continue;

@@ -146,7 +146,7 @@ typedef struct acino_fte_state {
   int32_t accepted;
   int32_t status;          /* 0 running, 1 ftol, 2 xtol, 3 gtol, 4 lambda overflow, 5 numeric */
   int32_t cur;             /* which of the two iterate buffers is current                   */
-  int32_t n_behind;        /* weighted detections dropped because z_cam < 1e-6              */
+  int32_t n_behind;        /* weighted detections with z_cam < 1e-6 (kept, as the reference)  */
   int32_t last_accept;
   int32_t pad0, pad1;
 } acino_fte_state;

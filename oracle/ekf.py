@@ -9,9 +9,14 @@ gating per pixel pair (:815-819), gain through the explicit inverse of S (:822),
 RTS smoother over frames N-2 .. 1 (:838-841, frame 0 is left unsmoothed), float32 rounding of the predicted state
 (:628).
 
-PARITY UNPINNED: ``lib.misc`` (``get_pose_params``, ``get_markers``, ``get_3d_marker_coords``) is not part of the
-reference tree and no EKF output is shipped.  The parameter order is taken from the ``qb_list`` comments (:734-746)
-and the marker function is the cheetah FK of the same file (:66-190, oracle/fk.py).
+PINNED (tests/test_ekf.py::test_oracle_matches_reference_ekf_text) to ``tests/golden/ekf_ref.npz``: the reference's
+OWN filter + smoother text (:582-593, :603-611, :615-649, :668-679, :684, :699-845) slice-executed on two synthetic
+clips by tests/golden/make_golden.py::gen_ekf.  Frame by frame from the reference's own previous state and
+covariance the oracle reproduces it to 1e-9; over whole clips to float32-ulp level (the reference rounds every
+predicted state to float32, :628, so a 1e-13 difference flips an ulp now and then and the filter carries it on).
+ONE ASSUMPTION LEFT: ``lib.misc`` (``get_pose_params``, ``get_markers``, ``get_3d_marker_coords``) is not part of the
+reference tree; the parameter order is taken from the ``qb_list`` comments (:734-746) and the marker function is the
+cheetah FK of the same file (:66-190, oracle/fk.py) evaluated in float64.
 """
 import numpy as np
 
@@ -36,9 +41,10 @@ IDX_X0, IDX_Y0, IDX_PSI0 = 0, 1, 5          # positions of x_0, y_0, psi_0 in EK
 
 
 def marker_coords(pose25):
-    """get_3d_marker_coords: 25 pose parameters -> (20, 3) marker positions (cheetah FK, :66-190)."""
+    """get_3d_marker_coords: 25 pose parameters -> (20, 3) marker positions (cheetah FK, :66-190), float64 arithmetic
+    whatever the input dtype."""
     q = np.zeros(fk.N_STATES)
-    q[EKF_ORDER] = pose25
+    q[EKF_ORDER] = np.asarray(pose25, dtype=np.float64)
     return fk.cheetah_fk(q[None])[0]
 
 
@@ -47,14 +53,20 @@ def h_function(pose25, k, d, r, t):
 
 
 def numerical_jacobian(func, x, *args):
-    """:631-646 - forward differences, eps = 1e-3, perturbation restored exactly."""
+    """:631-646 - forward differences, eps = 1e-3, perturbation restored exactly.  In the reference ``x`` is the
+    float32 array ``predict_next_state`` returned (:628), so ``xpeturb[i] + eps`` is a FLOAT32 sum (the Python float
+    is cast to float32 first) while the difference quotient still divides by the float64 1e-3: every column is off
+    by up to ~1e-4 relative, and the filter's output carries that.  Reproduced explicitly for float32 input."""
     n = len(x)
     eps = 1e-3
     fx = func(x, *args).flatten()
     xp = x.copy()
     jac = np.empty((len(fx), n))
     for i in range(n):
-        xp[i] = xp[i] + eps
+        if xp.dtype == np.float32:
+            xp[i] = np.float32(xp[i]) + np.float32(eps)
+        else:
+            xp[i] = xp[i] + eps
         jac[:, i] = (func(xp, *args).flatten() - fx) / eps
         xp[i] = x[i]
     return jac
@@ -92,9 +104,10 @@ def initial_state(nose_frames, nose_xyz, start_frame, sT):
     return states
 
 
-def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, cam_width, states0, keep_cov=False):
+def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, cam_width, states0, keep_cov=False, P_init=None):
     """det[N, C, 20, 3] (x, y, likelihood) for the frames to filter -> dict of x, dx, ddx, smoothed_x, smoothed_dx,
-    smoothed_ddx [N, 25] in EKF_ORDER, plus ``outliers_ignored``."""
+    smoothed_ddx [N, 25] in EKF_ORDER, plus ``outliers_ignored``.  ``P_init`` replaces P0 (used by the one-step
+    checks against the reference's stored per-frame covariances)."""
     det = np.asarray(det, dtype=np.float64)
     n_frames, n_cams, n_markers, _ = det.shape
     sT = 1.0 / fps
@@ -102,6 +115,8 @@ def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, cam_width, states0, ke
     max_pixel_err = cam_width
     dlc_cov = 5 ** 2
     P, Q, F = model_matrices(sT)
+    if P_init is not None:
+        P = np.asarray(P_init, dtype=np.float64).copy()
     states = np.asarray(states0, dtype=np.float64).copy()
     pixels_arr = det[..., :2].reshape(n_frames, -1)
     likelihood_arr = det[..., 2].reshape(n_frames, -1)
@@ -116,7 +131,8 @@ def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, cam_width, states0, ke
         acc = states[2 * N_POSE:]
         vel = states[N_POSE:2 * N_POSE] + sT * acc
         pos = states[:N_POSE] + sT * vel + (0.5 * sT ** 2) * acc
-        states = np.concatenate([pos, vel, acc]).astype(np.float32).astype(np.float64)      # :628
+        states32 = np.concatenate([pos, vel, acc]).astype(np.float32)                       # :628
+        states = states32.astype(np.float64)
         states_pred_hist[i] = states
         P = F @ P @ F.T + Q
         P_pred_hist[i] = P
@@ -125,7 +141,7 @@ def ekf(det, k_arr, d_arr, r_arr, t_arr, fps, dlc_thresh, cam_width, states0, ke
         h = np.zeros(n_cams * m)
         for j in range(n_cams):
             h[j * m:(j + 1) * m] = h_function(states[:N_POSE], *cams[j]).flatten()
-            H[j * m:(j + 1) * m, 0:N_POSE] = numerical_jacobian(h_function, states[:N_POSE], *cams[j])
+            H[j * m:(j + 1) * m, 0:N_POSE] = numerical_jacobian(h_function, states32[:N_POSE], *cams[j])
         bad = np.repeat(likelihood_arr[i] < dlc_thresh, 2)
         dlc_cov_arr = dlc_cov * np.ones(n_cams * m)
         dlc_cov_arr[bad] = max_pixel_err

@@ -76,10 +76,14 @@ class FTEProblem:
                     uv = camera.pt3d_to_2d(pos, self.K[ci], self.D[ci], self.R[ci], self.t[ci])
                     zc = (pos @ self.R[ci][2]) + self.t[ci][2]
                 w = self.w[sl, ci]                            # [n,L]
-                behind = zc < 1e-6
-                n_behind += int((behind & (w > 0)).sum())
-                w = np.where(behind, 0.0, w)
-                res = np.where(behind[..., None], 0.0, uv - self.meas[sl, ci])
+                # the reference's pt3d_to_2d (:193-209) has NO cut at z_cam <= 0: a marker behind a camera keeps its
+                # (mirrored) projection and is penalised like any other residual.  Only the singular plane itself
+                # (|z_cam| < 1e-9, where x/z is undefined) is dropped; n_behind counts weighted detections with
+                # z_cam < 1e-6 as a diagnostic.
+                n_behind += int(((zc < 1e-6) & (w > 0)).sum())
+                sing = np.abs(zc) < 1e-9
+                w = np.where(sing, 0.0, w)
+                res = np.where(sing[..., None], 0.0, uv - self.meas[sl, ci])
                 sres = w[..., None] * res                     # scaled residual [n,L,2]
                 rho, drho, h = loss.redescending_dloss(sres, a, b, c)
                 cost += float(rho.sum())

@@ -195,6 +195,272 @@ def gen_index_path():
     json.dump(dict(cases=cases), open(os.path.join(OUT, "index_path.json"), "w"))
 
 
+def _ref_lines(lo, hi):
+    """Lines lo..hi (1-based, inclusive) of the reference's src/all_optimizations.py, dedented."""
+    src = open(os.path.join(REF, "src", "all_optimizations.py")).read().splitlines()
+    return textwrap.dedent("\n".join(src[lo - 1:hi]))
+
+
+def gen_fte_model():
+    """The reference's OWN FTE model text on floats (fte_model.npz).
+
+    Slice-exec of src/all_optimizations.py: :25-27 (redescending a, b, c), :64-217 (sympy FK, pt3d_to_2d),
+    :226-241 (DataFrame accessors, proj_funcs), :243-252 (R, Q), :268-277 (nose-line estimate), :283-500 (sets, weights,
+    parameters, variables, initialisation, every constraint, the objective) against tests/golden/_float_pyomo.py,
+    whose Var/Param/Constraint/Objective hold floats: constraints evaluate to residuals, the objective to a number.
+    Recorded: Q, R, both weight tables, the 21 boxes (recovered by probing each inequality rule), init_x, and for
+    random iterates x the objective value with all equality constraints satisfied (dx, ddx, slack_model, poses and
+    slack_meas are SOLVED from the reference's own constraint residuals, one variable per constraint)."""
+    import pandas as pd
+    import sympy as sp
+    from scipy.stats import linregress
+    sys.path.insert(0, OUT)
+    import _float_pyomo as fp
+    sys.path.insert(0, os.path.join(REF, "src"))
+    import build as ref_build  # noqa: E402  (stubbed import; supplies redescending_loss = lib.misc's)
+
+    rng = np.random.default_rng(2024)
+    scene = json.load(open(os.path.join(REF, "configs", "dummy_scene.json")))
+    C = 3
+    K_arr = np.array([c["k"] for c in scene["cameras"]][:C], dtype=np.float64)
+    D_arr = np.array([c["d"] for c in scene["cameras"]][:C], dtype=np.float64).reshape((-1, 4))
+    R_arr = np.array([c["r"] for c in scene["cameras"]][:C], dtype=np.float64)
+    t_arr = np.array([c["t"] for c in scene["cameras"]][:C], dtype=np.float64)
+    markers = ["l_eye", "r_eye", "nose", "neck_base", "spine", "tail_base", "tail1", "tail2",
+               "l_shoulder", "l_front_knee", "l_front_ankle", "r_shoulder", "r_front_knee",
+               "r_front_ankle", "l_hip", "l_back_knee", "l_back_ankle", "r_hip", "r_back_knee", "r_back_ankle"]
+    tot_frames, start_frame, end_frame, fps, dlc_thresh = 9, 2, 8, 120.0, 0.5      # 0-based start (after :56)
+    N, L = end_frame - start_frame, 20
+    # INPUT data only: detections near the projections of a smooth trajectory (so residuals fall in every zone of
+    # the redescending loss), built with the repo's oracle - the expected outputs below come from the reference text
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import camera as ocam, fk as ofk
+    act = [0, 1, 2, 3, 4, 6] + list(range(17, 31)) + [31, 32, 34, 35, 36]
+    tt = np.arange(tot_frames)[:, None] / 120.0
+    X_true = np.zeros((tot_frames, 45))
+    X_true[:, act] = 0.15 * np.sin(2 * np.pi * 2.0 * tt + rng.uniform(0, 6, len(act))[None, :])
+    X_true[:, 0:3] = np.array([2.0, 6.0, 0.7]) + tt * np.array([8.0, -3.0, 0.1])
+    pos_true = ofk.cheetah_fk(X_true)
+    det = np.zeros((tot_frames, C, L, 3))
+    for c in range(C):
+        det[:, c, :, :2] = ocam.pt3d_to_2d(pos_true, K_arr[c], D_arr[c], R_arr[c], t_arr[c].reshape(3))
+    det[..., :2] += rng.normal(0, 3.0, det[..., :2].shape)
+    outl = rng.uniform(size=(tot_frames, C, L)) < 0.2
+    det[..., :2] += outl[..., None] * rng.uniform(-80, 80, det[..., :2].shape)
+    det[..., 2] = np.where(rng.uniform(size=(tot_frames, C, L)) < 0.3, rng.uniform(0, 0.49, (tot_frames, C, L)),
+                           rng.uniform(0.51, 1, (tot_frames, C, L)))
+    rows = [dict(frame=n, camera=c, marker=markers[l], x=det[n, c, l, 0], y=det[n, c, l, 1], likelihood=det[n, c, l, 2])
+            for c in range(C) for n in range(tot_frames) for l in range(L)]
+    points_2d_df = pd.DataFrame(rows, columns=["frame", "camera", "marker", "x", "y", "likelihood"])
+    nose_tab = np.stack([np.arange(tot_frames, dtype=np.float64),
+                         1.0 + 0.08 * np.arange(tot_frames) + rng.normal(0, 0.01, tot_frames),
+                         5.0 - 0.03 * np.arange(tot_frames) + rng.normal(0, 0.01, tot_frames),
+                         0.6 + rng.normal(0, 0.01, tot_frames)], 1)
+    nose_tab = np.delete(nose_tab, 4, axis=0)                                      # a frame without a nose
+    points_3d_df = pd.DataFrame(dict(frame=nose_tab[:, 0], marker="nose", x=nose_tab[:, 1], y=nose_tab[:, 2],
+                                     z=nose_tab[:, 3]))
+
+    class _Misc:
+        redescending_loss = staticmethod(ref_build.redescending_loss)
+    ns = dict(sp=sp, np=np, sin=fp.sin, cos=fp.cos, atan=fp.atan, linregress=linregress, misc=_Misc,
+              ConcreteModel=fp.ConcreteModel, RangeSet=fp.RangeSet, Param=fp.Param, Var=fp.Var,
+              Constraint=fp.Constraint, Objective=fp.Objective,
+              K_arr=K_arr, D_arr=D_arr, R_arr=R_arr, t_arr=t_arr, markers=markers, points_2d_df=points_2d_df,
+              points_3d_df=points_3d_df, start_frame=start_frame, end_frame=end_frame, dlc_thresh=dlc_thresh,
+              Ts=1.0 / fps, print=lambda *a, **k: None)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        for lo, hi in ((25, 27), (64, 217), (226, 241), (243, 252), (268, 277), (283, 500)):
+            exec(compile(_ref_lines(lo, hi), f"all_optimizations.py[{lo}:{hi}]", "exec"), ns)
+    m, P = ns["m"], ns["P"]
+    assert P == 45 and ns["N"] == N and ns["L"] == L and ns["C"] == C
+    out = dict(det=det, nose_table=nose_tab, start_frame=start_frame, end_frame=end_frame, fps=fps,
+               dlc_thresh=dlc_thresh, K=K_arr, D=D_arr, R=R_arr, t=t_arr,
+               redesc=np.array([ns["redesc_a"], ns["redesc_b"], ns["redesc_c"]], dtype=np.float64),
+               R_meas=float(ns["R"]), Q=np.asarray(ns["Q"], dtype=np.float64),
+               model_err_weight=np.array([m.model_err_weight[p] for p in range(1, P + 1)], dtype=np.float64),
+               meas_err_weight=np.array([[[float(fp._val(m.meas_err_weight[n, c, l])) for l in range(1, L + 1)]
+                                          for c in range(1, C + 1)] for n in range(1, N + 1)]),
+               meas=np.array([[[[m.meas[n, c, l, d] for d in (1, 2)] for l in range(1, L + 1)]
+                               for c in range(1, C + 1)] for n in range(1, N + 1)]),
+               init_x=np.array([[m.x[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]),
+               init_poses=np.array([[[m.poses[n, l, d].value for d in (1, 2, 3)] for l in range(1, L + 1)]
+                                    for n in range(1, N + 1)]),
+               x_est=np.stack([ns["x_est"], ns["y_est"], ns["z_est"]], 1), psi_est=float(ns["psi_est"]))
+
+    # ---- the 21 boxes: every component whose rule returned an inequality touches ONE state p as |x_p + s| <= c
+    lo_b, hi_b = np.full(P, -np.inf), np.full(P, np.inf)
+    names = []
+    for cname, comp in m._components.items():
+        if not isinstance(comp, fp.Constraint) or not isinstance(next(iter(comp.data.values())), fp.Ineq):
+            continue
+        for p in range(1, P + 1):
+            m.x[1, p].reads = 0
+        comp.rule(m, 1)
+        touched = [p for p in range(1, P + 1) if m.x[1, p].reads]
+        assert len(touched) == 1, (cname, touched)
+        p = touched[0]
+        keep = m.x[1, p].value
+        f = []
+        for v in (0.0, 1.0):
+            m.x[1, p].value = v
+            q = comp.rule(m, 1)
+            f.append(q.lhs)
+            c_lim = q.rhs
+        m.x[1, p].value = keep
+        s = (f[1] ** 2 - f[0] ** 2 - 1.0) / 2.0
+        assert abs(abs(s) - f[0]) < 1e-12
+        lo_b[p - 1], hi_b[p - 1] = -c_lim - s, c_lim - s
+        names.append(f"{cname}:{p}")
+    out["bounds_lo"], out["bounds_hi"], out["bound_rules"] = lo_b, hi_b, np.array(names)
+
+    # ---- objective at feasible points: choose x, then satisfy every equality of :359-399 through the reference's
+    # own residuals (each is affine with unit slope in the variable it defines)
+    def set_from_residual(comp, idx, var):
+        v0 = 0.0 if var.value is None else var.value
+        var.value = v0
+        r0 = comp.rule(m, *idx).r
+        var.value = v0 + 1.0
+        slope = comp.rule(m, *idx).r - r0              # +-1 or +-Ts: the constraint is affine in `var`
+        var.value = v0 - r0 / slope
+
+    cases_x, cases_obj, cases_slack, cases_dx, cases_ddx, max_res = [], [], [], [], [], []
+    for case in range(5):
+        X = X_true[start_frame:end_frame].copy()
+        X[:, act] += rng.normal(0, (1e-5, 3e-4, 3e-3, 3e-4, 3e-4)[case], (N, len(act)))
+        if case == 3:
+            X[:, 5] = rng.normal(0, 0.01, N)          # a state with Q = 0: weight 0, must not change the objective
+        if case == 4:
+            X[:, 0:2] -= np.array([4.5, 8.0])         # the animal BEHIND camera 0: pt3d_to_2d has no z cut (:193-209)
+        for n in range(1, N + 1):
+            for p in range(1, P + 1):
+                m.x[n, p].value = float(X[n - 1, p - 1])
+                m.dx[n, p].value = 0.0
+                m.ddx[n, p].value = 0.0
+                m.slack_model[n, p].value = 0.0
+        for p in range(1, P + 1):                      # n = 2..N: dx_n from integrate_p, then dx_1, ddx free
+            for n in range(2, N + 1):
+                set_from_residual(m.integrate_p, (n, p), m.dx[n, p])
+            # free variables dx_1, ddx_1 chosen so that slack_2 = slack_3 = 0 (the optimum of the free variables)
+            ddx3 = (m.dx[3, p].value - m.dx[2, p].value) / m.Ts
+            m.ddx[1, p].value = m.ddx[2, p].value = ddx3
+            m.dx[1, p].value = m.dx[2, p].value - m.Ts * ddx3
+            for n in range(3, N + 1):
+                set_from_residual(m.integrate_v, (n, p), m.ddx[n, p])
+            for n in range(2, N + 1):
+                set_from_residual(m.constant_acc, (n, p), m.slack_model[n, p])
+        for n in range(1, N + 1):
+            for l in range(1, L + 1):
+                for d in (1, 2, 3):
+                    set_from_residual(m.pose_constraint, (n, l, d), m.poses[n, l, d])
+                for c in range(1, C + 1):
+                    for d in (1, 2):
+                        m.slack_meas[n, c, l, d].value = 0.0
+                        set_from_residual(m.measurement, (n, c, l, d), m.slack_meas[n, c, l, d])
+        worst = 0.0
+        for cname in ("pose_constraint", "integrate_p", "integrate_v", "constant_acc", "measurement"):
+            for v in getattr(m, cname).evaluate(m).values():
+                if v is not fp.Constraint.Skip:
+                    worst = max(worst, abs(v.r))
+        max_res.append(worst)
+        cases_x.append(X)
+        cases_obj.append(m.obj.value(m))
+        cases_slack.append(np.array([[m.slack_model[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
+        cases_dx.append(np.array([[m.dx[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
+        cases_ddx.append(np.array([[m.ddx[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
+    out.update(x_true=X_true, case_x=np.array(cases_x), case_obj=np.array(cases_obj), case_slack_model=np.array(cases_slack),
+               case_dx=np.array(cases_dx), case_ddx=np.array(cases_ddx), case_max_eq_residual=np.array(max_res))
+    np.savez_compressed(os.path.join(OUT, "fte_model.npz"), **out)
+    print("fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
+          "boxes", int(np.isfinite(lo_b).sum()), names[:3])
+
+
+def gen_ekf():
+    """The reference's OWN EKF + RTS-smoother text on two short synthetic clips (ekf_ref.npz).
+
+    Slice-exec of src/all_optimizations.py ``ekf``: :582-593 (state indices), :603, :606-611, :615-649 (h_function,
+    predict_next_state, numerical_jacobian), :668-679 (DLC table -> pixels / likelihood arrays), :684, :699-845
+    (initial state, P0, Q, F, the filter loop, the smoother).  Supplied from outside, because ``lib.misc`` and cv2 are
+    not in the reference tree: ``misc.get_pose_params`` = the 25 parameter names in the order of the ``qb_list``
+    comments (:734-746) - THE ONE ASSUMPTION LEFT -, ``misc.get_3d_marker_coords`` = the reference's own sympy
+    ``pose_to_3d`` (slice :64-190) evaluated in float64 under that order, ``project_points_fisheye`` = the KAT-1-pinned
+    oracle projection.  Everything else (float32 state rounding, float32 forward-difference perturbation, gating, the
+    explicit inverses) is whatever the reference text does under this container's numpy."""
+    import pandas as pd
+    import sympy as sp
+    from scipy.stats import linregress
+    from time import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import camera as ocam, synth as osynth
+    fk_ns = {"sp": sp, "np": np, "sin": np.sin, "cos": np.cos}
+    exec(compile(_ref_lines(64, 190), "all_optimizations.py[64:190]", "exec"), fk_ns)
+    pose_to_3d = fk_ns["pose_to_3d"]
+    names = ["x_0", "y_0", "z_0", "phi_0", "theta_0", "psi_0", "phi_1", "theta_1", "psi_1", "theta_2",
+             "phi_3", "theta_3", "psi_3", "theta_4", "psi_4", "theta_5", "psi_5"] + [f"theta_{i}" for i in range(6, 14)]
+    sym_names = [str(v).replace("\\", "").replace("{", "").replace("}", "") for v in fk_ns["sym_list"]]   # "\\phi_{0}" -> "phi_0"
+    slot = {"x_0": "x", "y_0": "y", "z_0": "z"}
+    order = [sym_names.index(slot.get(nm, nm)) for nm in names]          # position of each EKF parameter in sym_list
+    markers = ["l_eye", "r_eye", "nose", "neck_base", "spine", "tail_base", "tail1", "tail2",
+               "l_shoulder", "l_front_knee", "l_front_ankle", "r_shoulder", "r_front_knee",
+               "r_front_ankle", "l_hip", "l_back_knee", "l_back_ankle", "r_hip", "r_back_knee", "r_back_ankle"]
+
+    class _Misc:
+        @staticmethod
+        def get_pose_params():
+            return {nm: i for i, nm in enumerate(names)}
+
+        @staticmethod
+        def get_markers():
+            return list(markers)
+
+        @staticmethod
+        def get_3d_marker_coords(x):
+            q = np.zeros(45)
+            q[order] = np.asarray(x, dtype=np.float64)
+            return np.asarray(pose_to_3d(*q), dtype=np.float64)
+
+    out = dict(param_names=np.array(names), order45=np.array(order))
+    import io, contextlib
+    for tag, (n_tot, kind, seed, cams, sf1, ef) in (("a", (16, "sprint", 5, [0, 1, 2, 3, 4, 5], 3, 15)),
+                                                    ("b", (12, "loop", 6, [0, 2, 5], 1, 12))):
+        seq = osynth.make_sequence(n_tot, kind, seed=20210313 + seed)
+        det = seq["det"][:, cams].copy()
+        rng = np.random.default_rng(77 + seed)
+        bad = rng.uniform(size=det.shape[:3]) < 0.04          # confident but wrong detections: exercise the 3-sigma gate
+        det[..., :2] += bad[..., None] * rng.uniform(60, 140, det[..., :2].shape) * rng.choice([-1, 1], det[..., :2].shape)
+        det[..., 2] = np.where(bad, 0.93, det[..., 2])
+        k_arr, d_arr, r_arr, t_arr = seq["K"][cams], seq["D"][cams], seq["R"][cams], seq["t"][cams]
+        C = len(cams)
+        rows = [dict(frame=n, camera=c, marker=markers[l], x=det[n, c, l, 0], y=det[n, c, l, 1],
+                     likelihood=det[n, c, l, 2]) for c in range(C) for n in range(n_tot) for l in range(20)]
+        points_2d_df = pd.DataFrame(rows, columns=["frame", "camera", "marker", "x", "y", "likelihood"])
+        nose = seq["pos_true"][:, 2] + rng.normal(0, 0.01, (n_tot, 3))
+        points_3d_df = pd.DataFrame(dict(frame=np.arange(n_tot, dtype=np.float64), marker="nose", x=nose[:, 0],
+                                         y=nose[:, 1], z=nose[:, 2]))
+        ns = dict(np=np, pd=pd, linregress=linregress, time=time, misc=_Misc,
+                  project_points_fisheye=ocam.project_points_fisheye, k_arr=k_arr, d_arr=d_arr, r_arr=r_arr, t_arr=t_arr,
+                  cam_res=(2704, 1520), fps=120.0, n_cams=C, points_2d_df=points_2d_df, points_3d_df=points_3d_df,
+                  start_frame=sf1, end_frame=ef, dlc_thresh=0.5, t0=time())
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for lo, hi in ((582, 593), (603, 603), (606, 611), (615, 649), (668, 679), (684, 684), (699, 845)):
+                exec(compile(_ref_lines(lo, hi), f"all_optimizations.py[{lo}:{hi}]", "exec"), ns)
+        sf = ns["start_frame"]                                                     # 0-based after :606
+        assert ns["pixels_arr"].shape == (n_tot, C * 40) and ns["n_states"] == 75
+        assert np.array_equal(ns["pixels_arr"], det[..., :2].reshape(n_tot, -1))  # :668-674 == the dense layout
+        assert np.array_equal(ns["likelihood_arr"], det[..., 2].reshape(n_tot, -1))
+        out.update({f"{tag}_det": det[sf:ef], f"{tag}_K": k_arr, f"{tag}_D": d_arr, f"{tag}_R": r_arr, f"{tag}_t": t_arr,
+                    f"{tag}_nose_frames": np.arange(n_tot, dtype=np.float64)[sf:ef], f"{tag}_nose_xyz": nose[sf:ef],
+                    f"{tag}_start_frame": sf, f"{tag}_P0": ns["P_pred_hist"][0], f"{tag}_Q": ns["Q"], f"{tag}_F": ns["F"],
+                    f"{tag}_est": ns["states_est_hist"], f"{tag}_pred": ns["states_pred_hist"],
+                    f"{tag}_smooth": ns["smooth_states_est_hist"], f"{tag}_outliers": ns["outliers_ignored"],
+                    f"{tag}_P_est_last": ns["P_est_hist"][-1], f"{tag}_smooth_P_1": ns["smooth_P_est_hist"][1],
+                    f"{tag}_P_est_head": ns["P_est_hist"][:5]})
+        print("ekf", tag, "frames", ef - sf, "cams", C, "outliers", ns["outliers_ignored"],
+              "pred dtype", ns["states"].dtype)
+    np.savez_compressed(os.path.join(OUT, "ekf_ref.npz"), **out)
+
+
 def gen_kat1():
     base = os.path.join(REF, "data", "sunday_amelia", "extrinsic_calib")
     out = {}
@@ -277,8 +543,8 @@ def gen_dummy_scene():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: golden fixtures can only be regenerated in the build container"
     install_stubs()
-    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc"]
+    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "ekf"]
     for name, fn in (("helpers", gen_ref_helpers), ("fk", gen_cheetah_fk), ("index", gen_index_path),
-                     ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
+                     ("fte_model", gen_fte_model), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
         if name in parts:
             fn()

@@ -1,6 +1,9 @@
-"""EKF + RTS smoother.  CPU: structure of the oracle (oracle/ekf.py, a line-by-line
-restatement of src/all_optimizations.py:569-865; parity unpinned - no EKF output ships with the reference).
-GPU: the HIP filter against the oracle on seeded synthetic clips."""
+"""EKF + RTS smoother.  CPU: the oracle (oracle/ekf.py, a restatement of
+src/all_optimizations.py:569-865) against the reference's OWN filter text slice-executed on two synthetic clips
+(tests/golden/ekf_ref.npz, made by make_golden.py::gen_ekf).  GPU: the HIP filter against the oracle on seeded
+synthetic clips and against the same reference vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,6 +29,43 @@ def test_model_matrices_and_order():
     _pos, Ja = ofk.cheetah_fk(q[None], with_jac=True)
     Ja = Ja[0].reshape(60, 45)[:, oekf.EKF_ORDER]
     assert np.abs(J - Ja).max() < 2e-3
+
+
+def _ref(golden_dir):
+    return np.load(os.path.join(golden_dir, "ekf_ref.npz"), allow_pickle=False)
+
+
+def test_oracle_matches_reference_ekf_text(golden_dir):
+    g = _ref(golden_dir)
+    assert np.array_equal(g["order45"], oekf.EKF_ORDER)                 # qb_list order -> the FK's sym_list slots
+    P0, Q, F = oekf.model_matrices(1 / 120)
+    for tag in "ab":
+        det, rig = g[f"{tag}_det"], (g[f"{tag}_K"], g[f"{tag}_D"], g[f"{tag}_R"], g[f"{tag}_t"])
+        sf = int(g[f"{tag}_start_frame"])
+        assert np.array_equal(Q, g[f"{tag}_Q"]) and np.array_equal(F, g[f"{tag}_F"])            # :733-766
+        assert np.array_equal(F @ P0 @ F.T + Q, g[f"{tag}_P0"])                                  # :713-730 through :787
+        s0 = oekf.initial_state(g[f"{tag}_nose_frames"], g[f"{tag}_nose_xyz"], sf, 1 / 120)     # :699-711
+        out = oekf.ekf(det, *rig, 120.0, 0.5, 2704, s0, keep_cov=True)
+        est = np.hstack([out["x"], out["dx"], out["ddx"]])
+        sm = np.hstack([out["smoothed_x"], out["smoothed_dx"], out["smoothed_ddx"]])
+        assert out["outliers_ignored"] == int(g[f"{tag}_outliers"]) > 20                        # the gate is exercised
+        # frame 0: nothing has been rounded differently yet
+        assert np.array_equal(out["x_pred"][0], g[f"{tag}_pred"][0])
+        assert np.abs(est[0] - g[f"{tag}_est"][0]).max() < 1e-9
+        # whole clip: float32-ulp level (:628 rounds every prediction to float32; one flipped ulp is carried on)
+        for blk, tol in ((slice(0, 25), 5e-6), (slice(25, 50), 5e-5), (slice(50, 75), 1e-3)):
+            for got, want in ((est, g[f"{tag}_est"]), (sm, g[f"{tag}_smooth"])):
+                scale = max(1.0, np.abs(want[:, blk]).max())
+                assert np.abs(got[:, blk] - want[:, blk]).max() < tol * scale
+        assert np.array_equal(sm[0], est[0]) and np.array_equal(sm[-1], est[-1])                # :842 leaves both ends
+        # one step at a time from the reference's own previous state and covariance: no accumulated flips
+        Ph = g[f"{tag}_P_est_head"]
+        for i in range(1, len(Ph)):
+            one = oekf.ekf(det[i:i + 1], *rig, 120.0, 0.5, 2704, g[f"{tag}_est"][i - 1], keep_cov=True, P_init=Ph[i - 1])
+            assert np.array_equal(one["x_pred"][0], g[f"{tag}_pred"][i])
+            got = np.hstack([one["x"], one["dx"], one["ddx"]])[0]
+            assert np.abs(got - g[f"{tag}_est"][i]).max() < 1e-9 * max(1.0, np.abs(g[f"{tag}_est"][i]).max())
+            assert np.abs(one["P_est"][0] - Ph[i]).max() < 1e-9 * np.abs(Ph[i]).max()
 
 
 def test_oracle_tracks_a_synthetic_sprint():
@@ -98,3 +138,22 @@ def test_hip_smoother_solvers_agree_and_long_clip_tracks(gpu_lib):
     truth = seq["q_true"][:, ekf.EKF_ORDER]
     assert np.abs(a["x"][200:, :3] - truth[200:, :3]).max() < 0.03            # metres
     assert np.abs(a["smoothed_x"][200:, :3] - truth[200:, :3]).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_hip_ekf_matches_reference_ekf_text(gpu_lib, golden_dir):
+    """The HIP filter against vectors produced by the reference's own filter + smoother text (ekf_ref.npz)."""
+    from acinoset_amd import ekf
+    g = _ref(golden_dir)
+    for tag in "ab":
+        det, rig = g[f"{tag}_det"], (g[f"{tag}_K"], g[f"{tag}_D"], g[f"{tag}_R"], g[f"{tag}_t"])
+        s0 = oekf.initial_state(g[f"{tag}_nose_frames"], g[f"{tag}_nose_xyz"], int(g[f"{tag}_start_frame"]), 1 / 120)
+        got = ekf.ekf(det, *rig, 120.0, 0.5, (2704, 1520), states0=s0)
+        assert got["outliers_ignored"] == int(g[f"{tag}_outliers"])
+        est = np.hstack([got["x"], got["dx"], got["ddx"]])
+        sm = np.hstack([got["smoothed_x"], got["smoothed_dx"], got["smoothed_ddx"]])
+        assert np.abs(est[0] - g[f"{tag}_est"][0]).max() < 1e-8          # before any float32 ulp can have flipped
+        for blk, tol in ((slice(0, 25), 5e-6), (slice(25, 50), 5e-5), (slice(50, 75), 1e-3)):
+            for have, want in ((est, g[f"{tag}_est"]), (sm, g[f"{tag}_smooth"])):
+                scale = max(1.0, np.abs(want[:, blk]).max())
+                assert np.abs(have[:, blk] - want[:, blk]).max() < tol * scale, (tag, blk)

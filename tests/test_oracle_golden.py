@@ -177,3 +177,57 @@ def test_smoothness_term_equals_third_difference():
     assert abs(cl + cr - cost) < 1e-9 * abs(cost)
     assert np.abs(np.vstack([gl, gr]) - grad).max() < 1e-9 * np.abs(grad).max()
     assert np.allclose(np.hstack([pl.s_band(), pr.s_band()]), band)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fte_model.npz: the reference's OWN model text (all_optimizations.py:25-27, 243-252, 268-277, 283-500) executed on
+# floats by tests/golden/make_golden.py::gen_fte_model - constants, weights, boxes, initialisation, objective.
+def _fte_model_problem(g, **kw):
+    s, e = int(g["start_frame"]), int(g["end_frame"])
+    det = g["det"][s:e]
+    return ofte.FTEProblem(det[..., :2], det[..., 2], g["K"], g["D"], g["R"], g["t"], 1.0 / float(g["fps"]),
+                           dlc_thresh=float(g["dlc_thresh"]), **kw)
+
+
+def test_constants_match_reference_model_text(golden_dir):
+    g = _g(golden_dir, "fte_model.npz")
+    assert np.array_equal(fk.Q_SIGMA ** 2, g["Q"])                       # :245-252
+    assert float(g["R_meas"]) == 5.0 and g["redesc"].tolist() == [3.0, 10.0, 20.0]
+    wq = np.where(g["Q"] != 0, 1.0 / np.where(g["Q"] != 0, g["Q"], 1.0), 0.0)
+    assert np.array_equal(wq, g["model_err_weight"])                    # :310-315
+    lo, hi = fk.bounds45()
+    assert np.array_equal(np.isfinite(lo), np.isfinite(g["bounds_lo"])) and len(g["bound_rules"]) == 21
+    fin = np.isfinite(lo)
+    assert np.abs(lo[fin] - g["bounds_lo"][fin]).max() < 1e-15 and np.abs(hi[fin] - g["bounds_hi"][fin]).max() < 1e-15
+    prob = _fte_model_problem(g)
+    assert np.array_equal(prob.w, g["meas_err_weight"])                 # :302-308, binary 1/R
+    assert np.array_equal(prob.meas, g["meas"])
+    assert np.array_equal(prob.q_w, (g["model_err_weight"] / prob.Ts ** 4)[fk.ACTIVE])
+    # the inactive states are exactly those the reference gives weight 0
+    assert set(np.where(g["model_err_weight"] == 0)[0]) == set(np.setdiff1d(np.arange(45), fk.ACTIVE))
+
+
+def test_nose_line_init_matches_reference_text(golden_dir):
+    g = _g(golden_dir, "fte_model.npz")
+    s, e = int(g["start_frame"]), int(g["end_frame"])
+    tab = g["nose_table"]                                               # regression over ALL triangulated frames
+    x0 = ofte.nose_line_init(tab[:, 0], tab[:, 1:4], e - s, start_frame=s)
+    assert np.abs(x0 - g["init_x"]).max() < 1e-12
+    assert np.abs(fk.cheetah_fk(x0) - g["init_poses"]).max() < 1e-13   # :351-355
+
+
+def test_objective_matches_reference_model_text(golden_dir):
+    """obj (:486-500) with every equality of :359-399 satisfied == the oracle's reduced objective."""
+    g = _g(golden_dir, "fte_model.npz")
+    prob = _fte_model_problem(g)
+    assert g["case_max_eq_residual"].max() < 1e-9
+    for X, want, slack in zip(g["case_x"], g["case_obj"], g["case_slack_model"]):
+        cost, _g_, _H, _nb = prob.evaluate(X[:, fk.ACTIVE], need_jac=False)
+        assert abs(cost - want) < 1e-10 * abs(want), (cost, want)
+        # the eliminated slacks are the scaled third differences; slack_2 = slack_3 = 0 (free dx_1, ddx_1)
+        third = (X[3:] - 3 * X[2:-1] + 3 * X[1:-2] - X[:-3]) / prob.Ts ** 2
+        assert np.abs(slack[3:] - third).max() < 1e-6 * max(1.0, np.abs(third).max())
+        assert np.abs(slack[:3]).max() < 1e-9 * max(1.0, np.abs(third).max())
+    # case 4 has the animal behind camera 0: the reference applies no z cut, neither does the oracle
+    prob.measurement_terms(g["case_x"][4][:, fk.ACTIVE], need_jac=False)
+    assert prob.measurement_terms(g["case_x"][4][:, fk.ACTIVE], need_jac=False)[3] > 0
