@@ -11,6 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
+BUILD_ID_SOURCE = "camera_kernels.hip"      # defines acino_build_id()
 SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
 HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
@@ -87,6 +88,8 @@ REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c
 SIGNATURES = {
     "acino_last_error_string": (C.c_char_p, []),
     "acino_abi_version": (_I, []),
+    "acino_build_id": (C.c_char_p, []),
+    "acino_triangulate_pairs_pinhole": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P]),
     "acino_device_count": (_I, []),
     "acino_undistort_fisheye": (_I, [_P, _L, _P, _P, _I, _D, _P]),
     "acino_triangulate_fisheye": (_I, [_P, _P, _L, _P, _P, _P, _P]),
@@ -148,32 +151,96 @@ SIGNATURES = {
 _lib = None
 
 
-def _needs_build():
+def source_hash():
+    """sha256 over every HIP source and header (name + content): the identity of a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + HEADERS):
+        path = os.path.join(_CSRC, rel)
+        h.update(os.path.basename(rel).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_id():
+    """Build id embedded in the shared object on disk, read from the file (dlopen caches a path once loaded, so a
+    rebuilt library would keep answering with the old id inside one process).  None when absent / unstamped."""
     if not os.path.exists(SO_PATH):
-        return True
-    so_m = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > so_m for d in deps)
+        return None
+    with open(SO_PATH, "rb") as f:
+        blob = f.read()
+    i = blob.find(b"ACINO_BUILD_ID=")
+    if i < 0:
+        return None
+    return blob[i + 15:i + 31].decode("ascii", "replace")
+
+
+def _needs_build():
+    # identity, not mtimes: the .so travels with the tree (gpurun snapshot), a stale binary must not pass build()
+    return built_id() != source_hash()
 
 
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into acinoset_amd/libacinoset_hip.so (hipcc cross-compiles
-    without a GPU).  Raises on any compiler error."""
+    without a GPU).  Every source becomes one object under csrc/_obj/ keyed by the hash of its text and all
+    headers (unchanged files are not recompiled), the objects compile in parallel, and the source hash is
+    embedded as ``acino_build_id()``.  Raises on any compiler error."""
     if not force and not _needs_build():
         return SO_PATH
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-DNDEBUG"]
-    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
-    cmd += ["-o", SO_PATH]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    sid = source_hash()
+    hdr = hashlib.sha256()
+    for rel in sorted(HEADERS):
+        with open(os.path.join(_CSRC, rel), "rb") as f:
+            hdr.update(f.read())
+    objdir = os.path.join(_CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG"]
+    jobs = []
+    for src in SOURCES:
+        with open(os.path.join(_CSRC, src), "rb") as f:
+            key = hashlib.sha256(hdr.digest() + f.read() + " ".join(flags).encode()).hexdigest()[:16]
+        extra = [f'-DACINO_BUILD_ID="{sid}"'] if src == BUILD_ID_SOURCE else []
+        if extra:
+            key = hashlib.sha256((key + sid).encode()).hexdigest()[:16]
+        obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}.{key}.o")
+        jobs.append((src, obj, [hipcc] + flags + extra + ["-c", os.path.join(_CSRC, src), "-o", obj]))
+
+    def run(job):
+        src, obj, cmd = job
+        if os.path.exists(obj) and not force:
+            return None
+        for old in os.listdir(objdir):                       # one object per source is kept
+            if old.startswith(os.path.splitext(src)[0] + ".") and old.endswith(".o"):
+                os.unlink(os.path.join(objdir, old))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or res.returncode != 0:
+            print(" ".join(cmd))
+            print(res.stdout)
+            print(res.stderr)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + res.stderr[-4000:])
+        return src
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(run, jobs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[1] for j in jobs] + ["-o", SO_PATH + ".tmp"]
+    res = subprocess.run(link, capture_output=True, text=True)
     if verbose or res.returncode != 0:
-        print(" ".join(cmd))
+        print(" ".join(link))
         print(res.stdout)
         print(res.stderr)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libacinoset_hip.so:\n" + res.stderr[-4000:])
+        raise RuntimeError("hipcc failed linking libacinoset_hip.so:\n" + res.stderr[-4000:])
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    got = built_id()
+    if got != sid:
+        raise RuntimeError(f"built library reports build id {got}, sources hash to {sid}")
     return SO_PATH
 
 

@@ -148,22 +148,34 @@ def undistort_points_fisheye(pts, k, d, max_iter=10, eps=1e-8):
 
 
 # --------------------------------------------------------------------------- dense index path
-def triangulate_pairs_dense(det, thresh, k_arr, d_arr, r_arr, t_arr, return_masks=True):
+def pinhole_records(k_arr, d_arr, r_arr, t_arr):
+    k_arr, r_arr = _host(k_arr), _host(r_arr)
+    d_arr = _host(d_arr).reshape(len(k_arr), -1)
+    t_arr = _host(t_arr).reshape(len(k_arr), -1)
+    return np.stack([pinhole_record(k_arr[i], d_arr[i], r_arr[i], t_arr[i]) for i in range(len(k_arr))])
+
+
+def triangulate_pairs_dense(det, thresh, k_arr, d_arr, r_arr, t_arr, return_masks=True, model="fisheye"):
     """det[N,C,L,3] (x, y, likelihood) -> tri[N,L,3] (NaN where no adjacent pair), npairs[N,L] u8,
-    pairmask[N,L] u8.  The dense form of get_pairwise_3d_points_from_df (adjacent pairs, mean)."""
+    pairmask[N,L] u8.  The dense form of get_pairwise_3d_points_from_df (adjacent pairs, mean).
+    ``model``: "fisheye" (triangulate_points_fisheye, calib.py:121-130) or "pinhole" (triangulate_points,
+    calib.py:52-61) - the two functions the reference injects through ``triangulate_func`` (app.py:215-223)."""
     dev = _dev()
     d = _to_dev(det, dev)
     if d.dim() != 4 or d.shape[-1] != 3:
         raise ValueError("det must be [N, C, L, 3]")
+    if model not in ("fisheye", "pinhole"):
+        raise ValueError("model must be 'fisheye' or 'pinhole'")
     N, Cn, L, _ = d.shape
-    cams = torch.as_tensor(fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
+    recs = fisheye_records if model == "fisheye" else pinhole_records
+    cams = torch.as_tensor(recs(k_arr, d_arr, r_arr, t_arr), device=dev)
     if cams.shape[0] != Cn:
         raise ValueError("camera count mismatch")
     tri = torch.empty((N, L, 3), dtype=torch.float64, device=dev)
     npairs = torch.empty((N, L), dtype=torch.uint8, device=dev)
     mask = torch.empty((N, L), dtype=torch.uint8, device=dev)
-    check(lib().acino_triangulate_pairs(ptr(d), N, Cn, L, float(thresh), ptr(cams), ptr(tri), ptr(npairs),
-                                        ptr(mask), stream_ptr()))
+    fn = lib().acino_triangulate_pairs if model == "fisheye" else lib().acino_triangulate_pairs_pinhole
+    check(fn(ptr(d), N, Cn, L, float(thresh), ptr(cams), ptr(tri), ptr(npairs), ptr(mask), stream_ptr()))
     if not return_masks:
         return _ret(tri, det)
     return _ret(tri, det), _ret(npairs, det), _ret(mask, det)
@@ -229,17 +241,24 @@ def get_pairwise_3d_points_from_df(points_2d_df, k_arr, d_arr, r_arr, t_arr, tri
 
     Output rows are sorted by (frame, marker) with ``frame`` as float64, exactly as the reference's
     groupby().mean().reset_index().  The caller pre-filters by likelihood (all_optimizations.py:262-263),
-    so every row present is valid.  ``triangulate_func`` is kept for signature compatibility: the fused
-    HIP kernel implements ``triangulate_points_fisheye``; any other callable raises (no CPU path here).
+    so every row present is valid.  ``triangulate_func`` is the reference's injection seam (calib.py:394,
+    412-413; app.py:215-223 injects either pair function): ``triangulate_points_fisheye`` (default) and
+    ``triangulate_points`` select the fused dense HIP kernel of that camera model; any other callable raises
+    (there is no CPU path here to run foreign Python per pair).
     Like the reference, raises KeyError when no adjacent pair exists at all.
     """
     import pandas as pd
-    if triangulate_func is not None and triangulate_func is not triangulate_points_fisheye:
-        raise NotImplementedError("the dense HIP index path implements triangulate_points_fisheye only")
+    if triangulate_func is None or triangulate_func is triangulate_points_fisheye:
+        model = "fisheye"
+    elif triangulate_func is triangulate_points:
+        model = "pinhole"
+    else:
+        raise NotImplementedError("triangulate_func must be acinoset_amd.calib.triangulate_points_fisheye or "
+                                  "acinoset_amd.calib.triangulate_points (the dense HIP index path has no CPU fallback)")
     n_cam = len(k_arr)
     det, frames, markers = dataframe_to_dense(points_2d_df, n_cam)
     det[..., 2] = np.where(np.isfinite(det[..., 2]), np.inf, -np.inf)   # presence == valid
-    tri, cnt, _ = triangulate_pairs_dense(det, 0.0, k_arr, d_arr, r_arr, t_arr)
+    tri, cnt, _ = triangulate_pairs_dense(det, 0.0, k_arr, d_arr, r_arr, t_arr, model=model)
     has = cnt > 0
     if not has.any():
         raise KeyError("['frame', 'marker'] not in index")

@@ -267,6 +267,75 @@ k_triangulate_pairs(const double* __restrict__ det, int64_t n_frames, int n_cams
   }
 }
 
+// Dense adjacent-pair triangulation with the PINHOLE model (the reference's other injected ``triangulate_func``:
+// calib.py:52-61 through the seam of calib.py:394-417; app.py:215-218 injects this pair).  Same index path as
+// k_triangulate_pairs - pairs (i, i+1), Kahan mean in pair order, NaN when no pair - with cv2.undistortPoints'
+// 5-step fixed-point undistortion.  One thread per (frame, marker); the 24-byte records are read from HBM directly
+// (the pinhole path is the calibration-time SBA preparation, not the per-frame hot loop).
+__global__ void __launch_bounds__(256)
+k_triangulate_pairs_pinhole(const double* __restrict__ det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                            const double* __restrict__ cams, double* __restrict__ tri, uint8_t* __restrict__ npairs,
+                            uint8_t* __restrict__ pairmask) {
+  __shared__ Pin c[ACINO_MAX_PAIR_CAMS];
+  __shared__ Cam e[ACINO_MAX_PAIR_CAMS];     // only R, t are read by the DLT
+  for (int i = threadIdx.x; i < n_cams * ACINO_PINHOLE_STRIDE; i += blockDim.x)
+    reinterpret_cast<double*>(c)[i] = cams[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_cams * 12; i += blockDim.x) {
+    const int ci = i / 12, j = i % 12;
+    if (j < 9) e[ci].R[j] = c[ci].R[j];
+    else e[ci].t[j - 9] = c[ci].t[j - 9];
+  }
+  __syncthreads();
+  const int64_t total = n_frames * n_markers;
+  const int64_t frame_doubles = (int64_t)n_cams * n_markers * 3;
+  for (int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t n = idx / n_markers;
+    const int l = (int)(idx - n * n_markers);
+    const double* base = det + n * frame_doubles + (int64_t)l * 3;
+    double sum[3] = {0, 0, 0}, comp[3] = {0, 0, 0};
+    int cnt = 0;
+    unsigned mask = 0;
+    bool pv = false;
+    double px = 0, py = 0;
+    for (int ci = 0; ci < n_cams; ++ci) {
+      const double* d = base + (int64_t)ci * n_markers * 3;
+      const double u = d[0], v = d[1], lik = d[2];
+      const bool valid = lik > thresh;
+      double x = 0, y = 0;
+      if (valid) undistort_pinhole_pt(c[ci], u, v, x, y);
+      if (valid && pv) {
+        double X[3];
+        triangulate_two_view(e[ci - 1], e[ci], px, py, x, y, X);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // Kahan step (pandas group mean)
+          double yk = X[k] - comp[k];
+          double t = sum[k] + yk;
+          comp[k] = (t - sum[k]) - yk;
+          sum[k] = t;
+        }
+        ++cnt;
+        mask |= 1u << (ci - 1);
+      }
+      pv = valid;
+      px = x;
+      py = y;
+    }
+    double X = __builtin_nan(""), Y = X, Z = X;
+    if (cnt > 0) {
+      X = sum[0] / cnt;
+      Y = sum[1] / cnt;
+      Z = sum[2] / cnt;
+    }
+    double* o = tri + idx * 3;
+    o[0] = X;
+    o[1] = Y;
+    o[2] = Z;
+    if (npairs) npairs[idx] = (uint8_t)cnt;
+    if (pairmask) pairmask[idx] = (uint8_t)mask;
+  }
+}
+
 // Reprojection residual of pts3[N][L][3] in every camera; one thread per (frame, marker).
 __global__ void __launch_bounds__(256)
 k_reproject_residuals(const double* __restrict__ pts3, const double* __restrict__ det, int64_t n_frames, int n_cams,
@@ -334,6 +403,11 @@ extern "C" {
 
 const char* acino_last_error_string(void) { return acino::last_error(); }
 int acino_abi_version(void) { return ACINO_ABI_VERSION; }
+#ifndef ACINO_BUILD_ID
+#define ACINO_BUILD_ID "unstamped"
+#endif
+static const char k_build_id[] = "ACINO_BUILD_ID=" ACINO_BUILD_ID;   // the tag lets build() read it from the file
+const char* acino_build_id(void) { return k_build_id + 15; }
 size_t acino_sizeof_fte_params(void) { return sizeof(acino_fte_params); }
 size_t acino_sizeof_fte_state(void) { return sizeof(acino_fte_state); }
 int acino_device_count(void) {
@@ -426,18 +500,32 @@ int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, i
                             const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                             void* stream) {
   ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
-  ACINO_REQUIRE(n_cams >= 1 && n_cams <= 8, "n_cams must be 1..8 (pair mask is one byte)");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= ACINO_MAX_PAIR_CAMS, "n_cams must be 1..8 (pair mask is one byte)");
   if (n_frames == 0 || n_markers == 0) return ACINO_OK;
   ACINO_REQUIRE(d_det && d_cams24 && d_tri, "null buffer");
   return launch_pairs(false, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, nullptr,
                       nullptr, stream);
 }
 
+int acino_triangulate_pairs_pinhole(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                                    const double* d_cams32, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                                    void* stream) {
+  ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= ACINO_MAX_PAIR_CAMS, "n_cams must be 1..8 (pair mask is one byte)");
+  if (n_frames == 0 || n_markers == 0) return ACINO_OK;
+  ACINO_REQUIRE(d_det && d_cams32 && d_tri, "null buffer");
+  hipLaunchKernelGGL(k_triangulate_pairs_pinhole, dim3(grid_for(n_frames * n_markers, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_det, n_frames, n_cams, n_markers, thresh, d_cams32, d_tri, d_npairs,
+                     d_pairmask);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
 int acino_triangulate_reproject(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                                 const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                                 double* d_res, double* d_sums, void* stream) {
   ACINO_REQUIRE(n_frames >= 0 && n_markers >= 0, "sizes");
-  ACINO_REQUIRE(n_cams >= 1 && n_cams <= 8, "n_cams must be 1..8 (pair mask is one byte)");
+  ACINO_REQUIRE(n_cams >= 1 && n_cams <= ACINO_MAX_PAIR_CAMS, "n_cams must be 1..8 (pair mask is one byte)");
   if (n_frames == 0 || n_markers == 0) return ACINO_OK;
   ACINO_REQUIRE(d_det && d_cams24 && d_tri && d_res, "null buffer");
   return launch_pairs(true, d_det, n_frames, n_cams, n_markers, thresh, d_cams24, d_tri, d_npairs, d_pairmask, d_res,

@@ -191,22 +191,34 @@ def cheetah_fk(q):
     return calib._ret(pos, q)
 
 
-def nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, n_frames=None, start_frame=0):
+def nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, n_frames=None, start_frame=0, det_first_frame=None):
     """Initial guess of :262-277,333-337: adjacent-pair triangulation of the detections above the
     likelihood threshold, least-squares line (linregress) through the nose (marker 2) over frames,
-    psi_0 = atan2(y_slope, x_slope), every other state 0.  Returns x0[N,45] (numpy)."""
+    psi_0 = atan2(y_slope, x_slope), every other state 0.  Returns x0[N,45] (numpy) for the frames
+    start_frame .. start_frame + N - 1.
+
+    The reference regresses over ALL triangulated frames of the video (:268-271) and evaluates the line on the window
+    (:272-276, :334-337): pass the whole video's detections with ``det_first_frame=0`` and the window through
+    ``start_frame`` / ``n_frames`` for exactly that.  By default (``det_first_frame=None``) ``det`` IS the window -
+    its first row is frame ``start_frame`` - and the line is fitted to the window's own frames."""
     tri = calib.triangulate_pairs_dense(det, dlc_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
     nose = tri[:, 2] if isinstance(tri, np.ndarray) else tri[:, 2].cpu().numpy()
-    N = nose.shape[0] if n_frames is None else n_frames
+    first = start_frame if det_first_frame is None else det_first_frame
+    N = (nose.shape[0] if det_first_frame is None else nose.shape[0] - (start_frame - first)) if n_frames is None else n_frames
     ok = np.isfinite(nose).all(1)
     if ok.sum() < 2:
         raise ValueError("fewer than two triangulated nose points: cannot fit the initial line")
-    f = np.arange(nose.shape[0], dtype=np.float64)[ok] + start_frame
+    return nose_line_from_points(np.arange(nose.shape[0], dtype=np.float64)[ok] + first, nose[ok], N, start_frame)
+
+
+def nose_line_from_points(frames, nose_xyz, n_frames, start_frame=0):
+    """The regression itself (:268-277, :333-337) on a table of triangulated nose points (frame, xyz)."""
+    f = np.asarray(frames, dtype=np.float64)
     A = np.stack([f, np.ones_like(f)], 1)
-    coef, *_ = np.linalg.lstsq(A, nose[ok], rcond=None)
-    frames = np.arange(start_frame, start_frame + N, dtype=np.float64)
-    x0 = np.zeros((N, N_STATES))
-    x0[:, 0:3] = frames[:, None] * coef[0][None, :] + coef[1][None, :]
+    coef, *_ = np.linalg.lstsq(A, np.asarray(nose_xyz, dtype=np.float64), rcond=None)
+    out_frames = np.arange(start_frame, start_frame + n_frames, dtype=np.float64)
+    x0 = np.zeros((n_frames, N_STATES))
+    x0[:, 0:3] = out_frames[:, None] * coef[0][None, :] + coef[1][None, :]
     x0[:, PSI + 0] = np.arctan2(coef[0][1], coef[0][0])
     return x0
 

@@ -110,8 +110,8 @@ def secondary_metrics(det, rig, Ts):
                                                 hbm_gbs=N * bytes_per_frame / (ms * 1e-3) / 1e9,
                                                 frac_hbm=N * bytes_per_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 algorithmic_bytes_per_frame=bytes_per_frame)
-    # config 3: 1 000-frame sprint, nose-line init (all_optimizations.py:268-277), solve to the default tolerances (ftol = xtol = 1e-10)
-    seq = synth.make_sequence(1000, "sprint")
+    # config 3: 1 000-frame straight run through the rig ("trot"), nose-line init (all_optimizations.py:268-277), solve to the default tolerances (ftol = xtol = 1e-10)
+    seq = synth.make_sequence(1000, "trot")
     r3 = (seq["K"], seq["D"], seq["R"], seq["t"])
     det3 = torch.as_tensor(seq["det"], device=dev)
     for tag in ("warm", "timed"):

@@ -10,7 +10,8 @@
  *   acino_triangulate_pinhole        triangulate_points               src/calib/calib.py:52-61
  *   acino_project_fisheye            project_points_fisheye           src/calib/calib.py:132-136
  *   acino_project_pinhole            project_points                   src/calib/calib.py:64-66
- *   acino_triangulate_pairs          get_pairwise_3d_points_from_df   src/calib/calib.py:394-423
+ *   acino_triangulate_pairs          get_pairwise_3d_points_from_df   src/calib/calib.py:394-423 (triangulate_func = triangulate_points_fisheye)
+ *   acino_triangulate_pairs_pinhole  get_pairwise_3d_points_from_df   src/calib/calib.py:394-423 (triangulate_func = triangulate_points; app.py:215-218)
  *   acino_reproject_residuals        project(triangulate(.)) - pts    src/calib/calib.py:312-316 (cost_func_points_only)
  *   acino_triangulate_reproject      the two above fused (one pass over the detections)
  *   acino_cheetah_fk                 pose_to_3d                       src/all_optimizations.py:66-190
@@ -56,12 +57,16 @@ typedef enum acino_status {
 #define ACINO_CAM_STRIDE 24
 #define ACINO_PINHOLE_STRIDE 32
 #define ACINO_MAX_CAMS 16
+#define ACINO_MAX_PAIR_CAMS 8   /* dense pair path: the pair mask is one byte (pairs (c, c+1), c < 7) */
 #define ACINO_N_MARKERS 20     /* cheetah markers (all_optimizations.py:170-179)            */
 #define ACINO_N_STATES 45      /* x,y,z, phi_0..13, theta_0..13, psi_0..13                   */
 #define ACINO_N_ACTIVE 25      /* states with Q != 0 (all_optimizations.py:245-252)          */
 
 const char* acino_last_error_string(void);
 int acino_abi_version(void);
+/* sha256 prefix over every HIP source and header this binary was built from (acinoset_amd/_lib.py::source_hash):
+ * build() and the profile stamps compare it instead of file times. */
+const char* acino_build_id(void);
 /* Number of visible HIP devices, or a negative status. */
 int acino_device_count(void);
 
@@ -85,10 +90,14 @@ int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32,
  * For each (frame, marker): triangulate every adjacent camera pair (c, c+1) with both valid, take
  * the Kahan-compensated mean in pair order (what pandas' groupby().mean() computes).
  * d_tri[N][L][3] (NaN when no pair), d_npairs[N][L] u8, d_pairmask[N][L] u8 (bit c = pair (c,c+1)).
- * d_npairs / d_pairmask may be NULL. */
+ * d_npairs / d_pairmask may be NULL.  1 <= n_cams <= ACINO_MAX_PAIR_CAMS. */
 int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                             const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                             void* stream);
+/* The same index path with the injected pinhole pair (calib.py:52-61): d_cams32 = C pinhole records. */
+int acino_triangulate_pairs_pinhole(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
+                                    const double* d_cams32, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
+                                    void* stream);
 /* The two calls below in one pass over d_det (BASELINE configs[1]: triangulation + reprojection residual of the
  * triangulated points in every camera): d_tri / d_npairs / d_pairmask as acino_triangulate_pairs, d_res / d_sums as
  * acino_reproject_residuals applied to d_tri. */

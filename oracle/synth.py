@@ -53,16 +53,19 @@ def trajectory(n_frames, kind="loop", seed_phase=0.0):
     """Ground-truth 45-state trajectory; all 21 angle boxes hold."""
     tt = np.arange(n_frames) / FPS
     q = np.zeros((n_frames, fk.N_STATES))
-    if kind == "loop":
-        radius, speed = 2.5, 10.0
+    if kind in ("loop", "walk"):
+        radius, speed = 2.5, (10.0 if kind == "loop" else 2.0)
         om = speed / radius
         ang = om * tt + seed_phase
         q[:, 0] = LOOK_AT[0] + radius * np.cos(ang)
         q[:, 1] = LOOK_AT[1] + radius * np.sin(ang)
         q[:, 2] = LOOK_AT[2]
         q[:, fk.PSI + 0] = ang + np.pi / 2                       # unwrapped tangent heading
-    elif kind == "sprint":
-        speed = 10.0
+    elif kind in ("sprint", "trot"):
+        # "trot": the same straight run at 1.2 m/s - 1 000 frames span 10 m, i.e. stay inside the rig's field of view
+        # (a 10 m/s sprint of 1 000 frames is 83 m long: most of it is seen by no camera and constrained by the
+        # smoothness prior alone).  The straight nose-line initialisation of the reference fits both.
+        speed = 10.0 if kind == "sprint" else 1.2
         span = speed * (n_frames - 1) / FPS
         heading = 0.35 + seed_phase
         dirv = np.array([np.cos(heading), np.sin(heading)])

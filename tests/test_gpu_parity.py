@@ -160,6 +160,42 @@ def test_pair_index_path_bit_exact(mods, seq60, golden_dir):
         calib.get_pairwise_3d_points_from_df(df, *rig, lambda *a: None)
 
 
+def test_pair_index_path_pinhole_seam(mods, seq60):
+    """The reference's injection seam (calib.py:394-417; app.py:215-218 injects the pinhole pair): passing
+    ``triangulate_points`` selects the dense pinhole pair kernel.  Index path bit-exact, values to 1e-9."""
+    calib = mods[0]
+    K, R, t = seq60["K"], seq60["R"], seq60["t"]
+    rng = np.random.default_rng(5)
+    # OpenCV rational model (k1 k2 p1 p2 k3 k4 k5 k6), as calibrated with CALIB_RATIONAL_MODEL (calib.py:18)
+    D = np.tile(np.array([0.11, -0.05, 1e-3, -7e-4, 0.01, 0.02, -0.01, 2e-3]), (6, 1)) * rng.uniform(0.8, 1.2, (6, 8))
+    N, L = 40, 20
+    det = np.zeros((N, 6, L, 3))
+    for c in range(6):
+        det[:, c, :, :2] = ocam.project_points(seq60["pos_true"][:N].reshape(-1, 3), K[c], D[c], R[c], t[c]).reshape(N, L, 2)
+    det[..., :2] += rng.normal(0, 1.0, det[..., :2].shape)
+    det[..., 2] = np.where(rng.uniform(size=(N, 6, L)) < 0.35, 0.2, 0.9)
+    det[3, :, :, 2] = 0.0
+    det[4, 1:, 2, 2] = 0.0
+    rig = (K, D, R, t)
+    tri, cnt, mask = calib.triangulate_pairs_dense(det, 0.5, *rig, model="pinhole")
+    tro, cno, mko = oidx.pairwise_dense(det, 0.5, *rig, ocam.triangulate_points)
+    assert np.array_equal(cnt, cno) and np.array_equal(mask, mko) and cnt.max() >= 4
+    assert np.array_equal(np.isnan(tri), np.isnan(tro)) and np.isnan(tri[3]).all() and np.isnan(tri[4, 2]).all()
+    assert np.nanmax(np.abs(tri - tro)) < 1e-9
+    # the pinhole pair is a different function from the fisheye pair on the same data
+    trf = calib.triangulate_pairs_dense(det, 0.5, K, D[:, :4], R, t, return_masks=False)
+    assert np.nanmax(np.abs(trf - tri)) > 1e-3
+    import pandas as pd
+    rows = [dict(frame=n, camera=c, marker=f"m{l:02d}", x=det[n, c, l, 0], y=det[n, c, l, 1], likelihood=det[n, c, l, 2])
+            for c in range(6) for n in range(10) for l in range(20)]
+    df = pd.DataFrame(rows)
+    df = df[df["likelihood"] > 0.5]
+    out = calib.get_pairwise_3d_points_from_df(df, *rig, calib.triangulate_points)
+    ref = oidx.get_pairwise_3d_points_from_df(df, *rig, ocam.triangulate_points)
+    assert list(out["frame"]) == list(ref["frame"]) and list(out["marker"]) == list(ref["marker"])
+    assert np.abs(out[["x", "y", "z"]].to_numpy() - ref[["x", "y", "z"]].to_numpy()).max() < 1e-9
+
+
 def _ctx(fte, seq, **kw):
     return fte.FTEContext(seq["det"], seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], **kw)
 
@@ -216,6 +252,59 @@ def test_fte_solve_matches_oracle_trajectory(mods, n, kind):
     assert np.allclose(res["x"][1:], res["x"][:-1] + Ts * res["dx"][1:], atol=1e-12)
     assert np.allclose(res["dx"][1:], res["dx"][:-1] + Ts * res["ddx"][1:], atol=1e-9 * max(1, np.abs(res["dx"]).max()))
     assert res["ddx"].shape == (n, 25) and np.allclose(res["ddx"][0], res["ddx"][2]) and np.allclose(res["ddx"][1], res["ddx"][2])
+
+
+def test_nose_line_init_equals_oracle_and_reference_text(mods, golden_dir):
+    """a-9: fte.nose_line_init == oracle.fte.nose_line_init on the same triangulation, and the regression itself
+    reproduces init_x of the reference's own text (fte_model.npz, all_optimizations.py:268-277, 333-337)."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(90, "sprint")
+    det = seq["det"].copy()
+    det[10:14, :, 2, 2] = 0.0                                     # frames without a nose
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    tri = calib.triangulate_pairs_dense(det, 0.5, *rig, return_masks=False)
+    ok = np.isfinite(tri[:, 2]).all(1)
+    assert not ok[10:14].any() and ok.sum() > 60
+    # window == det
+    got = fte.nose_line_init(det, *rig, 0.5)
+    want = ofte.nose_line_init(np.arange(90.0)[ok], tri[ok, 2], 90, start_frame=0)
+    assert np.abs(got - want).max() < 1e-10
+    # the reference's form: regression over the whole video, window [20, 70)
+    got = fte.nose_line_init(det, *rig, 0.5, n_frames=50, start_frame=20, det_first_frame=0)
+    want = ofte.nose_line_init(np.arange(90.0)[ok], tri[ok, 2], 50, start_frame=20)
+    assert got.shape == (50, 45) and np.abs(got - want).max() < 1e-10
+    g = np.load(os.path.join(golden_dir, "fte_model.npz"))
+    s, e = int(g["start_frame"]), int(g["end_frame"])
+    x0 = fte.nose_line_from_points(g["nose_table"][:, 0], g["nose_table"][:, 1:4], e - s, start_frame=s)
+    assert np.abs(x0 - g["init_x"]).max() < 1e-12
+
+
+def test_config3_exact_size_against_committed_oracle_solution(mods, golden_dir):
+    """BASELINE config 3 at its exact workload: 6 cameras x 20 markers x 1 000 frames, nose-line initialisation,
+    solve to the default tolerances - against tests/golden/config3_solution.npz (oracle LM, made by
+    tests/golden/make_config3.py in the build container)."""
+    calib, fte, synth = mods
+    from oracle import synth as osynth
+    g = np.load(os.path.join(golden_dir, "config3_solution.npz"))
+    N = int(g["n_frames"])
+    seq = osynth.make_sequence(N, str(g["kind"]), seed=int(g["seed"]))           # the seeded CPU generator of the fixture
+    det = seq["det"]
+    assert abs(float(det.sum()) - float(g["det_checksum"])) < 1e-6 * abs(float(g["det_checksum"]))
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = fte.nose_line_init(det, *rig, 0.5)
+    assert np.abs(x0[[0, -1], :3] - g["x0_line"]).max() < 1e-8 and abs(x0[0, 31] - float(g["psi0"])) < 1e-9
+    res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x0, max_iter=200)
+    assert info["status_name"] in ("ftol", "xtol", "gtol"), info
+    want_cost = float(g["cost"])
+    assert abs(info["cost"] - want_cost) < 1e-6 * abs(want_cost), (info["cost"], want_cost)
+    assert abs(info["iter"] - int(g["iterations"])) <= 3, (info["iter"], int(g["iterations"]))
+    q = np.zeros((N, 45))
+    q[:, ofk.ACTIVE] = g["x"]
+    pos_o = ofk.cheetah_fk(q)
+    assert np.abs(pos_o[::50] - g["positions_probe"]).max() < 1e-12
+    err = np.abs(res["positions"] - pos_o).max()
+    assert err < 1e-3, err                                                      # north_star tolerance, metres
+    assert np.abs(res["positions"] - seq["pos_true"]).max() < 0.1
 
 
 def test_edge_cases(mods):
