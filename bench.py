@@ -40,19 +40,12 @@ FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD data
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
-    """The numpy/scipy oracle's LM iteration timed on the host, 1 thread, on a bounded sample."""
-    from oracle import fk as ofk
+def _oracle_lm_iterations(det, rig, Ts, x0_active, iters):
+    """`iters` LM iterations (+ the initial evaluation) of the numpy/scipy oracle on one block of frames; seconds."""
     from oracle import fte as ofte
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
-    except Exception:                                  # pragma: no cover
-        limiter = None
-    n = min(sample_frames, det.shape[0])
     K, D, R, t = rig
-    prob = ofte.FTEProblem(det[:n, ..., :2], det[:n, ..., 2], K, D, R, t, Ts)
-    x = np.clip(x0_full[:n, ofk.ACTIVE], prob.lo, prob.hi)
+    prob = ofte.FTEProblem(det[..., :2], det[..., 2], K, D, R, t, Ts)
+    x = np.clip(x0_active, prob.lo, prob.hi)
     t0 = time.perf_counter()
     F, g, H, _ = prob.evaluate(x)
     lam = 1e-3
@@ -66,13 +59,87 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
             lam /= 3
         else:
             lam *= 2
-    dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
+    return time.perf_counter() - t0
+
+
+def _oracle_worker(args):
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:                                  # pragma: no cover
+        pass
+    return _oracle_lm_iterations(*args)
+
+
+def probe_reference_cpu_path():
+    """SURVEY 8(d) "CPU baseline timing" (ii): is the reference's own CPU path (Pyomo + IPOPT, cv2) on this host?"""
+    import importlib.util
+    import shutil
+    have = {m: importlib.util.find_spec(m) is not None for m in ("cv2", "pyomo")}
+    have["ipopt"] = shutil.which("ipopt") is not None
+    missing = [k for k, v in have.items() if not v]
+    if missing:
+        return dict(available=False, probe=have,
+                    note="reference CPU path unavailable on this host (missing: " + ", ".join(missing) +
+                         "): the Pyomo/IPOPT FTE solve and the cv2 triangulation cannot be timed here; the baseline "
+                         "below is this repo's numpy/scipy oracle of the same LM iteration (kind = port)")
+    return dict(available=True, probe=have, note="pyomo, ipopt and cv2 are importable on this host (not timed: the "
+                "repo ships no Pyomo formulation; the oracle port below is the reported baseline)")
+
+
+def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
+    """The numpy/scipy oracle's LM iteration timed on the host on a bounded sample: 1 thread on the first
+    `sample_frames` frames, then all cores (one single-threaded oracle process per core, each on its own contiguous
+    block of the same frames - the frame-sharded form of the same iteration), plus BASELINE config 1 (one frame,
+    6-camera adjacent-pair triangulation of 20 keypoints through the oracle's numpy path)."""
+    import multiprocessing as mp
+    from oracle import camera as ocam
+    from oracle import fk as ofk
+    from oracle import index_path as oidx
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:                                  # pragma: no cover
+        limiter = None
+    n = min(sample_frames, det.shape[0])
+    xa = x0_full[:n, ofk.ACTIVE]
+    dt = _oracle_lm_iterations(det[:n], rig, Ts, xa, iters)
     per_iter = dt / (iters + 0.5)      # the initial evaluation is ~half an iteration of work
-    return dict(value=n / per_iter, unit="frames/s", cores=1, kind="port",
-                sample=f"{iters} LM iterations (+ initial evaluation) of the numpy/scipy oracle on the first {n} "
-                       f"frames of the same sequence, 1 thread, {dt:.1f} s")
+    # config 1: N = 1
+    t0 = time.perf_counter()
+    reps = 200
+    for _ in range(reps):
+        oidx.pairwise_dense(det[:1], 0.5, *rig, ocam.triangulate_points_fisheye)
+    c1 = (time.perf_counter() - t0) / reps
+    if limiter is not None and hasattr(limiter, "restore_original_limits"):
+        limiter.restore_original_limits()
+    out = dict(value=n / per_iter, unit="frames/s", cores=1, kind="port",
+               sample=f"{iters} LM iterations (+ initial evaluation) of the numpy/scipy oracle on the first {n} "
+                      f"frames of the same sequence, 1 thread, {dt:.1f} s",
+               reference_cpu_path=probe_reference_cpu_path(),
+               config1_single_frame_triangulation=dict(seconds_per_frame=c1, frames_per_s=1.0 / c1, cores=1,
+                                                       what="oracle.index_path.pairwise_dense on 1 frame x 6 cameras x "
+                                                            "20 keypoints (5 adjacent pairs, numpy SVD DLT), mean of "
+                                                            f"{reps} calls"))
+    ncpu = os.cpu_count() or 1
+    procs = max(1, min(ncpu, 64, n // 96))
+    try:
+        bounds = np.linspace(0, n, procs + 1).astype(int)
+        jobs = [(det[a:b], rig, Ts, xa[a:b], iters) for a, b in zip(bounds[:-1], bounds[1:])]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(procs) as pool:
+            pool.map(_oracle_worker, jobs[:procs])         # warm: interpreter start + imports are not the oracle's work
+            t1 = time.perf_counter()
+            each = pool.map(_oracle_worker, jobs)
+        wall = time.perf_counter() - t1
+        out["all_cores"] = dict(value=n / (wall / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu,
+                                sample=f"the same {n} frames cut into {procs} contiguous blocks, one single-threaded "
+                                       f"oracle process per block, {iters} LM iterations each, wall {wall:.1f} s "
+                                       f"(slowest block {max(each):.1f} s); blocks are solved independently (no "
+                                       "coupling across block boundaries), i.e. an upper bound for a sharded CPU port")
+    except Exception as exc:                           # pragma: no cover
+        out["all_cores"] = dict(value=None, error=repr(exc), nproc=ncpu)
+    return out
 
 
 def secondary_metrics(det, rig, Ts):
