@@ -31,7 +31,7 @@ class FteParams(C.Structure):
                 ("redesc_c", C.c_double), ("q_w", C.c_double * N_ACTIVE), ("lo", C.c_double * N_ACTIVE),
                 ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
                 ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32),
-                ("clip_len", C.c_int64)]
+                ("clip_len", C.c_int64), ("precision", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class FteState(C.Structure):

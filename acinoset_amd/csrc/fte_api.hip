@@ -449,6 +449,7 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->gtol = p->gtol;
   c->lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
   c->clamp_lambda = p->clamp_lambda;
+  c->precision = p->precision;
   memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
   return ACINO_OK;
 }
@@ -461,6 +462,7 @@ static int validate(const acino_fte_params* p) {
                 "shard range inside the sequence");
   ACINO_REQUIRE(!p->pin_left || (p->n_offset >= 3 && p->n_offset % 3 == 0), "pinned-left shard must start at a multiple of 3");
   ACINO_REQUIRE(p->clip_len >= 0, "clip_len");
+  ACINO_REQUIRE(p->precision == ACINO_PREC_F64 || p->precision == ACINO_PREC_BF16_ROWS, "precision");
   ACINO_REQUIRE(p->clip_len == 0 || (!p->pin_left && !p->pin_right && p->n_offset == 0 && p->n_global == p->n_frames &&
                                      p->n_frames % p->clip_len == 0),
                 "clips: single-GPU context whose n_frames is a multiple of clip_len");

@@ -32,7 +32,42 @@ struct FrameLds {
 // index of (i,j), i<=j, in the packed upper triangle of a 6x6
 __device__ __forceinline__ int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
-template <bool JAC>
+// float twin of redescending<> (common.hpp) for the mixed-precision rows of ACINO_PREC_BF16_ROWS
+struct LossF {
+  float a, b, c, ea, eb, ec, d0, t4, icb;
+};
+template <bool DERIV>
+__device__ __forceinline__ void redescending_f(const LossF& L, float err, float& rho, float& drho, float& h) {
+  const float e = fabsf(err);
+  const float u = __expf(-e);
+  const float da = 1.0f + L.ea * u, db = 1.0f + L.eb * u, dc = 1.0f + L.ec * u;
+  const float inv = __frcp_rn(da * db * dc);
+  const float sa = inv * (db * dc), sb = inv * (da * dc), sc = inv * (da * db);
+  const float cb = L.c - L.b;
+  const float t2 = L.a * e - L.a * L.a * 0.5f;
+  const float ce = (L.c - e) * L.icb;
+  const float t3 = L.a * L.b - L.a * L.a * 0.5f + (L.a * cb * 0.5f) * (1.0f - ce * ce);
+  rho = (1.0f - sa) * 0.5f * e * e + (sa - sb) * t2 + (sb - sc) * t3 + sc * L.t4;
+  if (DERIV) {
+    const float dsa = sa * (1.0f - sa), dsb = sb * (1.0f - sb), dsc = sc * (1.0f - sc);
+    drho = -dsa * 0.5f * e * e + (1.0f - sa) * e + (dsa - dsb) * t2 + (sa - sb) * L.a + (dsb - dsc) * t3 +
+           (sb - sc) * (L.a * ce) + dsc * L.t4;
+    const float hh = e > 1e-6f ? (drho - L.d0) * __frcp_rn(e) : 1.0f;
+    h = fminf(fmaxf(hh, 0.0f), 1.0f);
+  }
+}
+// bf16 storage rounding (round-to-nearest-even on the upper 16 bits of the float)
+__device__ __forceinline__ float bf16_round(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
+// PREC = ACINO_PREC_F64: everything fp64.  PREC = ACINO_PREC_BF16_ROWS (BASELINE config 5): camera-frame coordinates
+// in fp64, projection / Jacobian / robust weights in fp32, the scaled residuals and the 2x3 Jacobian ROWS rounded to
+// bf16, M_l and v_l accumulated in fp32; from Lambda_l on (phases C-tail, D, E) fp64 as before.  The cost is summed in
+// fp64 from the UNROUNDED fp32 residuals (accept / reject decisions need more than 8 bits).
+template <bool JAC, int PREC>
 __global__ void __launch_bounds__(256)
 k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
                const double* __restrict__ det, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -101,6 +136,13 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     const int n = f0 + f;
     const double px = F[f].pos[l][0], py = F[f].pos[l][1], pz = F[f].pos[l][2];
     double M[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+    float Mf[6] = {0, 0, 0, 0, 0, 0}, vf[3] = {0, 0, 0};
+    LossF lossf;
+    if (PREC == ACINO_PREC_BF16_ROWS) {
+      lossf.a = (float)K.loss.a; lossf.b = (float)K.loss.b; lossf.c = (float)K.loss.c;
+      lossf.ea = (float)K.loss.ea; lossf.eb = (float)K.loss.eb; lossf.ec = (float)K.loss.ec;
+      lossf.d0 = (float)K.loss.d0; lossf.t4 = (float)K.loss.t4; lossf.icb = (float)K.loss.icb;
+    }
     double rho0, dd, hh;
     redescending<false>(K.loss, 0.0, rho0, dd, hh);
     int behind = 0;
@@ -132,49 +174,111 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
         my_cost += 2.0 * rho0;
         continue;
       }
-      double iz = rcp64(zc);
-      double a = xc * iz, b = yc * iz;
-      const double r2 = a * a + b * b + 1e-12;
-      const double ir = rsqrt(r2);                 // every later "/ r" is a multiplication
-      double r = r2 * ir;
-      double th = atan(r);
-      double th2 = th * th;
-      double poly = 1 + th2 * (cam.k1 + th2 * (cam.k2 + th2 * (cam.k3 + th2 * cam.k4)));
-      double thD = th * poly;
-      double m = thD * ir;
-      double su = w * (cam.fx * a * m + cam.cx - um);
-      double sv = w * (cam.fy * b * m + cam.cy - vm);
-      double rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0;
-      redescending<JAC>(K.loss, su, rho_u, drho_u, h_u);
-      redescending<JAC>(K.loss, sv, rho_v, drho_v, h_v);
-      my_cost += rho_u + rho_v;
-      if (JAC) {
-        double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
-        double dm_dr = (dthD * rcp64(1 + r2) * r - thD) * (ir * ir);
-        double dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
-        double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
-        double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
-        double uc0 = du_da * iz, uc1 = du_db * iz, uc2 = -(du_da * a + du_db * b) * iz;
-        double vc0 = dv_da * iz, vc1 = dv_db * iz, vc2 = -(dv_da * a + dv_db * b) * iz;
-        double ju[3], jv[3];
+      if (PREC == ACINO_PREC_BF16_ROWS) {
+        // ---- fp32 projection from the fp64 camera-frame point; the pixel offset (c - z) is formed in fp64 first
+        const float xf = (float)xc, yf = (float)yc, zf = (float)zc;
+        const float izf = __frcp_rn(zf);
+        const float a = xf * izf, b = yf * izf;
+        const float r2 = a * a + b * b + 1e-12f;
+        const float ir = __frsqrt_rn(r2);
+        const float r = r2 * ir;
+        const float th = atanf(r);
+        const float th2 = th * th;
+        const float k1 = (float)cam.k1, k2 = (float)cam.k2, k3 = (float)cam.k3, k4 = (float)cam.k4;
+        const float fxf = (float)cam.fx, fyf = (float)cam.fy, wf = (float)w;
+        const float poly = 1.0f + th2 * (k1 + th2 * (k2 + th2 * (k3 + th2 * k4)));
+        const float thD = th * poly;
+        const float m = thD * ir;
+        const float su_f = wf * (fxf * a * m + (float)(cam.cx - um));
+        const float sv_f = wf * (fyf * b * m + (float)(cam.cy - vm));
+        // the residual ROW as stored: bf16
+        const float su = bf16_round(su_f), sv = bf16_round(sv_f);
+        float rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0, dmy0 = 0, dmy1 = 0;
+        redescending_f<false>(lossf, su_f, rho_u, dmy0, dmy1);          // cost: unrounded residual, summed in fp64
+        redescending_f<false>(lossf, sv_f, rho_v, dmy0, dmy1);
+        my_cost += (double)rho_u + (double)rho_v;
+        if (JAC) {
+          float r0, r1;
+          redescending_f<true>(lossf, su, r0, drho_u, h_u);             // weights: from the stored (bf16) residual
+          redescending_f<true>(lossf, sv, r1, drho_v, h_v);
+          const float dthD = 1.0f + th2 * (3.0f * k1 + th2 * (5.0f * k2 + th2 * (7.0f * k3 + th2 * 9.0f * k4)));
+          const float dm_dr = (dthD * __frcp_rn(1.0f + r2) * r - thD) * (ir * ir);
+          const float dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
+          const float du_da = fxf * (m + a * dm_da), du_db = fxf * a * dm_db;
+          const float dv_da = fyf * b * dm_da, dv_db = fyf * (m + b * dm_db);
+          const float uc0 = du_da * izf, uc1 = du_db * izf, uc2 = -(du_da * a + du_db * b) * izf;
+          const float vc0 = dv_da * izf, vc1 = dv_db * izf, vc2 = -(dv_da * a + dv_db * b) * izf;
+          float ju[3], jv[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          ju[j] = uc0 * cam.R[j] + uc1 * cam.R[3 + j] + uc2 * cam.R[6 + j];
-          jv[j] = vc0 * cam.R[j] + vc1 * cam.R[3 + j] + vc2 * cam.R[6 + j];
+          for (int j = 0; j < 3; ++j) {                                   // the Jacobian ROWS as stored: bf16
+            ju[j] = bf16_round(uc0 * (float)cam.R[j] + uc1 * (float)cam.R[3 + j] + uc2 * (float)cam.R[6 + j]);
+            jv[j] = bf16_round(vc0 * (float)cam.R[j] + vc1 * (float)cam.R[3 + j] + vc2 * (float)cam.R[6 + j]);
+          }
+          const float gu = wf * drho_u * (su > 0 ? 1.0f : (su < 0 ? -1.0f : 0.0f));
+          const float gv = wf * drho_v * (sv > 0 ? 1.0f : (sv < 0 ? -1.0f : 0.0f));
+          const float hu = wf * wf * h_u, hv = wf * wf * h_v;
+          Mf[0] += hu * ju[0] * ju[0] + hv * jv[0] * jv[0];              // fp32 accumulation
+          Mf[1] += hu * ju[0] * ju[1] + hv * jv[0] * jv[1];
+          Mf[2] += hu * ju[0] * ju[2] + hv * jv[0] * jv[2];
+          Mf[3] += hu * ju[1] * ju[1] + hv * jv[1] * jv[1];
+          Mf[4] += hu * ju[1] * ju[2] + hv * jv[1] * jv[2];
+          Mf[5] += hu * ju[2] * ju[2] + hv * jv[2] * jv[2];
+          vf[0] += gu * ju[0] + gv * jv[0];
+          vf[1] += gu * ju[1] + gv * jv[1];
+          vf[2] += gu * ju[2] + gv * jv[2];
         }
-        double gu = w * drho_u * (su > 0 ? 1.0 : (su < 0 ? -1.0 : 0.0));
-        double gv = w * drho_v * (sv > 0 ? 1.0 : (sv < 0 ? -1.0 : 0.0));
-        double hu = w * w * h_u, hv = w * w * h_v;
-        M[0] += hu * ju[0] * ju[0] + hv * jv[0] * jv[0];
-        M[1] += hu * ju[0] * ju[1] + hv * jv[0] * jv[1];
-        M[2] += hu * ju[0] * ju[2] + hv * jv[0] * jv[2];
-        M[3] += hu * ju[1] * ju[1] + hv * jv[1] * jv[1];
-        M[4] += hu * ju[1] * ju[2] + hv * jv[1] * jv[2];
-        M[5] += hu * ju[2] * ju[2] + hv * jv[2] * jv[2];
-        v[0] += gu * ju[0] + gv * jv[0];
-        v[1] += gu * ju[1] + gv * jv[1];
-        v[2] += gu * ju[2] + gv * jv[2];
+      } else {
+        double iz = rcp64(zc);
+        double a = xc * iz, b = yc * iz;
+        const double r2 = a * a + b * b + 1e-12;
+        const double ir = rsqrt(r2);                 // every later "/ r" is a multiplication
+        double r = r2 * ir;
+        double th = atan(r);
+        double th2 = th * th;
+        double poly = 1 + th2 * (cam.k1 + th2 * (cam.k2 + th2 * (cam.k3 + th2 * cam.k4)));
+        double thD = th * poly;
+        double m = thD * ir;
+        double su = w * (cam.fx * a * m + cam.cx - um);
+        double sv = w * (cam.fy * b * m + cam.cy - vm);
+        double rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0;
+        redescending<JAC>(K.loss, su, rho_u, drho_u, h_u);
+        redescending<JAC>(K.loss, sv, rho_v, drho_v, h_v);
+        my_cost += rho_u + rho_v;
+        if (JAC) {
+          double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
+          double dm_dr = (dthD * rcp64(1 + r2) * r - thD) * (ir * ir);
+          double dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
+          double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
+          double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
+          double uc0 = du_da * iz, uc1 = du_db * iz, uc2 = -(du_da * a + du_db * b) * iz;
+          double vc0 = dv_da * iz, vc1 = dv_db * iz, vc2 = -(dv_da * a + dv_db * b) * iz;
+          double ju[3], jv[3];
+  #pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            ju[j] = uc0 * cam.R[j] + uc1 * cam.R[3 + j] + uc2 * cam.R[6 + j];
+            jv[j] = vc0 * cam.R[j] + vc1 * cam.R[3 + j] + vc2 * cam.R[6 + j];
+          }
+          double gu = w * drho_u * (su > 0 ? 1.0 : (su < 0 ? -1.0 : 0.0));
+          double gv = w * drho_v * (sv > 0 ? 1.0 : (sv < 0 ? -1.0 : 0.0));
+          double hu = w * w * h_u, hv = w * w * h_v;
+          M[0] += hu * ju[0] * ju[0] + hv * jv[0] * jv[0];
+          M[1] += hu * ju[0] * ju[1] + hv * jv[0] * jv[1];
+          M[2] += hu * ju[0] * ju[2] + hv * jv[0] * jv[2];
+          M[3] += hu * ju[1] * ju[1] + hv * jv[1] * jv[1];
+          M[4] += hu * ju[1] * ju[2] + hv * jv[1] * jv[2];
+          M[5] += hu * ju[2] * ju[2] + hv * jv[2] * jv[2];
+          v[0] += gu * ju[0] + gv * jv[0];
+          v[1] += gu * ju[1] + gv * jv[1];
+          v[2] += gu * ju[2] + gv * jv[2];
+        }
+    
       }
+    }
+    if (PREC == ACINO_PREC_BF16_ROWS) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) M[k] = (double)Mf[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = (double)vf[k];
     }
     if (behind) atomicAdd(nbehind, behind);
     if (JAC) {
@@ -354,19 +458,28 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
   const size_t lds = sizeof(FrameLds) * FPB + 64;
   static PerDeviceOnce attr;
   if (attr.first()) {
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true>),
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_F64>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false>),
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_F64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_BF16_ROWS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_BF16_ROWS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
   }
-  if (need_jac)
-    hipLaunchKernelGGL(k_fte_assemble<true>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
-                       H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
-  else
-    hipLaunchKernelGGL(k_fte_assemble<false>, dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0],
-                       H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);
+#define ACINO_LAUNCH_ASSEMBLE(J, P)                                                                                  \
+  hipLaunchKernelGGL((k_fte_assemble<J, P>), dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0], \
+                     H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0)
+  if (h_c.precision == ACINO_PREC_BF16_ROWS) {
+    if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_BF16_ROWS);
+    else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_BF16_ROWS);
+  } else {
+    if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_F64);
+    else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_F64);
+  }
+#undef ACINO_LAUNCH_ASSEMBLE
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }

@@ -26,7 +26,8 @@ struct FteConst {
   double q_w[NP], lo[NP], hi[NP];
   double ftol, xtol, gtol;
   double lam_max;
-  int32_t clamp_lambda, pad1;
+  int32_t clamp_lambda;
+  int32_t precision;       // ACINO_PREC_*
   int64_t clip_len;        // > 0: independent clips of this many frames laid end to end (no coupling across clips)
   Cam cams[ACINO_MAX_CAMS];
 };

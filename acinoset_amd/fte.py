@@ -28,6 +28,8 @@ Q_SIGMA = np.array([4, 7, 5,
                     9, 18, 43, 53, 90, 118, 247, 186, 194, 164, 295, 243, 334, 149,
                     26, 12, 0, 34, 43, 51, 0, 0, 0, 0, 0, 0, 0, 0], dtype=np.float64)
 R_MEAS = 5.0                          # measurement std-dev, px (:243)
+# acino_fte_params::precision: "f64" everywhere, or BASELINE config 5's "bf16 residuals with fp32 accumulate"
+PRECISIONS = {"f64": 0, "bf16": 1}
 REDESC = (3.0, 10.0, 20.0)            # redescending a, b, c (:25-27)
 
 
@@ -50,7 +52,7 @@ def bounds45():
 
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
-                lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0):
+                lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0, precision="f64"):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -74,6 +76,9 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
     p.lam_max, p.clamp_lambda = float(lam_max), int(bool(clamp_lambda))
     p.shared_gpu = int(bool(shared_gpu))
     p.clip_len = int(clip_len)
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    p.precision = PRECISIONS[precision]
     return p
 
 

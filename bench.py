@@ -212,27 +212,35 @@ def secondary_metrics(det, rig, Ts):
     for c in ctxs:
         c.close()
     out["config5_batched_fte_8x1k"] = dict(sequences=8, frames_each=1000, steps=20, streams=8, ms_per_round=1e3 * dt / 20,
-                                           frames_per_s=8 * 1000 * 20 / dt, precision="f64 (the bf16-residual variant is not built)")
+                                           frames_per_s=8 * 1000 * 20 / dt, precision="f64")
     # ... and at full width: 64 clips x 1 000 frames laid end to end as ONE chain (prior cut at the clip boundaries)
     det64 = det3.repeat(64, 1, 1, 1)
-    c = fte.FTEContext(det64, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, clip_len=1000)
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        c.enable_graph(True)
-        c.set_x(x3.repeat(64, 1) if isinstance(x3, torch.Tensor) else np.tile(x3, (64, 1)))
-        for _ in range(3):
-            c.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            c.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    c.close()
+    for prec, key in (("f64", "config5_clips_one_chain_64x1k"), ("bf16", "config5_bf16")):
+        c = fte.FTEContext(det64, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, clip_len=1000, precision=prec)
+        with torch.cuda.stream(side):
+            c.enable_graph(True)
+            c.set_x(x3.repeat(64, 1) if isinstance(x3, torch.Tensor) else np.tile(x3, (64, 1)))
+            for _ in range(3):
+                c.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                c.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            c.profile_begin()
+            for _ in range(5):
+                c.step()
+            prof = c.profile_end()
+        c.close()
+        out[key] = dict(sequences=64, frames_each=1000, steps=20, ms_per_step=1e3 * dt / 20,
+                        frames_per_s=64 * 1000 * 20 / dt,
+                        precision="f64" if prec == "f64" else "bf16 residual / Jacobian rows, fp32 accumulation of M_l and v_l, "
+                                                              "fp64 from the 6x6 spatial blocks on (acino_fte_params::precision = 1)",
+                        assemble_ms_per_step=prof["assemble"]["ms"] / 5,
+                        lm="one controller over the sum of the clips' costs")
     del det64
-    out["config5_clips_one_chain_64x1k"] = dict(sequences=64, frames_each=1000, steps=20, ms_per_step=1e3 * dt / 20,
-                                                frames_per_s=64 * 1000 * 20 / dt, precision="f64",
-                                                lm="one controller over the sum of the clips' costs")
     t0 = time.perf_counter()
     _res, info = fte.fte_solve(d[..., :2], d[..., 2], *rig, Ts=Ts, max_iter=200, init="triangulation", return_numpy=False)
     torch.cuda.synchronize()

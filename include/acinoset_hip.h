@@ -143,7 +143,17 @@ typedef struct acino_fte_params {
                             * this many frames laid end to end (BASELINE config 5): the smoothness prior does not couple
                             * frames of different clips, everything else - kernels, schedule, one LM controller over the
                             * sum of the clips' costs - is unchanged.  Single-GPU contexts only. */
+  int32_t precision;       /* ACINO_PREC_F64 (0, default) or ACINO_PREC_BF16_ROWS (1) = BASELINE config 5's "bf16 residuals
+                            * with fp32 accumulate": FK and camera-frame coordinates in fp64, projection / 2x3 Jacobian /
+                            * robust weights in fp32, every per-(frame, camera, marker) residual and Jacobian ROW rounded
+                            * to bf16 (round-to-nearest-even) before it enters the normal equations, the per-marker
+                            * M_l = sum J^T W J and v_l = sum J^T w rho' accumulated in fp32; everything from the 6x6
+                            * spatial blocks onward - subtree sums, H, g, the smoothness prior with its 1/Ts^4 weights, the
+                            * band factorisation, the LM controller and the cost - stays fp64. */
+  int32_t reserved0;
 } acino_fte_params;
+#define ACINO_PREC_F64 0
+#define ACINO_PREC_BF16_ROWS 1
 
 /* LM state mirrored in device memory (read back with acino_fte_get_state). */
 typedef struct acino_fte_state {

@@ -86,14 +86,52 @@ def sparsity(n_cameras, n_params_per_camera, camera_indices, n_points, point_ind
     return A
 
 
+def sparsity_by_layout(n_cameras, camera_indices, n_points, point_indices):
+    """The Jacobian pattern of the parameter vector calib.py:373-375 actually builds: [all rvecs | all tvecs | points].
+    ``sparsity`` above (= calib.py:196-207) assumes six CONTIGUOUS parameters per camera instead, so with it the
+    finite-difference Jacobian of the reference loses the translation columns of camera 0 and the rotation columns
+    of camera 1 (two cameras: it marks columns 0-5 for camera 0 where the parameters sit in 0-2 and 6-8).  That is
+    why the recorded KAT-2 runs stop on xtol with first-order optimality 3.6e+03 / 7.1e+03.  NOT the reference's
+    behaviour - used only to show where its solver would have gone with a consistent mask."""
+    m = camera_indices.size * 2
+    A = lil_matrix((m, n_cameras * 6 + n_points * 3), dtype=int)
+    i = np.arange(camera_indices.size)
+    for s in range(3):
+        for row in (2 * i, 2 * i + 1):
+            A[row, camera_indices * 3 + s] = 1
+            A[row, n_cameras * 3 + camera_indices * 3 + s] = 1
+            A[row, n_cameras * 6 + point_indices * 3 + s] = 1
+    return A
+
+
+def relative_pose(r_mats, t_arr, a=0, b=1):
+    """Gauge-invariant part of a two-camera end state (the points+extrinsics problem is free up to a similarity):
+    rotation of camera b relative to camera a, and the baseline vector between the centres in camera a's frame."""
+    Ra, Rb = np.asarray(r_mats[a]), np.asarray(r_mats[b])
+    ca = -Ra.T @ np.asarray(t_arr[a]).reshape(3)
+    cb = -Rb.T @ np.asarray(t_arr[b]).reshape(3)
+    return Rb @ Ra.T, Ra @ (cb - ca)
+
+
+def pose_distance(r1, t1, r2, t2):
+    """(relative-rotation difference in degrees, baseline-direction difference in degrees, baseline lengths in mm)."""
+    Ra, ba = relative_pose(r1, t1)
+    Rb, bb = relative_pose(r2, t2)
+    ang = np.degrees(np.arccos(np.clip((np.trace(Ra @ Rb.T) - 1.0) / 2.0, -1.0, 1.0)))
+    dire = np.degrees(np.arccos(np.clip(ba @ bb / (np.linalg.norm(ba) * np.linalg.norm(bb)), -1.0, 1.0)))
+    return float(ang), float(dire), float(np.linalg.norm(ba) * 1e3), float(np.linalg.norm(bb) * 1e3)
+
+
 def cauchy_cost(res, f_scale=1.0):
     """scipy's cost for loss='cauchy': 0.5 * f_scale^2 * sum ln(1 + (r/f_scale)^2)."""
     return 0.5 * f_scale ** 2 * float(np.sum(np.log1p((np.asarray(res) / f_scale) ** 2)))
 
 
 def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr,
-                                        t_arr, max_nfev=1000, ftol=1e-10, verbose=0, project_func=None):
-    """calib.py:369-390 with the reference's least_squares settings."""
+                                        t_arr, max_nfev=1000, ftol=1e-10, verbose=0, project_func=None,
+                                        consistent_mask=False):
+    """calib.py:369-390 with the reference's least_squares settings (``consistent_mask=True``: the same call with the
+    Jacobian pattern that matches the parameter layout - see ``sparsity_by_layout``; not the reference's behaviour)."""
     n_points, n_cameras = len(points_3d), len(k_arr)
     r_vecs = np.array([rodrigues_to_vec(r) for r in r_arr]).flatten()
     x0 = np.concatenate([r_vecs, np.asarray(t_arr, dtype=np.float64).flatten(), np.asarray(points_3d, dtype=np.float64).flatten()])
@@ -109,7 +147,8 @@ def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, 
         return residuals(pts, rm, tt, k_arr, d_arr, point_3d_indices, camera_indices, points_2d, project_func)
 
     f0 = fun(x0)
-    A = sparsity(n_cameras, 6, camera_indices, n_points, point_3d_indices)
+    A = (sparsity_by_layout(n_cameras, camera_indices, n_points, point_3d_indices) if consistent_mask else
+         sparsity(n_cameras, 6, camera_indices, n_points, point_3d_indices))
     res = least_squares(fun, x0, jac_sparsity=A, verbose=verbose, x_scale="jac", ftol=ftol, method="trf", loss="cauchy",
                         max_nfev=max_nfev)
     pts, rm, tt = unpack(res.x)

@@ -603,3 +603,60 @@ def test_randomised_solves_match_oracle(mods, seed):
     assert info["status_name"] in ("ftol", "xtol", "gtol")
     assert abs(info["cost"] - oinfo["cost"]) < 1e-5 * abs(oinfo["cost"])
     assert np.abs(res["positions"] - out["positions"]).max() < 1e-3            # north_star tolerance, metres
+
+
+def test_bf16_rows_assembly_is_a_rounded_version_of_the_fp64_one(mods):
+    """ACINO_PREC_BF16_ROWS at the function level: same cost to fp32 accuracy, gradient and Gauss-Newton blocks within
+    the 2^-8 relative rounding of the stored rows, and everything downstream (smoothness prior, its 1/Ts^4 weights)
+    untouched - the smoothness part of g and H is bit-identical because it never passes through bf16 / fp32."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(120, "loop")
+    x = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(8).normal(0, 0.01, (120, 25))
+    out = {}
+    for prec in ("f64", "bf16"):
+        c = _ctx(fte, seq, precision=prec)
+        c.set_x(x)
+        g, h = c.grad_hess()
+        out[prec] = (c.state()["cost"], g.cpu().numpy(), h.cpu().numpy())
+        c.close()
+    (c64, g64, h64), (c16, g16, h16) = out["f64"], out["bf16"]
+    assert abs(c16 - c64) < 3e-6 * abs(c64)                               # cost: fp32 projection, fp64 sum
+    assert 0 < np.abs(g16 - g64).max() < 2e-2 * np.abs(g64).max()          # bf16 rows: ~2^-8 relative per term
+    assert np.linalg.norm(g16 - g64) < 4e-3 * np.linalg.norm(g64)
+    assert np.linalg.norm(h16 - h64) < 4e-3 * np.linalg.norm(h64)
+    # with no valid detection the measurement part vanishes and the two precisions agree bit for bit
+    det0 = seq["det"].copy()
+    det0[..., 2] = 0.0
+    res = []
+    for prec in ("f64", "bf16"):
+        c = fte.FTEContext(det0, seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], precision=prec)
+        c.set_x(x)
+        g, h = c.grad_hess()
+        res.append((c.state()["cost"], g.cpu().numpy(), h.cpu().numpy()))
+        c.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    with pytest.raises(ValueError):
+        fte.make_params(10, 6, 1 / 120, precision="fp8")
+
+
+def test_config5_bf16_rows_solve_lands_on_the_fp64_solution(mods):
+    """BASELINE config 5's FTE half at its size: 64 clips x 1 000 frames as one chain (fte_solve_clips), solved with
+    bf16 residual / Jacobian rows + fp32 accumulation and with fp64, from the same nose-line start.  North-star bar:
+    marker positions within 1e-3 m.  (The smoothness prior with its 1/Ts^4 = 2e8 weights, the band factorisation
+    and the controller are fp64 in both; the stopping tolerance of the mixed-precision run is the cost's fp32 noise
+    floor.)"""
+    calib, fte, synth = mods
+    B, S = 64, 1000
+    seqs = [synth.make_sequence(S, "trot", seed=20210313 + b) for b in range(B)]
+    rig = (seqs[0]["K"], seqs[0]["D"], seqs[0]["R"], seqs[0]["t"])
+    dets = [torch.as_tensor(s["det"], device="cuda") for s in seqs]
+    ref = fte.fte_solve_clips(dets, *rig, seqs[0]["Ts"], max_iter=120)
+    mix = fte.fte_solve_clips(dets, *rig, seqs[0]["Ts"], max_iter=120, precision="bf16", ftol=1e-8)
+    assert ref[0][1]["status_name"] in ("ftol", "xtol", "gtol") and mix[0][1]["status_name"] in ("ftol", "xtol", "gtol")
+    errs = np.array([np.abs(m[0]["positions"] - r[0]["positions"]).max() for m, r in zip(mix, ref)])
+    print(f"config 5 bf16 rows vs fp64: max |dpos| over 64 clips {errs.max():.3e} m (median {np.median(errs):.3e}); "
+          f"iterations {mix[0][1]['iter']} vs {ref[0][1]['iter']}; cost {mix[0][1]['cost']:.6f} vs {ref[0][1]['cost']:.6f}")
+    assert errs.max() < 1e-3, errs.max()
+    assert abs(mix[0][1]["cost"] - ref[0][1]["cost"]) < 1e-5 * abs(ref[0][1]["cost"])
+    truth = np.array([np.abs(m[0]["positions"] - s["pos_true"]).max() for m, s in zip(mix, seqs)])
+    assert truth.max() < 0.1

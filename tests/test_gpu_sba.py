@@ -88,6 +88,49 @@ def test_kat2_points_and_extrinsics(gsba, golden_dir):
         assert info["gnorm_inf"] < 1e-2 * (3.63e3 if row == 0 else 7.05e3), info
 
 
+def test_kat2_distance_from_the_reference_end_state(gsba, golden_dir, capsys):
+    """How far the returned extrinsics are from the reference's (= the scipy oracle's) end state, in gauge-invariant
+    terms (rotation of camera 2 relative to camera 1 in degrees, baseline direction in degrees, baseline length in
+    mm) - and that the difference is "the reference stopped early", not "a different problem": the same scipy call
+    with a Jacobian mask that matches the parameter layout (oracle.sba.sparsity_by_layout; the reference's mask
+    calib.py:196-207 does not, see tests/test_oracle_sba.py) converges to the GPU's stationary point."""
+    sba, calib = gsba
+    g, _, data, (K, D, R, t) = _kat(golden_dir, "static", 3, 4)
+    _pts, rm, tt, _res = sba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t, calib.project_points_fisheye)
+    cost_gpu = sba.last_info["cost_final"]
+    _p, rm_ref, tt_ref, _r, res_ref = osba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t)
+    _p, rm_ok, tt_ok, _r, res_ok = osba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t, consistent_mask=True)
+    d_ref = osba.pose_distance(rm, tt, rm_ref, tt_ref)
+    d_ok = osba.pose_distance(rm, tt, rm_ok, tt_ok)
+    d_move = osba.pose_distance(R, t, rm_ref, tt_ref)
+    with capsys.disabled():
+        print(f"\nKAT-2 static: GPU cost {cost_gpu:.4f}; scipy/reference mask {res_ref.cost:.4f}; scipy/consistent mask "
+              f"{res_ok.cost:.4f}\n  GPU vs reference end state: {d_ref[0]:.4f} deg rel. rotation, {d_ref[1]:.4f} deg "
+              f"baseline direction, baseline {d_ref[2]:.2f} vs {d_ref[3]:.2f} mm\n  GPU vs consistent-mask scipy: "
+              f"{d_ok[0]:.2e} deg, {d_ok[1]:.2e} deg, {d_ok[2]:.3f} vs {d_ok[3]:.3f} mm\n  reference end state vs its own "
+              f"start: {d_move[0]:.4f} deg, {d_move[1]:.4f} deg, {d_move[2]:.2f} -> {d_move[3]:.2f} mm")
+    assert abs(cost_gpu - res_ok.cost) < 1e-4 * res_ok.cost                       # same minimum of the same cost
+    assert d_ok[0] < 5e-3 and d_ok[1] < 5e-3 and abs(d_ok[2] - d_ok[3]) < 0.2      # deg, deg, mm
+    assert d_ref[0] < 1.0 and d_ref[1] < 1.0 and abs(d_ref[2] - d_ref[3]) < 20.0   # bounded distance from the reference's
+    assert d_move[0] < 0.05                                                        # ... which barely left its start
+    # rotating pair: the consistent-mask run is still creeping after 300 evaluations; the GPU end state lies below it
+    g, _, data, (K, D, R, t) = _kat(golden_dir, "rotating", 1, 2)
+    _pts, rm, tt, _res = sba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t, calib.project_points_fisheye)
+    cost_gpu = sba.last_info["cost_final"]
+    _p, rm_ref, tt_ref, _r, res_ref = osba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t)
+    _p, rm_ok, tt_ok, _r, res_ok = osba.bundle_adjust_points_and_extrinsics(*data, K, D, R, t, consistent_mask=True,
+                                                                            max_nfev=300)
+    d_ref = osba.pose_distance(rm, tt, rm_ref, tt_ref)
+    d_ok = osba.pose_distance(rm, tt, rm_ok, tt_ok)
+    with capsys.disabled():
+        print(f"KAT-2 rotating: GPU cost {cost_gpu:.4f}; scipy/reference mask {res_ref.cost:.4f}; scipy/consistent mask "
+              f"(300 nfev) {res_ok.cost:.4f}\n  GPU vs reference end state: {d_ref[0]:.4f} deg, {d_ref[1]:.4f} deg, "
+              f"baseline {d_ref[2]:.2f} vs {d_ref[3]:.2f} mm\n  GPU vs consistent-mask scipy: {d_ok[0]:.4f} deg, "
+              f"{d_ok[1]:.4f} deg, {d_ok[2]:.2f} vs {d_ok[3]:.2f} mm")
+    assert cost_gpu <= res_ok.cost * (1 + 1e-6) < res_ref.cost
+    assert d_ref[0] < 2.0 and d_ref[1] < 5.0 and d_ok[0] <= d_ref[0] + 1e-3
+
+
 def test_points_only_matches_scipy_minimiser(gsba, golden_dir):
     sba, calib = gsba
     g, _, data, (K, D, R, t) = _kat(golden_dir, "static", 3, 4)
