@@ -31,17 +31,19 @@ class FteParams(C.Structure):
                 ("redesc_c", C.c_double), ("q_w", C.c_double * N_ACTIVE), ("lo", C.c_double * N_ACTIVE),
                 ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
                 ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32),
-                ("clip_len", C.c_int64), ("precision", C.c_int32), ("reserved0", C.c_int32)]
+                ("clip_len", C.c_int64), ("precision", C.c_int32), ("bcr_levels", C.c_int32), ("trunc_tol", C.c_double)]
 
 
 class FteState(C.Structure):
     _fields_ = [("cost", C.c_double), ("cost_trial", C.c_double), ("lam", C.c_double), ("nu", C.c_double),
                 ("gain", C.c_double), ("pred", C.c_double), ("step_inf", C.c_double), ("gnorm_inf", C.c_double),
                 ("iter", C.c_int32), ("accepted", C.c_int32), ("status", C.c_int32), ("cur", C.c_int32),
-                ("n_behind", C.c_int32), ("last_accept", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32)]
+                ("n_behind", C.c_int32), ("last_accept", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
+                ("trunc_eps", C.c_double)]
 
     def as_dict(self):
-        names = {0: "running", 1: "ftol", 2: "xtol", 3: "gtol", 4: "lambda_overflow", 5: "numeric"}
+        names = {0: "running", 1: "ftol", 2: "xtol", 3: "gtol", 4: "lambda_overflow", 5: "numeric", 6: "sync_timeout",
+                 7: "truncation"}
         d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
         d["status_name"] = names.get(self.status, "?")
         return d

@@ -737,7 +737,7 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
 // the launch); visibility between CUs / XCDs: agent-scope release after the solution is written, agent-scope
 // acquire by one lane + barrier before it is read.
 __global__ void __launch_bounds__(256)
-k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status) {
+k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status, int* __restrict__ numeric_err) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Ml = reinterpret_cast<double*>(smem_raw);
@@ -778,7 +778,17 @@ k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status) {
   }
   const double yi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;     // y_i: written by the reduction, long ago
   if (tid == 0) {   // cheap relaxed polls, ONE acquire (cache invalidation) once the deeper levels are done
-    while (__hip_atomic_load(ch.d_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+    // BOUNDED: a workgroup only waits for lower block indices, which the dispatcher starts first in practice but HIP does
+    // not promise; if the wait outlives ~0.5 s of polling (a step is < 1 ms) the kernel gives up, flags the step
+    // (numeric_err bit 1 -> LM status 6 -> ACINO_ERR_HIP from the solve) and lets the launch drain instead of hanging
+    long long polls = 0;
+    while (__hip_atomic_load(ch.d_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++polls > (1ll << 23)) {
+        if (numeric_err) atomicOr(numeric_err, 2);
+        break;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -984,16 +994,105 @@ k_bcr_backsub0(BcrChain ch, const int* __restrict__ elim, const FteConst* __rest
   if (tid < BS) ch.b[(size_t)i * BS + tid] = zi - ((ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid]);
 }
 
+// ---- incomplete reduction: size of the dropped couplings -----------------------------------------------------
+// After the isolated last level D[a] = U_a = L_a^-T and D[b] = U_b for the two ends of every dropped coupling block
+// C = block(b, a) (stored at Cpl[a]).  Dropping C perturbs the remaining system by E = [[0, C^T], [C, 0]]; in the energy
+// norm of the kept block-diagonal part that is || L_b^-1 C L_a^-T ||_2 <= || U_b^T C U_a ||_F =: eps(a, b), and the solve's
+// relative error in that norm is <= eps / (1 - eps).  One workgroup per pair: T = C U_a, then N = U_b^T T on the matrix
+// cores (U upper triangular: the k loops stop at the diagonal tile), eps^2 = sum N^2 -> trunc_eps2[pair].
+__global__ void __launch_bounds__(256)
+k_bcr_trunc_check(BcrChain ch, const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Cm = reinterpret_cast<double*>(smem_raw);
+  double* Ua = Cm + MAT;
+  double* Ub = Ua + MAT;
+  double* red = Ub + MAT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int a = ch.d_pairs[2 * blockIdx.x], b = ch.d_pairs[2 * blockIdx.x + 1];
+  const size_t MB = (size_t)BS * BS;
+  load_mat(Cm, ch.Cpl + a * MB, tid);
+  load_mat(Ua, ch.D + a * MB, tid);
+  load_mat(Ub, ch.D + b * MB, tid);
+  __syncthreads();
+  // (the elimination stores the factor's LOWER tiles as workspace: only entries on or above the diagonal are U)
+  auto up = [](const double* U, int r, int c) { return c >= r ? U[r * LD + c] : 0.0; };
+  // phase 1: T(ib, jb) = sum_{k <= jb} C(ib, k) U_a(k, jb); tiles dealt to the waves, kept in registers
+  d4 acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int t = wave + 4 * q;
+    d4 c4 = {0, 0, 0, 0};
+    if (t < 25) {
+      const int ib = t / 5, jb = t % 5;
+      for (int k4 = 0; k4 < 4 * (jb + 1); ++k4) {
+        const int kk = 4 * k4 + lk;
+        c4 = mfma(Cm[(ib * 16 + li) * LD + kk], up(Ua, kk, jb * 16 + li), c4);
+      }
+    }
+    acc[q] = c4;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int t = wave + 4 * q;
+    if (t < 25) {
+      const int ib = t / 5, jb = t % 5;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Cm[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = acc[q][rr];
+    }
+  }
+  __syncthreads();
+  // phase 2: N(ib, jb) = sum_{k <= ib} U_b(k, ib)^T T(k, jb)
+  double s2 = 0.0;
+  for (int t = wave; t < 25; t += 4) {
+    const int ib = t / 5, jb = t % 5;
+    d4 c4 = {0, 0, 0, 0};
+    for (int k4 = 0; k4 < 4 * (ib + 1); ++k4) {
+      const int kk = 4 * k4 + lk;
+      c4 = mfma(up(Ub, kk, ib * 16 + li), Cm[kk * LD + jb * 16 + li], c4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) s2 += c4[rr] * c4[rr];
+  }
+  for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+  if (lane == 0) red[wave] = s2;
+  __syncthreads();
+  if (tid == 0) ch.trunc_eps2[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---- host side ------------------------------------------------------------------------------
-void BcrSchedule::build(int n, bool pin_left, bool pin_right) {
+void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels) {
   levels.clear();
   elim.clear();
   remain.clear();
+  pairs.clear();
   std::vector<int> act(n);
   for (int i = 0; i < n; ++i) act[i] = i;
   auto pinned = [&](int node) { return (pin_left && node == 0) || (pin_right && node == n - 1); };
   while (true) {
     const int R = (int)act.size();
+    if (max_levels > 0 && (int)levels.size() == max_levels && R > 1 && !pin_left && !pin_right) {
+      // incomplete reduction: drop the couplings between the R remaining nodes, solve each on its own
+      BcrLevel lv;
+      lv.elim_off = (int)elim.size() / 3;
+      lv.remain_off = (int)remain.size() / 4;
+      lv.n_elim = R;
+      lv.n_remain = 0;
+      lv.adjacent = false;
+      lv.isolated = true;
+      for (int p = 0; p < R; ++p) {
+        elim.push_back(act[p]);
+        elim.push_back(-1);
+        elim.push_back(-1);
+        if (p + 1 < R) {
+          pairs.push_back(act[p]);
+          pairs.push_back(act[p + 1]);
+        }
+      }
+      levels.push_back(lv);
+      break;
+    }
     std::vector<char> pick(R, 0);
     int n_pick = 0;
     for (int p = 0; p < R; ++p)
@@ -1065,6 +1164,7 @@ static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(do
 static constexpr size_t kBacksubLds = (MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kBacksubTailLds = (3 * MAT + 6 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
+static constexpr size_t kTruncCheckLds = (3 * MAT + 8) * sizeof(double);
 
 int bcr_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_elim),
@@ -1081,6 +1181,8 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdate0Lds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_trunc_check),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTruncCheckLds));
   return ACINO_OK;
 }
 
@@ -1093,8 +1195,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       const bool deep = !fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64;
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
-        const int T = std::min(10, 256 / lv.n_elim);   // strip workgroups per node (+ 1 that stores the factor)
-        const int extra = lv.n_elim * (T + 1) <= 256 ? 1 : 0;
+        // (isolated nodes of an incomplete reduction have no W strips: one workgroup per node factors and stores)
+        const int T = lv.isolated ? 1 : std::min(10, 256 / lv.n_elim);   // strip workgroups per node (+ 1 that stores the factor)
+        const int extra = (!lv.isolated && lv.n_elim * (T + 1) <= 256) ? 1 : 0;
         const int total = lv.n_elim * (T + extra), nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
         hipLaunchKernelGGL(k_bcr_elim_deep, dim3(8 * per), dim3(256), kElimDeepLds, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, extra, nx, per, total);
@@ -1123,18 +1226,24 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     }
     ++level;
   }
+  if (!sch.pairs.empty() && ch.d_pairs && ch.trunc_eps2) {
+    ProfSpan sp(prof, PC_TRUNC_CHECK, s, (long long)sch.pairs.size() / 2);
+    hipLaunchKernelGGL(k_bcr_trunc_check, dim3((unsigned)(sch.pairs.size() / 2)), dim3(256), kTruncCheckLds, s, ch,
+                       d_status);
+    ACINO_LAUNCH_CHECK();
+  }
   return ACINO_OK;
 }
 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
-                Profiler* prof) {
+                Profiler* prof, int* d_numeric_err) {
   int top = (int)sch.levels.size() - 1;
   if (ch.d_tail && sch.tail_levels > 0) {
     const int n_tail = (int)sch.tail.size() / 4;
     ACINO_HIP_CHECK(hipMemsetAsync(ch.d_done, 0, sizeof(int), s));
     {
       ProfSpan sp(prof, PC_BACKSUB_TAIL, s, n_tail);
-      hipLaunchKernelGGL(k_bcr_backsub_tail, dim3(n_tail), dim3(256), kBacksubTailLds, s, ch, d_status);
+      hipLaunchKernelGGL(k_bcr_backsub_tail, dim3(n_tail), dim3(256), kBacksubTailLds, s, ch, d_status, d_numeric_err);
     }
     ACINO_LAUNCH_CHECK();
     top -= sch.tail_levels;

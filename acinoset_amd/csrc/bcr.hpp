@@ -10,6 +10,7 @@ struct BcrLevel {
   int n_elim, n_remain;
   int elim_off, remain_off;  // offsets (in entries) into the device schedule arrays
   bool adjacent;             // some eliminated node still has a neighbour at original distance 1 (implicit coupling)
+  bool isolated = false;     // last level of an INCOMPLETE reduction: every remaining node solved on its own
 };
 
 // Host-side elimination schedule for a chain of n nodes; pinned ends are never eliminated.
@@ -21,8 +22,12 @@ struct BcrSchedule {
   // 4 ints per entry: node, left, right, number of entries that must be finished before this one may start
   std::vector<int> tail;
   int tail_levels = 0;
-  size_t ints() const { return elim.size() + remain.size() + tail.size() + 4; }   // (+ the tail's progress counter)
-  void build(int n, bool pin_left, bool pin_right);
+  // Incomplete reduction (max_levels > 0): after max_levels levels the couplings between the remaining nodes are
+  // DROPPED and every remaining node is factorised on its own.  pairs = (left node, right node) of every dropped
+  // coupling block (stored at Cpl[left]); their normalised size is measured on the device (k_bcr_trunc_check).
+  std::vector<int> pairs;
+  size_t ints() const { return elim.size() + remain.size() + tail.size() + pairs.size() + 4; }   // (+ the tail's progress counter)
+  void build(int n, bool pin_left, bool pin_right, int max_levels = 0);
 };
 
 // Device views of one chain.
@@ -37,6 +42,9 @@ struct BcrChain {
   const int* d_remain;
   const int* d_tail;         // device copy of BcrSchedule::tail (null: no fused tail)
   int* d_done;               // progress counter of the tail kernel
+  const int* d_pairs = nullptr;   // dropped couplings of an incomplete reduction (2 ints each) ...
+  int n_pairs = 0;
+  double* trunc_eps2 = nullptr;   // ... and [n_pairs] squared Frobenius norms of L_b^-1 C L_a^-T, written every reduction
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
   long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
   // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build
@@ -50,7 +58,7 @@ struct BcrChain {
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof = nullptr);
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
-                Profiler* prof = nullptr);
+                Profiler* prof = nullptr, int* d_numeric_err = nullptr);
 int bcr_set_func_attributes();
 
 }  // namespace acino

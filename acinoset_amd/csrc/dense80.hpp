@@ -149,7 +149,7 @@ __device__ __forceinline__ bool chol16_inv_acc(double* T, d4 acc, int lane, int*
       uacc = mfma(-p, pu, uacc);     // register r of lane (i,k) is result[4r+k][i] = -(P PU^T)[4r+k][i] = dU[i][4r+k]
     }
   }
-  if (bad && err && lane == 0) atomicExch(err, 1);
+  if (bad && err && lane == 0) atomicOr(err, 1);
   return !bad;
 }
 __device__ __forceinline__ void chol16_inv(double* T, int lane, int* err) {

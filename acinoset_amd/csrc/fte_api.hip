@@ -22,7 +22,8 @@ struct Buffers {
   double* totals;     // [8]
   int* nbehind;
   int* numeric_err;
-  int* sched;         // elim (3/entry) then remain (4/entry)
+  int* sched;         // elim (3/entry), remain (4/entry), tail (4/entry), dropped-coupling pairs (2/entry), tail counter
+  double* trunc_eps2; // [n_pairs + 1]
 };
 
 }  // namespace acino
@@ -65,7 +66,7 @@ struct Carver {
   }
 };
 
-static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChain* ch, size_t sched_ints) {
+static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChain* ch, size_t sched_ints, size_t n_pairs) {
   Carver c{base, 0};
   const size_t N = p->n_frames, T = chain_nodes(p);
   Buffers b;
@@ -83,6 +84,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.nbehind = c.take<int>(4);
   b.numeric_err = b.nbehind + 1;
   b.sched = c.take<int>(sched_ints);
+  b.trunc_eps2 = c.take<double>(n_pairs + 1);
   BcrChain chn;
   chn.n_nodes = (int)T;
   chn.D = c.take<double>(T * BS * BS);
@@ -94,6 +96,9 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.d_remain = nullptr;
   chn.d_tail = nullptr;
   chn.d_done = nullptr;
+  chn.d_pairs = nullptr;
+  chn.n_pairs = 0;
+  chn.trunc_eps2 = b.trunc_eps2;
   chn.implicit_couplings = 1;
   chn.dbg = nullptr;
   chn.st = b.state;
@@ -167,7 +172,8 @@ __device__ void lm_control(const FteConst& K, acino_fte_state* st, const double*
 __global__ void __launch_bounds__(1024)
 k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double* pred_part,
          const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
-         int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control) {
+         int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control,
+         const double* __restrict__ trunc_eps2, int n_trunc) {
   if (st->status != 0) return;
   // the four reductions run together: strided per-thread partials, one shuffle tree per wave, the sixteen waves
   // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
@@ -178,11 +184,15 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
   acino_fte_state S;
   LmTol T{0, 0, 0, 0, 0};
   int ne = 0, nb = 0;
+  double e2 = 0.0, ttol = 0.0;
   if (threadIdx.x == 0) {
     S = *st;
     T = LmTol{cst->gtol, cst->ftol, cst->xtol, cst->lam_max, cst->clamp_lambda};
     ne = *numeric_err;
     nb = *nbehind;
+    ttol = cst->trunc_tol;
+    if (with_step)                       // incomplete reduction: the largest dropped coupling of this step's solve
+      for (int i = 0; i < n_trunc; ++i) e2 = fmax(e2, trunc_eps2[i]);
   }
   double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
   for (int i = threadIdx.x; i < n_cost; i += 64 * NW) c += cost_part[i];
@@ -222,6 +232,11 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
 #pragma unroll
     for (int q = 0; q < 8; ++q) totals[q] = tot[q];
     *nbehind = 0;
+    if (with_step && n_trunc > 0) {
+      S.trunc_eps = sqrt(e2);
+      if (!(S.trunc_eps <= ttol)) ne |= 4;           // (also catches NaN)
+      if (fused_control < 0) st->trunc_eps = S.trunc_eps;
+    }
     if (fused_control >= 0) {
       lm_control_local(T, S, tot, ne, fused_control);
       *st = S;
@@ -246,8 +261,8 @@ __device__ void lm_control_local(const LmTol& K, acino_fte_state& S, const doubl
   S.step_inf = step;
   S.gnorm_inf = gnorm;
   S.iter += 1;
-  if (numeric_err) {
-    S.status = 5;
+  if (numeric_err) {      // bit 0: non-positive pivot, bit 1: back-substitution tail timed out, bit 2: dropped couplings too large
+    S.status = (numeric_err & 1) ? 5 : ((numeric_err & 2) ? 6 : 7);
     return;
   }
   if (gnorm <= K.gtol) {   // the iterate the step started from was already stationary: keep it
@@ -450,6 +465,7 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
   c->clamp_lambda = p->clamp_lambda;
   c->precision = p->precision;
+  c->trunc_tol = p->trunc_tol > 0.0 ? p->trunc_tol : 1e-10;
   memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
   return ACINO_OK;
 }
@@ -463,6 +479,9 @@ static int validate(const acino_fte_params* p) {
   ACINO_REQUIRE(!p->pin_left || (p->n_offset >= 3 && p->n_offset % 3 == 0), "pinned-left shard must start at a multiple of 3");
   ACINO_REQUIRE(p->clip_len >= 0, "clip_len");
   ACINO_REQUIRE(p->precision == ACINO_PREC_F64 || p->precision == ACINO_PREC_BF16_ROWS, "precision");
+  ACINO_REQUIRE(p->bcr_levels >= 0 && p->trunc_tol >= 0.0, "bcr_levels, trunc_tol");
+  ACINO_REQUIRE(p->bcr_levels == 0 || (!p->pin_left && !p->pin_right),
+                "incomplete reduction (bcr_levels > 0): single-GPU contexts only");
   ACINO_REQUIRE(p->clip_len == 0 || (!p->pin_left && !p->pin_right && p->n_offset == 0 && p->n_global == p->n_frames &&
                                      p->n_frames % p->clip_len == 0),
                 "clips: single-GPU context whose n_frames is a multiple of clip_len");
@@ -491,7 +510,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1024), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
                        b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
-                       with_step ? 1 : 0, b.cst, b.numeric_err, fused_control);
+                       with_step ? 1 : 0, b.cst, b.numeric_err, fused_control, b.trunc_eps2, ctx->chain.n_pairs);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
@@ -502,8 +521,8 @@ extern "C" {
 size_t acino_fte_workspace_bytes(const acino_fte_params* p) {
   if (!p || p->n_frames < 1) return 0;
   BcrSchedule sch;
-  sch.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
-  return carve(p, nullptr, nullptr, nullptr, sch.ints()) + 256;
+  sch.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels);
+  return carve(p, nullptr, nullptr, nullptr, sch.ints(), sch.pairs.size() / 2) + 256;
 }
 
 int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det, const double* d_cams24,
@@ -521,9 +540,9 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     return ACINO_ERR_INVALID_ARG;
   }
   ctx->lam0 = p->lam0;
-  ctx->sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0);
+  ctx->sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels);
   const size_t sched_ints = ctx->sched.ints();
-  const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, sched_ints);
+  const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, sched_ints, ctx->sched.pairs.size() / 2);
   if (need > workspace_bytes) {
     set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     delete ctx;
@@ -559,6 +578,10 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   if (e == hipSuccess && !ctx->sched.tail.empty())
     e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size(), ctx->sched.tail.data(),
                        sizeof(int) * ctx->sched.tail.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !ctx->sched.pairs.empty())
+    e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size(),
+                       ctx->sched.pairs.data(), sizeof(int) * ctx->sched.pairs.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (ctx->sched.pairs.size() / 2 + 1), s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     set_error("context upload failed: %s", hipGetErrorString(e));
@@ -569,7 +592,12 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   ctx->chain.d_remain = ctx->b.sched + ctx->sched.elim.size();
   if (!ctx->sched.tail.empty() && !p->shared_gpu) {
     ctx->chain.d_tail = ctx->chain.d_remain + ctx->sched.remain.size();
-    ctx->chain.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
+    ctx->chain.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() +
+                        ctx->sched.pairs.size();
+  }
+  if (!ctx->sched.pairs.empty()) {
+    ctx->chain.d_pairs = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
+    ctx->chain.n_pairs = (int)(ctx->sched.pairs.size() / 2);
   }
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
@@ -790,7 +818,7 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
                        d_sep_x + (size_t)rank * BS);
     ACINO_LAUNCH_CHECK();
   }
-  return bcr_backsub(ctx->chain, ctx->sched, ctx->b.cst, &ctx->b.state->status, s, &ctx->prof);
+  return bcr_backsub(ctx->chain, ctx->sched, ctx->b.cst, &ctx->b.state->status, s, &ctx->prof, ctx->b.numeric_err);
 }
 
 int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
@@ -990,6 +1018,13 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
     set_error("non-positive pivot in the block factorisation (system not positive definite)");
     return ACINO_ERR_NUMERIC;
   }
+  if (st.status == 6) {
+    set_error("the fused back-substitution tail timed out waiting for lower workgroups (scheduling order not as assumed); "
+              "create the context with shared_gpu = 1 to use the per-level kernels");
+    return ACINO_ERR_HIP;
+  }
+  // (status 7 - dropped couplings of an incomplete reduction above trunc_tol - is returned in the state: the caller
+  //  re-creates the context with more levels and continues from the current iterate, acinoset_amd/fte.py does)
   return ACINO_OK;
 }
 

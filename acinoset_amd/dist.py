@@ -175,6 +175,32 @@ class ShardedFTE:
         self._all_partials = backend.new(world, 8)
         self._sep = backend.new(max(world - 1, 1), SEP_DOUBLES)
         self._sep_x = backend.new(max(world - 1, 1), BS)
+        self._timing = None
+
+    # -- per-collective timing (bench.py --gpus N): HIP events on the launch stream around every collective -------
+    def collect_timing(self, on=True):
+        self._timing = {} if on else None
+
+    def _timed(self, name, fn, *args):
+        if self._timing is None or not torch.cuda.is_available():
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args)
+        e1.record()
+        self._timing.setdefault(name, []).append((e0, e1))
+        return out
+
+    def timing_summary(self):
+        """{collective: {calls, mean_us, max_us}} since collect_timing(True); synchronises."""
+        if not self._timing:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self._timing.items():
+            us = [1e3 * a.elapsed_time(b) for a, b in pairs]
+            out[name] = dict(calls=len(us), mean_us=float(np.mean(us)), max_us=float(np.max(us)))
+        return out
 
     # -- collectives ---------------------------------------------------------------------------------
     def _exchange_halo(self, which):
@@ -223,11 +249,11 @@ class ShardedFTE:
         if self.world > 1 and getattr(self.b, "fused_phases", False):
             # 4 launches + 3 collectives per iteration; every buffer is persistent, so the phases replay as graphs
             self.b.phase_reduce(self._sep)
-            self.comm.all_reduce_sum(self._sep)
+            self._timed("all_reduce_separators", self.comm.all_reduce_sum, self._sep)
             self.b.phase_solve(self._sep, self._sep_x, self._edges)
-            self.comm.all_gather(self._all_edges, self._edges)
+            self._timed("all_gather_edges", self.comm.all_gather, self._all_edges, self._edges)
             self.b.phase_eval(1, self._all_edges, self._partial)
-            self.comm.all_gather(self._all_partials, self._partial)
+            self._timed("all_gather_scalars", self.comm.all_gather, self._all_partials, self._partial)
             self.b.phase_control(self._all_partials, False)
             return
         self.b.reduce_local()

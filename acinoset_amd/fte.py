@@ -52,7 +52,8 @@ def bounds45():
 
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
-                lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0, precision="f64"):
+                lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0, precision="f64", bcr_levels=0,
+                trunc_tol=1e-10):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -79,6 +80,7 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     p.precision = PRECISIONS[precision]
+    p.bcr_levels, p.trunc_tol = int(bcr_levels), float(trunc_tol)
     return p
 
 
@@ -156,10 +158,11 @@ class FTEContext:
         return x, pos, dx, ddx
 
     PROF_CLASSES = ("elim", "elim_deep", "update0", "update", "update_deep", "backsub0", "backsub", "trial", "assemble",
-                    "totals", "control", "backsub_tail")
+                    "totals", "control", "backsub_tail", "trunc_check")
     PROF_KERNELS = dict(elim="k_bcr_elim", elim_deep="k_bcr_elim_deep", update0="k_bcr_update0", update="k_bcr_update",
                         update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
-                        backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true>", totals="k_totals", control="k_control")
+                        backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true>", totals="k_totals", control="k_control",
+                        trunc_check="k_bcr_trunc_check")
 
     def profile_begin(self):
         check(lib().acino_fte_profile_begin(self._h))
@@ -280,6 +283,20 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
         ctx.set_x(x0[:, ACTIVE])
         info = ctx.solve(max_iter)
         x, pos, dx, ddx = ctx.result()
+        while info["status"] == 7:
+            # incomplete reduction whose dropped couplings exceeded trunc_tol: the rejected step was never applied.
+            # Continue from the current iterate with one more level (a complete reduction once the chain is exhausted).
+            done = info["iter"]
+            kw = dict(kw, bcr_levels=kw.get("bcr_levels", 0) + 1)
+            if 3 * 2 ** kw["bcr_levels"] >= det.shape[0]:
+                kw["bcr_levels"] = 0
+            ctx.close()
+            ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+            ctx.set_x(x)
+            info = ctx.solve(max(max_iter - done, 1))
+            info["iter"] += done
+            info["bcr_levels"] = kw["bcr_levels"]
+            x, pos, dx, ddx = ctx.result()
     finally:
         ctx.close()
     if info["status"] == 5:

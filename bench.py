@@ -38,37 +38,12 @@ ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0
+PROFILE_DIR = "round2_final"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
 
 
-def _oracle_lm_iterations(det, rig, Ts, x0_active, iters):
-    """`iters` LM iterations (+ the initial evaluation) of the numpy/scipy oracle on one block of frames; seconds."""
-    from oracle import fte as ofte
-    K, D, R, t = rig
-    prob = ofte.FTEProblem(det[..., :2], det[..., 2], K, D, R, t, Ts)
-    x = np.clip(x0_active, prob.lo, prob.hi)
-    t0 = time.perf_counter()
-    F, g, H, _ = prob.evaluate(x)
-    lam = 1e-3
-    for _ in range(iters):
-        fixed = ((x <= prob.lo) & (g > 0)) | ((x >= prob.hi) & (g < 0))
-        delta, _diag = prob.solve_banded(H, g, lam, fixed)
-        xt = np.clip(x + delta, prob.lo, prob.hi)
-        Ft, gt, Ht, _ = prob.evaluate(xt)
-        if Ft < F:
-            x, F, g, H = xt, Ft, gt, Ht
-            lam /= 3
-        else:
-            lam *= 2
-    return time.perf_counter() - t0
-
-
-def _oracle_worker(args):
-    try:
-        from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=1)
-    except Exception:                                  # pragma: no cover
-        pass
-    return _oracle_lm_iterations(*args)
+def _log(msg):
+    """Progress marker on stderr (stdout carries exactly one JSON line)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def probe_reference_cpu_path():
@@ -92,10 +67,10 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
     `sample_frames` frames, then all cores (one single-threaded oracle process per core, each on its own contiguous
     block of the same frames - the frame-sharded form of the same iteration), plus BASELINE config 1 (one frame,
     6-camera adjacent-pair triangulation of 20 keypoints through the oracle's numpy path)."""
-    import multiprocessing as mp
     from oracle import camera as ocam
     from oracle import fk as ofk
     from oracle import index_path as oidx
+    from oracle.cpu_baseline import lm_iterations as _oracle_lm_iterations
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=1)
@@ -122,22 +97,36 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
                                                             "20 keypoints (5 adjacent pairs, numpy SVD DLT), mean of "
                                                             f"{reps} calls"))
     ncpu = os.cpu_count() or 1
-    procs = max(1, min(ncpu, 64, n // 96))
+    procs = max(1, min(ncpu, 32, n // 96))
     try:
-        bounds = np.linspace(0, n, procs + 1).astype(int)
-        jobs = [(det[a:b], rig, Ts, xa[a:b], iters) for a, b in zip(bounds[:-1], bounds[1:])]
-        t0 = time.perf_counter()
-        with mp.get_context("spawn").Pool(procs) as pool:
-            pool.map(_oracle_worker, jobs[:procs])         # warm: interpreter start + imports are not the oracle's work
+        import subprocess
+        import tempfile
+        K, D, R, t = rig
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "sample.npz")
+            np.savez(path, det=det[:n], K=K, D=D, R=R, t=t, Ts=Ts, xa=xa)
+            bounds = np.linspace(0, n, procs + 1).astype(int)
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
             t1 = time.perf_counter()
-            each = pool.map(_oracle_worker, jobs)
-        wall = time.perf_counter() - t1
-        out["all_cores"] = dict(value=n / (wall / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu,
+            ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", path, str(a), str(b), str(iters)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT, text=True)
+                  for a, b in zip(bounds[:-1], bounds[1:])]
+            each = []
+            for pr in ps:       # plain numpy processes (no torch, no GPU); bounded: a stuck host never hangs the bench
+                o, _ = pr.communicate(timeout=max(60.0, 6.0 * dt))
+                each.append(float(o.strip().splitlines()[-1]))
+            wall = time.perf_counter() - t1
+        slow = max(each)
+        out["all_cores"] = dict(value=n / (slow / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu,
                                 sample=f"the same {n} frames cut into {procs} contiguous blocks, one single-threaded "
-                                       f"oracle process per block, {iters} LM iterations each, wall {wall:.1f} s "
-                                       f"(slowest block {max(each):.1f} s); blocks are solved independently (no "
-                                       "coupling across block boundaries), i.e. an upper bound for a sharded CPU port")
+                                       f"oracle process per block (python -m oracle.cpu_baseline), {iters} LM iterations "
+                                       f"each, run together: slowest block {slow:.1f} s (wall incl. interpreter start "
+                                       f"{wall:.1f} s); blocks are solved independently (no coupling across block "
+                                       "boundaries), i.e. an upper bound for a frame-sharded CPU port")
     except Exception as exc:                           # pragma: no cover
+        for pr in locals().get("ps", []):
+            if pr.poll() is None:
+                pr.kill()
         out["all_cores"] = dict(value=None, error=repr(exc), nproc=ncpu)
     return out
 
@@ -149,6 +138,7 @@ def secondary_metrics(det, rig, Ts):
     from acinoset_amd import calib, fte, synth
     from acinoset_amd._lib import check, lib, ptr, stream_ptr
     out = {}
+    _log("secondary: config 2")
     dev = torch.device("cuda", torch.cuda.current_device())
     d = torch.as_tensor(det, device=dev)
     N, Cn, L, _ = d.shape
@@ -178,6 +168,7 @@ def secondary_metrics(det, rig, Ts):
                                                 frac_hbm=N * bytes_per_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 algorithmic_bytes_per_frame=bytes_per_frame)
     # config 3: 1 000-frame straight run through the rig ("trot"), nose-line init (all_optimizations.py:268-277), solve to the default tolerances (ftol = xtol = 1e-10)
+    _log("secondary: config 3")
     seq = synth.make_sequence(1000, "trot")
     r3 = (seq["K"], seq["D"], seq["R"], seq["t"])
     det3 = torch.as_tensor(seq["det"], device=dev)
@@ -190,6 +181,7 @@ def secondary_metrics(det, rig, Ts):
     out["config3_solve_1k_frames"] = dict(seconds=dt, iterations=info["iter"], status=info["status_name"], cost=info["cost"],
                                           init="nose line", includes="init triangulation, workspace setup, LM loop, outputs")
     # config 5's FTE half on one GPU: 8 clips x 1 000 frames, one HIP stream each (the runtime multiplexes them onto its 4 hardware queues), 20 LM steps
+    _log("secondary: config 5 (8 streams)")
     x3 = fte.nose_line_init(det3, *r3, 0.5)[:, fte.ACTIVE]
     streams = [torch.cuda.Stream() for _ in range(8)]
     ctxs = []
@@ -217,6 +209,7 @@ def secondary_metrics(det, rig, Ts):
     det64 = det3.repeat(64, 1, 1, 1)
     side = torch.cuda.Stream()
     for prec, key in (("f64", "config5_clips_one_chain_64x1k"), ("bf16", "config5_bf16")):
+        _log(f"secondary: config 5, 64 clips as one chain, {prec}")
         c = fte.FTEContext(det64, *r3, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, clip_len=1000, precision=prec)
         with torch.cuda.stream(side):
             c.enable_graph(True)
@@ -241,6 +234,30 @@ def secondary_metrics(det, rig, Ts):
                         assemble_ms_per_step=prof["assemble"]["ms"] / 5,
                         lm="one controller over the sum of the clips' costs")
     del det64
+    # the benchmark sequence with an INCOMPLETE reduction (acino_fte_params::bcr_levels): couplings between nodes
+    # 3 * 2^K frames apart dropped, their measured size eps reported; same LM trajectory to ~eps
+    x10 = fte.triangulation_init(d, *rig, 0.5)[:, fte.ACTIVE]
+    inc = {}
+    for K in (0, 8, 7):
+        _log(f"secondary: incomplete reduction, levels = {K}")
+        c = fte.FTEContext(d, *rig, Ts, ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, bcr_levels=K)
+        with torch.cuda.stream(side):
+            c.enable_graph(True)
+            c.set_x(x10)
+            for _ in range(3):
+                c.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                c.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            stK = c.state()
+        c.close()
+        inc["complete" if K == 0 else f"levels_{K}"] = dict(ms_per_step=1e3 * dt / 20, frames_per_s=N * 20 / dt, cost_after_23_steps=stK["cost"],
+                                                          accepted=stK["accepted"], trunc_eps=stK["trunc_eps"], status=stK["status_name"])
+    out["incomplete_reduction_10k"] = inc
+    _log("secondary: end-to-end solve of the 10 000-frame sequence")
     t0 = time.perf_counter()
     _res, info = fte.fte_solve(d[..., :2], d[..., 2], *rig, Ts=Ts, max_iter=200, init="triangulation", return_numpy=False)
     torch.cuda.synchronize()
@@ -259,6 +276,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / solve-to-tolerance extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
+    ap.add_argument("--bcr-levels", type=int, default=0,
+                    help="incomplete block cyclic reduction after this many levels (0 = complete; single GPU only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -290,13 +309,16 @@ def main():
     from acinoset_amd import fte, synth
 
     # ---- synthetic workload (every rank builds the same sequence, then keeps its shard) ----
+    if rank == 0:
+        _log(f"building the {args.frames}-frame sequence")
     seq = synth.make_sequence(args.frames, "loop")
     det = seq["det"]
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     x0_full = fte.triangulation_init(det, *rig, 0.5)
     solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world,
                                           ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,    # never stops: every step is full work
-                                          shared_gpu="ACINO_FORCE_DEVICE" in os.environ)      # (ranks sharing one GPU: functional runs only)
+                                          shared_gpu="ACINO_FORCE_DEVICE" in os.environ,      # (ranks sharing one GPU: functional runs only)
+                                          **({"bcr_levels": args.bcr_levels} if args.bcr_levels and world == 1 else {}))
     x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
 
     def sync():
@@ -315,6 +337,8 @@ def main():
         for _ in range(args.warmup):
             solver.step()
         sync()
+        if rank == 0:
+            _log("timed region")
         # ---- timed region: exactly K steps -------------------------------------------------------------
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -328,12 +352,15 @@ def main():
             solver.step()
         sync()
         ctx.profile_begin()
+        solver.collect_timing(True)       # N > 1: HIP events around the three collectives of every step
         t1 = time.perf_counter()
         for _ in range(args.steps):
             solver.step()
         sync()
         dt_eager = time.perf_counter() - t1
         prof = ctx.profile_end()
+        coll = solver.timing_summary()
+        solver.collect_timing(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" or world == 1 else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -354,17 +381,45 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
         kname = fte.FTEContext.PROF_KERNELS[dom]
-        traffic = None     # HBM bytes / launch of the dominant kernel from the committed PMC passes (profiles/)
-        mfma = None
+        # HBM bytes / launch and matrix-core counters of the dominant kernel: from the committed PMC passes under
+        # profiles/ (counters need their own rocprofv3 runs) - quoted ONLY when that summary was measured on this very
+        # binary (build_id = hash over all HIP sources, embedded in the .so); otherwise null, never a stale number
+        traffic, mfma, pmc_note = None, None, None
+        per_kernel = None
         try:
-            pdir = os.path.join(ROOT, "profiles", "round1_final")
-            if args.frames == N_FRAMES and world == 1:
-                traffic = json.load(open(os.path.join(pdir, "pmc_traffic.json")))["kernels"]["acino::" + kname]["bytes_per_launch"]
-                mk = json.load(open(os.path.join(pdir, "pmc_mfma_lds.json")))["kernels"]["acino::" + kname]
+            from acinoset_amd import _lib
+            pdir = os.path.join(ROOT, "profiles", PROFILE_DIR)
+            tj = json.load(open(os.path.join(pdir, "pmc_traffic.json")))
+            mj = json.load(open(os.path.join(pdir, "pmc_mfma_lds.json")))
+            bid = _lib.built_id()
+            if tj.get("build_id") != bid or mj.get("build_id") != bid:
+                pmc_note = (f"profiles/{PROFILE_DIR} was measured on build {tj.get('build_id')}, this library is {bid}: "
+                            "traffic / pmc not quoted")
+            elif args.frames == N_FRAMES and world == 1 and not args.bcr_levels:
+                traffic = tj["kernels"]["acino::" + kname]["bytes_per_launch"]
+                mk = mj["kernels"]["acino::" + kname]
                 mfma = dict(mfma_f64_flops_executed_per_launch=mk["mfma_f64_flops_per_launch"],
                             mfma_util_percent=mk["mfma_util_percent"], lds_bank_conflict_rate=mk["lds_bank_conflict_rate"])
-        except Exception:
-            pass
+                # per kernel: executed / algorithmic flops and measured / algorithmic bytes (regressions show up here)
+                per_kernel = {}
+                for cls, kn in fte.FTEContext.PROF_KERNELS.items():
+                    full = "acino::" + kn
+                    if full not in tj["kernels"] or prof[cls]["launches"] == 0:
+                        continue
+                    lps = prof[cls]["launches"] / args.steps
+                    ent = dict(launches_per_step=lps, hbm_bytes_per_step=tj["kernels"][full]["bytes_per_launch"] * lps)
+                    if full in mj["kernels"]:
+                        ent["mfma_flops_executed_per_step"] = mj["kernels"][full]["mfma_f64_flops_per_launch"] * lps
+                        ent["mfma_util_percent"] = mj["kernels"][full]["mfma_util_percent"]
+                    per_kernel[cls] = ent
+                hbm_step = sum(v["hbm_bytes_per_step"] for v in per_kernel.values())
+                exe_step = sum(v.get("mfma_flops_executed_per_step", 0.0) for v in per_kernel.values())
+                per_kernel["_step"] = dict(hbm_bytes=hbm_step, hbm_over_algorithmic=hbm_step / (ALG_BYTES_STEP * args.frames),
+                                           mfma_flops_executed=exe_step,
+                                           mfma_executed_over_algorithmic_solve=exe_step / ((ALG_FLOPS["elim"] + ALG_FLOPS["update"] +
+                                                                                             ALG_FLOPS["backsub"]) * args.frames))
+        except Exception as exc:
+            pmc_note = f"no PMC summary quoted ({exc!r})"
         out = {
             "metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -380,7 +435,7 @@ def main():
                          "launches_per_step": launches / args.steps, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "share_of_phase": {"phase": phase, "nodes_or_frames": share},
-                         "pmc": mfma,
+                         "pmc": mfma, "pmc_note": pmc_note, "per_kernel": per_kernel,
                          "step": {"achieved_tflops": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12,
                                   "frac_fp64": ALG_FLOPS_STEP * n_loc / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
@@ -389,12 +444,21 @@ def main():
                                   "launch": "eager" if args.no_graph else ("hipGraph replay" if world == 1 else "4 hipGraph phases + 3 collectives"),
                                   "ms_per_step_eager_with_events": 1e3 * dt_eager / args.steps},
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
-            "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name")},
+            "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},
         }
+        if world > 1:
+            out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
+                                  "per_step": coll,
+                                  "payload_bytes": {"all_reduce_separators": (world - 1) * (2 * 80 * 80 + 80) * 8,
+                                                    "all_gather_edges": world * 6 * 25 * 8, "all_gather_scalars": world * 8 * 8},
+                                  "note": "rank 0's HIP-event time around each collective on the launch stream (includes "
+                                          "waiting for the slowest rank); kernel_ms_per_step above is rank 0's shard"}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(det, rig, seq["Ts"])
         if not args.no_cpu_baseline and world == 1:
+            _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline(det, rig, seq["Ts"], x0_full)
+            _log("done")
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))

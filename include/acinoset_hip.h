@@ -150,7 +150,15 @@ typedef struct acino_fte_params {
                             * M_l = sum J^T W J and v_l = sum J^T w rho' accumulated in fp32; everything from the 6x6
                             * spatial blocks onward - subtree sums, H, g, the smoothness prior with its 1/Ts^4 weights, the
                             * band factorisation, the LM controller and the cost - stays fp64. */
-  int32_t reserved0;
+  int32_t bcr_levels;      /* 0 (default): complete block cyclic reduction.  K > 0: INCOMPLETE reduction - after K levels the
+                            * couplings between the remaining nodes (3 * 2^K frames apart) are dropped and every remaining
+                            * node is solved on its own.  The dropped blocks decay geometrically with the node distance
+                            * (the Gauss-Newton matrix is banded SPD); their normalised size
+                            * eps = max || L_b^-1 C L_a^-T ||_F is MEASURED on the device every iteration
+                            * (acino_fte_state::trunc_eps) - the solve's relative energy-norm error is <= eps / (1 - eps) -
+                            * and an iteration with eps > trunc_tol stops the solve with status 7 instead of returning an
+                            * unverified step.  Single-GPU contexts only (no pinned separators). */
+  double trunc_tol;        /* admissible eps of an incomplete reduction (0 = 1e-10)                                */
 } acino_fte_params;
 #define ACINO_PREC_F64 0
 #define ACINO_PREC_BF16_ROWS 1
@@ -163,11 +171,13 @@ typedef struct acino_fte_state {
   double gain, pred, step_inf, gnorm_inf;
   int32_t iter;            /* LM iterations performed                                       */
   int32_t accepted;
-  int32_t status;          /* 0 running, 1 ftol, 2 xtol, 3 gtol, 4 lambda overflow, 5 numeric */
+  int32_t status;          /* 0 running, 1 ftol, 2 xtol, 3 gtol, 4 lambda overflow, 5 numeric (non-positive pivot),
+                            * 6 device synchronisation timeout (backsub tail), 7 dropped couplings above trunc_tol */
   int32_t cur;             /* which of the two iterate buffers is current                   */
   int32_t n_behind;        /* weighted detections with z_cam < 1e-6 (kept, as the reference)  */
   int32_t last_accept;
   int32_t pad0, pad1;
+  double trunc_eps;        /* incomplete reduction: measured size of the dropped couplings in the last iteration (0: complete) */
 } acino_fte_state;
 
 typedef struct acino_fte_ctx acino_fte_ctx;   /* opaque host handle */
@@ -205,9 +215,9 @@ int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* 
 int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
 /* Live per-kernel timing for bench.py: HIP events recorded on the launch stream around every kernel between
  * begin and end.  end synchronises and returns, per class {elim, elim_deep, update0, update, update_deep, backsub0,
- * backsub, trial, assemble, totals, control, backsub_tail} (one class per kernel), the summed event time in ms, the launch
+ * backsub, trial, assemble, totals, control, backsub_tail, trunc_check} (one class per kernel), the summed event time in ms, the launch
  * count and the work units (chain nodes for the block-reduction kernels, frames for trial/assemble; may be NULL). */
-#define ACINO_PROF_CLASSES 12
+#define ACINO_PROF_CLASSES 13
 int acino_fte_profile_begin(acino_fte_ctx* ctx);
 /* Debug aid: phase timestamps (wall_clock64 ticks) of workgroup 0 of the elimination kernel -> d_dbg[16]; NULL disables. */
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);

@@ -18,6 +18,11 @@ from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from acinoset_amd import _lib  # noqa: E402
+# identity of the binary these counters were measured on (hash over every HIP source + header): bench.py only quotes a
+# profiles/ JSON whose build_id equals the library it is running
+BUILD_ID = _lib.built_id()
 
 
 def short(name):
@@ -40,7 +45,7 @@ csv.writer(open(os.path.join(dst, "rocprofv3_pmc_by_kernel.csv"), "w")).writerow
 
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1 "
                      "--no-secondary at 10 000 frames; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B)",
-           "kernels": {}}
+           "build_id": BUILD_ID, "kernels": {}}
 for k in acc.get("FETCH_SIZE", {}):
     if not k.startswith("acino::"):
         continue
@@ -53,7 +58,7 @@ json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 if "SQ_VALU_MFMA_BUSY_CYCLES" in acc:
     out = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
                      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES (one pass, own run)",
-           "kernels": {}}
+           "build_id": BUILD_ID, "kernels": {}}
     for k, (n, busy) in acc["SQ_VALU_MFMA_BUSY_CYCLES"].items():
         if not k.startswith("acino::"):
             continue
