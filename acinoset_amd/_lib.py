@@ -31,7 +31,8 @@ class FteParams(C.Structure):
                 ("redesc_c", C.c_double), ("q_w", C.c_double * N_ACTIVE), ("lo", C.c_double * N_ACTIVE),
                 ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
                 ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32),
-                ("clip_len", C.c_int64), ("precision", C.c_int32), ("bcr_levels", C.c_int32), ("trunc_tol", C.c_double)]
+                ("clip_len", C.c_int64), ("precision", C.c_int32), ("bcr_levels", C.c_int32), ("trunc_tol", C.c_double),
+                ("own_first", C.c_int32), ("own_count", C.c_int32)]
 
 
 class FteState(C.Structure):
@@ -114,6 +115,9 @@ SIGNATURES = {
     "acino_fte_solve": (_I, [_P, _I, C.POINTER(FteState), _P]),
     "acino_fte_get_state": (_I, [_P, C.POINTER(FteState), _P]),
     "acino_fte_get_result": (_I, [_P, _D, _P, _P, _P, _P, _P]),
+    "acino_fte_copy_frames": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "acino_fte_set_precision": (_I, [_P, _I]),
+    "acino_fte_reevaluate": (_I, [_P, _P]),
     "acino_fte_cost": (_I, [_P, _P, _P, _P]),
     "acino_fte_get_grad_hess": (_I, [_P, _P, _P, _P]),
     "acino_fte_derivatives": (_I, [_P, _L, _D, _P, _P, _P]),

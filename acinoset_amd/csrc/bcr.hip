@@ -99,7 +99,8 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
       if (fixed) d *= FIX_SCALE;
       Dm[tid * LD + tid] = d;
       b = fixed ? 0.0 : -gv;
-      gmax = fabs(b);
+      const int nloc = fbase + tid / NP;
+      gmax = (nloc >= K.own_lo && nloc < K.own_hi) ? fabs(b) : 0.0;   // (window sharding: owned frames only)
     }
     bv[tid] = b;
   }

@@ -140,8 +140,10 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
     const double d0 = hd[e];
     const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
     xt[(size_t)(n + HALO) * NP + p] = xn;
-    pred = 0.5 * d * (lam * d0 * d - pg);
-    step = fabs(xn - xv);
+    if (n >= K.own_lo && n < K.own_hi) {          // (window sharding: only owned frames enter the global sums)
+      pred = 0.5 * d * (lam * d0 * d - pg);
+      step = fabs(xn - xv);
+    }
   }
   __shared__ double rp[4], rs[4];
   for (int off = 32; off > 0; off >>= 1) {
@@ -403,6 +405,17 @@ __global__ void k_export_edges(const acino_fte_state* __restrict__ st, int which
 }
 
 __global__ void __launch_bounds__(256)
+k_copy_frames(const acino_fte_state* __restrict__ st, int which, int import, double* x0, double* x1, int first, int n,
+              double* __restrict__ buf) {
+  double* xh = ((st->cur ^ which) ? x1 : x0) + (size_t)(first + HALO) * NP;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n * NP) {
+    if (import) xh[e] = buf[e];
+    else buf[e] = xh[e];
+  }
+}
+
+__global__ void __launch_bounds__(256)
 k_export_sep(BcrChain ch, int node_left, int node_right, double* __restrict__ rec_left, double* __restrict__ rec_right) {
   // rec layout: D[6400] | C[6400] | b[80]
   const size_t MB = (size_t)BS * BS;
@@ -466,6 +479,8 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->clamp_lambda = p->clamp_lambda;
   c->precision = p->precision;
   c->trunc_tol = p->trunc_tol > 0.0 ? p->trunc_tol : 1e-10;
+  c->own_lo = p->own_count > 0 ? p->own_first : 0;
+  c->own_hi = p->own_count > 0 ? p->own_first + p->own_count : p->n_frames;
   memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
   return ACINO_OK;
 }
@@ -478,8 +493,11 @@ static int validate(const acino_fte_params* p) {
                 "shard range inside the sequence");
   ACINO_REQUIRE(!p->pin_left || (p->n_offset >= 3 && p->n_offset % 3 == 0), "pinned-left shard must start at a multiple of 3");
   ACINO_REQUIRE(p->clip_len >= 0, "clip_len");
-  ACINO_REQUIRE(p->precision == ACINO_PREC_F64 || p->precision == ACINO_PREC_BF16_ROWS, "precision");
+  ACINO_REQUIRE(p->precision >= ACINO_PREC_F64 && p->precision <= ACINO_PREC_BF16_RES, "precision");
   ACINO_REQUIRE(p->bcr_levels >= 0 && p->trunc_tol >= 0.0, "bcr_levels, trunc_tol");
+  ACINO_REQUIRE(p->own_count >= 0 && (p->own_count == 0 || (p->own_first >= 0 && p->own_first + p->own_count <= p->n_frames &&
+                                                           !p->pin_left && !p->pin_right && p->clip_len == 0)),
+                "own range must lie inside the window (and windows have no pinned separators / clips)");
   ACINO_REQUIRE(p->bcr_levels == 0 || (!p->pin_left && !p->pin_right),
                 "incomplete reduction (bcr_levels > 0): single-GPU contexts only");
   ACINO_REQUIRE(p->clip_len == 0 || (!p->pin_left && !p->pin_right && p->n_offset == 0 && p->n_global == p->n_frames &&
@@ -653,6 +671,49 @@ int acino_fte_set_halo(acino_fte_ctx* ctx, int which, const double* d_halo_l, co
   ACINO_REQUIRE(which == 0 || which == 1, "which");
   hipLaunchKernelGGL(k_set_halo, dim3(1), dim3(128), 0, (hipStream_t)stream, ctx->b.state, which, ctx->b.x[0],
                      ctx->b.x[1], ctx->h.n_frames, d_halo_l, d_halo_r);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+__global__ void k_restart_status(acino_fte_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && st->status >= 1 && st->status <= 4) {
+    st->status = 0;
+    st->nu = 2.0;
+  }
+}
+
+int acino_fte_set_precision(acino_fte_ctx* ctx, int precision) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(precision >= ACINO_PREC_F64 && precision <= ACINO_PREC_BF16_RES, "precision");
+  ctx->h.precision = precision;            // the assembly kernel is chosen on the host; the device block does not need it
+  if (ctx->gexec) {
+    (void)hipGraphExecDestroy(ctx->gexec);
+    ctx->gexec = nullptr;
+  }
+  for (auto& g : ctx->seg)
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+  return ACINO_OK;
+}
+
+int acino_fte_reevaluate(acino_fte_ctx* ctx, void* stream) {
+  ACINO_REQUIRE(ctx, "null");
+  ACINO_REQUIRE(!ctx->h.pin_left && !ctx->h.pin_right, "single-GPU contexts");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_restart_status, dim3(1), dim3(64), 0, s, ctx->b.state);
+  ACINO_LAUNCH_CHECK();
+  return eval_iterate(ctx, 0, true, false, false, s, 1);      // assembly of the current iterate + cost (init-style control)
+}
+
+int acino_fte_copy_frames(acino_fte_ctx* ctx, int which, int import, int first, int n, double* d_buf, void* stream) {
+  ACINO_REQUIRE(ctx && d_buf, "null");
+  ACINO_REQUIRE(which == 0 || which == 1, "which");
+  ACINO_REQUIRE(n >= 0 && first >= -HALO && first + n <= ctx->h.n_frames + HALO, "frame range");
+  if (n == 0) return ACINO_OK;
+  hipLaunchKernelGGL(k_copy_frames, dim3((unsigned)((n * NP + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ctx->b.state, which, import ? 1 : 0, ctx->b.x[0], ctx->b.x[1], first, n, d_buf);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }

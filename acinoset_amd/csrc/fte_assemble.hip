@@ -134,11 +134,13 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
   if (tid < nproj) {
     const int f = tid / NL, l = tid - f * NL;
     const int n = f0 + f;
+    const bool owned = n >= K.own_lo && n < K.own_hi;      // window sharding: only owned frames enter the cost
+    double cost_c = 0.0;
     const double px = F[f].pos[l][0], py = F[f].pos[l][1], pz = F[f].pos[l][2];
     double M[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
     float Mf[6] = {0, 0, 0, 0, 0, 0}, vf[3] = {0, 0, 0};
     LossF lossf;
-    if (PREC == ACINO_PREC_BF16_ROWS) {
+    if (PREC != ACINO_PREC_F64) {
       lossf.a = (float)K.loss.a; lossf.b = (float)K.loss.b; lossf.c = (float)K.loss.c;
       lossf.ea = (float)K.loss.ea; lossf.eb = (float)K.loss.eb; lossf.ec = (float)K.loss.ec;
       lossf.d0 = (float)K.loss.d0; lossf.t4 = (float)K.loss.t4; lossf.icb = (float)K.loss.icb;
@@ -171,10 +173,10 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       if (zc < 1e-6 && w > 0) ++behind;
       if (fabs(zc) < 1e-9) w = 0.0;
       if (w == 0.0) {
-        my_cost += 2.0 * rho0;
+        cost_c += 2.0 * rho0;
         continue;
       }
-      if (PREC == ACINO_PREC_BF16_ROWS) {
+      if (PREC != ACINO_PREC_F64) {
         // ---- fp32 projection from the fp64 camera-frame point; the pixel offset (c - z) is formed in fp64 first
         const float xf = (float)xc, yf = (float)yc, zf = (float)zc;
         const float izf = __frcp_rn(zf);
@@ -196,7 +198,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
         float rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0, dmy0 = 0, dmy1 = 0;
         redescending_f<false>(lossf, su_f, rho_u, dmy0, dmy1);          // cost: unrounded residual, summed in fp64
         redescending_f<false>(lossf, sv_f, rho_v, dmy0, dmy1);
-        my_cost += (double)rho_u + (double)rho_v;
+        cost_c += (double)rho_u + (double)rho_v;
         if (JAC) {
           float r0, r1;
           redescending_f<true>(lossf, su, r0, drho_u, h_u);             // weights: from the stored (bf16) residual
@@ -211,8 +213,12 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
           float ju[3], jv[3];
 #pragma unroll
           for (int j = 0; j < 3; ++j) {                                   // the Jacobian ROWS as stored: bf16
-            ju[j] = bf16_round(uc0 * (float)cam.R[j] + uc1 * (float)cam.R[3 + j] + uc2 * (float)cam.R[6 + j]);
-            jv[j] = bf16_round(vc0 * (float)cam.R[j] + vc1 * (float)cam.R[3 + j] + vc2 * (float)cam.R[6 + j]);
+            ju[j] = uc0 * (float)cam.R[j] + uc1 * (float)cam.R[3 + j] + uc2 * (float)cam.R[6 + j];
+            jv[j] = vc0 * (float)cam.R[j] + vc1 * (float)cam.R[3 + j] + vc2 * (float)cam.R[6 + j];
+            if (PREC == ACINO_PREC_BF16_ROWS) {
+              ju[j] = bf16_round(ju[j]);
+              jv[j] = bf16_round(jv[j]);
+            }
           }
           const float gu = wf * drho_u * (su > 0 ? 1.0f : (su < 0 ? -1.0f : 0.0f));
           const float gv = wf * drho_v * (sv > 0 ? 1.0f : (sv < 0 ? -1.0f : 0.0f));
@@ -243,7 +249,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
         double rho_u, drho_u = 0, h_u = 0, rho_v, drho_v = 0, h_v = 0;
         redescending<JAC>(K.loss, su, rho_u, drho_u, h_u);
         redescending<JAC>(K.loss, sv, rho_v, drho_v, h_v);
-        my_cost += rho_u + rho_v;
+        cost_c += rho_u + rho_v;
         if (JAC) {
           double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
           double dm_dr = (dthD * rcp64(1 + r2) * r - thD) * (ir * ir);
@@ -274,13 +280,14 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     
       }
     }
-    if (PREC == ACINO_PREC_BF16_ROWS) {
+    if (PREC != ACINO_PREC_F64) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) M[k] = (double)Mf[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) v[k] = (double)vf[k];
     }
-    if (behind) atomicAdd(nbehind, behind);
+    if (owned) my_cost += cost_c;
+    if (behind && owned) atomicAdd(nbehind, behind);
     if (JAC) {
       // Lambda = [[M, -B], [-B^T, -P B]],  B = M P,  P = [p]x ;  f = [v, p x v]
       const double Mm[3][3] = {{M[0], M[1], M[2]}, {M[1], M[3], M[4]}, {M[2], M[4], M[5]}};
@@ -344,7 +351,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     const double q = K.q_w[bq];
     const double* xc = xh + (int64_t)(n + HALO) * NP + bq;   // x[n][bq]; neighbours at +-k*NP
     // smoothness cost: rows whose last frame is this one
-    if ((K.clip_len > 0 ? ng % K.clip_len : ng) >= 3) {
+    if ((K.clip_len > 0 ? ng % K.clip_len : ng) >= 3 && n >= K.own_lo && n < K.own_hi) {
       double d3 = xc[0] - 3.0 * xc[-NP] + 3.0 * xc[-2 * NP] - xc[-3 * NP];
       my_cost += q * d3 * d3;
     }
@@ -466,6 +473,10 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_BF16_ROWS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_BF16_RES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_BF16_RES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
   }
@@ -475,6 +486,9 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
   if (h_c.precision == ACINO_PREC_BF16_ROWS) {
     if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_BF16_ROWS);
     else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_BF16_ROWS);
+  } else if (h_c.precision == ACINO_PREC_BF16_RES) {
+    if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_BF16_RES);
+    else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_BF16_RES);
   } else {
     if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_F64);
     else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_F64);

@@ -29,6 +29,7 @@ struct FteConst {
   int32_t clamp_lambda;
   int32_t precision;       // ACINO_PREC_*
   int64_t clip_len;        // > 0: independent clips of this many frames laid end to end (no coupling across clips)
+  int32_t own_lo, own_hi;  // local frames [own_lo, own_hi) count towards cost / pred / step / gradient norms (window sharding)
   double trunc_tol;        // incomplete reduction: largest admissible eps of a dropped coupling (status 7 above it)
   Cam cams[ACINO_MAX_CAMS];
 };

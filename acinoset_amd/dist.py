@@ -301,3 +301,123 @@ def make_sharded(det_full, k_arr, d_arr, r_arr, t_arr, Ts, rank, world, group=No
     n0, n1 = plan[rank]
     backend = HipBackend(det_full[n0:n1], k_arr, d_arr, r_arr, t_arr, Ts, n_global, n0, rank, world, **kw)
     return ShardedFTE(backend, rank, world, group, comm), (n0, n1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Overlapping windows: the inexact-step variant (no separator system, two small collectives per iteration)
+# ---------------------------------------------------------------------------------------------------------------
+def window_plan(n_frames, world, halo):
+    """[(w0, w1, n0, n1)] per rank: owned frames [n0, n1) as shard_plan, window [w0, w1) = owned + `halo` frames on
+    either side (clipped to the sequence).  halo is rounded up to a multiple of 3 (windows start on a node boundary)."""
+    halo = 3 * ((int(halo) + 2) // 3)
+    plan = shard_plan(n_frames, world) if world > 1 else [(0, n_frames)]
+    if world > 1 and min(n1 - n0 for n0, n1 in plan) < halo + 3:
+        raise ValueError(f"shards of {min(n1 - n0 for n0, n1 in plan)} frames are shorter than the halo ({halo} + 3 frames)")
+    return [(max(0, n0 - halo), min(n_frames, n1 + halo), n0, n1) for n0, n1 in plan], halo
+
+
+class WindowedFTE:
+    """One LM solve over a sequence sharded across the process group WITHOUT a separator system.
+
+    The Gauss-Newton matrix is banded and SPD, so the influence of a right-hand side entry on the step decays
+    geometrically with the frame distance (measured on the benchmark sequence: 5e-3 at 96 frames, 6e-6 at 192, 2e-9 at
+    300 with lambda -> 0, faster with damping).  Every rank therefore solves its OWN window - owned frames plus `halo`
+    frames of its neighbours', with the step pinned to 0 outside the window - by the complete single-GPU reduction, keeps
+    the step on its owned frames and discards the rest (restricted additive Schwarz).  The step is inexact by
+    ~decay(halo); cost, gradient, accept / reject and the damping are EXACT and global: the trial iterate's edge slabs
+    travel in one all-gather, the eight partial sums in a second one, and every rank runs the same controller on the
+    same totals.  Two small collectives per iteration, no all-reduce, no redundant separator solve."""
+
+    def __init__(self, ctx, rank, world, own, halo, group=None, comm=None):
+        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.own_first, self.own_count = own           # local frame indices inside the window
+        self.halo = halo
+        self.slab = halo + 3                           # + the three stencil rows beyond the window
+        dev = ctx.device
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+        self._edges = z(2, self.slab, N_ACTIVE)        # first / last `slab` owned frames of the trial iterate
+        self._all_edges = z(world, 2, self.slab, N_ACTIVE)
+        self._partial = z(8)
+        self._all_partials = z(world, 8)
+        self._timing = None
+
+    collect_timing = ShardedFTE.collect_timing
+    _timed = ShardedFTE._timed
+    timing_summary = ShardedFTE.timing_summary
+
+    def _c(self, fn, *args):
+        check(fn(self.ctx._h, *args))
+
+    def _exchange(self, which):
+        L = lib()
+        if self.world == 1:
+            return
+        first, cnt, s = self.own_first, self.own_count, self.slab
+        self._c(L.acino_fte_copy_frames, which, 0, first, s, ptr(self._edges[0]), stream_ptr())
+        self._c(L.acino_fte_copy_frames, which, 0, first + cnt - s, s, ptr(self._edges[1]), stream_ptr())
+        self._timed("all_gather_edge_slabs", self.comm.all_gather, self._all_edges, self._edges)
+        if self.rank > 0:                              # the left neighbour's LAST slab sits just before my owned frames
+            self._c(L.acino_fte_copy_frames, which, 1, first - s, s, ptr(self._all_edges[self.rank - 1, 1]), stream_ptr())
+        if self.rank + 1 < self.world:                 # the right neighbour's FIRST slab just after them
+            self._c(L.acino_fte_copy_frames, which, 1, first + cnt, s, ptr(self._all_edges[self.rank + 1, 0]), stream_ptr())
+
+    def _control(self, init):
+        L = lib()
+        self._c(L.acino_fte_export_partials, ptr(self._partial), stream_ptr())
+        if self.world > 1:
+            self._timed("all_gather_scalars", self.comm.all_gather, self._all_partials, self._partial)
+            total = combine_partials(self._all_partials)
+        else:
+            total = self._partial
+        self._keep = total
+        self._c(L.acino_fte_control, ptr(total), int(init), stream_ptr())
+
+    def set_x(self, x_window):
+        """x_window[n_window, 25]: the initial iterate on this rank's WHOLE window."""
+        L = lib()
+        self._x0 = calib_to_dev(x_window, self.ctx.device)
+        self._c(L.acino_fte_load_x, ptr(self._x0), stream_ptr())
+        self._c(L.acino_fte_eval, 0, stream_ptr())
+        self._control(True)
+
+    def step(self):
+        L = lib()
+        self._c(L.acino_fte_reduce_local, stream_ptr())
+        self._c(L.acino_fte_backsub_local, C.c_void_p(0), 0, 1, stream_ptr())
+        self._c(L.acino_fte_trial, stream_ptr())
+        self._exchange(1)                              # neighbours' owned values replace my halo estimate of the trial
+        self._c(L.acino_fte_eval, 1, stream_ptr())
+        self._control(False)
+
+    def state(self):
+        return self.ctx.state()
+
+    def solve(self, max_iter, peek_every=8):
+        for it in range(max_iter):
+            self.step()
+            if (it % peek_every) == peek_every - 1 and self.ctx.state()["status"] != 0:
+                break
+        return self.ctx.state()
+
+    def result_x(self):
+        """This rank's OWNED frames of the current iterate."""
+        return self.ctx.result()[0][self.own_first:self.own_first + self.own_count]
+
+
+def calib_to_dev(a, dev):
+    from . import calib
+    return calib._to_dev(a, dev)
+
+
+def make_windowed(det_full, k_arr, d_arr, r_arr, t_arr, Ts, rank, world, halo=192, group=None, comm=None, **kw):
+    """This rank's window of a full det[N,C,20,3] and the driver over it.  Returns (driver, (w0, w1, n0, n1)): the
+    window and the owned frame range in global indices (set_x takes the initial iterate of [w0, w1))."""
+    n_global = int(det_full.shape[0])
+    plan, halo = window_plan(n_global, world, halo)
+    w0, w1, n0, n1 = plan[rank]
+    if w0 > 0 and n0 - w0 < halo:
+        raise ValueError("window does not hold the halo")
+    ctx = fte.FTEContext(det_full[w0:w1], k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=w0,
+                         own_first=n0 - w0, own_count=n1 - n0, **kw)
+    return WindowedFTE(ctx, rank, world, (n0 - w0, n1 - n0), halo, group, comm), (w0, w1, n0, n1)

@@ -29,7 +29,7 @@ Q_SIGMA = np.array([4, 7, 5,
                     26, 12, 0, 34, 43, 51, 0, 0, 0, 0, 0, 0, 0, 0], dtype=np.float64)
 R_MEAS = 5.0                          # measurement std-dev, px (:243)
 # acino_fte_params::precision: "f64" everywhere, or BASELINE config 5's "bf16 residuals with fp32 accumulate"
-PRECISIONS = {"f64": 0, "bf16": 1}
+PRECISIONS = {"f64": 0, "bf16": 1, "bf16_residuals": 2}
 REDESC = (3.0, 10.0, 20.0)            # redescending a, b, c (:25-27)
 
 
@@ -53,7 +53,7 @@ def bounds45():
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
                 lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0, precision="f64", bcr_levels=0,
-                trunc_tol=1e-10):
+                trunc_tol=1e-10, own_first=0, own_count=0):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -81,6 +81,7 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     p.precision = PRECISIONS[precision]
     p.bcr_levels, p.trunc_tol = int(bcr_levels), float(trunc_tol)
+    p.own_first, p.own_count = int(own_first), int(own_count)
     return p
 
 
@@ -126,6 +127,12 @@ class FTEContext:
             raise ValueError(f"x0 must be [{self.N}, 25] active states")
         self._x0 = x
         check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
+
+    def set_precision(self, precision):
+        """Switch the assembly arithmetic (PRECISIONS) and re-evaluate the current iterate in it; the controller keeps
+        its damping and goes back to "running" - used to polish a mixed-precision solve with fp64 iterations."""
+        check(lib().acino_fte_set_precision(self._h, PRECISIONS[precision]))
+        check(lib().acino_fte_reevaluate(self._h, stream_ptr()))
 
     def enable_graph(self, on=True):
         """Replay the LM step as a hipGraph (takes effect on a non-default stream)."""
@@ -347,10 +354,17 @@ def fte_solve_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0
         x0_all[b * S:(b + 1) * S] = x0
     dev = torch.device("cuda", torch.cuda.current_device())
     det_all = torch.cat([d.to(device=dev, dtype=torch.float64) for d in dets_t], dim=0)
+    polish = kw.pop("polish_f64", False)
     ctx = FTEContext(det_all, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, clip_len=S, **kw)
     try:
         ctx.set_x(x0_all[:, ACTIVE])
         info = ctx.solve(max_iter)
+        if polish and kw.get("precision", "f64") != "f64" and info["status"] in (1, 2, 3):
+            # mixed-precision solve finished: a few fp64 iterations from its end point (same controller, same damping)
+            n_mixed = info["iter"]
+            ctx.set_precision("f64")
+            info = ctx.solve(max(max_iter - n_mixed, 1))
+            info["iter_mixed"] = n_mixed
         x, pos, _dx, _ddx = ctx.result()
         if info["status"] == 5:
             raise RuntimeError("FTE: block factorisation hit a non-positive pivot")

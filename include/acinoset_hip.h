@@ -159,9 +159,15 @@ typedef struct acino_fte_params {
                             * and an iteration with eps > trunc_tol stops the solve with status 7 instead of returning an
                             * unverified step.  Single-GPU contexts only (no pinned separators). */
   double trunc_tol;        /* admissible eps of an incomplete reduction (0 = 1e-10)                                */
+  int32_t own_first;       /* overlapping-window sharding (acinoset_amd/dist.py WindowedFTE): the n_frames of this context */
+  int32_t own_count;       /* are a WINDOW [n_offset, n_offset + n_frames) of the sequence, of which only the local frames
+                            * [own_first, own_first + own_count) are owned: the whole window is assembled and solved
+                            * (frames outside it keep delta = 0), but cost, predicted reduction, step and gradient norms
+                            * count owned frames only.  own_count = 0 (default): every frame is owned. */
 } acino_fte_params;
 #define ACINO_PREC_F64 0
 #define ACINO_PREC_BF16_ROWS 1
+#define ACINO_PREC_BF16_RES 2    /* as BF16_ROWS but only the residual rows are rounded to bf16; Jacobian rows stay fp32 */
 
 /* LM state mirrored in device memory (read back with acino_fte_get_state). */
 typedef struct acino_fte_state {
@@ -208,6 +214,18 @@ int acino_fte_get_state(acino_fte_ctx* ctx, acino_fte_state* out, void* stream);
  * relations (all_optimizations.py:369-383).  Any output may be NULL.  Synchronises. */
 int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_pos, double* d_dx, double* d_ddx,
                          void* stream);
+/* Switches the arithmetic of the assembly for the following evaluations (ACINO_PREC_*): a mixed-precision solve is
+ * finished ("polished") with a few fp64 iterations this way.  Drops the captured step graph; the next
+ * acino_fte_step re-evaluates nothing by itself - call acino_fte_reevaluate to refresh cost / gradient / blocks of
+ * the current iterate in the new precision before stepping. */
+int acino_fte_set_precision(acino_fte_ctx* ctx, int precision);
+/* Re-evaluates the CURRENT iterate (cost, gradient, Gauss-Newton blocks) and restarts the controller's stopping
+ * state (status -> running, lambda kept). */
+int acino_fte_reevaluate(acino_fte_ctx* ctx, void* stream);
+/* Copies n frames of the current (which = 0) or trial (which = 1) iterate, starting at local frame `first`
+ * (-3 <= first, first + n <= n_frames + 3: the three halo rows on either side are addressable), to d_buf[n][25]
+ * (import = 0) or from it (import = 1).  The overlapping-window driver exchanges its edge slabs with these. */
+int acino_fte_copy_frames(acino_fte_ctx* ctx, int which, int import, int first, int n, double* d_buf, void* stream);
 /* Cost only at d_x[N][25] -> d_cost[1]; evaluated in the trial buffer (call between LM steps). */
 int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* stream);
 /* Gradient d_g[N][25] and Gauss-Newton blocks d_h[N][25][25] (measurement part + smoothness diagonal) of the
