@@ -1193,7 +1193,11 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
   for (const BcrLevel& lv : sch.levels) {
     {
       const bool fused0 = level == 0 && ch.st != nullptr;
-      const bool deep = !fused0 && !(ch.implicit_couplings && lv.adjacent) && lv.n_elim <= 64;
+      const bool explicit_c = !fused0 && !(ch.implicit_couplings && lv.adjacent);
+      const bool deep = explicit_c && lv.n_elim <= 64;
+      // (measured dead end, round 2: the wide levels >= 1 in the strip form of k_bcr_elim_deep with T = 1, compiled for
+      //  THREE workgroups per CU - 168 VGPRs, 12 B/lane of scratch -: k_bcr_elim 0.288 -> 0.341 ms per step.  The
+      //  level is not occupancy-bound; the third workgroup only adds contention for the one LDS pipe.)
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
         // (isolated nodes of an incomplete reduction have no W strips: one workgroup per node factors and stores)

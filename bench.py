@@ -276,6 +276,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / solve-to-tolerance extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
+    ap.add_argument("--shard", choices=("windows", "separators"), default="windows",
+                    help="N > 1: overlapping windows (two all-gathers per step, step exact to the decay over --halo frames) or "
+                         "exact separator system (one all-reduce + two all-gathers)")
+    ap.add_argument("--halo", type=int, default=192, help="--shard windows: frames of overlap on either side")
     ap.add_argument("--bcr-levels", type=int, default=0,
                     help="incomplete block cyclic reduction after this many levels (0 = complete; single GPU only)")
     args = ap.parse_args()
@@ -315,23 +319,29 @@ def main():
     det = seq["det"]
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     x0_full = fte.triangulation_init(det, *rig, 0.5)
-    solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world,
-                                          ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,    # never stops: every step is full work
-                                          shared_gpu="ACINO_FORCE_DEVICE" in os.environ,      # (ranks sharing one GPU: functional runs only)
-                                          **({"bcr_levels": args.bcr_levels} if args.bcr_levels and world == 1 else {}))
-    x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
+    windows = world > 1 and args.shard == "windows"
+    common = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,                           # never stops: every step is full work
+                  shared_gpu="ACINO_FORCE_DEVICE" in os.environ)                             # (ranks sharing one GPU: functional runs only)
+    if windows:
+        solver, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(det), *rig, seq["Ts"], rank, world, halo=args.halo, **common)
+        x0_local = torch.as_tensor(x0_full[w0:w1][:, fte.ACTIVE])
+        ctx = solver.ctx
+    else:
+        solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world, **common,
+                                              **({"bcr_levels": args.bcr_levels} if args.bcr_levels and world == 1 else {}))
+        x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
+        ctx = solver.b.ctx
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx = solver.b.ctx
     use_graph = world == 1 and not args.no_graph
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        if not args.no_graph:
+        if not args.no_graph and not windows:
             ctx.enable_graph(True)        # no host sync inside a step: capture once, replay (N > 1: the 4 phases between the collectives)
         solver.set_x(x0_local)
         for _ in range(args.warmup):
@@ -365,7 +375,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    st = solver.b.state()
+    st = ctx.state()
 
     if rank == 0:
         n_loc = n1 - n0
@@ -428,7 +438,9 @@ def main():
             "config": {"workload": f"FTE LM iteration, {N_CAMS} cam x 20 markers x {args.frames} frames (BASELINE configs[3] shape"
                                    f"{'' if world > 1 else ' on one GPU'}), loop trajectory, seed 20210313",
                        "frames": args.frames, "cams": N_CAMS, "markers": 20, "states": 25,
-                       "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"frames sharded x{world}, " + (f"overlapping windows (halo {args.halo} frames), 2 all-gathers / step"
+                                                                        if windows else "separator system, 1 all-reduce + 2 all-gathers / step"))
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
@@ -441,7 +453,7 @@ def main():
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
                                   "frac_hbm": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "gpu_kernel_ms_per_step": gpu_ms_step,
-                                  "launch": "eager" if args.no_graph else ("hipGraph replay" if world == 1 else "4 hipGraph phases + 3 collectives"),
+                                  "launch": "eager" if (args.no_graph or windows) else ("hipGraph replay" if world == 1 else "4 hipGraph phases + 3 collectives"),
                                   "ms_per_step_eager_with_events": 1e3 * dt_eager / args.steps},
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},
@@ -449,8 +461,10 @@ def main():
         if world > 1:
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
-                                  "payload_bytes": {"all_reduce_separators": (world - 1) * (2 * 80 * 80 + 80) * 8,
-                                                    "all_gather_edges": world * 6 * 25 * 8, "all_gather_scalars": world * 8 * 8},
+                                  "payload_bytes": ({"all_gather_edge_slabs": world * 2 * (args.halo + 3) * 25 * 8, "all_gather_scalars": world * 8 * 8}
+                                                    if windows else
+                                                    {"all_reduce_separators": (world - 1) * (2 * 80 * 80 + 80) * 8,
+                                                     "all_gather_edges": world * 6 * 25 * 8, "all_gather_scalars": world * 8 * 8}),
                                   "note": "rank 0's HIP-event time around each collective on the launch stream (includes "
                                           "waiting for the slowest rank); kernel_ms_per_step above is rank 0's shard"}
         if world == 1 and not args.no_secondary:

@@ -19,8 +19,11 @@ dets = [torch.as_tensor(s["det"], device="cuda") for s in seqs]
 Ts = seqs[0]["Ts"]
 
 
+FTOL = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-10
+
+
 def run(**kw):
-    out = fte.fte_solve_clips(dets, *rig, Ts, max_iter=150, **kw)
+    out = fte.fte_solve_clips(dets, *rig, Ts, max_iter=400, ftol=FTOL, xtol=1e-12, **kw)
     return np.stack([o[0]["positions"] for o in out]), out[0][1]
 
 
