@@ -378,6 +378,7 @@ class WindowedFTE:
         L = lib()
         self._x0 = calib_to_dev(x_window, self.ctx.device)
         self._c(L.acino_fte_load_x, ptr(self._x0), stream_ptr())
+        self._exchange(0)          # the three stencil rows beyond the window (and my halo) take the neighbours' values
         self._c(L.acino_fte_eval, 0, stream_ptr())
         self._control(True)
 
