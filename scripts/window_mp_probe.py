@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Overlapping windows, one PROCESS per shard over torch.distributed (gloo, all ranks on GPU 0): debug probe.
+   python -m torch.distributed.run --nproc-per-node W scripts/window_mp_probe.py <frames> <halo> <iters>"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+n, halo, iters = (int(v) for v in sys.argv[1:4])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+from acinoset_amd import dist as adist, fte, synth  # noqa: E402
+seq = synth.make_sequence(n, "loop")
+rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+x0 = fte.triangulation_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
+use_side = len(sys.argv) > 4 and sys.argv[4] == "side"
+stream = torch.cuda.Stream() if use_side else torch.cuda.current_stream()
+with torch.cuda.stream(stream):
+    d, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world, halo=halo, shared_gpu=True,
+                                              ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+    d.set_x(torch.as_tensor(x0[w0:w1]))
+    st = d.state()
+    print(f"rank {rank} window {(w0, w1)} owned {(n0, n1)} initial cost {st['cost']:.6f}", flush=True)
+    for it in range(iters):
+        d.step()
+        st = d.state()
+        if rank == 0 or it == 0:
+            print(f"rank {rank} it {it + 1} cost {st['cost']:.6f} trial {st['cost_trial']:.6f} lam {st['lam']:.2e} acc {st['accepted']} pred {st['pred']:.3e} step {st['step_inf']:.3e}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
