@@ -26,9 +26,18 @@ with torch.cuda.stream(stream):
     d.set_x(torch.as_tensor(x0[w0:w1]))
     st = d.state()
     print(f"rank {rank} window {(w0, w1)} owned {(n0, n1)} initial cost {st['cost']:.6f}", flush=True)
+    from acinoset_amd._lib import lib, ptr, stream_ptr, check
+    nwin = w1 - w0
+    buf = torch.zeros((nwin + 6, 25), dtype=torch.float64, device="cuda")
     for it in range(iters):
         d.step()
         st = d.state()
+        for which in (0, 1):
+            check(lib().acino_fte_copy_frames(d.ctx._h, which, 0, -3, nwin + 6, ptr(buf), stream_ptr()))
+            bad = torch.isnan(buf).any(1).nonzero().flatten().cpu().numpy()
+            if bad.size:
+                print(f"rank {rank} it {it + 1} which {which}: NaN frames (window-local, halo rows = -3..-1) {bad[:6] - 3} ... {bad[-3:] - 3} n={bad.size}", flush=True)
+        print(f"rank {rank} it {it + 1} partial {d._partial.cpu().numpy()[:4]} edges nan {int(torch.isnan(d._all_edges).sum())} own {int(torch.isnan(d._edges).sum())}", flush=True)
         if rank == 0 or it == 0:
             print(f"rank {rank} it {it + 1} cost {st['cost']:.6f} trial {st['cost_trial']:.6f} lam {st['lam']:.2e} acc {st['accepted']} pred {st['pred']:.3e} step {st['step_inf']:.3e}", flush=True)
 dist.barrier()
