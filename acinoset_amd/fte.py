@@ -9,6 +9,7 @@ reject controller (fte_api.hip).  ``fte_solve`` returns the reference's ``fte.pi
 (:548-559): ``{positions [N,20,3], x [N,25], dx [N,25], ddx [N,25], start_frame}``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -103,6 +104,8 @@ class FTEContext:
         self.params = make_params(self.N, self.C, Ts, **kw)
         nbytes = lib().acino_fte_workspace_bytes(C.byref(self.params))
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        if os.environ.get("ACINO_POISON_WORKSPACE"):      # debug: every read-before-write of the workspace becomes a NaN
+            self.workspace.view(torch.float64)[: (nbytes + 256) // 8].fill_(float("nan"))
         base = self.workspace.data_ptr()
         self._ws_ptr = (base + 255) // 256 * 256
         self._h = C.c_void_p()
