@@ -18,7 +18,8 @@ from acinoset_amd import dist as adist, fte, synth  # noqa: E402
 seq = synth.make_sequence(n, "loop")
 rig = (seq["K"], seq["D"], seq["R"], seq["t"])
 x0 = fte.triangulation_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
-use_side = len(sys.argv) > 4 and sys.argv[4] == "side"
+use_side = len(sys.argv) > 4 and sys.argv[4].startswith("side")
+quiet = len(sys.argv) > 4 and sys.argv[4].endswith("quiet")
 stream = torch.cuda.Stream() if use_side else torch.cuda.current_stream()
 with torch.cuda.stream(stream):
     d, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world, halo=halo, shared_gpu=True,
@@ -31,6 +32,11 @@ with torch.cuda.stream(stream):
     buf = torch.zeros((nwin + 6, 25), dtype=torch.float64, device="cuda")
     for it in range(iters):
         d.step()
+        if quiet:
+            if it == iters - 1:
+                st = d.state()
+                print(f"rank {rank} after {iters} unsynchronised steps: cost {st['cost']:.6f} acc {st['accepted']} lam {st['lam']:.2e}", flush=True)
+            continue
         st = d.state()
         for which in (0, 1):
             check(lib().acino_fte_copy_frames(d.ctx._h, which, 0, -3, nwin + 6, ptr(buf), stream_ptr()))
