@@ -152,6 +152,7 @@ SIGNATURES = {
     "acino_ekf_run": (_I, [C.POINTER(EkfParams), _P, _P, _P, _P, _Z, _P, _P, _P, _P]),
     "acino_skeleton_fk": (_I, [_P, _L, _I, _I, C.POINTER(SkelOp), _I, _P, _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
+    "acino_debug_poison_lds": (_I, [_I, _I, _P]),
 }
 
 _lib = None

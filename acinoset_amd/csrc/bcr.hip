@@ -1279,6 +1279,25 @@ __global__ void k_selftest_mfma(const double* a, const double* b, int k, double*
 
 }  // namespace acino
 
+// Debug aid: fills the LDS of the CUs it lands on with NaN patterns (n_blocks workgroups x 64 KB).  Run on a second stream
+// beside a solve it turns every read of LDS that the reading kernel did not write itself into a NaN.
+namespace acino {
+__global__ void __launch_bounds__(256) k_poison_lds(int spin) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* p = reinterpret_cast<double*>(smem_raw);
+  for (int r = 0; r < spin; ++r)
+    for (int e = threadIdx.x; e < 8192; e += 256) p[e] = __builtin_nan("");
+  __syncthreads();
+  if (p[threadIdx.x] == 1.0) p[0] = 2.0;     // keep the stores
+}
+}  // namespace acino
+extern "C" int acino_debug_poison_lds(int n_blocks, int spin, void* stream) {
+  using namespace acino;
+  hipLaunchKernelGGL(k_poison_lds, dim3(n_blocks), dim3(256), 65536, (hipStream_t)stream, spin);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
 extern "C" int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream) {
   using namespace acino;
   ACINO_REQUIRE(k > 0 && k % 4 == 0, "k must be a positive multiple of 4");

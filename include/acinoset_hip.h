@@ -385,6 +385,9 @@ int acino_fte_shard_eval(acino_fte_ctx* ctx, int which, const double* d_all_edge
 int acino_fte_shard_control(acino_fte_ctx* ctx, const double* d_all_partials, int world, int init, void* stream);
 
 /* Self-test of the fp64 MFMA tile layout used by the block solver: d_a[16][K], d_b[K][16] -> d_c[16][16]. */
+/* Debug aid: n_blocks workgroups that fill 64 KB of LDS each with NaN (to be run on a second stream beside a solve:
+ * any kernel that reads LDS it has not written itself then produces NaN). */
+int acino_debug_poison_lds(int n_blocks, int spin, void* stream);
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
 
 #ifdef __cplusplus
