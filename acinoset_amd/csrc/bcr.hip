@@ -1187,8 +1187,39 @@ int bcr_set_func_attributes() {
   return ACINO_OK;
 }
 
+// Debug (ACINO_DEBUG_SYNC=1): after every launch of the reduction, synchronise and report the first kernel after which
+// the numeric-error flag is set or the level's outputs hold a NaN.
+static bool dbg_check(const char* what, int level, const BcrChain& ch, const int* ent, int n_ent, int stride, int* d_err,
+                      hipStream_t s) {
+  if (hipStreamSynchronize(s) != hipSuccess) return true;
+  int e = 0;
+  (void)hipMemcpy(&e, d_err, sizeof(int), hipMemcpyDeviceToHost);
+  std::vector<int> h(n_ent * stride);
+  (void)hipMemcpy(h.data(), ent, sizeof(int) * h.size(), hipMemcpyDeviceToHost);
+  std::vector<double> m((size_t)BS * BS), bb(BS);
+  long long nan_d = 0, nan_b = 0;
+  int first = -1;
+  for (int k = 0; k < n_ent; ++k) {
+    const int node = h[(size_t)k * stride];
+    (void)hipMemcpy(m.data(), ch.D + (size_t)node * BS * BS, sizeof(double) * m.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(bb.data(), ch.b + (size_t)node * BS, sizeof(double) * BS, hipMemcpyDeviceToHost);
+    long long c = 0;
+    for (double v : m) c += (v != v);
+    long long cb = 0;
+    for (double v : bb) cb += (v != v);
+    if ((c || cb) && first < 0) first = node;
+    nan_d += c;
+    nan_b += cb;
+  }
+  fprintf(stderr, "[acino debug] level %d %s: numeric_err %d, NaN in D %lld, in b %lld (first node %d of %d)\n", level, what, e,
+          nan_d, nan_b, first, n_ent);
+  return e != 0 || nan_d || nan_b;
+}
+
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof) {
+  static const bool dbg = getenv("ACINO_DEBUG_SYNC") != nullptr;
+  bool dbg_hit = false;
   int level = 0;
   for (const BcrLevel& lv : sch.levels) {
     {
@@ -1211,6 +1242,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
                            d_c, d_numeric_err, d_status, level);
     }
     ACINO_LAUNCH_CHECK();
+    if (dbg && !dbg_hit) dbg_hit = dbg_check("elim", level, ch, ch.d_elim + 3 * lv.elim_off, lv.n_elim, 3, d_numeric_err, s);
     if (lv.n_remain > 0) {
       {
         const bool up0 = level == 0 && ch.st != nullptr;
@@ -1228,6 +1260,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
       }
       ACINO_LAUNCH_CHECK();
+      if (dbg && !dbg_hit) dbg_hit = dbg_check("update", level, ch, ch.d_remain + 4 * lv.remain_off, lv.n_remain, 4, d_numeric_err, s);
     }
     ++level;
   }
