@@ -15,8 +15,8 @@ with torch.cuda.stream(sa):
     c.set_x(x0)
 torch.cuda.synchronize()
 for it in range(2):
-    for _ in range(40):
-        check(lib().acino_debug_poison_lds(512, 60, C.c_void_p(sb.cuda_stream)))
+    for _ in range(int(os.environ.get('POISON_N', '300'))):
+        check(lib().acino_debug_poison_lds(512, int(os.environ.get('POISON_SPIN', '20000')), C.c_void_p(sb.cuda_stream)))
     with torch.cuda.stream(sa):
         c.step()
     torch.cuda.synchronize()
