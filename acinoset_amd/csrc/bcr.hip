@@ -298,7 +298,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     ysc[tid] = yy;
   }
   ACINO_STAMP(4);
-  store_mat(ch.D + i * MB, Lm, tid);
+  store_mat(ch.U + i * MB, Lm, tid);
   __syncthreads();
   if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
   ACINO_STAMP(5);
@@ -373,7 +373,10 @@ k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, con
       for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
       ysc[tid] = yy;
     }
-    store_mat(ch.D + i * MB, Lm, tid);
+    // (into ch.U, NOT over D_i: the sibling workgroups of this node may not have loaded D_i yet - on a busy GPU they are
+    //  dispatched late - and would factor a mixture of D_i and U.  Found in round 2 with several contexts running
+    //  concurrently; alone, all siblings start together and the in-place store went unnoticed.)
+    store_mat(ch.U + i * MB, Lm, tid);
     __syncthreads();
     if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
   }
@@ -691,7 +694,7 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
   double2 vl[13], vr[13], vu[13];
   if (l >= 0) fetch_mat(vl, ch.Wl + i * MB, tid);
   if (r >= 0) fetch_mat(vr, ch.Wr + i * MB, tid);
-  fetch_mat(vu, ch.D + i * MB, tid);
+  fetch_mat(vu, ch.U + i * MB, tid);
   double t = (tid < BS) ? ch.b[(size_t)i * BS + tid] : 0.0;
   if (tid < BS) {
     xv[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
@@ -755,7 +758,7 @@ k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status, int* __restrict_
   {  // all three matrices in flight before the first LDS write
     const double2* s0 = reinterpret_cast<const double2*>(ch.Wl + i * MB);
     const double2* s1 = reinterpret_cast<const double2*>(ch.Wr + i * MB);
-    const double2* s2 = reinterpret_cast<const double2*>(ch.D + i * MB);
+    const double2* s2 = reinterpret_cast<const double2*>(ch.U + i * MB);
     double2 v0[13], v1[13], v2[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
@@ -996,7 +999,7 @@ k_bcr_backsub0(BcrChain ch, const int* __restrict__ elim, const FteConst* __rest
 }
 
 // ---- incomplete reduction: size of the dropped couplings -----------------------------------------------------
-// After the isolated last level D[a] = U_a = L_a^-T and D[b] = U_b for the two ends of every dropped coupling block
+// After the isolated last level U[a] = U_a = L_a^-T and U[b] = U_b for the two ends of every dropped coupling block
 // C = block(b, a) (stored at Cpl[a]).  Dropping C perturbs the remaining system by E = [[0, C^T], [C, 0]]; in the energy
 // norm of the kept block-diagonal part that is || L_b^-1 C L_a^-T ||_2 <= || U_b^T C U_a ||_F =: eps(a, b), and the solve's
 // relative error in that norm is <= eps / (1 - eps).  One workgroup per pair: T = C U_a, then N = U_b^T T on the matrix
@@ -1013,8 +1016,8 @@ k_bcr_trunc_check(BcrChain ch, const int* __restrict__ status) {
   const int a = ch.d_pairs[2 * blockIdx.x], b = ch.d_pairs[2 * blockIdx.x + 1];
   const size_t MB = (size_t)BS * BS;
   load_mat(Cm, ch.Cpl + a * MB, tid);
-  load_mat(Ua, ch.D + a * MB, tid);
-  load_mat(Ub, ch.D + b * MB, tid);
+  load_mat(Ua, ch.U + a * MB, tid);
+  load_mat(Ub, ch.U + b * MB, tid);
   __syncthreads();
   // (the elimination stores the factor's LOWER tiles as workspace: only entries on or above the diagonal are U)
   auto up = [](const double* U, int r, int c) { return c >= r ? U[r * LD + c] : 0.0; };

@@ -33,7 +33,9 @@ struct BcrSchedule {
 // Device views of one chain.
 struct BcrChain {
   int n_nodes;
-  double* D;     // [n][80][80] working diagonal blocks -> Cholesky factors (+ inverse diagonal tiles)
+  double* D;     // [n][80][80] working diagonal blocks (level 0 of an FTE chain: -> G = D^-1); never overwritten by a factor
+  double* U;     // [n][80][80] U = L^-T of every eliminated node (own array: the T + 1 workgroups of a narrow-level
+                 //             elimination all read D_i, and a late one must not find the factor there)
   double* Cpl;   // [n][80][80] coupling block (right neighbour rows, own cols)
   double* Wl;    // [n][80][80] W_l of eliminated nodes
   double* Wr;    // [n][80][80] W_r of eliminated nodes

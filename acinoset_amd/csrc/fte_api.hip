@@ -88,6 +88,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   BcrChain chn;
   chn.n_nodes = (int)T;
   chn.D = c.take<double>(T * BS * BS);
+  chn.U = c.take<double>(T * BS * BS);
   chn.Cpl = c.take<double>(T * BS * BS);
   chn.Wl = c.take<double>(T * BS * BS);
   chn.Wr = c.take<double>(T * BS * BS);
@@ -774,7 +775,7 @@ size_t acino_sep_scratch_bytes(int n_sep) {
   BcrSchedule sch;
   sch.build(n_sep, false, false);
   size_t ints = sch.elim.size() + sch.remain.size() + 8;
-  return 5 * align_up((size_t)n_sep * BS * BS * sizeof(double)) + align_up(ints * sizeof(int)) + 1024;
+  return 6 * align_up((size_t)n_sep * BS * BS * sizeof(double)) + align_up(ints * sizeof(int)) + 1024;   // D U Cpl Wl Wr, b
 }
 
 namespace acino {
@@ -793,6 +794,7 @@ static BcrChain sep_chain(void* d_scratch, int n_sep, const BcrSchedule& sch) {
   BcrChain ch;
   ch.n_nodes = n_sep;
   ch.D = c.take<double>((size_t)n_sep * BS * BS);
+  ch.U = c.take<double>((size_t)n_sep * BS * BS);
   ch.Cpl = c.take<double>((size_t)n_sep * BS * BS);
   ch.Wl = c.take<double>((size_t)n_sep * BS * BS);
   ch.Wr = c.take<double>((size_t)n_sep * BS * BS);
