@@ -547,7 +547,8 @@ def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
     parts = [np.load(outw + f".{r}.npz") for r in range(world)]
     assert all(int(p["it"]) == steps_w and int(p["accepted"]) == int(parts[0]["accepted"]) for p in parts)
     assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-7 * abs(st_ref["cost"])
-    assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 1e-4      # converged: same optimum
+    # (angles of the last frames of a sprint are barely observed: the iterates agree to 1e-3 rad there, the cost to 1e-7)
+    assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 5e-3
 
 
 def test_rccl_sharded_solve_equals_single_gpu(mods, tmp_path):
@@ -785,6 +786,49 @@ def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods):
     assert np.abs(got["positions"] - ref["positions"]).max() < 1e-3 and abs(igot["cost"] - iref["cost"]) < 1e-6 * abs(iref["cost"])
     with pytest.raises(ValueError):
         fte.FTEContext(det, *rig, seq["Ts"], bcr_levels=3, pin_right=True, n_global=n + 300)
+
+
+def test_concurrent_contexts_do_not_interfere(mods):
+    """Regression (round 2): the T + 1 workgroups that share one node of a narrow elimination level all read D_i; the one
+    that stores the factor used to overwrite D_i in place, so a sibling dispatched late - which only happens when
+    OTHER kernels keep the CUs busy - factored a mixture of D_i and U (NaN, status 5).  Four 2 700-frame contexts
+    stepping concurrently on their own streams, plus a stream of LDS-heavy filler kernels, must reproduce their solo runs."""
+    import ctypes as C
+    from acinoset_amd._lib import check, lib
+    calib, fte, synth = mods
+    seq = synth.make_sequence(10000, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = fte.triangulation_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
+    wins = [(0, 2691), (2307, 5193), (4809, 7692), (7308, 10000)]
+    kw = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, shared_gpu=True)
+    solo = []
+    for w0, w1 in wins:
+        c = fte.FTEContext(seq["det"][w0:w1], *rig, seq["Ts"], **kw)
+        c.set_x(x0[w0:w1])
+        for _ in range(6):
+            c.step()
+        solo.append((c.state(), c.result()[0].cpu().numpy()))
+        c.close()
+    streams = [torch.cuda.Stream() for _ in wins]
+    filler = torch.cuda.Stream()
+    ctxs = []
+    for s, (w0, w1) in zip(streams, wins):
+        with torch.cuda.stream(s):
+            c = fte.FTEContext(seq["det"][w0:w1], *rig, seq["Ts"], **kw)
+            c.set_x(x0[w0:w1])
+            ctxs.append(c)
+    for _ in range(6):
+        for _k in range(8):
+            check(lib().acino_debug_poison_lds(512, 300, C.c_void_p(filler.cuda_stream)))
+        for s, c in zip(streams, ctxs):
+            with torch.cuda.stream(s):
+                c.step()
+    torch.cuda.synchronize()
+    for c, (st0, x_solo) in zip(ctxs, solo):
+        st = c.state()
+        assert st["status"] == 0 and st["accepted"] == st0["accepted"], (st, st0)
+        assert st["cost"] == st0["cost"] and np.array_equal(c.result()[0].cpu().numpy(), x_solo)   # bit-identical
+        c.close()
 
 
 def test_overlapping_windows_converge_to_the_single_gpu_optimum(mods):
