@@ -56,13 +56,15 @@ for halo in (96, 192):
             s = torch.cuda.Stream()
             with torch.cuda.stream(s):
                 ctx = fte.FTEContext(seq["det"][1000:1000 + n], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,
-                                     n_global=N, n_offset=999, own_first=halo, own_count=n - 2 * halo, bcr_levels=K, trunc_tol=1.0)
+                                     n_global=N, n_offset=1000, own_first=halo, own_count=n - 2 * halo, bcr_levels=K, trunc_tol=1.0)
                 ctx.enable_graph(True); ctx.set_x(x0[1000:1000 + n])
                 for _ in range(5): ctx.step()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(50): ctx.step()
                 torch.cuda.synchronize(); tw = 1e3 * (time.perf_counter() - t0) / 50
-                eps = ctx.state()["trunc_eps"]
+                stw = ctx.state()
+                eps = stw["trunc_eps"]
+                assert stw["status"] == 0 and stw["accepted"] > 20, stw
                 ctx.close()
             print(f"windows: world {world}, halo {halo}: {n} frames/rank" + (f", incomplete reduction after {K} levels (eps {eps:.1e})" if K else "") +
                   f": step {tw:.3f} ms -> speed-up over 1 GPU without collectives {t1 / tw:.2f}x, with 2 x 25 us of collectives {t1 / (tw + 0.05):.2f}x")
