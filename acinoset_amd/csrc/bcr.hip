@@ -122,14 +122,20 @@ __device__ void publish_gmax(double gmax, double* red, double* gn_part, int node
 // coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
 // right: columns in node i+1).  450 doubles, filled once per workgroup.
 __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
-  const int64_t f_i = K.n_offset + 3 * (int64_t)(node_i - K.pin_left);
+  const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
+  const int64_t f_i = K.n_offset + (int64_t)loc_i;
   for (int e = tid; e < 2 * 9 * NP; e += 256) {
     const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
     double v = 0.0;
     if (ii <= jj) {
       const int k = 3 + ii - jj;
-      v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
-                                            : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
+      // left table: frame jj of node i-1 with frame ii of node i; right table: frame jj of node i with frame ii of node i+1.
+      // A slot beyond the local frames (the last node of a window that ends inside the sequence holds 1 or 2 live
+      // frames) is an identity row of the chain and must not be coupled, whatever the global band says there.
+      const int hi = side == 0 ? loc_i + ii : loc_i + 3 + ii;
+      if (hi < K.n_frames)
+        v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
+                                              : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
     }
     (side == 0 ? coefL : coefR)[q] = v;
   }
