@@ -1,18 +1,28 @@
 #!/bin/bash
-# One GPU-box round: tests, bench, rocprof kernel stats, PMC counters.  Outputs under gpurun_out/.
+# One GPU-box round: tests, smoke, bench, rocprof kernel stats, PMC counters.  Outputs under gpurun_out/round/;
+# copy the summaries to profiles/<round>/ afterwards (scripts/collect_profiles.sh).
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/round
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd $R
-python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
-python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+timeout 1200 python -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/rocprof_pmc_sq -o sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/rocprof_pmc_sq.err
+B="python $R/bench.py --no-cpu-baseline --no-secondary"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_write.err
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/rocprof_pmc_sq -o sq -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_sq.err
 cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
-tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log | tail -2; cat $OUT/bench.json | cut -c1-600; ls -R $OUT | head -40
+# the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
+mkdir -p $R/profiles/round2_final && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round2_final/ 2>/dev/null
+timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
+cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
+cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
+# keep the merge-back small: the raw counter dumps are not needed once summarised
+rm -rf $OUT/rocprof_pmc_fetch $OUT/rocprof_pmc_write $OUT/rocprof_pmc_sq
+find $OUT/rocprof_stats -type f ! -name "*kernel_stats.csv" -delete
+tail -4 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cut -c1-700 $OUT/bench.json; ls $OUT/summary
