@@ -489,7 +489,7 @@ def _mp_shard_worker(rank, world, port, n, steps, out_path, backend="gloo", mode
         with torch.cuda.stream(side):
             if mode == "windows":                         # overlapping windows: two all-gathers per iteration
                 drv, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world,
-                                                            halo=48, ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=not own_gpu)
+                                                            halo=96, ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=not own_gpu)
                 drv.set_x(torch.as_tensor(x0[w0:w1]))
                 for _ in range(steps):
                     drv.step()
@@ -532,8 +532,8 @@ def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
     assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-9 * abs(st_ref["cost"])
     assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 1e-8
     # the overlapping-window driver through the same torch.distributed path (its step is inexact by the decay over
-    # the 48-frame halo of this small case: same accept/reject sequence, iterate equal to ~1e-4 of a step)
-    nw, steps_w = 160 * world, 25
+    # the 96-frame halo of this small case: same accept/reject sequence, iterate equal to ~1e-4 of a step)
+    nw, steps_w = 200 * world, 40
     seq = synth.make_sequence(nw, "sprint")
     x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(4).normal(0, 0.03, (nw, 25))
     ref = fte.FTEContext(seq["det"], seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
@@ -546,7 +546,7 @@ def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
     mp.spawn(_mp_shard_worker, args=(world, 29740 + world, nw, steps_w, outw, "gloo", "windows"), nprocs=world, join=True)
     parts = [np.load(outw + f".{r}.npz") for r in range(world)]
     assert all(int(p["it"]) == steps_w and int(p["accepted"]) == int(parts[0]["accepted"]) for p in parts)
-    assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-7 * abs(st_ref["cost"])
+    assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-6 * abs(st_ref["cost"])
     # (angles of the last frames of a sprint are barely observed: the iterates agree to 1e-3 rad there, the cost to 1e-7)
     assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 5e-3
 
