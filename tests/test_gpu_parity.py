@@ -581,15 +581,20 @@ def test_rccl_sharded_solve_equals_single_gpu(mods, tmp_path):
         assert all(int(p["accepted"]) == st_ref["accepted"] and int(p["it"]) == steps for p in parts)
         assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-9 * abs(st_ref["cost"])
         assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 1e-8
-        ref = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
+        # the overlapping-window driver over RCCL (its own size: every shard must hold the 96-frame halo)
+        nw, steps_w = 200 * world, 40
+        seq = synth.make_sequence(nw, "sprint")
+        x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(4).normal(0, 0.03, (nw, 25))
+        ref = fte.FTEContext(seq["det"], seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
         ref.set_x(x0)
-        for _ in range(25):
+        for _ in range(steps_w):
             ref.step()
-        x_ref25 = ref.result()[0].cpu().numpy()
+        x_refw, st_refw = ref.result()[0].cpu().numpy(), ref.state()
         ref.close()
-        mp.spawn(_mp_shard_worker, args=(world, 29760 + world, n, 25, out + "w", "nccl", "windows"), nprocs=world, join=True)
+        mp.spawn(_mp_shard_worker, args=(world, 29760 + world, nw, steps_w, out + "w", "nccl", "windows"), nprocs=world, join=True)
         parts = [np.load(out + f"w.{r}.npz") for r in range(world)]
-        assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref25).max() < 1e-4
+        assert abs(float(parts[0]["cost"]) - st_refw["cost"]) < 1e-6 * abs(st_refw["cost"])
+        assert np.abs(np.concatenate([p["x"] for p in parts]) - x_refw).max() < 5e-3
 
 
 @pytest.mark.parametrize("n,cams", [(5, 6), (8, 2), (47, 4), (64, 6), (95, 3), (193, 6), (385, 6), (1537, 6), (9998, 6)])
