@@ -1234,17 +1234,17 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     {
       const bool fused0 = level == 0 && ch.st != nullptr;
       const bool explicit_c = !fused0 && !(ch.implicit_couplings && lv.adjacent);
-      static const int deep_max = getenv("ACINO_DEEP_ELIM_MAX") ? atoi(getenv("ACINO_DEEP_ELIM_MAX")) : 64;
-      const bool deep = explicit_c && lv.n_elim <= deep_max;
+      // (64: measured again in round 2 - the strip form for levels of up to 128 / 256 / 512 nodes moves time from k_bcr_elim
+      //  to k_bcr_elim_deep one for one: 0.889 / 0.902 / 0.968 ms per step against 0.893)
+      const bool deep = explicit_c && lv.n_elim <= 64;
       // (measured dead end, round 2: the wide levels >= 1 in the strip form of k_bcr_elim_deep with T = 1, compiled for
       //  THREE workgroups per CU - 168 VGPRs, 12 B/lane of scratch -: k_bcr_elim 0.288 -> 0.341 ms per step.  The
       //  level is not occupancy-bound; the third workgroup only adds contention for the one LDS pipe.)
       ProfSpan sp(prof, deep ? PC_ELIM_DEEP : PC_ELIM, s, lv.n_elim);
       if (deep) {   // narrow level: T workgroups per node
         // (isolated nodes of an incomplete reduction have no W strips: one workgroup per node factors and stores)
-        static const int deep_slots = getenv("ACINO_DEEP_SLOTS") ? atoi(getenv("ACINO_DEEP_SLOTS")) : 256;
-        const int T = lv.isolated ? 1 : std::max(1, std::min(10, deep_slots / lv.n_elim));   // strip workgroups per node (+ 1 that stores the factor)
-        const int extra = (!lv.isolated && lv.n_elim * (T + 1) <= deep_slots) ? 1 : 0;
+        const int T = lv.isolated ? 1 : std::min(10, 256 / lv.n_elim);   // strip workgroups per node (+ 1 that stores the factor)
+        const int extra = (!lv.isolated && lv.n_elim * (T + 1) <= 256) ? 1 : 0;
         const int total = lv.n_elim * (T + extra), nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
         hipLaunchKernelGGL(k_bcr_elim_deep, dim3(8 * per), dim3(256), kElimDeepLds, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, extra, nx, per, total);

@@ -341,8 +341,9 @@ def main():
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        if not args.no_graph and not windows:
-            ctx.enable_graph(True)        # no host sync inside a step: capture once, replay (N > 1: the 4 phases between the collectives)
+        if not args.no_graph:
+            # no host sync inside a step: capture once, replay (N > 1: the phases between the collectives)
+            (solver if windows else ctx).enable_graph(True)
         solver.set_x(x0_local)
         for _ in range(args.warmup):
             solver.step()
@@ -453,7 +454,7 @@ def main():
                                   "achieved_hbm_gbs": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9,
                                   "frac_hbm": ALG_BYTES_STEP * n_loc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "gpu_kernel_ms_per_step": gpu_ms_step,
-                                  "launch": "eager" if (args.no_graph or windows) else ("hipGraph replay" if world == 1 else "4 hipGraph phases + 3 collectives"),
+                                  "launch": "eager" if args.no_graph else ("hipGraph replay" if world == 1 else ("2 graph phases + 2 all-gathers" if windows else "4 hipGraph phases + 3 collectives")),
                                   "ms_per_step_eager_with_events": 1e3 * dt_eager / args.steps},
                          "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()}},
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},

@@ -490,10 +490,12 @@ def _mp_shard_worker(rank, world, port, n, steps, out_path, backend="gloo", mode
             if mode == "windows":                         # overlapping windows: two all-gathers per iteration
                 drv, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world,
                                                             halo=96, ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=not own_gpu)
+                drv.enable_graph(True)                    # phases A and B captured after two eager iterations
                 drv.set_x(torch.as_tensor(x0[w0:w1]))
                 for _ in range(steps):
                     drv.step()
-                x, st, graphs = drv.result_x().cpu().numpy(), drv.state(), 0
+                x, st = drv.result_x().cpu().numpy(), drv.state()
+                graphs = sum(1 for k, v in drv._graphs.items() if not k.endswith("_warm") and v is not None)
             else:
                 drv, (n0, n1) = adist.make_sharded(torch.as_tensor(seq["det"]), *rig, seq["Ts"], rank, world,
                                                    ftol=0.0, xtol=0.0, gtol=0.0, shared_gpu=not own_gpu)   # (gloo: the ranks share GPU 0)
@@ -546,6 +548,7 @@ def test_multiprocess_graph_phases_equal_single_shard(mods, world, tmp_path):
     mp.spawn(_mp_shard_worker, args=(world, 29740 + world, nw, steps_w, outw, "gloo", "windows"), nprocs=world, join=True)
     parts = [np.load(outw + f".{r}.npz") for r in range(world)]
     assert all(int(p["it"]) == steps_w and int(p["accepted"]) == int(parts[0]["accepted"]) for p in parts)
+    assert all(int(p["graphs"]) == 2 for p in parts)               # both phases really were graph replays
     assert abs(float(parts[0]["cost"]) - st_ref["cost"]) < 1e-6 * abs(st_ref["cost"])
     # (angles of the last frames of a sprint are barely observed: the iterates agree to 1e-3 rad there, the cost to 1e-7)
     assert np.abs(np.concatenate([p["x"] for p in parts]) - x_ref).max() < 5e-3
