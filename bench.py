@@ -362,8 +362,10 @@ def main():
         for _ in range(args.warmup):
             solver.step()
         sync()
+        if windows:
+            solver.enable_graph(False)    # (events cannot be recorded inside the driver's captured phases either)
         ctx.profile_begin()
-        solver.collect_timing(True)       # N > 1: HIP events around the three collectives of every step
+        solver.collect_timing(True)       # N > 1: HIP events around the collectives of every step
         t1 = time.perf_counter()
         for _ in range(args.steps):
             solver.step()
@@ -389,7 +391,7 @@ def main():
         phase_units = sum(prof[k]["units"] for k in PHASE_OF if PHASE_OF[k] == phase)
         share = prof[dom]["units"] / max(phase_units, 1)             # of the phase's nodes (frames for assemble)
         flops_per_launch = ALG_FLOPS[phase] * n_loc * args.steps * share / launches
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        achieved = flops_per_launch / (max(avg_ms, 1e-9) * 1e-3) / 1e12
         gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
         kname = fte.FTEContext.PROF_KERNELS[dom]
         # HBM bytes / launch and matrix-core counters of the dominant kernel: from the committed PMC passes under
