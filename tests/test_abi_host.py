@@ -105,3 +105,45 @@ def test_no_product_module_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{fn} imports the oracle"
+
+
+def test_window_plan_and_params_host_logic():
+    """Host-side logic of round 2 that needs no GPU: the overlapping-window plan, the new acino_fte_params fields."""
+    from acinoset_amd import dist as adist
+    from acinoset_amd import fte
+    plan, halo = adist.window_plan(10000, 4, 190)
+    assert halo == 192 and [p[2:] for p in plan] == adist.shard_plan(10000, 4)
+    assert plan[0][:2] == (0, 2499 + 192) and plan[3][:2] == (7500 - 192, 10000)
+    for (w0, w1, n0, n1) in plan:
+        assert w0 % 3 == 0 and w0 <= n0 < n1 <= w1 and (w1 == 10000 or (w1 - w0) % 3 == 0)
+        assert (n0 - w0 in (0, halo)) and (w1 - n1 in (0, halo))
+    with pytest.raises(ValueError):
+        adist.window_plan(600, 4, 192)                     # shards shorter than the halo
+    assert adist.window_plan(500, 1, 96)[0] == [(0, 500, 0, 500)]
+    p = fte.make_params(100, 6, 1 / 120, precision="bf16", bcr_levels=3, trunc_tol=1e-9, own_first=12, own_count=60)
+    assert (p.precision, p.bcr_levels, p.trunc_tol, p.own_first, p.own_count) == (1, 3, 1e-9, 12, 60)
+    assert fte.make_params(100, 6, 1 / 120).precision == 0 and fte.PRECISIONS["bf16_residuals"] == 2
+    with pytest.raises(ValueError):
+        fte.make_params(100, 6, 1 / 120, precision="fp8")
+
+
+def test_build_id_matches_sources_and_cpu_baseline_worker(tmp_path):
+    """The shared object carries the hash of the sources it was built from (build() and the PMC summaries key on it);
+    the CPU-baseline worker of bench.py runs as a plain numpy process."""
+    import subprocess
+    import sys
+    import numpy as np
+    from acinoset_amd import _lib
+    from oracle import fk as ofk
+    from oracle import synth as osynth
+    assert _lib.built_id() == _lib.source_hash() == _lib.lib().acino_build_id().decode()
+    seq = osynth.make_sequence(12, "sprint")
+    path = str(tmp_path / "s.npz")
+    np.savez(path, det=seq["det"], K=seq["K"], D=seq["D"], R=seq["R"], t=seq["t"], Ts=seq["Ts"], xa=seq["q_true"][:, ofk.ACTIVE])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", path, "0", "12", "1"], cwd=root, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and float(out.stdout.strip()) > 0.0
+    import bench
+    probe = bench.probe_reference_cpu_path()
+    assert set(probe["probe"]) == {"cv2", "pyomo", "ipopt"} and ("unavailable" in probe["note"]) == (not probe["available"])
