@@ -86,6 +86,14 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
     return p
 
 
+def auto_bcr_levels(n_frames, min_distance_frames=384):
+    """Smallest K with 3 * 2^K >= min_distance_frames, or 0 (complete reduction) when the chain has no level beyond it."""
+    K = 0
+    while 3 * 2 ** K < min_distance_frames:
+        K += 1
+    return K if (n_frames + 2) // 3 > 2 ** (K + 1) else 0
+
+
 class FTEContext:
     """Owns the device buffers of one FTE problem (one shard of a sequence on one GPU)."""
 
@@ -101,6 +109,10 @@ class FTEContext:
         self.cams = torch.as_tensor(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
         if self.cams.shape[0] != self.C:
             raise ValueError("camera count mismatch between det and the rig")
+        if kw.get("bcr_levels") == "auto":
+            # incomplete reduction where the chain is long enough to have levels beyond a node distance of 384 frames
+            # (eps ~1e-11 on the benchmark sequence; verified on the device every iteration, status 7 otherwise)
+            kw = dict(kw, bcr_levels=auto_bcr_levels(self.N))
         self.params = make_params(self.N, self.C, Ts, **kw)
         nbytes = lib().acino_fte_workspace_bytes(C.byref(self.params))
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
@@ -288,6 +300,8 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
     if np.any(x0[:, inactive] != 0):
         raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
+    if kw.get("bcr_levels") == "auto":
+        kw = dict(kw, bcr_levels=auto_bcr_levels(int(det.shape[0])))
     ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
     try:
         ctx.set_x(x0[:, ACTIVE])

@@ -125,6 +125,7 @@ def test_window_plan_and_params_host_logic():
     assert fte.make_params(100, 6, 1 / 120).precision == 0 and fte.PRECISIONS["bf16_residuals"] == 2
     with pytest.raises(ValueError):
         fte.make_params(100, 6, 1 / 120, precision="fp8")
+    assert fte.auto_bcr_levels(10000) == 7 and fte.auto_bcr_levels(1000) == 7 and fte.auto_bcr_levels(700) == 0
 
 
 def test_build_id_matches_sources_and_cpu_baseline_worker(tmp_path):
