@@ -212,23 +212,6 @@ def test_pinhole_model_bundle_adjustment(gsba):
     assert info["cost_final"] <= oopt.cost * (1 + 1e-6), (info, oopt.cost)
 
 
-def test_trajectory_pipelines_tri_and_sba_points(gsba):
-    """tri / sba_points (all_optimizations.py:868-940) on a synthetic clip: same NaN pattern, and refining every
-    point against all cameras that see it must not be worse than the two-view means it starts from."""
-    from acinoset_amd import pipelines, synth
-    seq = synth.make_sequence(40, "sprint")
-    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
-    p_tri = pipelines.tri(seq["det"], *rig, 0.5)
-    p_sba, res = pipelines.sba_points(seq["det"], *rig, 0.5)
-    assert p_tri.shape == p_sba.shape == (40, 20, 3)
-    assert np.array_equal(np.isfinite(p_tri), np.isfinite(p_sba))
-    ok = np.isfinite(p_tri).all(-1)
-    e_tri = np.linalg.norm(p_tri - seq["pos_true"], axis=-1)[ok]
-    e_sba = np.linalg.norm(p_sba - seq["pos_true"], axis=-1)[ok]
-    assert np.median(e_sba) <= np.median(e_tri) * 1.02 and np.median(e_sba) < 0.03
-    assert osba.cauchy_cost(res["after"], 50) <= osba.cauchy_cost(res["before"], 50)
-
-
 def _rig_problem(seed=5, n_pts=400):
     from acinoset_amd import synth
     rng = np.random.default_rng(seed)
