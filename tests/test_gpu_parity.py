@@ -934,3 +934,25 @@ class _LockStepComm:
         [t.join() for t in ts]
         if errs:
             raise errs[0]
+
+
+def test_clips_as_one_chain_at_bench_size(mods):
+    """fte_solve_clips at the clip length the benchmark uses (1 000 frames; 8 clips here): the shared LM controller must
+    bring every clip to the optimum of its own solve.  Compared at the level this landscape allows (two
+    fp64 solves of the same clip end up to 1.4e-3 m apart in their least constrained marker): summed cost to 1e-6,
+    median marker distance below 5e-4 m, worst below 3e-3 m, and nothing differentiated across a clip boundary."""
+    calib, fte, synth = mods
+    B, S = 8, 1000
+    seqs = [synth.make_sequence(S, "trot", seed=20210313 + 100 + b) for b in range(B)]
+    rig = (seqs[0]["K"], seqs[0]["D"], seqs[0]["R"], seqs[0]["t"])
+    chain = fte.fte_solve_clips([s["det"] for s in seqs], *rig, seqs[0]["Ts"], max_iter=120)
+    assert chain[0][1]["status_name"] in ("ftol", "xtol", "gtol") and chain[0][1]["clips"] == B
+    cost_sum, errs = 0.0, []
+    for s, (res, _info) in zip(seqs, chain):
+        one, info1 = fte.fte_solve(s["det"][..., :2], s["det"][..., 2], *rig, Ts=s["Ts"], max_iter=120)
+        cost_sum += info1["cost"]
+        errs.append(np.abs(res["positions"] - one["positions"]).max())
+        assert np.allclose(res["x"][1:], res["x"][:-1] + s["Ts"] * res["dx"][1:], atol=1e-12)     # per clip, from its own frame 0
+    errs = np.array(errs)
+    assert abs(chain[0][1]["cost"] - cost_sum) < 1e-6 * abs(cost_sum), (chain[0][1]["cost"], cost_sum)
+    assert np.median(errs) < 5e-4 and errs.max() < 3e-3, errs
