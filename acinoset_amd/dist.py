@@ -316,6 +316,52 @@ def window_plan(n_frames, world, halo):
     return [(max(0, n0 - halo), min(n_frames, n1 + halo), n0, n1) for n0, n1 in plan], halo
 
 
+class HipWindowBackend:
+    """One rank's window on this process's GPU: thin calls into the C ABI (single-GPU context with an owned range)."""
+
+    def __init__(self, det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global, n_offset, own_first, own_count, **kw):
+        self.ctx = fte.FTEContext(det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=n_offset,
+                                  own_first=own_first, own_count=own_count, **kw)
+        self.device = self.ctx.device
+        self.own_first, self.own_count = own_first, own_count
+
+    def new(self, *shape):
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def _c(self, fn, *args):
+        check(fn(self.ctx._h, *args))
+
+    def load_x(self, x_window):
+        self._x0 = calib_to_dev(x_window, self.device)
+        self._c(lib().acino_fte_load_x, ptr(self._x0), stream_ptr())
+
+    def solve_and_trial(self):
+        L = lib()
+        self._c(L.acino_fte_reduce_local, stream_ptr())
+        self._c(L.acino_fte_backsub_local, C.c_void_p(0), 0, 1, stream_ptr())
+        self._c(L.acino_fte_trial, stream_ptr())
+
+    def copy_frames(self, which, imp, first, n, buf):
+        self._c(lib().acino_fte_copy_frames, which, int(imp), first, n, ptr(buf), stream_ptr())
+
+    def eval(self, which):
+        self._c(lib().acino_fte_eval, which, stream_ptr())
+
+    def export_partials(self, out):
+        self._c(lib().acino_fte_export_partials, ptr(out), stream_ptr())
+
+    def control(self, total, init):
+        self._c(lib().acino_fte_control, ptr(total), int(init), stream_ptr())
+
+    def state(self):
+        return self.ctx.state()
+
+    def result_owned(self):
+        return self.ctx.result()[0][self.own_first:self.own_first + self.own_count]
+
+    supports_graphs = True
+
+
 class WindowedFTE:
     """One LM solve over a sequence sharded across the process group WITHOUT a separator system.
 
@@ -326,61 +372,58 @@ class WindowedFTE:
     the step on its owned frames and discards the rest (restricted additive Schwarz).  The step is inexact by
     ~decay(halo); cost, gradient, accept / reject and the damping are EXACT and global: the trial iterate's edge slabs
     travel in one all-gather, the eight partial sums in a second one, and every rank runs the same controller on the
-    same totals.  Two small collectives per iteration, no all-reduce, no redundant separator solve."""
+    same totals.  Two small collectives per iteration, no all-reduce, no redundant separator solve.
+    The numerical work lives behind a backend (``HipWindowBackend``; tests plug the numpy oracle in under gloo)."""
 
-    def __init__(self, ctx, rank, world, own, halo, group=None, comm=None):
-        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+    def __init__(self, backend, rank, world, own, halo, group=None, comm=None):
+        self.b, self.rank, self.world, self.group = backend, rank, world, group
+        self.ctx = getattr(backend, "ctx", None)
         self.comm = comm if comm is not None else TorchComm(group)
         self.own_first, self.own_count = own           # local frame indices inside the window
         self.halo = halo
         self.slab = halo + 3                           # + the three stencil rows beyond the window
-        dev = ctx.device
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
-        self._edges = z(2, self.slab, N_ACTIVE)        # first / last `slab` owned frames of the trial iterate
-        self._all_edges = z(world, 2, self.slab, N_ACTIVE)
-        self._partial = z(8)
-        self._all_partials = z(world, 8)
+        self._edges = backend.new(2, self.slab, N_ACTIVE)        # first / last `slab` owned frames of the trial iterate
+        self._all_edges = backend.new(world, 2, self.slab, N_ACTIVE)
+        self._partial = backend.new(8)
+        self._all_partials = backend.new(world, 8)
         self._timing = None
+        self._graph_on, self._graphs = False, {}
 
     collect_timing = ShardedFTE.collect_timing
     _timed = ShardedFTE._timed
     timing_summary = ShardedFTE.timing_summary
 
-    def _c(self, fn, *args):
-        check(fn(self.ctx._h, *args))
-
-    def _exchange(self, which):
-        L = lib()
-        if self.world == 1:
-            return
+    def _export_slabs(self, which):
         first, cnt, s = self.own_first, self.own_count, self.slab
-        self._c(L.acino_fte_copy_frames, which, 0, first, s, ptr(self._edges[0]), stream_ptr())
-        self._c(L.acino_fte_copy_frames, which, 0, first + cnt - s, s, ptr(self._edges[1]), stream_ptr())
-        self._timed("all_gather_edge_slabs", self.comm.all_gather, self._all_edges, self._edges)
-        if self.rank > 0:                              # the left neighbour's LAST slab sits just before my owned frames
-            self._c(L.acino_fte_copy_frames, which, 1, first - s, s, ptr(self._all_edges[self.rank - 1, 1]), stream_ptr())
-        if self.rank + 1 < self.world:                 # the right neighbour's FIRST slab just after them
-            self._c(L.acino_fte_copy_frames, which, 1, first + cnt, s, ptr(self._all_edges[self.rank + 1, 0]), stream_ptr())
+        self.b.copy_frames(which, 0, first, s, self._edges[0])
+        self.b.copy_frames(which, 0, first + cnt - s, s, self._edges[1])
 
-    def _control(self, init):
-        L = lib()
-        self._c(L.acino_fte_export_partials, ptr(self._partial), stream_ptr())
+    def _import_slabs(self, which):
+        first, cnt, s = self.own_first, self.own_count, self.slab
+        if self.rank > 0:                              # the left neighbour's LAST slab sits just before my owned frames
+            self.b.copy_frames(which, 1, first - s, s, self._all_edges[self.rank - 1, 1])
+        if self.rank + 1 < self.world:                 # the right neighbour's FIRST slab just after them
+            self.b.copy_frames(which, 1, first + cnt, s, self._all_edges[self.rank + 1, 0])
+
+    def _gather_scalars(self):
         if self.world > 1:
             self._timed("all_gather_scalars", self.comm.all_gather, self._all_partials, self._partial)
             total = combine_partials(self._all_partials)
         else:
             total = self._partial
         self._keep = total
-        self._c(L.acino_fte_control, ptr(total), int(init), stream_ptr())
+        return total
 
     def set_x(self, x_window):
         """x_window[n_window, 25]: the initial iterate on this rank's WHOLE window."""
-        L = lib()
-        self._x0 = calib_to_dev(x_window, self.ctx.device)
-        self._c(L.acino_fte_load_x, ptr(self._x0), stream_ptr())
-        self._exchange(0)          # the three stencil rows beyond the window (and my halo) take the neighbours' values
-        self._c(L.acino_fte_eval, 0, stream_ptr())
-        self._control(True)
+        self.b.load_x(x_window)
+        if self.world > 1:     # the three stencil rows beyond the window (and my halo) take the neighbours' values
+            self._export_slabs(0)
+            self._timed("all_gather_edge_slabs", self.comm.all_gather, self._all_edges, self._edges)
+            self._import_slabs(0)
+        self.b.eval(0)
+        self.b.export_partials(self._partial)
+        self.b.control(self._gather_scalars(), True)
 
     # The iteration between the collectives is two fixed launch sequences on persistent buffers:
     #   A: reduce + back-substitution + trial iterate + export of my two edge slabs        -> all-gather (slabs)
@@ -388,76 +431,57 @@ class WindowedFTE:
     # and the controller.  With enable_graph() each is captured once (torch.cuda.CUDAGraph around the C-ABI calls) and
     # replayed: 3 launches + 2 collectives per iteration instead of ~45 kernel launches.
     def enable_graph(self, on=True):
-        self._graph_on = bool(on)
+        self._graph_on = bool(on) and getattr(self.b, "supports_graphs", False)
         self._graphs = {}
 
     def _phase(self, name, body):
-        if not getattr(self, "_graph_on", False):
+        if not self._graph_on:
             return body()
         g = self._graphs.get(name)
-        if g is None:
-            body()                                     # warm (eager) run: the capture below then records the same sequence
-            if self._graphs.get(name + "_warm"):
-                g = torch.cuda.CUDAGraph()
-                try:
-                    with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                        body()
-                    self._graphs[name] = g
-                    return                              # (a capture executes nothing: this iteration already ran eagerly above)
-                except Exception:                       # capture not possible here: stay eager
-                    self._graph_on = False
-                    return
+        if g is not None:
+            return g.replay()
+        body()                                         # eager: this iteration's work
+        if not self._graphs.get(name + "_warm"):
             self._graphs[name + "_warm"] = True
             return
-        g.replay()
+        g = torch.cuda.CUDAGraph()                     # second iteration: record the same sequence (a capture executes nothing)
+        try:
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                body()
+            self._graphs[name] = g
+        except Exception:                              # capture not possible here (e.g. the default stream): stay eager
+            self._graph_on = False
 
     def _phase_a(self):
-        L = lib()
-        first, cnt, s = self.own_first, self.own_count, self.slab
-        self._c(L.acino_fte_reduce_local, stream_ptr())
-        self._c(L.acino_fte_backsub_local, C.c_void_p(0), 0, 1, stream_ptr())
-        self._c(L.acino_fte_trial, stream_ptr())
+        self.b.solve_and_trial()
         if self.world > 1:
-            self._c(L.acino_fte_copy_frames, 1, 0, first, s, ptr(self._edges[0]), stream_ptr())
-            self._c(L.acino_fte_copy_frames, 1, 0, first + cnt - s, s, ptr(self._edges[1]), stream_ptr())
+            self._export_slabs(1)
 
     def _phase_b(self):
-        L = lib()
-        first, cnt, s = self.own_first, self.own_count, self.slab
-        if self.rank > 0:                              # neighbours' owned values replace my halo estimate of the trial
-            self._c(L.acino_fte_copy_frames, 1, 1, first - s, s, ptr(self._all_edges[self.rank - 1, 1]), stream_ptr())
-        if self.rank + 1 < self.world:
-            self._c(L.acino_fte_copy_frames, 1, 1, first + cnt, s, ptr(self._all_edges[self.rank + 1, 0]), stream_ptr())
-        self._c(L.acino_fte_eval, 1, stream_ptr())
-        self._c(L.acino_fte_export_partials, ptr(self._partial), stream_ptr())
+        self._import_slabs(1)                          # neighbours' owned values replace my halo estimate of the trial
+        self.b.eval(1)
+        self.b.export_partials(self._partial)
 
     def step(self):
-        L = lib()
         self._phase("a", self._phase_a)
         if self.world > 1:
             self._timed("all_gather_edge_slabs", self.comm.all_gather, self._all_edges, self._edges)
         self._phase("b", self._phase_b)
-        if self.world > 1:
-            self._timed("all_gather_scalars", self.comm.all_gather, self._all_partials, self._partial)
-            total = combine_partials(self._all_partials)
-        else:
-            total = self._partial
-        self._keep = total
-        self._c(L.acino_fte_control, ptr(total), 0, stream_ptr())
+        self.b.control(self._gather_scalars(), False)
 
     def state(self):
-        return self.ctx.state()
+        return self.b.state()
 
     def solve(self, max_iter, peek_every=8):
         for it in range(max_iter):
             self.step()
-            if (it % peek_every) == peek_every - 1 and self.ctx.state()["status"] != 0:
+            if (it % peek_every) == peek_every - 1 and self.b.state()["status"] != 0:
                 break
-        return self.ctx.state()
+        return self.b.state()
 
     def result_x(self):
         """This rank's OWNED frames of the current iterate."""
-        return self.ctx.result()[0][self.own_first:self.own_first + self.own_count]
+        return self.b.result_owned()
 
 
 def calib_to_dev(a, dev):
@@ -473,6 +497,5 @@ def make_windowed(det_full, k_arr, d_arr, r_arr, t_arr, Ts, rank, world, halo=19
     w0, w1, n0, n1 = plan[rank]
     if w0 > 0 and n0 - w0 < halo:
         raise ValueError("window does not hold the halo")
-    ctx = fte.FTEContext(det_full[w0:w1], k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=w0,
-                         own_first=n0 - w0, own_count=n1 - n0, **kw)
-    return WindowedFTE(ctx, rank, world, (n0 - w0, n1 - n0), halo, group, comm), (w0, w1, n0, n1)
+    backend = HipWindowBackend(det_full[w0:w1], k_arr, d_arr, r_arr, t_arr, Ts, n_global, w0, n0 - w0, n1 - n0, **kw)
+    return WindowedFTE(backend, rank, world, (n0 - w0, n1 - n0), halo, group, comm), (w0, w1, n0, n1)

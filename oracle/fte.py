@@ -53,11 +53,12 @@ class FTEProblem:
         q[..., fk.ACTIVE] = xa
         return q
 
-    def measurement_terms(self, xa, need_jac=True, chunk=2048):
-        """Returns (cost, g[N,P], H[N,P,P], n_behind) of the measurement term."""
+    def measurement_terms(self, xa, need_jac=True, chunk=2048, per_frame=False):
+        """Returns (cost, g[N,P], H[N,P,P], n_behind) of the measurement term (per_frame: cost as an array [N])."""
         a, b, c = self.redesc
         N, P = xa.shape
         cost = 0.0
+        cost_n = np.zeros(N)
         g = np.zeros((N, P))
         H = np.zeros((N, P, P)) if need_jac else None
         n_behind = 0
@@ -87,13 +88,15 @@ class FTEProblem:
                 sres = w[..., None] * res                     # scaled residual [n,L,2]
                 rho, drho, h = loss.redescending_dloss(sres, a, b, c)
                 cost += float(rho.sum())
+                if per_frame:
+                    cost_n[sl] += rho.sum(axis=(1, 2))
                 if need_jac:
                     J = np.einsum("nlij,nljp->nlip", Jpi, G)  # [n,L,2,P]
                     gs = w[..., None] * drho * np.sign(sres)  # d rho / d(raw residual)
                     g[sl] += np.einsum("nlip,nli->np", J, gs)
                     hw = (w[..., None] ** 2) * h
                     H[sl] += np.einsum("nlip,nli,nliq->npq", J, hw, J)
-        return cost, g, H, n_behind
+        return (cost_n if per_frame else cost), g, H, n_behind
 
     def s_band(self):
         """(D3^T D3)[n, n+k], k=0..3, for LOCAL frames, honouring global sequence ends."""
@@ -111,7 +114,7 @@ class FTEProblem:
                 band[k, i] = tot
         return band
 
-    def smooth_terms(self, xa, halo_l=None, halo_r=None):
+    def smooth_terms(self, xa, halo_l=None, halo_r=None, per_frame=False):
         """Third-difference smoothness: cost and gradient on local frames.
 
         Stencil row j couples frames j..j+3: d_j = -x_j + 3x_{j+1} - 3x_{j+2} + x_{j+3}
@@ -136,12 +139,16 @@ class FTEProblem:
         gX[3:] += 2 * qd
         last = np.arange(3, M)                                          # last frame of each row
         own = (last >= o) & (last < o + N)
+        if per_frame:                                                   # cost of the row whose LAST frame is local frame i
+            cost_n = np.zeros(N)
+            cost_n[last[own] - o] = (qd[own] * d[own]).sum(axis=1)
+            return cost_n, gX[o:o + N]
         cost = float((qd[own] * d[own]).sum())
         return cost, gX[o:o + N]
 
-    def evaluate(self, xa, need_jac=True, halo_l=None, halo_r=None):
-        cm, g, H, nb = self.measurement_terms(xa, need_jac)
-        cs, gs = self.smooth_terms(xa, halo_l, halo_r)
+    def evaluate(self, xa, need_jac=True, halo_l=None, halo_r=None, per_frame=False):
+        cm, g, H, nb = self.measurement_terms(xa, need_jac, per_frame=per_frame)
+        cs, gs = self.smooth_terms(xa, halo_l, halo_r, per_frame=per_frame)
         return cm + cs, g + gs, H, nb
 
     # ------------------------------------------------------------------ linear algebra

@@ -244,3 +244,84 @@ class OracleBackend:
 
     def result_x(self):
         return torch.as_tensor(self.x[self.cur])
+
+
+class OracleWindowBackend:
+    """CPU stand-in for acinoset_amd.dist.HipWindowBackend (overlapping-window sharding) on the numpy oracle: the window
+    [n_offset, n_offset + n) of the sequence is assembled and solved as a principal submatrix of the global system
+    (step pinned to 0 outside it), only the owned frames [own_first, own_first + own_count) enter the sums."""
+
+    def __init__(self, det_window, K, D, R, t, Ts, n_global, n_offset, own_first, own_count, lam0=1e-3, ftol=1e-10,
+                 xtol=1e-10, gtol=1e-8, dlc_thresh=0.5):
+        det_window = np.asarray(det_window, dtype=np.float64)
+        self.prob = ofte.FTEProblem(det_window[..., :2], det_window[..., 2], K, D, R, t, Ts, dlc_thresh=dlc_thresh,
+                                    n_global=n_global, n_offset=n_offset)
+        self.N, self.n_global, self.n_offset = det_window.shape[0], n_global, n_offset
+        self.own = slice(own_first, own_first + own_count)
+        self.lam0, self.ftol, self.xtol, self.gtol = lam0, ftol, xtol, gtol
+        self.device = torch.device("cpu")
+
+    def new(self, *shape):
+        return torch.zeros(shape, dtype=torch.float64)
+
+    def load_x(self, x_window):
+        x = np.clip(np.asarray(x_window, dtype=np.float64), self.prob.lo, self.prob.hi)
+        buf = np.zeros((self.N + 6, NP))                # three stencil rows on either side, as the device buffers
+        buf[3:-3] = x
+        self.x = [buf.copy(), buf.copy()]
+        self.ev = [None, None]
+        self.cur = 0
+        self.st = dict(cost=0.0, lam=self.lam0, nu=2.0, iter=0, accepted=0, status=0)
+        self.partial = np.zeros(8)
+
+    def _buf(self, which):
+        return self.cur ^ which
+
+    def copy_frames(self, which, imp, first, n, buf):
+        x = self.x[self._buf(which)]
+        if imp:
+            x[first + 3:first + 3 + n] = np.asarray(buf, dtype=np.float64)
+        else:
+            buf[:] = torch.as_tensor(x[first + 3:first + 3 + n])
+
+    def eval(self, which):
+        if which == 1 and self.st["status"] != 0:
+            return
+        b = self._buf(which)
+        X = self.x[b]
+        hl = X[:3] if self.n_offset > 0 else None
+        hr = X[-3:] if self.n_offset + self.N < self.n_global else None
+        Fn, g, H, nb = self.prob.evaluate(X[3:-3], halo_l=hl, halo_r=hr, per_frame=True)
+        self.ev[b] = (g, H)
+        self.partial[0] = float(Fn[self.own].sum())
+        self.partial[4] = 0
+        if which == 0:
+            self.partial[1:4] = 0
+
+    def export_partials(self, out):
+        out[:] = torch.as_tensor(self.partial)
+
+    control = OracleBackend.control
+
+    def solve_and_trial(self):
+        if self.st["status"] != 0:
+            return
+        X = self.x[self.cur]
+        x = X[3:-3]
+        g, H = self.ev[self.cur]
+        fixed = ((x <= self.prob.lo) & (g > 0)) | ((x >= self.prob.hi) & (g < 0))
+        delta, diag = self.prob.solve_banded(H, g, self.st["lam"], fixed)
+        pg = np.where(fixed, 0.0, g)
+        xt = np.clip(x + delta, self.prob.lo, self.prob.hi)
+        T = self.x[self.cur ^ 1]
+        T[3:-3] = xt
+        o = self.own
+        self.partial[1] = 0.5 * float((delta[o] * (self.st["lam"] * diag[o] * delta[o] - pg[o])).sum())
+        self.partial[2] = float(np.abs(xt[o] - x[o]).max())
+        self.partial[3] = float(np.abs(pg[o]).max())
+
+    def state(self):
+        return dict(self.st, cur=self.cur)
+
+    def result_owned(self):
+        return torch.as_tensor(self.x[self.cur][3:-3][self.own])

@@ -113,3 +113,65 @@ def test_sba_reduce_hook_sums_workspace_slices_over_ranks(tmp_path, world):
         assert got[3] == 4.0 * tri                                 # summed through the C function pointer
         assert got[4] == 5.0 * world                               # max
         assert list(got[5:]) == [0, 0, 1, 0, 3]                    # return codes; three collectives completed
+
+
+def _window_worker(rank, world, port, n_frames, halo, n_steps, out_path):
+    try:                                   # several oracle processes on a few cores: one BLAS thread each
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from acinoset_amd import dist as adist
+    from oracle import fk, synth
+    from oracle_backend import OracleWindowBackend
+    seq = synth.make_sequence(n_frames, "trot")
+    plan, halo = adist.window_plan(n_frames, world, halo)
+    w0, w1, n0, n1 = plan[rank]
+    be = OracleWindowBackend(seq["det"][w0:w1], seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], n_frames, w0, n0 - w0, n1 - n0,
+                             ftol=0.0, xtol=0.0, gtol=0.0)
+    drv = adist.WindowedFTE(be, rank, world, (n0 - w0, n1 - n0), halo)
+    rng = np.random.default_rng(5)
+    x0 = seq["q_true"][:, fk.ACTIVE] + rng.normal(0, 0.03, (n_frames, 25))
+    drv.set_x(torch.as_tensor(x0[w0:w1]))
+    cost0 = be.state()["cost"]
+    for _ in range(n_steps):
+        drv.step()
+    st = be.state()
+    np.savez(out_path + f".{rank}.npz", x=drv.result_x().numpy(), cost=st["cost"], cost0=cost0, it=st["iter"], acc=st["accepted"],
+             lam=st["lam"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,halo", [(2, 96)])        # (3 and 4 shards: GPU tests, lock step and multi-process)
+def test_windowed_driver_matches_single_process_oracle(tmp_path, world, halo):
+    """The overlapping-window driver (dist.WindowedFTE: slab all-gather, owned-range sums, replicated controller) under
+    gloo with the oracle backend.  Cost bookkeeping is exact (initial cost == the single-process cost, identical on every
+    rank); the step is inexact by the decay over the 96-frame halo (a few 1e-3 with lambda -> 0), so the trajectory is
+    compared after convergence."""
+    from oracle import fk, synth
+    from oracle import fte as ofte
+    n_frames, n_steps = 110 * world, 16
+    out = str(tmp_path / "w")
+    mp.spawn(_window_worker, args=(world, _free_port(), n_frames, halo, n_steps, out), nprocs=world, join=True)
+    parts = [np.load(out + f".{r}.npz") for r in range(world)]
+    seq = synth.make_sequence(n_frames, "trot")
+    prob = ofte.FTEProblem(seq["det"][..., :2], seq["det"][..., 2], seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"])
+    rng = np.random.default_rng(5)
+    x0 = np.clip(seq["q_true"][:, fk.ACTIVE] + rng.normal(0, 0.03, (n_frames, 25)), prob.lo, prob.hi)
+    F0 = prob.evaluate(x0, need_jac=False)[0]
+    assert all(abs(float(p["cost0"]) - F0) < 1e-9 * abs(F0) for p in parts)            # owned ranges add up exactly
+    assert len({(float(p["cost"]), int(p["acc"]), float(p["lam"])) for p in parts}) == 1   # one controller, replicated
+    xo, info = ofte.lm_solve(prob, x0, max_iter=60, ftol=1e-13)
+    x = np.concatenate([p["x"] for p in parts])
+    assert x.shape == xo.shape and int(parts[0]["it"]) == n_steps
+    assert abs(float(parts[0]["cost"]) - info["cost"]) < 1e-5 * abs(info["cost"]), (float(parts[0]["cost"]), info["cost"])
+    pos = fk.cheetah_fk(prob.full_state(x))
+    pos_o = fk.cheetah_fk(prob.full_state(xo))
+    assert np.abs(pos - pos_o).max() < 1e-3                                                # north-star tolerance, metres
