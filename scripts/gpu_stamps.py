@@ -1,17 +1,26 @@
+#!/usr/bin/env python3
+"""In-kernel phase timing of k_bcr_elim: wall-clock stamps (100 MHz ticks) of ONE workgroup of the launch at a given
+level, under the full load of a real step.   python scripts/gpu_stamps.py [frames]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from acinoset_amd import fte, synth
 from acinoset_amd._lib import lib, ptr, check
-seq = synth.make_sequence(3000, "loop"); det = seq["det"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+seq = synth.make_sequence(n, "loop"); det = seq["det"]
 x0 = fte.triangulation_init(det, seq["K"], seq["D"], seq["R"], seq["t"], 0.5)
 ctx = fte.FTEContext(det, seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
 ctx.set_x(x0[:, fte.ACTIVE])
 dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
 check(lib().acino_fte_debug_stamps(ctx._h, ptr(dbg)))
-for _ in range(3): ctx.step()
-torch.cuda.synchronize()
-d = dbg.cpu().numpy()
-names = ["load/gen", "chol80", "trsm", "y", "store"]
-print("ticks (100MHz => 10ns):", [(names[k], int(d[k+1]-d[k])) for k in range(5)], "total", int(d[5]-d[0]))
-print("chol16_inv (kb=1) ticks", int(d[17]-d[16]))
+names = ["load / build", "chol80", "-", "W strips (level 0: z and G)", "store"]
+for level in (0, 1, 2, 3):
+    for wg in (0, 100, 700):
+        dbg.zero_(); dbg[29] = wg; dbg[30] = level
+        for _ in range(2): ctx.step()
+        torch.cuda.synchronize()
+        d = dbg.cpu().numpy()
+        if d[5] == 0:
+            continue
+        print(f"level {level} workgroup {wg}: " + ", ".join(f"{names[k]} {10 * int(d[k + 1] - d[k])} ns" for k in range(5) if k != 2) +
+              f"; total {10 * int(d[5] - d[0])} ns; one 16x16 tile chain {10 * int(d[17] - d[16])} ns")
