@@ -262,18 +262,18 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
         const int ib = c_tri_i[t], jb = c_tri_j[t];
         const double* pa = Lm + (ib * 16 + li) * LD + ib * 16 + lk;   // U(ib, k >= ib)[i][kk]
         const double* pb = Lm + (jb * 16 + li) * LD + ib * 16 + lk;   // U(jb, k >= ib)[j][kk]
-        d4 acc = {0, 0, 0, 0}, acct = {0, 0, 0, 0};      // G(ib, jb) and its mirror G(jb, ib): both stored row-major
+        d4 acc = {0, 0, 0, 0};
         switch (ib) {
-          case 0: mma_seq_both<20>(acc, acct, pa, 4, pb, 4); break;
-          case 1: mma_seq_both<16>(acc, acct, pa, 4, pb, 4); break;
-          case 2: mma_seq_both<12>(acc, acct, pa, 4, pb, 4); break;
-          case 3: mma_seq_both<8>(acc, acct, pa, 4, pb, 4); break;
-          default: mma_seq_both<4>(acc, acct, pa, 4, pb, 4); break;
+          case 0: acc = mma_seq<20, false>(acc, pa, 4, pb, 4); break;
+          case 1: acc = mma_seq<16, false>(acc, pa, 4, pb, 4); break;
+          case 2: acc = mma_seq<12, false>(acc, pa, 4, pb, 4); break;
+          case 3: acc = mma_seq<8, false>(acc, pa, 4, pb, 4); break;
+          default: acc = mma_seq<4, false>(acc, pa, 4, pb, 4); break;
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           Gg[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = acc[rr];
-          if (ib != jb) Gg[(jb * 16 + lk + 4 * rr) * BS + ib * 16 + li] = acct[rr];
+          if (ib != jb) Gg[(jb * 16 + li) * BS + ib * 16 + lk + 4 * rr] = acc[rr];
         }
       }
     }

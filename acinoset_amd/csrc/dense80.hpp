@@ -80,22 +80,6 @@ __device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const do
   return acc;
 }
 
-// The same product AND its transpose (operands swapped) from ONE set of operand reads: a symmetric result is stored
-// as two row-major tiles with coalesced stores instead of one tile plus a lane-strided mirror store.
-template <int NS>
-__device__ __forceinline__ void mma_seq_both(d4& acc, d4& acc_t, const double* pa, int sa, const double* pb, int sb) {
-  double av[NS], bv[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    av[s] = pa[s * sa];
-    bv[s] = pb[s * sb];
-  }
-#pragma unroll
-  for (int s = 0; s < NS; ++s) acc = mfma(av[s], bv[s], acc);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) acc_t = mfma(bv[s], av[s], acc_t);
-}
-
 // One wave (all 64 lanes): Cholesky of the symmetric 16x16 tile T (LDS, leading dim LD) and the inverse of
 // its factor, entirely in registers.  Lane (i = lane & 15, k = lane >> 4) holds row i, columns {k, k+4, k+8,
 // k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  The right-looking column
@@ -115,9 +99,6 @@ __device__ __forceinline__ bool chol16_inv_acc(double* T, d4 acc, int lane, int*
 #pragma unroll
   for (int r = 0; r < 4; ++r) uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
   bool bad = false;
-  // the 16-pivot chain is the critical path of the workgroup AND shares its SIMD with a wave of the co-resident
-  // workgroup (measured under load: 1.9-2.4 us per tile against 1.56 alone): ask the arbiter to prefer this wave
-  __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     double col[4], ucol[4];
@@ -168,7 +149,6 @@ __device__ __forceinline__ bool chol16_inv_acc(double* T, d4 acc, int lane, int*
       uacc = mfma(-p, pu, uacc);     // register r of lane (i,k) is result[4r+k][i] = -(P PU^T)[4r+k][i] = dU[i][4r+k]
     }
   }
-  __builtin_amdgcn_s_setprio(0);
   if (bad && err && lane == 0) atomicOr(err, 1);
   return !bad;
 }
