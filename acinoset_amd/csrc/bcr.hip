@@ -230,7 +230,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(1);
   chol80(Lm, tid, numeric_err, (ch.dbg && (long long)blockIdx.x == ch.dbg[29] && (long long)level == ch.dbg[30]) ? ch.dbg : nullptr);
   ACINO_STAMP(2);
-  ACINO_STAMP(3);
+  if (fused) ACINO_STAMP(3);
   if (fused) {
     // Level 0 of an FTE chain: both couplings are the sparse third-difference blocks E, so the consumers
     // need only G = D_i^-1 = U U^T (W^T W = E^T G E is a <= 9-term stencil) and z = D_i^-1 b = U y.
@@ -289,6 +289,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
       for (int ct = wave; ct < 5; ct += 4) gemm_strip_g(Lm, A, BS, 1, ch.Wl + i * MB, ct * 16, lane);
     }
   }
+  if (!fused) ACINO_STAMP(3);       // (wave 0: after its W_l strips, before its W_r strip)
   if (r >= 0) {
     if (impl_r) {
       sparse_coupling_w(Lm, ch.Wr + i * MB, coefR, false, tid);

@@ -13,7 +13,7 @@ ctx = fte.FTEContext(det, seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], fto
 ctx.set_x(x0[:, fte.ACTIVE])
 dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
 check(lib().acino_fte_debug_stamps(ctx._h, ptr(dbg)))
-names = ["load / build", "chol80", "-", "W strips (level 0: z and G)", "store"]
+names = ["load / build", "chol80", "wave 0: two W_l strips (coalesced B operand)", "wave 0: one W_r strip (transposed B operand) [level 0: z and G]", "store"]
 for level in (0, 1, 2, 3):
     for wg in (0, 100, 700):
         dbg.zero_(); dbg[29] = wg; dbg[30] = level
@@ -22,5 +22,5 @@ for level in (0, 1, 2, 3):
         d = dbg.cpu().numpy()
         if d[5] == 0:
             continue
-        print(f"level {level} workgroup {wg}: " + ", ".join(f"{names[k]} {10 * int(d[k + 1] - d[k])} ns" for k in range(5) if k != 2) +
+        print(f"level {level} workgroup {wg}: " + ", ".join(f"{names[k]} {10 * int(d[k + 1] - d[k])} ns" for k in range(5)) +
               f"; total {10 * int(d[5] - d[0])} ns; one 16x16 tile chain {10 * int(d[17] - d[16])} ns")
