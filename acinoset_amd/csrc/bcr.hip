@@ -182,26 +182,17 @@ __device__ __forceinline__ void strip_row_r(const double* Lm, const double (&bv)
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) Wg[(IB * 16 + lk + 4 * rr) * BS + cc + li] = acc[rr];
 }
-// the two halves of a strip: request the 20 B operands of this lane / run the five row tiles on them
-__device__ __forceinline__ void strip_load(double (&bv)[20], const double* __restrict__ Ag, int rs, int cs, int cc, int li,
-                                           int lk) {
+__device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
+                                             double* __restrict__ Wg, int cc, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  double bv[20];
 #pragma unroll
   for (int t = 0; t < 20; ++t) bv[t] = Ag[(4 * t + lk) * rs + (cc + li) * cs];
-}
-__device__ __forceinline__ void strip_compute(const double* Lm, const double (&bv)[20], double* __restrict__ Wg, int cc,
-                                              int li, int lk) {
   strip_row_r<4>(Lm, bv, Wg, cc, li, lk);
   strip_row_r<3>(Lm, bv, Wg, cc, li, lk);
   strip_row_r<2>(Lm, bv, Wg, cc, li, lk);
   strip_row_r<1>(Lm, bv, Wg, cc, li, lk);
   strip_row_r<0>(Lm, bv, Wg, cc, li, lk);
-}
-__device__ __forceinline__ void gemm_strip_g(const double* Lm, const double* __restrict__ Ag, int rs, int cs,
-                                             double* __restrict__ Wg, int cc, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  double bv[20];
-  strip_load(bv, Ag, rs, cs, cc, li, lk);
-  strip_compute(Lm, bv, Wg, cc, li, lk);
 }
 
 // Eliminate node i: D_i = L L^T, U = L^-T, W_l = U^T A_il, W_r = U^T A_ir, y = U^T b_i.  Stores U (in the D
@@ -237,15 +228,6 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   }
   __syncthreads();
   ACINO_STAMP(1);
-  // Explicit couplings (every level >= 1): a wave owns up to three 16-column strips of [W_l | W_r] - W_l strip `wave`,
-  // W_r strip 3 - wave, and strip 4 of W_l (wave 0) / W_r (wave 3).  Measured per strip (stamps, under load): ~2 us of
-  // operand latency + 1.75 us of dependent matrix-core steps, three times in sequence.  Now the first strip's operands
-  // are requested BEFORE the factorisation (in flight during the 11-14 us of the pivot chains) and the other two
-  // together right after it: the latency is paid once.
-  const bool pre = !fused && !impl_l && !impl_r;
-  const int li_s = lane & 15, lk_s = lane >> 4;
-  double bvA[20];
-  if (pre && l >= 0) strip_load(bvA, ch.Cpl + l * MB, BS, 1, wave * 16, li_s, lk_s);
   chol80(Lm, tid, numeric_err, (ch.dbg && (long long)blockIdx.x == ch.dbg[29] && (long long)level == ch.dbg[30]) ? ch.dbg : nullptr);
   ACINO_STAMP(2);
   if (fused) ACINO_STAMP(3);
@@ -299,22 +281,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     ACINO_STAMP(5);
     return;
   }
-  if (pre) {
-    const double* Al = ch.Cpl + l * MB;                   // block(i, l): rows i, cols l
-    const double* Ar = ch.Cpl + i * MB;                   // block(r, i)^T: rows i, cols r
-    const bool hasC = (wave == 0 && l >= 0) || (wave == 3 && r >= 0);
-    double bvB[20], bvC[20];
-    if (r >= 0) strip_load(bvB, Ar, 1, BS, (3 - wave) * 16, li_s, lk_s);
-    if (hasC) {
-      if (wave == 0) strip_load(bvC, Al, BS, 1, 64, li_s, lk_s);
-      else strip_load(bvC, Ar, 1, BS, 64, li_s, lk_s);
-    }
-    if (l >= 0) strip_compute(Lm, bvA, ch.Wl + i * MB, wave * 16, li_s, lk_s);
-    ACINO_STAMP(3);
-    if (r >= 0) strip_compute(Lm, bvB, ch.Wr + i * MB, (3 - wave) * 16, li_s, lk_s);
-    if (hasC) strip_compute(Lm, bvC, (wave == 0 ? ch.Wl : ch.Wr) + i * MB, 64, li_s, lk_s);
-  }
-  if (!pre && l >= 0) {
+  if (l >= 0) {
     if (impl_l) {
       sparse_coupling_w(Lm, ch.Wl + i * MB, coefL, true, tid);
     } else {
@@ -322,7 +289,8 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
       for (int ct = wave; ct < 5; ct += 4) gemm_strip_g(Lm, A, BS, 1, ch.Wl + i * MB, ct * 16, lane);
     }
   }
-  if (!pre && r >= 0) {
+  if (!fused) ACINO_STAMP(3);       // (wave 0: after its W_l strips, before its W_r strip)
+  if (r >= 0) {
     if (impl_r) {
       sparse_coupling_w(Lm, ch.Wr + i * MB, coefR, false, tid);
     } else {
