@@ -1240,7 +1240,8 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       //  together after it - the time moves into chol80 (12.8 -> 14-17 us under load), k_bcr_elim stays at 0.287 ms; a raised
       //  wave priority on the pivot chain and swapped-operand mirror tiles of G change nothing either.  Per-workgroup phase
       //  times under load, scripts/gpu_stamps.py: level 0 build 5.2 / chol80 14.0 / z + G 7.6 us; level 1 load 6 / chol80
-      //  12.9 / strips 12-22 / store 1-3 us.)
+      //  12.9 / strips 12-22 / store 1-3 us.  An EXTRA 51 KB store per node at levels 1-4 (+80 MB per step) costs 10 us:
+      //  the wide eliminations are only mildly bandwidth-sensitive, so triangle-only transfers could save ~8 us at best.)
       // (64: measured again in round 2 - the strip form for levels of up to 128 / 256 / 512 nodes moves time from k_bcr_elim
       //  to k_bcr_elim_deep one for one: 0.889 / 0.902 / 0.968 ms per step against 0.893)
       const bool deep = explicit_c && lv.n_elim <= 64;
