@@ -80,75 +80,102 @@ __device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const do
   return acc;
 }
 
+// Panel gather for the 16-pivot chain.  Lane (i, k) holds a = C[i][4s+k] and u = Uwork[i][4s+k]; afterwards the lanes of
+// rows k = 0, 1 hold x[j] = C[i][4s+j] and the lanes of rows k = 2, 3 hold x[j] = Uwork[i][4s+j], j = 0..3 - both work
+// matrices of the panel side by side in ONE register set, so every column operation of the chain is one instruction
+// for both.  Three gfx950 row swaps per 32-bit half (see row_allgather for their semantics).
+__device__ __forceinline__ void panel_gather(double a, double u, double (&x)[4]) {
+  const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, u);
+  const u2v sl = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)ub, false, false);                 // [0]: a0 a1 u0 u1   [1]: a2 a3 u2 u3
+  const u2v sh = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(ub >> 32), false, false);
+  const u2v l01 = __builtin_amdgcn_permlane16_swap(sl[0], sl[0], false, false);   // [0]: a0 a0 u0 u0   [1]: a1 a1 u1 u1
+  const u2v l23 = __builtin_amdgcn_permlane16_swap(sl[1], sl[1], false, false);   // [0]: a2 a2 u2 u2   [1]: a3 a3 u3 u3
+  const u2v h01 = __builtin_amdgcn_permlane16_swap(sh[0], sh[0], false, false);
+  const u2v h23 = __builtin_amdgcn_permlane16_swap(sh[1], sh[1], false, false);
+  x[0] = __builtin_bit_cast(double, ((unsigned long long)h01[0] << 32) | l01[0]);
+  x[1] = __builtin_bit_cast(double, ((unsigned long long)h01[1] << 32) | l01[1]);
+  x[2] = __builtin_bit_cast(double, ((unsigned long long)h23[0] << 32) | l23[0]);
+  x[3] = __builtin_bit_cast(double, ((unsigned long long)h23[1] << 32) | l23[1]);
+}
+// The value of v held by lane (i, k ^ 2): the two halves of the wave trade places.
+__device__ __forceinline__ double half_swap(double v, bool upper) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const u2v l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);          // [0]: lo lo   [1]: hi hi
+  const u2v h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  const unsigned lo = upper ? l[0] : l[1], hi = upper ? h[0] : h[1];
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // One wave (all 64 lanes): Cholesky of the symmetric 16x16 tile T (LDS, leading dim LD) and the inverse of
 // its factor, entirely in registers.  Lane (i = lane & 15, k = lane >> 4) holds row i, columns {k, k+4, k+8,
 // k+12}: acc[r] = C[i][4r+k] - which IS the MFMA C layout of the symmetric tile.  The right-looking column
 // operations that turn C into L are applied at the same time to an identity tile (uacc), which they turn into
-// U = L^-T: no separate triangular inversion.  Columns go in four panels of four: every lane gathers its row's
-// four panel entries (one cross-lane exchange per PANEL), the pivots and multipliers L[4s+k'][c] are
-// wave-uniform and travel through SGPRs (v_readlane), so the 16-pivot dependency chain is readlane -> rsq ->
-// Newton -> mul -> readlane -> fma; ONE v_mfma_f64_16x16x4 per tile then applies the rank-4 update to the
-// remaining columns (the finished panel register is already both the A and the B operand).  The tile is
-// OVERWRITTEN by U_kk (upper triangular); L_kk is not kept.
+// U = L^-T: no separate triangular inversion.  Columns go in four panels of four.  The chain wave is bound by VALU
+// ISSUE (it keeps its SIMD's port ~65 % busy), so the panel is laid out to need the fewest
+// instructions: panel_gather puts the C columns into the lower half of the wave and the identity columns into the upper
+// half, one register set x[0..3] for both, and every scale / eliminate step is ONE instruction for the two matrices.
+// The pivots and multipliers L[4s+k'][c] are wave-uniform and travel through SGPRs (v_readlane from the lower half), so
+// the 16-pivot dependency chain is readlane -> rsq -> Newton -> mul -> readlane -> fma; for the rank-4 update of the
+// remaining columns the halves trade the two columns the other one lacks (half_swap) and ONE v_mfma_f64_16x16x4 per
+// tile applies it (the finished panel register is already both the A and the B operand).  The tile is OVERWRITTEN by
+// U_kk (upper triangular); L_kk is not kept.  No per-pivot checks: a non-positive (or NaN) pivot turns 1/sqrt into
+// NaN / inf, which the column operations and the rank-4 updates carry into every later pivot - ONE test of the last
+// 1/sqrt flags the tile.
 // LDT: leading dimension of T (and of Lout).  With KEEP_L the factor itself goes to Lout (lower triangle, zeros above).
 // Returns true when every pivot was positive (wave-uniform).
 template <int LDT = LD, bool KEEP_L = false>
 __device__ __forceinline__ bool chol16_inv_acc(double* T, d4 acc, int lane, int* err, double* Lout = nullptr) {
   const int i = lane & 15, k = lane >> 4;
+  const bool upper = k >= 2, odd = k & 1;
   d4 uacc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) uacc[r] = (i == 4 * r + k) ? 1.0 : 0.0;
-  bool bad = false;
+  double y = 1.0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    double col[4], ucol[4];
-    row_allgather(acc[s], col);
-    row_allgather(uacc[s], ucol);
+    double x[4];
+    panel_gather(acc[s], uacc[s], x);
     // The pivot chain inside the panel is kept as short as the arithmetic allows: the multipliers and the next
     // diagonal entry are broadcast RAW (before this pivot's 1/sqrt is known, i.e. beside its rsq chain), and the next
     // pivot a'(c+1,c+1) - (a(c+1,c) y)^2 is formed directly from them: rsq -> Newton -> mul -> fma -> next rsq.
-    double piv0 = readlane_d(col[0], 4 * s);
+    double piv = readlane_d(x[0], 4 * s);
 #pragma unroll
     for (int k0 = 0; k0 < 4; ++k0) {
       double mraw[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int kk = k0 + 1; kk < 4; ++kk) mraw[kk] = readlane_d(col[k0], 4 * s + kk);    // a[4s+kk][c], unscaled
-      const double dnext = k0 < 3 ? readlane_d(col[k0 + 1], 4 * s + k0 + 1) : 0.0;       // a[c+1][c+1] so far
-      bad |= !(piv0 > 0.0);                                   // flagged off the dependency chain
-      const double piv = fmax(piv0, 1e-300);
+      for (int kk = k0 + 1; kk < 4; ++kk) mraw[kk] = readlane_d(x[k0], 4 * s + kk);      // a[4s+kk][c], unscaled
+      const double dnext = k0 < 3 ? readlane_d(x[k0 + 1], 4 * s + k0 + 1) : 0.0;         // a[c+1][c+1] so far
       // 1/sqrt(piv): hardware estimate + one coupled Newton step (no range fix-ups: piv is a positive normal number)
-      double y = __builtin_amdgcn_rsq(piv);
+      y = __builtin_amdgcn_rsq(piv);
       const double e = fma(-(piv * y), y, 1.0);
       y = fma(y * e, fma(e, 0.375, 0.5), y);
       if (k0 < 3) {
         const double t = mraw[k0 + 1] * y;                    // L[c+1][c]
-        piv0 = fma(-t, t, dnext);
+        piv = fma(-t, t, dnext);
       }
-      col[k0] *= y;                                           // row c becomes sqrt(piv); rows < c hold don't-cares
-      ucol[k0] *= y;
+      x[k0] *= y;                                             // row c becomes sqrt(piv); rows < c hold don't-cares
 #pragma unroll
-      for (int kk = k0 + 1; kk < 4; ++kk) {
-        const double m = mraw[kk] * y;                        // L[4s+kk][c]
-        col[kk] -= col[k0] * m;
-        ucol[kk] -= ucol[k0] * m;
-      }
+      for (int kk = k0 + 1; kk < 4; ++kk) x[kk] -= x[k0] * (mraw[kk] * y);   // (mraw * y) = L[4s+kk][c]
     }
-    if (k == 0) {                                             // U[i][4s .. 4s+3] is final
+    if (k == 2) {                                             // U[i][4s .. 4s+3] is final
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) T[i * LDT + 4 * s + kk] = ucol[kk];
+      for (int kk = 0; kk < 4; ++kk) T[i * LDT + 4 * s + kk] = x[kk];
     }
     if (KEEP_L && k == 1) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) Lout[i * LDT + 4 * s + kk] = (i >= 4 * s + kk) ? col[kk] : 0.0;
+      for (int kk = 0; kk < 4; ++kk) Lout[i * LDT + 4 * s + kk] = (i >= 4 * s + kk) ? x[kk] : 0.0;
     }
     if (s < 3) {
-      const double pk = k == 0 ? col[0] : (k == 1 ? col[1] : (k == 2 ? col[2] : col[3]));
+      const double xa = odd ? x[1] : x[0], xb = odd ? x[3] : x[2];
+      const double mine = upper ? xb : xa;                    // x[k]:      L column k (lower half) / U column k (upper half)
+      const double other = half_swap(upper ? xa : xb, upper); // x[k ^ 2] of lane (i, k ^ 2): the column this half lacks
+      const double pk = upper ? other : mine, pu = upper ? mine : other;
       const double p = (i >= 4 * s + k) ? pk : 0.0;           // strictly-upper entries are discarded here, once
-      const double pu = k == 0 ? ucol[0] : (k == 1 ? ucol[1] : (k == 2 ? ucol[2] : ucol[3]));
       acc = mfma(-p, p, acc);
       uacc = mfma(-p, pu, uacc);     // register r of lane (i,k) is result[4r+k][i] = -(P PU^T)[4r+k][i] = dU[i][4r+k]
     }
   }
+  const bool bad = !(fabs(y) < 1e300);                        // NaN or inf (wave-uniform)
   if (bad && err && lane == 0) atomicOr(err, 1);
   return !bad;
 }

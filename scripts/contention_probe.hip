@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
