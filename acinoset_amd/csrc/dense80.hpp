@@ -40,25 +40,10 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
   return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-// All-gather across the four 16-lane rows of a wave: lane (i, k) holds x_k(i); afterwards every lane (i, *) holds
-// c[j] = x_j(i), j = 0..3.  Two gfx950 row-swap instructions per 32-bit half (v_permlane16_swap: odd rows of the first
-// operand <-> even rows of the second; v_permlane32_swap: upper half of the first <-> lower half of the second) -
-// plain VALU latency instead of four trips through the LDS crossbar (ds_bpermute).
+// gfx950 row swaps used below: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows
+// of the second, v_permlane32_swap the upper half of the first with the lower half of the second - plain VALU latency
+// instead of trips through the LDS crossbar (ds_bpermute).  The builtins return {new first, new second}.
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void row_allgather(double x, double (&c)[4]) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
-  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-  const u2v l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0]: x0 x0 x2 x2   [1]: x1 x1 x3 x3
-  const u2v h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  const u2v la = __builtin_amdgcn_permlane32_swap(l1[0], l1[0], false, false);   // [0]: x0 everywhere, [1]: x2
-  const u2v lb = __builtin_amdgcn_permlane32_swap(l1[1], l1[1], false, false);   // [0]: x1,            [1]: x3
-  const u2v ha = __builtin_amdgcn_permlane32_swap(h1[0], h1[0], false, false);
-  const u2v hb = __builtin_amdgcn_permlane32_swap(h1[1], h1[1], false, false);
-  c[0] = __builtin_bit_cast(double, ((unsigned long long)ha[0] << 32) | la[0]);
-  c[1] = __builtin_bit_cast(double, ((unsigned long long)hb[0] << 32) | lb[0]);
-  c[2] = __builtin_bit_cast(double, ((unsigned long long)ha[1] << 32) | la[1]);
-  c[3] = __builtin_bit_cast(double, ((unsigned long long)hb[1] << 32) | lb[1]);
-}
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -83,7 +68,7 @@ __device__ __forceinline__ d4 mma_seq(d4 acc, const double* pa, int sa, const do
 // Panel gather for the 16-pivot chain.  Lane (i, k) holds a = C[i][4s+k] and u = Uwork[i][4s+k]; afterwards the lanes of
 // rows k = 0, 1 hold x[j] = C[i][4s+j] and the lanes of rows k = 2, 3 hold x[j] = Uwork[i][4s+j], j = 0..3 - both work
 // matrices of the panel side by side in ONE register set, so every column operation of the chain is one instruction
-// for both.  Three gfx950 row swaps per 32-bit half (see row_allgather for their semantics).
+// for both.  Three gfx950 row swaps per 32-bit half (semantics above).
 __device__ __forceinline__ void panel_gather(double a, double u, double (&x)[4]) {
   const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, u);
   const u2v sl = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)ub, false, false);                 // [0]: a0 a1 u0 u1   [1]: a2 a3 u2 u3

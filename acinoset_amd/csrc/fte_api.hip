@@ -134,9 +134,13 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
   if (e < (int64_t)K.n_frames * NP) {
     const int n = (int)(e / NP), p = (int)(e % NP);
     const int node = n / 3 + K.pin_left, row = (n % 3) * NP + p;
-    const double d = delta_nodes[(size_t)node * BS + row];
     const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[e];
     const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+    // A bound-active variable is pinned in the linear system by the 2^70 diagonal boost, which leaves it a step of
+    // ~1e-21 instead of the exact 0 of a deleted row.  At a bound of 0.0 (theta_7, 9, 11, 13 - where the nose-line
+    // initialisation puts them) that residue is representable: x would leave the bound by 1e-21, count as free in the next
+    // iteration and take a different path than the active-set rule prescribes.  Its step is 0, exactly.
+    const double d = fixed ? 0.0 : delta_nodes[(size_t)node * BS + row];
     const double pg = fixed ? 0.0 : gv;
     const double d0 = hd[e];
     const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
@@ -676,8 +680,9 @@ int acino_fte_set_halo(acino_fte_ctx* ctx, int which, const double* d_halo_l, co
   return ACINO_OK;
 }
 
-__global__ void k_restart_status(acino_fte_state* st) {
+__global__ void k_restart_status(acino_fte_state* st, double lam0) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && st->status >= 1 && st->status <= 4) {
+    if (st->status == 4) st->lam = lam0;      // ended because no damping gave descent: that damping is not a start value
     st->status = 0;
     st->nu = 2.0;
   }
@@ -703,7 +708,7 @@ int acino_fte_reevaluate(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   ACINO_REQUIRE(!ctx->h.pin_left && !ctx->h.pin_right, "single-GPU contexts");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_restart_status, dim3(1), dim3(64), 0, s, ctx->b.state);
+  hipLaunchKernelGGL(k_restart_status, dim3(1), dim3(64), 0, s, ctx->b.state, ctx->lam0);
   ACINO_LAUNCH_CHECK();
   return eval_iterate(ctx, 0, true, false, false, s, 1);      // assembly of the current iterate + cost (init-style control)
 }

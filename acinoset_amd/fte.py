@@ -145,7 +145,8 @@ class FTEContext:
 
     def set_precision(self, precision):
         """Switch the assembly arithmetic (PRECISIONS) and re-evaluate the current iterate in it; the controller keeps
-        its damping and goes back to "running" - used to polish a mixed-precision solve with fp64 iterations."""
+        its damping (after a lambda overflow: lam0) and goes back to "running" - used to polish a mixed-precision solve
+        with fp64 iterations."""
         check(lib().acino_fte_set_precision(self._h, PRECISIONS[precision]))
         check(lib().acino_fte_reevaluate(self._h, stream_ptr()))
 
@@ -376,8 +377,10 @@ def fte_solve_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0
     try:
         ctx.set_x(x0_all[:, ACTIVE])
         info = ctx.solve(max_iter)
-        if polish and kw.get("precision", "f64") != "f64" and info["status"] in (1, 2, 3):
-            # mixed-precision solve finished: a few fp64 iterations from its end point (same controller, same damping)
+        if polish and kw.get("precision", "f64") != "f64" and info["status"] in (1, 2, 3, 4):
+            # mixed-precision solve finished - by a stopping test or because no damping gives descent any more against
+            # the fp64-summed cost (lambda overflow: the natural end of an inexact gradient) - : a few fp64 iterations
+            # from its end point (same controller; damping kept, or back to lam0 after an overflow)
             n_mixed = info["iter"]
             ctx.set_precision("f64")
             info = ctx.solve(max(max_iter - n_mixed, 1))

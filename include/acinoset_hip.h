@@ -220,7 +220,7 @@ int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_p
  * the current iterate in the new precision before stepping. */
 int acino_fte_set_precision(acino_fte_ctx* ctx, int precision);
 /* Re-evaluates the CURRENT iterate (cost, gradient, Gauss-Newton blocks) and restarts the controller's stopping
- * state (status -> running, lambda kept). */
+ * state (status -> running; lambda kept, or back to lam0 when the run had ended in lambda overflow). */
 int acino_fte_reevaluate(acino_fte_ctx* ctx, void* stream);
 /* Copies n frames of the current (which = 0) or trial (which = 1) iterate, starting at local frame `first`
  * (-3 <= first, first + n <= n_frames + 3: the three halo rows on either side are addressable), to d_buf[n][25]

@@ -201,8 +201,10 @@ def _ref_lines(lo, hi):
     return textwrap.dedent("\n".join(src[lo - 1:hi]))
 
 
-def gen_fte_model():
-    """The reference's OWN FTE model text on floats (fte_model.npz).
+def _fte_model_setup():
+    """Shared by gen_fte_model / gen_fte_stationary: inputs, slice-exec of the model text, constants, boxes.
+
+    The reference's OWN FTE model text on floats (fte_model.npz).
 
     Slice-exec of src/all_optimizations.py: :25-27 (redescending a, b, c), :64-217 (sympy FK, pt3d_to_2d),
     :226-241 (DataFrame accessors, proj_funcs), :243-252 (R, Q), :268-277 (nose-line estimate), :283-500 (sets, weights,
@@ -314,8 +316,15 @@ def gen_fte_model():
         names.append(f"{cname}:{p}")
     out["bounds_lo"], out["bounds_hi"], out["bound_rules"] = lo_b, hi_b, np.array(names)
 
-    # ---- objective at feasible points: choose x, then satisfy every equality of :359-399 through the reference's
-    # own residuals (each is affine with unit slope in the variable it defines)
+    return dict(m=m, P=P, N=N, L=L, C=C, fp=fp, out=out, rng=rng, X_true=X_true, act=act, start_frame=start_frame,
+                end_frame=end_frame, lo_b=lo_b, hi_b=hi_b, names=names)
+
+
+def _feasible_objective(ctx, X):
+    """obj (:486-500) at the iterate X [N,45] with every equality of :359-399 satisfied through the reference's own
+    residuals (each is affine with unit slope in the variable it defines).  Returns (obj, worst equality residual)."""
+    m, P, N, L, C, fp = (ctx[k] for k in ("m", "P", "N", "L", "C", "fp"))
+
     def set_from_residual(comp, idx, var):
         v0 = 0.0 if var.value is None else var.value
         var.value = v0
@@ -324,6 +333,46 @@ def gen_fte_model():
         slope = comp.rule(m, *idx).r - r0              # +-1 or +-Ts: the constraint is affine in `var`
         var.value = v0 - r0 / slope
 
+    for n in range(1, N + 1):
+        for p in range(1, P + 1):
+            m.x[n, p].value = float(X[n - 1, p - 1])
+            m.dx[n, p].value = 0.0
+            m.ddx[n, p].value = 0.0
+            m.slack_model[n, p].value = 0.0
+    for p in range(1, P + 1):                      # n = 2..N: dx_n from integrate_p, then dx_1, ddx free
+        for n in range(2, N + 1):
+            set_from_residual(m.integrate_p, (n, p), m.dx[n, p])
+        # free variables dx_1, ddx_1 chosen so that slack_2 = slack_3 = 0 (the optimum of the free variables)
+        ddx3 = (m.dx[3, p].value - m.dx[2, p].value) / m.Ts
+        m.ddx[1, p].value = m.ddx[2, p].value = ddx3
+        m.dx[1, p].value = m.dx[2, p].value - m.Ts * ddx3
+        for n in range(3, N + 1):
+            set_from_residual(m.integrate_v, (n, p), m.ddx[n, p])
+        for n in range(2, N + 1):
+            set_from_residual(m.constant_acc, (n, p), m.slack_model[n, p])
+    for n in range(1, N + 1):
+        for l in range(1, L + 1):
+            for d in (1, 2, 3):
+                set_from_residual(m.pose_constraint, (n, l, d), m.poses[n, l, d])
+            for c in range(1, C + 1):
+                for d in (1, 2):
+                    m.slack_meas[n, c, l, d].value = 0.0
+                    set_from_residual(m.measurement, (n, c, l, d), m.slack_meas[n, c, l, d])
+    worst = 0.0
+    for cname in ("pose_constraint", "integrate_p", "integrate_v", "constant_acc", "measurement"):
+        for v in getattr(m, cname).evaluate(m).values():
+            if v is not fp.Constraint.Skip:
+                worst = max(worst, abs(v.r))
+    return m.obj.value(m), worst
+
+
+def gen_fte_model():
+    """fte_model.npz: see _fte_model_setup; plus, for random iterates x, the objective value with all equality
+    constraints satisfied (dx, ddx, slack_model, poses and slack_meas are SOLVED from the reference's own constraint
+    residuals, one variable per constraint)."""
+    ctx = _fte_model_setup()
+    m, P, N, fp, out, rng, X_true, act = (ctx[k] for k in ("m", "P", "N", "fp", "out", "rng", "X_true", "act"))
+    start_frame, end_frame, lo_b, names = ctx["start_frame"], ctx["end_frame"], ctx["lo_b"], ctx["names"]
     cases_x, cases_obj, cases_slack, cases_dx, cases_ddx, max_res = [], [], [], [], [], []
     for case in range(5):
         X = X_true[start_frame:end_frame].copy()
@@ -332,39 +381,10 @@ def gen_fte_model():
             X[:, 5] = rng.normal(0, 0.01, N)          # a state with Q = 0: weight 0, must not change the objective
         if case == 4:
             X[:, 0:2] -= np.array([4.5, 8.0])         # the animal BEHIND camera 0: pt3d_to_2d has no z cut (:193-209)
-        for n in range(1, N + 1):
-            for p in range(1, P + 1):
-                m.x[n, p].value = float(X[n - 1, p - 1])
-                m.dx[n, p].value = 0.0
-                m.ddx[n, p].value = 0.0
-                m.slack_model[n, p].value = 0.0
-        for p in range(1, P + 1):                      # n = 2..N: dx_n from integrate_p, then dx_1, ddx free
-            for n in range(2, N + 1):
-                set_from_residual(m.integrate_p, (n, p), m.dx[n, p])
-            # free variables dx_1, ddx_1 chosen so that slack_2 = slack_3 = 0 (the optimum of the free variables)
-            ddx3 = (m.dx[3, p].value - m.dx[2, p].value) / m.Ts
-            m.ddx[1, p].value = m.ddx[2, p].value = ddx3
-            m.dx[1, p].value = m.dx[2, p].value - m.Ts * ddx3
-            for n in range(3, N + 1):
-                set_from_residual(m.integrate_v, (n, p), m.ddx[n, p])
-            for n in range(2, N + 1):
-                set_from_residual(m.constant_acc, (n, p), m.slack_model[n, p])
-        for n in range(1, N + 1):
-            for l in range(1, L + 1):
-                for d in (1, 2, 3):
-                    set_from_residual(m.pose_constraint, (n, l, d), m.poses[n, l, d])
-                for c in range(1, C + 1):
-                    for d in (1, 2):
-                        m.slack_meas[n, c, l, d].value = 0.0
-                        set_from_residual(m.measurement, (n, c, l, d), m.slack_meas[n, c, l, d])
-        worst = 0.0
-        for cname in ("pose_constraint", "integrate_p", "integrate_v", "constant_acc", "measurement"):
-            for v in getattr(m, cname).evaluate(m).values():
-                if v is not fp.Constraint.Skip:
-                    worst = max(worst, abs(v.r))
+        obj, worst = _feasible_objective(ctx, X)
         max_res.append(worst)
         cases_x.append(X)
-        cases_obj.append(m.obj.value(m))
+        cases_obj.append(obj)
         cases_slack.append(np.array([[m.slack_model[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
         cases_dx.append(np.array([[m.dx[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
         cases_ddx.append(np.array([[m.ddx[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]))
@@ -373,6 +393,52 @@ def gen_fte_model():
     np.savez_compressed(os.path.join(OUT, "fte_model.npz"), **out)
     print("fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
           "boxes", int(np.isfinite(lo_b).sum()), names[:3])
+
+
+def gen_fte_stationary():
+    """fte_stationary.npz: the fixed point of the projected LM is a first-order stationary point of the REFERENCE's
+    objective, evaluated by the reference's own model text (row a-10: IPOPT itself cannot run here).
+
+    On the inputs of fte_model.npz the oracle's LM (oracle/fte.py, the control flow of the HIP path) is run from the
+    reference's own initialisation to a tight tolerance; at its end point x* the reference objective (feasible
+    completion as in gen_fte_model) is differentiated by central differences in all N x 25 active states.  Recorded:
+    x*, obj_ref(x*), the finite-difference gradient at x* and at the initial point."""
+    ctx = _fte_model_setup()
+    out, N = ctx["out"], ctx["N"]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fk as ofk, fte as ofte
+    s, e = ctx["start_frame"], ctx["end_frame"]
+    det = out["det"][s:e]
+    prob = ofte.FTEProblem(det[..., :2], det[..., 2], out["K"], out["D"], out["R"], out["t"], 1.0 / float(out["fps"]),
+                           dlc_thresh=float(out["dlc_thresh"]))
+    X0 = out["init_x"].copy()
+    act = np.asarray(ofk.ACTIVE)
+    xs, info = ofte.lm_solve(prob, X0[:, act], max_iter=300, ftol=1e-15, xtol=1e-13, gtol=1e-9)
+    Xs = X0.copy()
+    Xs[:, act] = xs
+
+    def fd_grad(X, h=1e-6):
+        g = np.zeros((N, len(act)))
+        for n in range(N):
+            for k, p in enumerate(act):
+                Xp, Xm = X.copy(), X.copy()
+                Xp[n, p] += h
+                Xm[n, p] -= h
+                g[n, k] = (_feasible_objective(ctx, Xp)[0] - _feasible_objective(ctx, Xm)[0]) / (2 * h)
+        return g
+
+    obj_star, worst = _feasible_objective(ctx, Xs)
+    obj_init, _ = _feasible_objective(ctx, X0)
+    g_star, g_init = fd_grad(Xs), fd_grad(X0)
+    np.savez_compressed(os.path.join(OUT, "fte_stationary.npz"), x_star=Xs, obj_ref_star=obj_star, obj_ref_init=obj_init,
+                        grad_ref_star=g_star, grad_ref_init=g_init, fd_step=1e-6, max_eq_residual=worst,
+                        oracle_cost=info["cost"], oracle_iterations=info["iterations"], oracle_status=info["status"],
+                        oracle_gnorm=info["gnorm"])
+    lo, hi = prob.lo, prob.hi
+    fixed = ((xs <= lo) & (g_star > 0)) | ((xs >= hi) & (g_star < 0))
+    print("fte_stationary.npz: oracle", info["status"], info["iterations"], "it, cost", info["cost"], "obj_ref(x*)", obj_star,
+          "| grad_ref(init)|_inf", np.abs(g_init).max(), "| projected grad_ref(x*)|_inf", np.abs(np.where(fixed, 0, g_star)).max(),
+          "bound-active", int(fixed.sum()))
 
 
 def gen_ekf():
@@ -543,8 +609,8 @@ def gen_dummy_scene():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: golden fixtures can only be regenerated in the build container"
     install_stubs()
-    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "ekf"]
+    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "fte_stationary", "ekf"]
     for name, fn in (("helpers", gen_ref_helpers), ("fk", gen_cheetah_fk), ("index", gen_index_path),
-                     ("fte_model", gen_fte_model), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
+                     ("fte_model", gen_fte_model), ("fte_stationary", gen_fte_stationary), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
         if name in parts:
             fn()

@@ -231,3 +231,29 @@ def test_objective_matches_reference_model_text(golden_dir):
     # case 4 has the animal behind camera 0: the reference applies no z cut, neither does the oracle
     prob.measurement_terms(g["case_x"][4][:, fk.ACTIVE], need_jac=False)
     assert prob.measurement_terms(g["case_x"][4][:, fk.ACTIVE], need_jac=False)[3] > 0
+
+
+def test_lm_fixed_point_is_stationary_for_the_reference_objective(golden_dir):
+    """Row a-10 (the IPOPT call): IPOPT itself cannot run here, so its end state stays unpinned - but the point the
+    projected LM converges to is pinned as a first-order stationary point of the REFERENCE's own objective.
+    fte_stationary.npz (make_golden.py::gen_fte_stationary) holds central differences of the reference's model text
+    (all_optimizations.py:283-500 on floats, every equality constraint satisfied) in all N x 25 active states, at the
+    reference's initial point and at the LM end point x*."""
+    g, st = _g(golden_dir, "fte_model.npz"), _g(golden_dir, "fte_stationary.npz")
+    prob = _fte_model_problem(g)
+    act = fk.ACTIVE
+    x0 = g["init_x"][:, act]
+    xs, info = ofte.lm_solve(prob, x0, max_iter=300, ftol=1e-15, xtol=1e-13, gtol=1e-9)
+    assert np.abs(xs - st["x_star"][:, act]).max() < 1e-9, info
+    cost, grad, _H, _nb = prob.evaluate(xs)
+    assert abs(cost - float(st["obj_ref_star"])) < 1e-10 * abs(cost)
+    assert float(st["obj_ref_star"]) < float(st["obj_ref_init"]) and float(st["max_eq_residual"]) < 1e-9
+    # the oracle's analytic gradient IS the gradient of the reference objective (finite differences of the model text)
+    _c0, g0, _H0, _nb0 = prob.evaluate(x0)
+    scale = np.abs(st["grad_ref_init"]).max()
+    assert np.abs(g0 - st["grad_ref_init"]).max() < 1e-6 * scale
+    assert np.abs(grad - st["grad_ref_star"]).max() < 1e-6 * scale
+    # first-order optimality of the reference objective over the 21 boxes, at x*
+    gr = st["grad_ref_star"]
+    active = ((xs <= prob.lo) & (gr > 0)) | ((xs >= prob.hi) & (gr < 0))
+    assert np.abs(np.where(active, 0.0, gr)).max() < 1e-6 * scale
