@@ -18,8 +18,11 @@ upstream AcinoSet tree).  Pinning status:
   (cv2.projectPoints / cv2.undistortPoints): PARITY UNPINNED - no recorded
   output in the reference exercises them; restated from OpenCV's documented model.
 * the FTE solve (Pyomo + IPOPT, absent): PARITY UNPINNED end to end - no cheetah
-  IPOPT trajectory is shipped.  Structure is pinned by KAT-4 (integration /
-  third-difference identities on the stored build.py runs) and the objective
-  pieces above; the LM solution is the tightly converged minimiser of the same
-  reduced problem.
+  IPOPT trajectory is shipped.  Pinned instead: constants, weights, the 21 boxes,
+  the initialisation and the OBJECTIVE by the reference's own model text run on
+  floats (fte_model.npz); its GRADIENT and the first-order optimality of the LM
+  end point by central differences of that same text (fte_stationary.npz); the
+  reduction by KAT-4 (integration / third-difference identities on the stored
+  build.py runs).  I.e. the LM solution is a stationary point of the reference's
+  NLP; that IPOPT ends at the same one is not shown.
 """
