@@ -322,6 +322,20 @@ def test_gpu_lm_ends_at_a_stationary_point_of_the_reference_objective(mods, gold
     assert np.abs(np.asarray(res["positions"]) - ofk.cheetah_fk(st["x_star"])).max() < 1e-3
 
 
+def test_lm_path_identity_on_nasty_small_problems(mods):
+    """tests/tools/fuzz_lm_path.py in the suite: 16 seeded problems of 3 ... 40 frames, 2 ... 6 cameras, gross outliers,
+    dropped detections, starts on the bounds / near / far - the HIP solve and the oracle LM must produce the same trial
+    cost in every one of 8 iterations (accepted or rejected), i.e. the same controller decisions, active sets and
+    block solves, not merely nearby end points."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_lm_path", os.path.join(os.path.dirname(__file__), "tools", "fuzz_lm_path.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in range(1000, 1016):
+        worst, where, what = mod.run_case(seed, 8)
+        assert worst < 1e-6, (seed, what, worst, where)       # (rejected overshoots are weighted 1e-3: see the tool)
+
+
 def test_config3_exact_size_against_committed_oracle_solution(mods, golden_dir):
     """BASELINE config 3 at its exact workload: 6 cameras x 20 markers x 1 000 frames, nose-line initialisation,
     solve to the default tolerances - against tests/golden/config3_solution.npz (oracle LM, made by
