@@ -95,7 +95,7 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
       const int p = tid % NP;
       const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
       double d = Dm[tid * LD + tid];
-      d = d + lam * d;
+      d = d + lam * fmax(d, DIAG_FLOOR);
       if (fixed) d *= FIX_SCALE;
       Dm[tid * LD + tid] = d;
       b = fixed ? 0.0 : -gv;

@@ -146,7 +146,7 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
     const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
     xt[(size_t)(n + HALO) * NP + p] = xn;
     if (n >= K.own_lo && n < K.own_hi) {          // (window sharding: only owned frames enter the global sums)
-      pred = 0.5 * d * (lam * d0 * d - pg);
+      pred = 0.5 * d * (lam * fmax(d0, DIAG_FLOOR) * d - pg);
       step = fabs(xn - xv);
     }
   }

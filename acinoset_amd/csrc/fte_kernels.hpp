@@ -13,6 +13,10 @@ constexpr int BS = ACINO_BS;         // 80 = 3 frames x 25 states + 5 identity p
 constexpr int NGRP = 14;             // kinematic frames (rotation groups)
 constexpr int FPB = 8;               // frames per workgroup in the assembly kernel
 constexpr double FIX_SCALE = 1.1805916207174113e21;  // 2^70: diagonal boost pinning a bound-active variable
+// Marquardt scaling lam * diag(H) cannot lift a diagonal entry that is exactly 0: a state no camera observes in a clip of
+// fewer than 4 frames (no third-difference row either).  Its damping term is lam * DIAG_FLOOR instead: the variable is
+// decoupled (zero row, zero gradient), gets a positive pivot and a step of exactly 0.  Never active otherwise.
+constexpr double DIAG_FLOOR = 1e-30;
 
 // Device-resident constant block of one FTE problem.
 struct FteConst {

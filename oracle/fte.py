@@ -163,7 +163,9 @@ class FTEProblem:
         Hd = H.copy()
         idx = np.arange(P)
         Hd[:, idx, idx] += 2 * self.q_w[None, :] * band[0][:, None]
-        diag = Hd[:, idx, idx].copy()
+        # (a diagonal entry that is exactly 0 - a state no camera observes in a clip of < 4 frames, which has no
+        #  third-difference row either - gets lam * 1e-30: decoupled variable, positive pivot, step exactly 0)
+        diag = np.maximum(Hd[:, idx, idx], 1e-30)
         Hd[:, idx, idx] += lam * diag
         fx = fixed
         Hd = np.where(fx[:, :, None] | fx[:, None, :], 0.0, Hd)

@@ -89,7 +89,7 @@ if __name__ == "__main__":
     bad = 0
     for seed in range(first, first + count):
         worst, where, what = run_case(seed, iters, verbose=len(sys.argv) > 4)
-        ok = worst < 1e-6
+        ok = worst < 1e-5     # (4-frame problems at lam ~ 1e-6 reach 1e-5 after 20 iterations with identical decisions: conditioning)
         bad += not ok
         print(seed, what, f"worst rel trial-cost difference {worst:.1e} at it {where}", "ok" if ok else "MISMATCH", flush=True)
     print("mismatches:", bad)
