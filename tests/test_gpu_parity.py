@@ -383,6 +383,19 @@ def test_edge_cases(mods):
         x1[:, fte.ACTIVE] = s1["q_true"][:, fte.ACTIVE]
         r1, i1 = fte.fte_solve(s1["det"][..., :2], s1["det"][..., 2], *rig, s1["Ts"], x0=x1, max_iter=10)
         assert np.isfinite(r1["positions"]).all() and r1["dx"].shape == (n, 25)
+    # three frames (no third-difference row) and no detection of the tail markers: the tail angles have a zero diagonal,
+    # which Marquardt scaling cannot lift (DIAG_FLOOR) - they must simply stay where they are, in both implementations
+    s3 = synth.make_sequence(3, "trot")
+    d3 = s3["det"].copy()
+    d3[:, :, 6:8, 2] = 0.0
+    x3 = np.zeros((3, 45))
+    x3[:, fte.ACTIVE] = s3["q_true"][:, fte.ACTIVE] + np.random.default_rng(3).normal(0, 0.03, (3, 25))
+    r3, i3 = fte.fte_solve(d3[..., :2], d3[..., 2], *rig, s3["Ts"], x0=x3, max_iter=40)
+    p3 = ofte.FTEProblem(d3[..., :2], d3[..., 2], *rig, s3["Ts"])
+    xo3, oi3 = ofte.lm_solve(p3, x3[:, ofk.ACTIVE], max_iter=40)
+    assert i3["status_name"] in ("ftol", "xtol", "gtol") and abs(i3["cost"] - oi3["cost"]) < 1e-8 * abs(oi3["cost"])
+    unobserved = np.abs(p3.evaluate(x3[:, ofk.ACTIVE])[2][:, np.arange(25), np.arange(25)]) == 0.0
+    assert unobserved.any() and np.array_equal(np.asarray(r3["x"])[unobserved], x3[:, fte.ACTIVE][unobserved])
     with pytest.raises(ValueError):
         fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=np.ones((7, 45)))     # inactive states must be 0
     with pytest.raises(ValueError):
