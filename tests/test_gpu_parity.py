@@ -241,8 +241,11 @@ def test_fte_solve_matches_oracle_trajectory(mods, n, kind):
     xo, oinfo = ofte.lm_solve(prob, x0[:, ofk.ACTIVE], max_iter=80, ftol=1e-13)
     out = ofte.fte_outputs(prob, xo, x0)
     assert info["status_name"] in ("ftol", "xtol", "gtol")
-    assert abs(info["cost"] - oinfo["cost"]) < 1e-5 * abs(oinfo["cost"])
-    assert np.abs(res["positions"] - out["positions"]).max() < 1e-3            # north_star tolerance, metres
+    # north_star's bar is 1e-3 m.  Since the active-set fix of round 2 (k_trial: exact zero step for a bound-active
+    # variable) the two solves walk the same path and agree to rounding: observed 2e-12 m, 1e-15 relative in the cost
+    assert abs(info["cost"] - oinfo["cost"]) < 1e-11 * abs(oinfo["cost"])
+    assert np.abs(res["positions"] - out["positions"]).max() < 1e-8
+    assert abs(info["iter"] - oinfo["iterations"]) <= 1
     assert np.abs(res["positions"] - seq["pos_true"]).max() < 0.06
     lo, hi = fte.bounds45()
     assert (res["x"] >= lo[fte.ACTIVE] - 1e-12).all() and (res["x"] <= hi[fte.ACTIVE] + 1e-12).all()
@@ -353,14 +356,15 @@ def test_config3_exact_size_against_committed_oracle_solution(mods, golden_dir):
     res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x0, max_iter=200)
     assert info["status_name"] in ("ftol", "xtol", "gtol"), info
     want_cost = float(g["cost"])
-    assert abs(info["cost"] - want_cost) < 1e-6 * abs(want_cost), (info["cost"], want_cost)
-    assert abs(info["iter"] - int(g["iterations"])) <= 3, (info["iter"], int(g["iterations"]))
+    assert abs(info["cost"] - want_cost) < 1e-11 * abs(want_cost), (info["cost"], want_cost)
+    assert abs(info["iter"] - int(g["iterations"])) <= 1, (info["iter"], int(g["iterations"]))
+    assert np.abs(np.asarray(res["x"]) - g["x"]).max() < 1e-8                   # observed 1.3e-11
     q = np.zeros((N, 45))
     q[:, ofk.ACTIVE] = g["x"]
     pos_o = ofk.cheetah_fk(q)
     assert np.abs(pos_o[::50] - g["positions_probe"]).max() < 1e-12
     err = np.abs(res["positions"] - pos_o).max()
-    assert err < 1e-3, err                                                      # north_star tolerance, metres
+    assert err < 1e-8, err                                                      # (north_star tolerance: 1e-3 m)
     assert np.abs(res["positions"] - seq["pos_true"]).max() < 0.1
 
 
@@ -750,8 +754,8 @@ def test_randomised_solves_match_oracle(mods, seed):
     xo, oinfo = ofte.lm_solve(prob, x0[:, ofk.ACTIVE], max_iter=100, ftol=1e-13)
     out = ofte.fte_outputs(prob, xo, x0)
     assert info["status_name"] in ("ftol", "xtol", "gtol")
-    assert abs(info["cost"] - oinfo["cost"]) < 1e-5 * abs(oinfo["cost"])
-    assert np.abs(res["positions"] - out["positions"]).max() < 1e-3            # north_star tolerance, metres
+    assert abs(info["cost"] - oinfo["cost"]) < 1e-10 * abs(oinfo["cost"])
+    assert np.abs(res["positions"] - out["positions"]).max() < 1e-7            # (north_star tolerance: 1e-3 m)
 
 
 def test_bf16_rows_assembly_is_a_rounded_version_of_the_fp64_one(mods):
