@@ -78,7 +78,8 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
         limiter = None
     n = min(sample_frames, det.shape[0])
     xa = x0_full[:n, ofk.ACTIVE]
-    dt = _oracle_lm_iterations(det[:n], rig, Ts, xa, iters)
+    hist = []
+    dt = _oracle_lm_iterations(det[:n], rig, Ts, xa, iters, history=hist)
     per_iter = dt / (iters + 0.5)      # the initial evaluation is ~half an iteration of work
     # config 1: N = 1
     t0 = time.perf_counter()
@@ -96,6 +97,23 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
                                                        what="oracle.index_path.pairwise_dense on 1 frame x 6 cameras x "
                                                             "20 keypoints (5 adjacent pairs, numpy SVD DLT), mean of "
                                                             f"{reps} calls"))
+    # the oracle iterations just timed double as a full-size parity check: the HIP solve, from the same start on the same
+    # frames, must produce the same trial costs (untimed; the oracle is the checker here, never the thing measured)
+    try:
+        from acinoset_amd import fte as _fte
+        ctx = _fte.FTEContext(det[:n], *rig, Ts, ftol=0.0, xtol=0.0, gtol=0.0)
+        ctx.set_x(xa)
+        gpu_costs = []
+        for _ in hist:
+            ctx.step()
+            gpu_costs.append(ctx.state()["cost_trial"])
+        ctx.close()
+        out["parity_at_this_size"] = dict(
+            frames=n, iterations=len(hist), trial_cost_oracle=[h["Ft"] for h in hist], trial_cost_gpu=gpu_costs,
+            max_rel_diff=max(abs(a - h["Ft"]) / abs(h["Ft"]) for a, h in zip(gpu_costs, hist)),
+            what="trial cost of LM iteration 1..k from the same start: HIP solve vs oracle.fte.lm_solve")
+    except Exception as exc:                           # pragma: no cover
+        out["parity_at_this_size"] = dict(error=f"{type(exc).__name__}: {exc}")
     ncpu = os.cpu_count() or 1
     procs = max(1, min(ncpu, 32, n // 96))
     try:

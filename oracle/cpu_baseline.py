@@ -8,25 +8,15 @@ import time
 import numpy as np
 
 
-def lm_iterations(det, rig, Ts, x0_active, iters):
-    """`iters` LM iterations (+ the initial evaluation) on one block of frames; returns seconds."""
+def lm_iterations(det, rig, Ts, x0_active, iters, history=None):
+    """`iters` LM iterations (+ the initial evaluation) of oracle.fte.lm_solve on one block of frames, stopping tests
+    off; returns seconds.  `history` (a list) receives the per-iteration records (trial cost, lambda, gain, ...) -
+    bench.py holds the GPU's first iterations against them at full size."""
     from . import fte as ofte
     K, D, R, t = rig
     prob = ofte.FTEProblem(det[..., :2], det[..., 2], K, D, R, t, Ts)
-    x = np.clip(x0_active, prob.lo, prob.hi)
     t0 = time.perf_counter()
-    F, g, H, _ = prob.evaluate(x)
-    lam = 1e-3
-    for _ in range(iters):
-        fixed = ((x <= prob.lo) & (g > 0)) | ((x >= prob.hi) & (g < 0))
-        delta, _diag = prob.solve_banded(H, g, lam, fixed)
-        xt = np.clip(x + delta, prob.lo, prob.hi)
-        Ft, gt, Ht, _ = prob.evaluate(xt)
-        if Ft < F:
-            x, F, g, H = xt, Ft, gt, Ht
-            lam /= 3
-        else:
-            lam *= 2
+    ofte.lm_solve(prob, x0_active, max_iter=iters, ftol=0.0, xtol=0.0, gtol=0.0, history=history)
     return time.perf_counter() - t0
 
 
