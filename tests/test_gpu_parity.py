@@ -674,6 +674,35 @@ def test_rccl_sharded_solve_equals_single_gpu(mods, tmp_path):
         assert np.abs(np.concatenate([p["x"] for p in parts]) - x_refw).max() < 5e-3
 
 
+def test_rccl_backend_single_rank(mods, tmp_path):
+    """What a ONE-GPU box can show of the RCCL path: a process group with backend "nccl" (= RCCL) and world size 1 -
+    communicator creation, and every collective of both drivers (all-reduce of the separator blocks, all-gathers of the
+    edge slabs and of the scalar sums) issued through RCCL on the drivers' own device buffers and streams, graph phases
+    in between.  With one rank there is no separator and no neighbour, so both must reproduce the plain single-GPU solve.
+    (RCCL completes a one-rank collective without launching a device kernel - a kernel trace of this test shows none -,
+    so this exercises initialisation, the drivers' call sequence and stream use, NOT xGMI or a ring: the multi-rank run
+    stays test_rccl_sharded_solve_equals_single_gpu, which needs >= 2 GPUs.)"""
+    calib, fte, synth = mods
+    import torch.multiprocessing as mp
+    n, steps = 192, 8
+    seq = synth.make_sequence(n, "sprint")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(4).normal(0, 0.03, (n, 25))
+    ref = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
+    ref.set_x(x0)
+    for _ in range(steps):
+        ref.step()
+    x_ref, st_ref = ref.result()[0].cpu().numpy(), ref.state()
+    ref.close()
+    for k, mode in enumerate(("separators", "windows")):
+        out = str(tmp_path / f"rccl1{mode}")
+        mp.spawn(_mp_shard_worker, args=(1, 29790 + k, n, steps, out, "nccl", mode), nprocs=1, join=True)
+        p = np.load(out + ".0.npz")
+        assert int(p["accepted"]) == st_ref["accepted"] and int(p["it"]) == steps
+        assert abs(float(p["cost"]) - st_ref["cost"]) < 1e-10 * abs(st_ref["cost"])
+        assert np.abs(p["x"] - x_ref).max() < 1e-9
+
+
 @pytest.mark.parametrize("n,cams", [(5, 6), (8, 2), (47, 4), (64, 6), (95, 3), (193, 6), (385, 6), (1537, 6), (9998, 6)])
 def test_size_sweep_schedules(mods, n, cams):
     """Chain lengths around the kernel-selection thresholds (wide / narrow / fused-tail levels, odd node counts, frame
