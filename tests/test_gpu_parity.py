@@ -435,8 +435,8 @@ class ThreadComm:
         self.barrier.wait()
 
 
-@pytest.mark.parametrize("world,graphs", [(2, False), (3, False), (4, False)])
-def test_sharded_hip_path_equals_single_shard(mods, world, graphs):
+@pytest.mark.parametrize("world,graphs,start", [(2, False, "near"), (3, False, "near"), (4, False, "near"), (3, False, "line")])
+def test_sharded_hip_path_equals_single_shard(mods, world, graphs, start):
     """The multi-GPU code path (pinned separators, separator export/all-reduce/solve, halos, global control)
     run by `world` threads on one GPU must reproduce the single-shard HIP solve (phases launched eagerly: stream
     capture is a per-process affair, the multi-PROCESS test below replays them as hipGraphs)."""
@@ -447,6 +447,8 @@ def test_sharded_hip_path_equals_single_shard(mods, world, graphs):
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     rng = np.random.default_rng(4)
     x0 = seq["q_true"][:, fte.ACTIVE] + rng.normal(0, 0.03, (n, 25))
+    if start == "line":       # the reference's initialisation: several angles ON their 0.0 bound, active sets change every step
+        x0 = fte.nose_line_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
     ref = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
     ref.set_x(x0)
     for _ in range(steps):
