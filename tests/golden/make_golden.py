@@ -402,7 +402,8 @@ def gen_fte_stationary():
     On the inputs of fte_model.npz the oracle's LM (oracle/fte.py, the control flow of the HIP path) is run from the
     reference's own initialisation to a tight tolerance; at its end point x* the reference objective (feasible
     completion as in gen_fte_model) is differentiated by central differences in all N x 25 active states.  Recorded:
-    x*, obj_ref(x*), the finite-difference gradient at x* and at the initial point."""
+    x*, obj_ref(x*), the finite-difference gradient at x* and at the initial point.  (About 15 minutes: 600 evaluations
+    of the model text, each with every equality re-solved.)"""
     ctx = _fte_model_setup()
     out, N = ctx["out"], ctx["N"]
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
