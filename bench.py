@@ -115,7 +115,7 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
     except Exception as exc:                           # pragma: no cover
         out["parity_at_this_size"] = dict(error=f"{type(exc).__name__}: {exc}")
     ncpu = os.cpu_count() or 1
-    procs = max(1, min(ncpu, 32, n // 96))
+    procs = max(1, min(ncpu, 32, n // 96))       # (more blocks do not help: 128 processes measured 39.5 k frames/s against 51 k with 32 - fixed per-block cost)
     try:
         import subprocess
         import tempfile
