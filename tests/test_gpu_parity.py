@@ -737,6 +737,72 @@ def test_size_sweep_schedules(mods, n, cams):
         assert abs(costs[-1] - oinfo["cost"]) < 1e-6 * abs(oinfo["cost"])
 
 
+def _oracle_lm_clips(probs, x0s, iters, lam0=1e-3):
+    """The oracle's projected LM with ONE controller over several independent clips (what fte_solve_clips /
+    acino_fte_params::clip_len does on the GPU): cost, predicted reduction and step are sums / maxima over the clips, the
+    damping is shared, every clip solves its own banded system.  Same control flow as oracle.fte.lm_solve.  Returns the
+    trial cost and the accept decision of every iteration."""
+    xs = [np.clip(x, p.lo, p.hi) for p, x in zip(probs, x0s)]
+    ev = [p.evaluate(x) for p, x in zip(probs, xs)]
+    lam, nu, hist = lam0, 2.0, []
+    for _ in range(iters):
+        F = sum(e[0] for e in ev)
+        pred, trial = 0.0, []
+        for p, x, (Fc, g, H, _nb) in zip(probs, xs, ev):
+            fixed = ((x <= p.lo) & (g > 0)) | ((x >= p.hi) & (g < 0))
+            pg = np.where(fixed, 0.0, g)
+            delta, diag = p.solve_banded(H, g, lam, fixed)
+            xt = np.clip(x + delta, p.lo, p.hi)
+            pred += 0.5 * float((delta * (lam * diag * delta - pg)).sum())
+            trial.append((xt, p.evaluate(xt)))
+        Ft = sum(t[1][0] for t in trial)
+        gain = (F - Ft) / pred if pred > 0 else -1.0
+        hist.append((Ft, Ft < F))
+        if Ft < F:
+            xs, ev = [t[0] for t in trial], [t[1] for t in trial]
+            lam, nu = lam * max(1.0 / 3.0, 1.0 - (2.0 * gain - 1.0) ** 3), 2.0
+        else:
+            lam, nu = lam * nu, nu * 2.0
+    return hist
+
+
+@pytest.mark.parametrize("clip,start", [(45, "line"), (40, "far"), (7, "line")])
+def test_clips_chain_walks_the_oracle_path(mods, clip, start):
+    """clip_len (config 5's batched form) held to PATH identity: 5 clips as one chain against the oracle LM with one
+    shared controller over 5 independent problems - same accept / reject decisions and trial costs (1e-9) for 10
+    iterations, from the nose-line start (angles on their 0.0 bounds) and from a far start; clip lengths that put the
+    clip boundaries inside 3-frame nodes (40) and clips shorter than three nodes (7)."""
+    calib, fte, synth = mods
+    B = 5
+    seqs = [synth.make_sequence(clip, ("sprint", "trot", "loop")[i % 3], seed=4242 + i) for i in range(B)]
+    rig = (seqs[0]["K"], seqs[0]["D"], seqs[0]["R"], seqs[0]["t"])
+    rng = np.random.default_rng(clip)
+    lo, hi = fte.bounds45()
+    x0s = []
+    for sq in seqs:
+        x0 = np.zeros((clip, 45))
+        if start == "line":
+            x0[:, :3] = sq["q_true"][:, :3] + rng.normal(0, 0.05, (clip, 3))
+            x0[:, 31] = sq["q_true"][:, 31].mean()
+        else:
+            x0[:, fte.ACTIVE] = sq["q_true"][:, fte.ACTIVE] + rng.normal(0, 0.5, (clip, 25))
+        x0s.append(np.clip(x0, lo, hi))
+    probs = [ofte.FTEProblem(sq["det"][..., :2], sq["det"][..., 2], *rig, sq["Ts"]) for sq in seqs]
+    hist = _oracle_lm_clips(probs, [x[:, ofk.ACTIVE] for x in x0s], 10)
+    det_all = np.concatenate([sq["det"] for sq in seqs])
+    ctx = fte.FTEContext(det_all, *rig, seqs[0]["Ts"], clip_len=clip, ftol=0.0, xtol=0.0, gtol=0.0)
+    ctx.set_x(np.concatenate(x0s)[:, fte.ACTIVE])
+    acc = 0
+    for it, (Ft, accepted) in enumerate(hist):
+        ctx.step()
+        st = ctx.state()
+        assert st["status"] == 0
+        assert abs(st["cost_trial"] - Ft) < 1e-9 * abs(Ft), (it, st["cost_trial"], Ft)
+        assert (st["accepted"] > acc) == accepted, it
+        acc = st["accepted"]
+    ctx.close()
+
+
 @pytest.mark.parametrize("clip", [45, 40])           # 40: clip boundaries fall inside 3-frame nodes
 def test_clips_solved_as_one_chain(mods, clip):
     """fte_solve_clips: equal-length clips laid end to end with the smoothness prior cut at the clip boundaries.  The
