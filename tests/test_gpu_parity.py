@@ -1,9 +1,12 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the oracle, the golden fixtures and
 size-independent properties at BASELINE sizes.  Tolerances: index/mask work bit-exact; fp64 kernels
 within the tolerance written next to each assertion; the FTE trajectory within 1e-3 m of the oracle
-solution (BASELINE.json north_star)."""
+solution (BASELINE.json north_star) - and, since round 2, held much tighter: the HIP solve, the clips chain and the
+window backend must walk the oracle's Levenberg-Marquardt PATH (same accept / reject decisions, trial costs to 1e-9)
+and end within 1e-8 m of it."""
 import json
 import os
+import sys
 import threading
 
 import numpy as np
@@ -1060,6 +1063,54 @@ def test_overlapping_windows_converge_to_the_single_gpu_optimum(mods):
         assert st["iter"] <= st_ref["iter"] + 6
         for d, *_ in drv:
             d.ctx.close()
+
+
+@pytest.mark.parametrize("start", ["near", "line"])
+def test_window_backend_walks_the_oracle_backend_path(mods, start):
+    """dist.WindowedFTE twice in lock step - over the HIP window backend and over tests/oracle_backend.OracleWindowBackend
+    (numpy: the window as a principal submatrix of the global system, halos imported / exported by the same driver code):
+    identical windows, halos and start; the replicated controller must take the same decisions and see the same global
+    cost after every iteration (1e-9).  This pins n_global / n_offset / own_first / own_count, the halo rows of the
+    iterate buffers and the owned-range sums of the HIP path to an independent implementation, not just the converged
+    result to the single-GPU optimum."""
+    calib, fte, synth = mods
+    from acinoset_amd import dist as adist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import OracleWindowBackend
+    n, world, halo, steps = 420, 2, 96, 8
+    seq = synth.make_sequence(n, "trot")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    lo, hi = fte.bounds45()
+    if start == "near":
+        x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(9).normal(0, 0.03, (n, 25))
+    else:
+        x0 = fte.nose_line_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
+    x0 = np.clip(x0, lo[fte.ACTIVE], hi[fte.ACTIVE])
+    det = torch.as_tensor(seq["det"])
+    box_h, box_o = _LockStepComm(world), _LockStepComm(world)
+    hip, ora = [], []
+    for r in range(world):
+        d, (w0, w1, n0, n1) = adist.make_windowed(det, *rig, seq["Ts"], r, world, halo=halo, comm=box_h.rank(r), shared_gpu=True,
+                                                  ftol=0.0, xtol=0.0, gtol=0.0)
+        hip.append((d, w0, w1))
+        be = OracleWindowBackend(seq["det"][w0:w1], *rig, seq["Ts"], n, w0, n0 - w0, n1 - n0, ftol=0.0, xtol=0.0, gtol=0.0)
+        ora.append((adist.WindowedFTE(be, r, world, (n0 - w0, n1 - n0), halo, comm=box_o.rank(r)), w0, w1))
+    box_h.run([lambda d=d, a=a, b=b: d.set_x(x0[a:b]) for d, a, b in hip])
+    box_o.run([lambda d=d, a=a, b=b: d.set_x(torch.as_tensor(x0[a:b])) for d, a, b in ora])
+    c_h, c_o = hip[0][0].state()["cost"], ora[0][0].b.state()["cost"]
+    assert abs(c_h - c_o) < 1e-11 * abs(c_o)
+    for it in range(steps):
+        box_h.run([d.step for d, *_ in hip])
+        box_o.run([d.step for d, *_ in ora])
+        sh, so = hip[0][0].state(), ora[0][0].b.state()
+        assert sh["accepted"] == so["accepted"] and sh["status"] == so["status"] == 0, (it, sh, so)
+        assert abs(sh["cost"] - so["cost"]) < 1e-9 * abs(so["cost"]), (it, sh["cost"], so["cost"])
+        assert abs(sh["lam"] - so["lam"]) < 1e-6 * so["lam"]
+    xh = np.concatenate([d.result_x().cpu().numpy() for d, *_ in hip])
+    xo = np.concatenate([d.result_x().numpy() for d, *_ in ora])
+    assert np.abs(xh - xo).max() < 1e-8
+    for d, *_ in hip:
+        d.ctx.close()
 
 
 def _full(fte, xa):
