@@ -93,8 +93,9 @@ __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const F
     double b = 0.0;
     if (row_live) {
       const int p = tid % NP;
-      const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
       double d = Dm[tid * LD + tid];
+      const double gtol = GRAD_ZERO_REL * d;
+      const bool fixed = (xv <= K.lo[p] && gv > gtol) || (xv >= K.hi[p] && gv < -gtol);
       d = d + lam * fmax(d, DIAG_FLOOR);
       if (fixed) d *= FIX_SCALE;
       Dm[tid * LD + tid] = d;

@@ -135,14 +135,15 @@ k_trial(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st
     const int n = (int)(e / NP), p = (int)(e % NP);
     const int node = n / 3 + K.pin_left, row = (n % 3) * NP + p;
     const double xv = x[(size_t)(n + HALO) * NP + p], gv = g[e];
-    const bool fixed = (xv <= K.lo[p] && gv > 0.0) || (xv >= K.hi[p] && gv < 0.0);
+    const double d0 = hd[e];
+    const double gtol = GRAD_ZERO_REL * d0;
+    const bool fixed = (xv <= K.lo[p] && gv > gtol) || (xv >= K.hi[p] && gv < -gtol);
     // A bound-active variable is pinned in the linear system by the 2^70 diagonal boost, which leaves it a step of
     // ~1e-21 instead of the exact 0 of a deleted row.  At a bound of 0.0 (theta_7, 9, 11, 13 - where the nose-line
     // initialisation puts them) that residue is representable: x would leave the bound by 1e-21, count as free in the next
     // iteration and take a different path than the active-set rule prescribes.  Its step is 0, exactly.
     const double d = fixed ? 0.0 : delta_nodes[(size_t)node * BS + row];
     const double pg = fixed ? 0.0 : gv;
-    const double d0 = hd[e];
     const double xn = fmin(fmax(xv + d, K.lo[p]), K.hi[p]);
     xt[(size_t)(n + HALO) * NP + p] = xn;
     if (n >= K.own_lo && n < K.own_hi) {          // (window sharding: only owned frames enter the global sums)

@@ -17,6 +17,11 @@ constexpr double FIX_SCALE = 1.1805916207174113e21;  // 2^70: diagonal boost pin
 // fewer than 4 frames (no third-difference row either).  Its damping term is lam * DIAG_FLOOR instead: the variable is
 // decoupled (zero row, zero gradient), gets a positive pivot and a step of exactly 0.  Never active otherwise.
 constexpr double DIAG_FLOOR = 1e-30;
+// Active-set test: a gradient entry below GRAD_ZERO_REL * H_ii (a Newton step of 1e-14 in that variable alone) counts as
+// zero.  An entry that vanishes analytically (a joint none of whose markers is detected in the frame) comes out of the
+// subtree sums as +-1e-20, and a bare sign test would let that noise decide whether a variable sitting on its bound is
+// pinned.  Same rule in oracle.fte.FTEProblem.active_set.
+constexpr double GRAD_ZERO_REL = 1e-14;
 
 // Device-resident constant block of one FTE problem.
 struct FteConst {

@@ -151,6 +151,19 @@ class FTEProblem:
         cs, gs = self.smooth_terms(xa, halo_l, halo_r, per_frame=per_frame)
         return cm + cs, g + gs, H, nb
 
+    # ------------------------------------------------------------------ active set
+    GRAD_ZERO_REL = 1e-14
+
+    def active_set(self, x, g, H):
+        """Bound-active variables: at a bound with the gradient pushing outward.  A gradient entry below 1e-14 * H_ii
+        (a Newton step of 1e-14 rad / m in that variable alone) counts as ZERO: an entry that vanishes analytically -
+        a joint none of whose markers is detected in that frame - is exactly 0.0 here and +-1e-20 in the HIP kernel's
+        subtree sums, and a bare sign test would make the active set depend on that rounding noise."""
+        idx = np.arange(self.P)
+        diag = H[:, idx, idx] + 2 * self.q_w[None, :] * self.s_band()[0][:, None]
+        tol = self.GRAD_ZERO_REL * diag
+        return ((x <= self.lo) & (g > tol)) | ((x >= self.hi) & (g < -tol))
+
     # ------------------------------------------------------------------ linear algebra
     def solve_banded(self, H, g, lam, fixed):
         """Solve (H_gn + lam*diag(H_gn)) delta = -g over the whole (local = global) sequence,
@@ -208,7 +221,7 @@ def lm_solve(prob, x0_active, max_iter=50, lam0=1e-3, ftol=1e-10, xtol=1e-10, gt
     it = 0
     n_acc = 0
     for it in range(1, max_iter + 1):
-        fixed = ((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0))
+        fixed = prob.active_set(x, g, H)
         pg = np.where(fixed, 0.0, g)
         gnorm = float(np.abs(pg).max())
         if gnorm <= gtol:
@@ -243,7 +256,7 @@ def lm_solve(prob, x0_active, max_iter=50, lam0=1e-3, ftol=1e-10, xtol=1e-10, gt
                 status = "lambda_overflow"
                 break
     return x, dict(cost=F, iterations=it, accepted=n_acc, status=status, lam=lam, n_behind=nb,
-                   gnorm=float(np.abs(np.where(((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0)), 0.0, g)).max()))
+                   gnorm=float(np.abs(np.where(prob.active_set(x, g, H), 0.0, g)).max()))
 
 
 def fte_outputs(prob, x_active, x0_full, start_frame=0):

@@ -99,8 +99,8 @@ class OracleBackend:
     # ---- local reduction onto the separators -------------------------------------------------------
     def _fixed(self):
         x = self.x[self.cur]
-        g = self.ev[self.cur][1]
-        return ((x <= self.prob.lo) & (g > 0)) | ((x >= self.prob.hi) & (g < 0))
+        _F, g, H = self.ev[self.cur]
+        return self.prob.active_set(x, g, H)
 
     def reduce_local(self):
         if self.st["status"] != 0:
@@ -309,7 +309,7 @@ class OracleWindowBackend:
         X = self.x[self.cur]
         x = X[3:-3]
         g, H = self.ev[self.cur]
-        fixed = ((x <= self.prob.lo) & (g > 0)) | ((x >= self.prob.hi) & (g < 0))
+        fixed = self.prob.active_set(x, g, H)
         delta, diag = self.prob.solve_banded(H, g, self.st["lam"], fixed)
         pg = np.where(fixed, 0.0, g)
         xt = np.clip(x + delta, self.prob.lo, self.prob.hi)

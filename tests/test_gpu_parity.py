@@ -223,7 +223,7 @@ def test_fte_cost_gradient_hessian(mods, seq60):
     assert np.abs(h - Ho).max() < 1e-11 * np.abs(Ho).max()
     assert np.abs(h - h.transpose(0, 2, 1)).max() < 1e-12 * np.abs(h).max()
     # one LM step: block cyclic reduction vs LAPACK banded Cholesky
-    fixed = ((xa <= prob.lo) & (go > 0)) | ((xa >= prob.hi) & (go < 0))
+    fixed = prob.active_set(xa, go, prob.evaluate(xa)[2])
     delta, _ = prob.solve_banded(Ho * 0 + prob.evaluate(xa)[2], go, 1e-3, fixed)
     ctx.step()
     xg = ctx.result()[0].cpu().numpy()
@@ -752,7 +752,7 @@ def _oracle_lm_clips(probs, x0s, iters, lam0=1e-3):
         F = sum(e[0] for e in ev)
         pred, trial = 0.0, []
         for p, x, (Fc, g, H, _nb) in zip(probs, xs, ev):
-            fixed = ((x <= p.lo) & (g > 0)) | ((x >= p.hi) & (g < 0))
+            fixed = p.active_set(x, g, H)
             pg = np.where(fixed, 0.0, g)
             delta, diag = p.solve_banded(H, g, lam, fixed)
             xt = np.clip(x + delta, p.lo, p.hi)

@@ -17,8 +17,8 @@ from oracle import fte as ofte  # noqa: E402
 
 
 
-def run_case(seed, iters=10, verbose=False):
-    """-> (worst relative trial-cost difference over the iterations, iteration where, description)"""
+def make_case(seed):
+    """-> det[n,C,20,3], rig (K, D, R, t of the chosen cameras), Ts, x0[n,45], description fields"""
     rng = np.random.default_rng(seed)
     n = int(rng.integers(3, 41))
     cams = np.sort(rng.choice(6, size=int(rng.integers(2, 7)), replace=False))
@@ -41,6 +41,13 @@ def run_case(seed, iters=10, verbose=False):
         x0[:, fte.ACTIVE] = seq["q_true"][:, fte.ACTIVE] + rng.normal(0, 0.8, (n, 25))
         x0[:, :3] = seq["q_true"][:, :3] + rng.normal(0, 0.2, (n, 3))
     x0 = np.clip(x0, lo, hi)
+    return det, rig, seq["Ts"], x0, (n, kind, cams, mode)
+
+
+def run_case(seed, iters=10, verbose=False):
+    """-> (worst relative trial-cost difference over the iterations, iteration where, description)"""
+    det, rig, Ts, x0, (n, kind, cams, mode) = make_case(seed)
+    seq = {"Ts": Ts}
     prob = ofte.FTEProblem(det[..., :2], det[..., 2], *rig, seq["Ts"])
     hist = []
     singular = False

@@ -64,7 +64,7 @@ Ho2 = Ho.copy(); idx = np.arange(25); Ho2[:, idx, idx] += 2 * prob.q_w[None, :] 
 print("grad rel err", np.abs(gg - go).max() / np.abs(go).max(), "H rel err", np.abs(hh - Ho2).max() / np.abs(Ho2).max(), "H asym", np.abs(hh - hh.transpose(0, 2, 1)).max())
 print("cost-only", ctx.cost(xa), Fo)
 # 6. one LM step compare
-delta_o, diag = prob.solve_banded(Ho, go, 1e-3, ((xa <= prob.lo) & (go > 0)) | ((xa >= prob.hi) & (go < 0)))
+delta_o, diag = prob.solve_banded(Ho, go, 1e-3, prob.active_set(xa, go, Ho))
 ctx.step()
 st = ctx.state(); print("after step", st)
 xg = ctx.result()[0].cpu().numpy()
