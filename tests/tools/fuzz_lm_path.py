@@ -3,7 +3,7 @@
 (accepted and rejected) and the same accept / reject decisions, iteration by iteration, from the same start - a much sharper probe of the controller, the
 active-set rule and the block solve than comparing converged solutions (it is what exposed the 1e-21 drift off a 0.0
 bound in round 2).  Nasty cases on purpose: 3 ... 40 frames, 2 ... 6 cameras, gross outliers, dropped detections, starts
-ON the bounds (nose-line style: all angles 0) or random.  usage: fuzz_lm_path.py first_seed n_seeds [iterations]"""
+ON the bounds (nose-line style: all angles 0) or random.  usage: [FUZZ_MAX_FRAMES=40] fuzz_lm_path.py first_seed n_seeds [iterations] [v]"""
 import os
 import sys
 
@@ -20,7 +20,7 @@ from oracle import fte as ofte  # noqa: E402
 def make_case(seed):
     """-> det[n,C,20,3], rig (K, D, R, t of the chosen cameras), Ts, x0[n,45], description fields"""
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(3, 41))
+    n = int(rng.integers(3, int(os.environ.get("FUZZ_MAX_FRAMES", "40")) + 1))
     cams = np.sort(rng.choice(6, size=int(rng.integers(2, 7)), replace=False))
     kind = ("sprint", "loop", "trot")[int(rng.integers(0, 3))]
     seq = synth.make_sequence(n, kind, seed=seed)
