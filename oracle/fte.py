@@ -101,6 +101,8 @@ class FTEProblem:
     def s_band(self):
         """(D3^T D3)[n, n+k], k=0..3, for LOCAL frames, honouring global sequence ends."""
         N, NG, off = self.N, self.n_global, self.n_offset
+        if getattr(self, "_band", None) is not None:
+            return self._band
         band = np.zeros((4, N))
         for k in range(4):
             for i in range(N):
@@ -112,6 +114,7 @@ class FTEProblem:
                 for j in range(jlo, jhi + 1):
                     tot += C3[3 - (n - j)] * C3[3 - (n + k - j)]
                 band[k, i] = tot
+        self._band = band
         return band
 
     def smooth_terms(self, xa, halo_l=None, halo_r=None, per_frame=False):
