@@ -119,7 +119,11 @@ int acino_cheetah_fk(const double* d_q, int64_t n_frames, double* d_pos, void* s
  * Reduced problem of the reference NLP: unknowns xa[N][25] (active states),
  *   F = sum rho(w*(pi_c(FK_l(x_n)) - z)) + sum_{n>=3} q_p (x_n - 3x_{n-1} + 3x_{n-2} - x_{n-3})_p^2,
  * box bounds lo/hi, solved by a projected Levenberg-Marquardt whose Gauss-Newton system is
- * block-tridiagonal in super-blocks of 3 frames and solved by block cyclic reduction. */
+ * block-tridiagonal in super-blocks of 3 frames and solved by block cyclic reduction.
+ * Active set: a variable sitting ON a bound whose gradient entry pushes outward is pinned for the iteration (step exactly
+ * 0); "pushes" means |g_i| > 1e-14 * H_ii, i.e. a gradient below a Newton step of 1e-14 counts as zero.  Damping is
+ * Marquardt's lam * diag(H); a diagonal entry that is exactly 0 (clips of < 4 frames with an unobserved state) is damped
+ * by lam * 1e-30 and keeps its variable where it is. */
 typedef struct acino_fte_params {
   int32_t n_frames;        /* local frames on this GPU                                      */
   int32_t n_cams;
