@@ -75,3 +75,31 @@ def test_lm_converges_from_nose_line_init():
     Ts = s["Ts"]
     assert np.allclose(out["x"][1:], out["x"][:-1] + Ts * out["dx"][1:])
     assert np.allclose(out["dx"][1:], out["dx"][:-1] + Ts * out["ddx"][1:], atol=1e-6 * np.abs(out["dx"]).max())
+
+
+def test_active_set_ignores_gradient_noise_and_zero_diagonals_are_damped():
+    """The two rules round 2 added to the LM (GPU and oracle alike): (1) a variable on its bound is pinned only if its
+    gradient entry pushes outward by more than 1e-14 x H_ii - an analytically vanishing entry must not be decided by
+    rounding noise; (2) a diagonal entry that is exactly 0 (three frames, unobserved joint) is damped by lam x 1e-30: the
+    banded Cholesky goes through and the variable does not move."""
+    s, prob = _problem(12)
+    x = np.clip(s["q_true"][:, fk.ACTIVE], prob.lo, prob.hi)
+    F, g, H, _ = prob.evaluate(x)
+    p = int(np.where(np.isfinite(prob.hi))[0][0])
+    x[5, p] = prob.hi[p]
+    diag = H[5, p, p] + 2 * prob.q_w[p] * prob.s_band()[0][5]
+    for gval, want in ((-1.0, True), (-1e-20, False), (0.0, False), (-0.5e-14 * diag, False), (-2e-14 * diag, True), (+1.0, False)):
+        g2 = g.copy()
+        g2[5, p] = gval
+        assert bool(prob.active_set(x, g2, H)[5, p]) == want, gval
+    # (2) three frames, the tail markers never detected
+    s3 = synth.make_sequence(3, "trot")
+    d3 = s3["det"].copy()
+    d3[:, :, 6:8, 2] = 0.0
+    p3 = ofte.FTEProblem(d3[..., :2], d3[..., 2], s3["K"], s3["D"], s3["R"], s3["t"], s3["Ts"])
+    x3 = np.clip(s3["q_true"][:, fk.ACTIVE] + np.random.default_rng(3).normal(0, 0.03, (3, 25)), p3.lo, p3.hi)
+    H3 = p3.evaluate(x3)[2]
+    dead = H3[:, np.arange(25), np.arange(25)] == 0.0
+    assert dead.any()
+    xo, info = ofte.lm_solve(p3, x3, max_iter=40)
+    assert info["status"] in ("ftol", "xtol", "gtol") and np.array_equal(xo[dead], x3[dead])
