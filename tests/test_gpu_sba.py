@@ -227,6 +227,18 @@ def test_first_lm_step_equals_a_dense_numpy_step(gsba, model):
     assert info["iterations"] == 1 and info["accepted"] == 1
     assert abs(info["cost_initial"] - c0) < 1e-9 * c0 and abs(info["cost_final"] - c1) < 1e-6 * c1, (info, c0, c1)
     assert np.abs(pts - Xn).max() < 1e-6 and np.abs(rm - Rn).max() < 1e-6 and np.abs(tt - tn).max() < 1e-6
+    # points only (calib.py:327-341, Cauchy scale 50 px): the 3 x 3 point blocks alone
+    fs = 50.0
+    w = 1.0 / (1.0 + (r0 / fs) ** 2)
+    Jp = J[:, 6 * C:]
+    Ap = Jp.T @ (w[:, None] * Jp)
+    dp = -np.linalg.solve(Ap + lam * np.diag(np.diag(Ap)), Jp.T @ (w * r0))
+    c0, c1 = cost(r0), cost(resid(X0 + dp.reshape(P, 3), R0, t0))
+    pts, _r = sba.bundle_adjust_points_only(uv, X0, pi, ci, K, D, R0, t0, proj, f_scale=50, max_iter=1)
+    info = dict(sba.last_info)
+    assert info["iterations"] == 1 and info["accepted"] == 1 and c1 < c0
+    assert abs(info["cost_initial"] - c0) < 1e-9 * c0 and abs(info["cost_final"] - c1) < 1e-6 * c1, (info, c0, c1)
+    assert np.abs(pts - (X0 + dp.reshape(P, 3))).max() < 1e-6
 
 
 def test_pinhole_model_bundle_adjustment(gsba):
