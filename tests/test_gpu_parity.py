@@ -438,6 +438,41 @@ class ThreadComm:
         self.barrier.wait()
 
 
+@pytest.mark.parametrize("n_sep", [1, 2, 3, 7, 8, 31, 100])
+def test_separator_chain_solver_against_dense_numpy(gpu_lib, n_sep):
+    """acino_solve_separators on its own: a block-tridiagonal SPD chain of GENERAL 80 x 80 blocks (no identity padding, no
+    structure of the FTE problem) - records D | C = block(k+1, k) | b - against numpy's dense solve.  This is the
+    block cyclic reduction with every schedule shape (1 node, odd / even counts, wide and narrow levels, the fused tail)."""
+    import ctypes as C
+    from acinoset_amd._lib import BS, SEP_DOUBLES, check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(n_sep)
+    sep = np.zeros((n_sep, SEP_DOUBLES))
+    A = np.zeros((n_sep * BS, n_sep * BS))
+    b = rng.normal(size=n_sep * BS)
+    for k in range(n_sep):
+        M = rng.normal(size=(BS, BS))
+        Dk = M @ M.T + BS * np.eye(BS)
+        A[k * BS:(k + 1) * BS, k * BS:(k + 1) * BS] = Dk
+        sep[k, :BS * BS] = Dk.ravel()
+        sep[k, 2 * BS * BS:] = b[k * BS:(k + 1) * BS]
+        if k + 1 < n_sep:
+            Ck = 3.0 * rng.normal(size=(BS, BS))                        # strong couplings: ~0.3 of the diagonal blocks' scale
+            A[(k + 1) * BS:(k + 2) * BS, k * BS:(k + 1) * BS] = Ck
+            A[k * BS:(k + 1) * BS, (k + 1) * BS:(k + 2) * BS] = Ck.T
+            sep[k, BS * BS:2 * BS * BS] = Ck.ravel()
+    assert np.linalg.eigvalsh(A).min() > 0
+    want = np.linalg.solve(A, b).reshape(n_sep, BS)
+    d_sep = torch.as_tensor(sep, device="cuda")
+    d_x = torch.zeros(n_sep, BS, dtype=torch.float64, device="cuda")
+    nb = lib().acino_sep_scratch_bytes(n_sep)
+    scr = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    sp = (scr.data_ptr() + 255) // 256 * 256
+    check(lib().acino_solve_separators(ptr(d_sep), n_sep, ptr(d_x), C.c_void_p(sp), nb, stream_ptr()))
+    torch.cuda.synchronize()
+    got = d_x.cpu().numpy()
+    assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+
+
 @pytest.mark.parametrize("world,graphs,start", [(2, False, "near"), (3, False, "near"), (4, False, "near"), (3, False, "line")])
 def test_sharded_hip_path_equals_single_shard(mods, world, graphs, start):
     """The multi-GPU code path (pinned separators, separator export/all-reduce/solve, halos, global control)
