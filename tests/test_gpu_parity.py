@@ -121,6 +121,23 @@ def test_cheetah_fk_golden(mods, golden_dir):
     assert np.abs(fte.cheetah_fk(g["q"]) - g["positions"]).max() < 1e-13
 
 
+def test_fk_active_abi_entry(gpu_lib):
+    """acino_fk_active (FK of the 25 active states, the stand-alone helper of the C ABI) == the oracle FK of the full
+    45-state vector with the inactive states at 0."""
+    from acinoset_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(2)
+    n = 37
+    lo, hi = ofk.bounds45()
+    q = np.zeros((n, 45))
+    q[:, ofk.ACTIVE] = rng.normal(0, 0.4, (n, 25))
+    q = np.clip(q, lo, hi)
+    xa = torch.as_tensor(q[:, ofk.ACTIVE].copy(), device="cuda")
+    pos = torch.zeros(n, 20, 3, dtype=torch.float64, device="cuda")
+    check(lib().acino_fk_active(ptr(xa), n, ptr(pos), stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.abs(pos.cpu().numpy() - ofk.cheetah_fk(q)).max() < 1e-13
+
+
 def test_pair_index_path_bit_exact(mods, seq60, golden_dir):
     calib = mods[0]
     det = seq60["det"].copy()
