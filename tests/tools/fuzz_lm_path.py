@@ -3,7 +3,7 @@
 (accepted and rejected) and the same accept / reject decisions, iteration by iteration, from the same start - a much sharper probe of the controller, the
 active-set rule and the block solve than comparing converged solutions (it is what exposed the 1e-21 drift off a 0.0
 bound in round 2).  Nasty cases on purpose: 3 ... 40 frames, 2 ... 6 cameras, gross outliers, dropped detections, starts
-ON the bounds (nose-line style: all angles 0) or random.  usage: [FUZZ_MAX_FRAMES=40] fuzz_lm_path.py first_seed n_seeds [iterations] [v]"""
+ON the bounds (nose-line style: all angles 0) or random.  usage: [FUZZ_MAX_FRAMES=40] [FUZZ_RANDOM_TS=1] fuzz_lm_path.py first_seed n_seeds [iterations] [v]"""
 import os
 import sys
 
@@ -41,7 +41,10 @@ def make_case(seed):
         x0[:, fte.ACTIVE] = seq["q_true"][:, fte.ACTIVE] + rng.normal(0, 0.8, (n, 25))
         x0[:, :3] = seq["q_true"][:, :3] + rng.normal(0, 0.2, (n, 3))
     x0 = np.clip(x0, lo, hi)
-    return det, rig, seq["Ts"], x0, (n, kind, cams, mode)
+    Ts = seq["Ts"]
+    if os.environ.get("FUZZ_RANDOM_TS"):                # another frame rate: the smoothness weights 1 / (Q Ts^4) move by 256x either way
+        Ts = 1.0 / float((30, 60, 120, 240, 480)[int(rng.integers(0, 5))])
+    return det, rig, Ts, x0, (n, kind, cams, mode)
 
 
 def run_case(seed, iters=10, verbose=False):
