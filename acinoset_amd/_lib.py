@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
 BUILD_ID_SOURCE = "camera_kernels.hip"      # defines acino_build_id()
-SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
-HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "chunk.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
+HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "bcr_dev.hpp", "chunk.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
+ABI_VERSION = 2          # ACINO_ABI_VERSION of include/acinoset_hip.h
 N_ACTIVE = 25
 N_STATES = 45
 N_MARKERS = 20
@@ -32,7 +33,8 @@ class FteParams(C.Structure):
                 ("hi", C.c_double * N_ACTIVE), ("lam0", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double),
                 ("gtol", C.c_double), ("lam_max", C.c_double), ("clamp_lambda", C.c_int32), ("shared_gpu", C.c_int32),
                 ("clip_len", C.c_int64), ("precision", C.c_int32), ("bcr_levels", C.c_int32), ("trunc_tol", C.c_double),
-                ("own_first", C.c_int32), ("own_count", C.c_int32)]
+                ("own_first", C.c_int32), ("own_count", C.c_int32),
+                ("chunk_nodes", C.c_int32), ("refine_sweeps", C.c_int32)]
 
 
 class FteState(C.Structure):
@@ -109,6 +111,7 @@ SIGNATURES = {
     "acino_fte_workspace_bytes": (_Z, [C.POINTER(FteParams)]),
     "acino_fte_create": (_I, [C.POINTER(_P), C.POINTER(FteParams), _P, _P, _P, _Z, _P]),
     "acino_fte_destroy": (_I, [_P]),
+    "acino_fte_plan": (_I, [C.POINTER(FteParams), C.POINTER(C.c_int32)]),
     "acino_fte_set_x": (_I, [_P, _P, _P]),
     "acino_fte_step": (_I, [_P, _P]),
     "acino_fte_enable_graph": (_I, [_P, _I]),
@@ -139,6 +142,7 @@ SIGNATURES = {
     "acino_fte_shard_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "acino_fte_shard_control": (_I, [_P, _P, _I, _I, _P]),
     "acino_fte_profile_begin": (_I, [_P]),
+    "acino_fte_debug_read": (_I, [_P, _I, _P, _L, _P]),
     "acino_fte_debug_stamps": (_I, [_P, _P]),
     "acino_fte_profile_end": (_I, [_P, _P, _P, _P, _P]),
     "acino_sizeof_sba_params": (_Z, []),
@@ -267,6 +271,9 @@ def lib():
         fn = getattr(handle, name)   # AttributeError = ABI mismatch, let it surface
         fn.restype = res
         fn.argtypes = args
+    if handle.acino_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libacinoset_hip.so reports ABI version {handle.acino_abi_version()}, this binding is written for "
+                           f"{ABI_VERSION} (stale build?)")
     if handle.acino_sizeof_fte_params() != C.sizeof(FteParams) or handle.acino_sizeof_fte_state() != C.sizeof(FteState):
         raise RuntimeError("libacinoset_hip.so struct layout differs from the Python binding (stale build?)")
     if handle.acino_sizeof_sba_params() != C.sizeof(SbaParams) or handle.acino_sizeof_sba_info() != C.sizeof(SbaInfo):

@@ -18,129 +18,9 @@
 // built inside the level-0 kernels from the assembly's H/g (no separate set-up pass through HBM).
 #include "bcr.hpp"
 #include "dense80.hpp"
+#include "bcr_dev.hpp"
 
 namespace acino {
-
-// lower-triangular tile enumeration t -> (ib, jb)
-__constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
-__constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
-
-// Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
-// assembly's H/g (no set-up pass through HBM): D = H_gn + lam*diag(H_gn), bound-active variables
-// pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).
-// Returns this thread's max |projected gradient| contribution.  All 256 threads; one barrier inside (the
-// caller's publish_gmax barrier completes the block).  (Two barriers inside.)
-__device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const FteConst& K, int t, int tid) {
-  const int cur = ch.st->cur;
-  const double* x = cur ? ch.x1 : ch.x0;
-  const double* g = cur ? ch.g1 : ch.g0;
-  const double* H = cur ? ch.H1 : ch.H0;
-  const double lam = ch.st->lam;
-  const bool sep_left = K.pin_left && t == 0;
-  const int fbase = 3 * (t - K.pin_left);
-  // (1) every global read of the node is issued up front: the three 25x25 Gauss-Newton blocks (<= 8 per
-  //     thread) and, for the 75 row-owner threads, the state and gradient entry of their row
-  double hv[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = tid + 256 * k;
-    hv[k] = 0.0;
-    if (!sep_left && idx < 3 * NP * NP) {
-      const int n = fbase + idx / (NP * NP);
-      if (n < K.n_frames) hv[k] = H[(size_t)n * NP * NP + idx % (NP * NP)];
-    }
-  }
-  double xv = 0.0, gv = 0.0;
-  bool row_live = false;
-  if (!sep_left && tid < 3 * NP) {
-    const int n = fbase + tid / NP, p = tid % NP;
-    if (n < K.n_frames) {
-      row_live = true;
-      xv = x[(size_t)(n + HALO) * NP + p];
-      gv = g[(size_t)n * NP + p];
-    }
-  }
-  // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
-  for (int e = tid; e < BS * LD; e += 256) Dm[e] = 0.0;
-  __syncthreads();
-  if (!sep_left) {
-    if (tid < BS) {
-      const int nfr = fbase + tid / NP;
-      if (tid >= 3 * NP || nfr >= K.n_frames) Dm[tid * LD + tid] = 1.0;
-    } else if (tid < BS + 3 * NP) {
-      const int q = tid - BS, pr = q / NP, p = q % NP;          // frame pairs (0,1), (0,2), (1,2)
-      const int ii = pr == 2 ? 1 : 0, jj = pr == 0 ? 1 : 2;
-      if (fbase + jj < K.n_frames) {
-        const double v = 2.0 * K.q_w[p] * band_coef_clip(K.n_offset + fbase + ii, jj - ii, K.n_global, K.clip_len);
-        Dm[(ii * NP + p) * LD + jj * NP + p] = v;
-        Dm[(jj * NP + p) * LD + ii * NP + p] = v;
-      }
-    }
-  }
-  // (3) drop the H blocks in (their targets are disjoint from the entries written in (2))
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = tid + 256 * k;
-    if (!sep_left && idx < 3 * NP * NP) {
-      const int ii = idx / (NP * NP), rem = idx % (NP * NP), p = rem / NP, pc = rem % NP;
-      if (fbase + ii < K.n_frames) Dm[(ii * NP + p) * LD + ii * NP + pc] = hv[k];
-    }
-  }
-  __syncthreads();
-  // (4) Marquardt damping and pinning of the diagonal, right-hand side, projected-gradient norm
-  double gmax = 0.0;
-  if (tid < BS) {
-    double b = 0.0;
-    if (row_live) {
-      const int p = tid % NP;
-      double d = Dm[tid * LD + tid];
-      const double gtol = GRAD_ZERO_REL * d;
-      const bool fixed = (xv <= K.lo[p] && gv > gtol) || (xv >= K.hi[p] && gv < -gtol);
-      d = d + lam * fmax(d, DIAG_FLOOR);
-      if (fixed) d *= FIX_SCALE;
-      Dm[tid * LD + tid] = d;
-      b = fixed ? 0.0 : -gv;
-      const int nloc = fbase + tid / NP;
-      gmax = (nloc >= K.own_lo && nloc < K.own_hi) ? fabs(b) : 0.0;   // (window sharding: owned frames only)
-    }
-    bv[tid] = b;
-  }
-  return gmax;
-}
-
-// max over the workgroup -> gn_part[node]
-__device__ void publish_gmax(double gmax, double* red, double* gn_part, int node, int tid) {
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = gmax;
-  __syncthreads();
-  if (tid == 0) gn_part[node] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-
-// Level-0 couplings are the constant third-difference blocks E (<= 3 non-zeros per column, all on the
-// state's own diagonal), so W = U^T E needs no GEMM: column (jj,p) of W is a combination of <= 3 ROWS of U.
-//   left  (neighbour i-1): W_l[r][(jj,p)] = sum_{ii<=jj} U[(ii,p)][r] * 2 q_p band(f_i-3+jj, 3+ii-jj)
-//   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
-// coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
-// right: columns in node i+1).  450 doubles, filled once per workgroup.
-__device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
-  const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
-  const int64_t f_i = K.n_offset + (int64_t)loc_i;
-  for (int e = tid; e < 2 * 9 * NP; e += 256) {
-    const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
-    double v = 0.0;
-    if (ii <= jj) {
-      const int k = 3 + ii - jj;
-      // left table: frame jj of node i-1 with frame ii of node i; right table: frame jj of node i with frame ii of node i+1.
-      // A slot beyond the local frames (the last node of a window that ends inside the sequence holds 1 or 2 live
-      // frames) is an identity row of the chain and must not be coupled, whatever the global band says there.
-      const int hi = side == 0 ? loc_i + ii : loc_i + 3 + ii;
-      if (hi < K.n_frames)
-        v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
-                                              : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
-    }
-    (side == 0 ? coefL : coefR)[q] = v;
-  }
-}
 
 __device__ void sparse_coupling_w(const double* Um, double* __restrict__ Wout, const double* coef, bool left, int tid) {
   for (int e = tid; e < BS * BS; e += 256) {
@@ -1074,8 +954,109 @@ k_bcr_trunc_check(BcrChain ch, const int* __restrict__ status) {
   if (tid == 0) ch.trunc_eps2[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- incomplete reduction: block-Jacobi refinement --------------------------------------------------------------
+// The truncated solve x0_j = D_j^-1 b_j ignores the couplings C between the R isolated nodes.  One sweep re-introduces them:
+//   x_j <- x0_j - D_j^-1 ( block(j, l) x_l + block(j, r) x_r ),      D_j^-1 = U_j U_j^T,
+// with the neighbours' values of the PREVIOUS sweep (Jacobi: every node in parallel, deterministic).  The iteration matrix
+// has norm <= 2 eps in the energy norm of the block diagonal (eps = the measured size of the dropped blocks,
+// k_bcr_trunc_check), so r sweeps leave a relative error <= (2 eps)^(r+1) / (1 - 2 eps): "exact to rounding" after a few
+// sweeps wherever the couplings have decayed, at ~5 us per sweep instead of ~30 us per further reduction level.
+// block(j, l) = Cpl[l] (rows j, columns l); block(j, r) = Cpl[j]^T.  Entry p of the isolated level is node iso[3 p].
+// src / dst: iterates indexed by p (src == nullptr: the truncated solve's x0 is read from ch.b and saved to x0);
+// to_chain: the new iterate also goes to ch.b (only legal when src != nullptr: nobody reads ch.b then).
+__global__ void __launch_bounds__(256)
+k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* __restrict__ src, double* __restrict__ dst,
+             double* __restrict__ x0, int to_chain, const int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Ml = reinterpret_cast<double*>(smem_raw);
+  double* Mr = Ml + MAT;
+  double* Mu = Mr + MAT;
+  double* xl = Mu + MAT;          // [80] each
+  double* xr = xl + BS;
+  double* tv = xr + BS;
+  double* part = tv + BS;         // [3][80]
+  const int tid = threadIdx.x, p = blockIdx.x;
+  const int j = iso[3 * p], l = p > 0 ? iso[3 * (p - 1)] : -1, r = p + 1 < n_iso ? iso[3 * (p + 1)] : -1;
+  const size_t MB = (size_t)BS * BS;
+  {  // all three matrices in flight before the first LDS write
+    const double2* s0 = reinterpret_cast<const double2*>(ch.Cpl + (l >= 0 ? (size_t)l : 0) * MB);
+    const double2* s1 = reinterpret_cast<const double2*>(ch.Cpl + (size_t)j * MB);
+    const double2* s2 = reinterpret_cast<const double2*>(ch.U + (size_t)j * MB);
+    double2 v0[13], v1[13], v2[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < BS * BS / 2) {
+        v0[k] = l >= 0 ? s0[idx] : make_double2(0.0, 0.0);
+        v1[k] = r >= 0 ? s1[idx] : make_double2(0.0, 0.0);
+        v2[k] = s2[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < BS * BS / 2) {
+        const int e = 2 * idx, rr = e / BS, c = e % BS;
+        Ml[rr * LD + c] = v0[k].x;  Ml[rr * LD + c + 1] = v0[k].y;
+        Mr[rr * LD + c] = v1[k].x;  Mr[rr * LD + c + 1] = v1[k].y;
+        Mu[rr * LD + c] = v2[k].x;  Mu[rr * LD + c + 1] = v2[k].y;
+      }
+    }
+  }
+  double xj0 = 0.0;
+  if (tid < BS) {
+    if (src) {
+      xl[tid] = l >= 0 ? src[(size_t)(p - 1) * BS + tid] : 0.0;
+      xr[tid] = r >= 0 ? src[(size_t)(p + 1) * BS + tid] : 0.0;
+      xj0 = x0[(size_t)p * BS + tid];
+    } else {
+      xl[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
+      xr[tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
+      xj0 = ch.b[(size_t)j * BS + tid];
+      x0[(size_t)p * BS + tid] = xj0;
+    }
+  }
+  __syncthreads();
+  const int row = tid % BS, pr = tid / BS, k0 = 27 * pr, k1 = min(k0 + 27, BS);
+  if (tid < 3 * BS) {             // t = block(j, l) x_l + block(j, r) x_r
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s += Ml[row * LD + k] * xl[k] + Mr[k * LD + row] * xr[k];
+    part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < BS) tv[tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];
+  __syncthreads();
+  if (tid < 3 * BS) {             // w = U^T t  (U upper triangular: rows <= column)
+    double s = 0.0;
+    const int c1 = min(k1, row + 1);
+    for (int k = k0; k < c1; ++k) s += Mu[k * LD + row] * tv[k];
+    part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < BS) xl[tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];      // (xl reused: w)
+  __syncthreads();
+  if (tid < 3 * BS) {             // d = U w
+    double s = 0.0;
+    for (int k = max(k0, row); k < k1; ++k) s += Mu[row * LD + k] * xl[k];
+    part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < BS) {
+    const double x = xj0 - ((part[tid] + part[BS + tid]) + part[2 * BS + tid]);
+    dst[(size_t)p * BS + tid] = x;
+    if (to_chain) ch.b[(size_t)j * BS + tid] = x;
+  }
+}
+__global__ void k_bcr_refine_copy(BcrChain ch, const int* __restrict__ iso, const double* __restrict__ src,
+                                  const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  if (threadIdx.x < BS) ch.b[(size_t)iso[3 * blockIdx.x] * BS + threadIdx.x] = src[(size_t)blockIdx.x * BS + threadIdx.x];
+}
+
 // ---- host side ------------------------------------------------------------------------------
-void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels) {
+void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, int refine_sweeps) {
+  refine = 0;
   levels.clear();
   elim.clear();
   remain.clear();
@@ -1151,7 +1132,12 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels) {
   tail.clear();
   tail_levels = 0;
   int total = 0;
-  for (int k = (int)levels.size() - 1; k >= 1; --k) {     // (level 0 of an FTE chain has its own kernel)
+  int k_top = (int)levels.size() - 1;
+  if (refine_sweeps > 0 && !levels.empty() && levels.back().isolated) {
+    refine = refine_sweeps;                                // the isolated level is refined before the levels above it
+    --k_top;                                               // use it: it cannot be part of the fused tail
+  }
+  for (int k = k_top; k >= 1; --k) {                       // (level 0 of an FTE chain has its own kernel)
     const BcrLevel& lv = levels[k];
     if (total + lv.n_elim > 128) break;
     for (int e = 0; e < lv.n_elim; ++e) {
@@ -1196,6 +1182,8 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdate0Lds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_trunc_check),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTruncCheckLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_refine),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
   return ACINO_OK;
 }
 
@@ -1296,6 +1284,30 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof, int* d_numeric_err) {
   int top = (int)sch.levels.size() - 1;
+  if (sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf) {
+    // truncated solve of the isolated nodes, then the block-Jacobi sweeps over their dropped couplings
+    const BcrLevel& lv = sch.levels[top];
+    const int* iso = ch.d_elim + 3 * lv.elim_off;
+    {
+      ProfSpan sp(prof, PC_BACKSUB, s, lv.n_elim);
+      hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch, iso, d_status);
+    }
+    ACINO_LAUNCH_CHECK();
+    double* x0 = ch.refine_buf;
+    double* it[2] = {x0 + (size_t)lv.n_elim * BS, x0 + 2 * (size_t)lv.n_elim * BS};
+    for (int sw = 0; sw < sch.refine; ++sw) {
+      const bool last = sw + 1 == sch.refine;
+      ProfSpan sp(prof, PC_REFINE, s, lv.n_elim);
+      hipLaunchKernelGGL(k_bcr_refine, dim3(lv.n_elim), dim3(256), kBacksubTailLds, s, ch, iso, lv.n_elim,
+                         sw == 0 ? (const double*)nullptr : it[(sw - 1) & 1], it[sw & 1], x0, (last && sw > 0) ? 1 : 0, d_status);
+      ACINO_LAUNCH_CHECK();
+    }
+    if (sch.refine == 1) {      // (a single sweep reads its neighbours from ch.b: the result goes there afterwards)
+      hipLaunchKernelGGL(k_bcr_refine_copy, dim3(lv.n_elim), dim3(128), 0, s, ch, iso, it[0], d_status);
+      ACINO_LAUNCH_CHECK();
+    }
+    --top;
+  }
   if (ch.d_tail && sch.tail_levels > 0) {
     const int n_tail = (int)sch.tail.size() / 4;
     ACINO_HIP_CHECK(hipMemsetAsync(ch.d_done, 0, sizeof(int), s));

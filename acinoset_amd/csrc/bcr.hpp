@@ -27,7 +27,10 @@ struct BcrSchedule {
   // coupling block (stored at Cpl[left]); their normalised size is measured on the device (k_bcr_trunc_check).
   std::vector<int> pairs;
   size_t ints() const { return elim.size() + remain.size() + tail.size() + pairs.size() + 4; }   // (+ the tail's progress counter)
-  void build(int n, bool pin_left, bool pin_right, int max_levels = 0);
+  // refine > 0 (incomplete reductions only): block-Jacobi sweeps over the isolated nodes that re-introduce the dropped
+  // couplings after the truncated solve (k_bcr_refine); the isolated level then stays out of the fused tail.
+  int refine = 0;
+  void build(int n, bool pin_left, bool pin_right, int max_levels = 0, int refine_sweeps = 0);
 };
 
 // Device views of one chain.
@@ -47,6 +50,7 @@ struct BcrChain {
   const int* d_pairs = nullptr;   // dropped couplings of an incomplete reduction (2 ints each) ...
   int n_pairs = 0;
   double* trunc_eps2 = nullptr;   // ... and [n_pairs] squared Frobenius norms of L_b^-1 C L_a^-T, written every reduction
+  double* refine_buf = nullptr;   // [3][n_isolated][80] x0 and the two iterates of the refinement sweeps
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
   long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
   // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build

@@ -1,0 +1,146 @@
+// Device helpers shared by the block cyclic reduction (bcr.hip) and the chunk sweep (chunk.hip): the damped Gauss-Newton
+// node built in LDS straight from the assembly output, the per-node gradient norm, the third-difference coupling tables.
+#pragma once
+#include "bcr.hpp"
+#include "dense80.hpp"
+
+namespace acino {
+
+// lower-triangular tile enumeration t -> (ib, jb)
+static __constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+static __constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+
+// Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
+// assembly's H/g (no set-up pass through HBM): D = H_gn + lam*diag(H_gn), bound-active variables
+// pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).
+// Returns this thread's max |projected gradient| contribution.  All 256 threads; one barrier inside (the
+// caller's publish_gmax barrier completes the block).  (Two barriers inside.)
+// The global reads of one node, issued up front (a caller may issue them long before the node is built).
+struct NodeFetch {
+  double hv[8];
+  double xv, gv, lam;
+  bool row_live;
+};
+static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain& ch, const FteConst& K, int t, int tid) {
+  const int cur = ch.st->cur;
+  const double* x = cur ? ch.x1 : ch.x0;
+  const double* g = cur ? ch.g1 : ch.g0;
+  const double* H = cur ? ch.H1 : ch.H0;
+  f.lam = ch.st->lam;
+  const bool sep_left = K.pin_left && t == 0;
+  const int fbase = 3 * (t - K.pin_left);
+  // the three 25x25 Gauss-Newton blocks (<= 8 entries per thread) and, for the 75 row-owner threads, the state and
+  // gradient entry of their row
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k;
+    f.hv[k] = 0.0;
+    if (!sep_left && idx < 3 * NP * NP) {
+      const int n = fbase + idx / (NP * NP);
+      if (n < K.n_frames) f.hv[k] = H[(size_t)n * NP * NP + idx % (NP * NP)];
+    }
+  }
+  f.xv = 0.0;
+  f.gv = 0.0;
+  f.row_live = false;
+  if (!sep_left && tid < 3 * NP) {
+    const int n = fbase + tid / NP, p = tid % NP;
+    if (n < K.n_frames) {
+      f.row_live = true;
+      f.xv = x[(size_t)(n + HALO) * NP + p];
+      f.gv = g[(size_t)n * NP + p];
+    }
+  }
+}
+static __device__ __forceinline__ double build_finish(double* Dm, double* bv, const NodeFetch& f, const FteConst& K, int t,
+                                                      int tid) {
+  const bool sep_left = K.pin_left && t == 0;
+  const int fbase = 3 * (t - K.pin_left);
+  // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
+  for (int e = tid; e < BS * LD; e += 256) Dm[e] = 0.0;
+  __syncthreads();
+  if (!sep_left) {
+    if (tid < BS) {
+      const int nfr = fbase + tid / NP;
+      if (tid >= 3 * NP || nfr >= K.n_frames) Dm[tid * LD + tid] = 1.0;
+    } else if (tid < BS + 3 * NP) {
+      const int q = tid - BS, pr = q / NP, p = q % NP;          // frame pairs (0,1), (0,2), (1,2)
+      const int ii = pr == 2 ? 1 : 0, jj = pr == 0 ? 1 : 2;
+      if (fbase + jj < K.n_frames) {
+        const double v = 2.0 * K.q_w[p] * band_coef_clip(K.n_offset + fbase + ii, jj - ii, K.n_global, K.clip_len);
+        Dm[(ii * NP + p) * LD + jj * NP + p] = v;
+        Dm[(jj * NP + p) * LD + ii * NP + p] = v;
+      }
+    }
+  }
+  // (3) drop the H blocks in (their targets are disjoint from the entries written in (2))
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k;
+    if (!sep_left && idx < 3 * NP * NP) {
+      const int ii = idx / (NP * NP), rem = idx % (NP * NP), p = rem / NP, pc = rem % NP;
+      if (fbase + ii < K.n_frames) Dm[(ii * NP + p) * LD + ii * NP + pc] = f.hv[k];
+    }
+  }
+  __syncthreads();
+  // (4) Marquardt damping and pinning of the diagonal, right-hand side, projected-gradient norm
+  double gmax = 0.0;
+  if (tid < BS) {
+    double b = 0.0;
+    if (f.row_live) {
+      const int p = tid % NP;
+      double d = Dm[tid * LD + tid];
+      const double gtol = GRAD_ZERO_REL * d;
+      const bool fixed = (f.xv <= K.lo[p] && f.gv > gtol) || (f.xv >= K.hi[p] && f.gv < -gtol);
+      d = d + f.lam * fmax(d, DIAG_FLOOR);
+      if (fixed) d *= FIX_SCALE;
+      Dm[tid * LD + tid] = d;
+      b = fixed ? 0.0 : -f.gv;
+      const int nloc = fbase + tid / NP;
+      gmax = (nloc >= K.own_lo && nloc < K.own_hi) ? fabs(b) : 0.0;   // (window sharding: owned frames only)
+    }
+    bv[tid] = b;
+  }
+  return gmax;
+}
+static __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const FteConst& K, int t, int tid) {
+  NodeFetch f;
+  build_fetch(f, ch, K, t, tid);
+  return build_finish(Dm, bv, f, K, t, tid);
+}
+
+// max over the workgroup -> gn_part[node]
+static __device__ void publish_gmax(double gmax, double* red, double* gn_part, int node, int tid) {
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = gmax;
+  __syncthreads();
+  if (tid == 0) gn_part[node] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Level-0 couplings are the constant third-difference blocks E (<= 3 non-zeros per column, all on the
+// state's own diagonal), so W = U^T E needs no GEMM: column (jj,p) of W is a combination of <= 3 ROWS of U.
+//   left  (neighbour i-1): W_l[r][(jj,p)] = sum_{ii<=jj} U[(ii,p)][r] * 2 q_p band(f_i-3+jj, 3+ii-jj)
+//   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
+// coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
+// right: columns in node i+1).  450 doubles, filled once per workgroup.
+static __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
+  const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
+  const int64_t f_i = K.n_offset + (int64_t)loc_i;
+  for (int e = tid; e < 2 * 9 * NP; e += 256) {
+    const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
+    double v = 0.0;
+    if (ii <= jj) {
+      const int k = 3 + ii - jj;
+      // left table: frame jj of node i-1 with frame ii of node i; right table: frame jj of node i with frame ii of node i+1.
+      // A slot beyond the local frames (the last node of a window that ends inside the sequence holds 1 or 2 live
+      // frames) is an identity row of the chain and must not be coupled, whatever the global band says there.
+      const int hi = side == 0 ? loc_i + ii : loc_i + 3 + ii;
+      if (hi < K.n_frames)
+        v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
+                                              : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
+    }
+    (side == 0 ? coefL : coefR)[q] = v;
+  }
+}
+
+}  // namespace acino

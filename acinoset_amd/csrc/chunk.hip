@@ -1,0 +1,1053 @@
+// Chunked substructuring of the block-tridiagonal Gauss-Newton system (the step SURVEY.md section 7.6 describes):
+// the chain of 80x80 super-blocks is cut into runs of m consecutive nodes; ONE workgroup eliminates the m - 1 interior
+// nodes of a run IN ORDER with every operand resident in LDS, the last node of each run is a separator.  In sequential
+// order the couplings between consecutive interior nodes stay the constant third-difference stencils E (<= 3 terms per
+// entry, never stored); the only dense fill is the "spike" F_k = block(node k, left separator L):
+//
+//   node k (D~_k, F_k, b~_k in LDS):   D~_k = L L^T,  U = L^-T  (blocked Cholesky, dense80.hpp)
+//        y = U^T b~_k            z_k = U y                       (= D~_k^-1 b~_k)
+//        W = U^T F_k             T_k = U W                       (= D~_k^-1 F_k)
+//        G_k = U U^T                                              (= D~_k^-1)
+//      left separator:   D_L -= W^T W        b_L -= W^T y
+//      next node:        D~_k+1 = D_k+1 - E^T G_k E    F_k+1 = -E^T T_k    b~_k+1 = b_k+1 - E^T z_k     (E = E_r(k))
+//      (after the last interior node the "next node" is the right separator R: F becomes block(R, L))
+//   back-substitution, right to left:  x_k = z_k - G_k (E x_k+1) - T_k x_L.
+//
+// HBM traffic per interior node: H, g in (15 KB), G_k, T_k, z_k out (102 KB) and in again for the back-substitution;
+// the block cyclic reduction of the same nodes moved D, U, W_l, W_r and the coupling blocks through HBM at every level.
+// The separators (one per run, n_chunks - 1) are a block-tridiagonal chain with dense couplings: bcr.hip solves it.
+#include "chunk.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "bcr_dev.hpp"
+
+namespace acino {
+
+void ChunkPlan::build(int nodes, int chunk_nodes) {
+  n_nodes = nodes;
+  m = n_chunks = n_sep = 0;
+  if (chunk_nodes < 0 || nodes < 1) return;
+  int mm = chunk_nodes;
+  if (mm == 0) {
+    // automatic: one run per CU for the long chains, runs of at least 4 nodes for the short ones
+    mm = (nodes + 255) / 256;
+    mm = std::max(4, std::min(mm, 16));
+  }
+  mm = std::max(2, mm);
+  m = mm;
+  n_chunks = (nodes + mm - 1) / mm;
+  n_sep = n_chunks - 1;
+}
+
+// ---- tile products on LDS matrices (leading dimension LD), one 16x16 output tile per call, all operands read first ----
+// (U^T F)(ib, jb) = sum_{kb <= ib} U(kb, ib)^T F(kb, jb): U upper triangular in X (strictly-lower tiles are workspace)
+__device__ __forceinline__ d4 tile_ut_f(const double* X, const double* Y, int ib, int jb, int li, int lk) {
+  const double* pa = X + lk * LD + ib * 16 + li;
+  const double* pb = Y + lk * LD + jb * 16 + li;
+  const d4 z = {0, 0, 0, 0};
+  switch (ib) {
+    case 0: return mma_seq<4, false>(z, pa, 4 * LD, pb, 4 * LD);
+    case 1: return mma_seq<8, false>(z, pa, 4 * LD, pb, 4 * LD);
+    case 2: return mma_seq<12, false>(z, pa, 4 * LD, pb, 4 * LD);
+    case 3: return mma_seq<16, false>(z, pa, 4 * LD, pb, 4 * LD);
+    default: return mma_seq<20, false>(z, pa, 4 * LD, pb, 4 * LD);
+  }
+}
+// (U W)(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb)
+__device__ __forceinline__ d4 tile_u_w(const double* X, const double* Y, int ib, int jb, int li, int lk) {
+  const double* pa = X + (ib * 16 + li) * LD + ib * 16 + lk;
+  const double* pb = Y + (ib * 16 + lk) * LD + jb * 16 + li;
+  const d4 z = {0, 0, 0, 0};
+  switch (ib) {
+    case 0: return mma_seq<20, false>(z, pa, 4, pb, 4 * LD);
+    case 1: return mma_seq<16, false>(z, pa, 4, pb, 4 * LD);
+    case 2: return mma_seq<12, false>(z, pa, 4, pb, 4 * LD);
+    case 3: return mma_seq<8, false>(z, pa, 4, pb, 4 * LD);
+    default: return mma_seq<4, false>(z, pa, 4, pb, 4 * LD);
+  }
+}
+// (U U^T)(ib, jb), jb <= ib:  sum_{k >= 16 ib} U[ib16 + i][k] U[jb16 + j][k]
+__device__ __forceinline__ d4 tile_u_ut(const double* X, int ib, int jb, int li, int lk) {
+  const double* pa = X + (ib * 16 + li) * LD + ib * 16 + lk;
+  const double* pb = X + (jb * 16 + li) * LD + ib * 16 + lk;
+  const d4 z = {0, 0, 0, 0};
+  switch (ib) {
+    case 0: return mma_seq<20, false>(z, pa, 4, pb, 4);
+    case 1: return mma_seq<16, false>(z, pa, 4, pb, 4);
+    case 2: return mma_seq<12, false>(z, pa, 4, pb, 4);
+    case 3: return mma_seq<8, false>(z, pa, 4, pb, 4);
+    default: return mma_seq<4, false>(z, pa, 4, pb, 4);
+  }
+}
+__device__ __forceinline__ void tile_store(double* M, int ib, int jb, const d4& a, int li, int lk) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) M[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = a[rr];
+}
+
+// accL(ib, jb) -= W(:, ib)^T W(:, jb) over the lower tiles, rows of tiles dealt to the waves as in k_bcr_update (one
+// LDS operand read feeds every tile of a row): wave 0: row 4 | 1: row 3 | 2: row 2 and (0,0) | 3: row 1
+template <int WAVE>
+__device__ __forceinline__ void syrk_acc(const double* W, double* Acc, int li, int lk) {
+  constexpr int nb = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 3 : 2));
+  constexpr int nt = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 4 : 2));
+  d4 acc[nt];
+#pragma unroll
+  for (int q = 0; q < nt; ++q) {
+    const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
+    const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Acc[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li];
+  }
+  const double* p = W + lk * LD + li;
+#pragma unroll
+  for (int s = 0; s < BS / 4; ++s) {
+    double v[nb];
+#pragma unroll
+    for (int c = 0; c < nb; ++c) v[c] = p[(4 * s) * LD + c * 16];
+#pragma unroll
+    for (int q = 0; q < nt; ++q) {
+      const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
+      const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
+      acc[q] = mfma(-v[ib], v[jb], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < nt; ++q) {
+    const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
+    const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Acc[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = acc[q][rr];
+  }
+}
+
+constexpr int SW_VEC = 7 * BS + 8 + 18 * NP;   // bv yv zv blv ysc[3] | red | cL cR
+static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
+
+// One workgroup per run: forward elimination of its interior nodes, left to right.
+__global__ void __launch_bounds__(256)
+k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+              int m, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* X = reinterpret_cast<double*>(smem_raw);   // D~_k -> factor (U in the upper tiles) -> G_k -> stencil workspace
+  double* Y = X + MAT;                                // F_k -> W -> T_k -> F_k+1
+  double* Z = Y + MAT;                                // -(sum_k W^T W), the left separator's Schur update
+  double* bv = Z + MAT;                               // [80] b~_k
+  double* yv = bv + BS;                               // [80] y
+  double* zv = yv + BS;                               // [80] z_k
+  double* blv = zv + BS;                              // [80] sum_k W^T y
+  double* ysc = blv + BS;                             // [3][80] partial sums of the mat-vecs
+  double* red = ysc + 3 * BS;                         // [8]
+  double* cL = red + 8;                               // coupling tables of the current node
+  double* cR = cL + 9 * NP;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const FteConst& K = *cst;
+  const int c = blockIdx.x;
+  const int first = c * m;
+  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
+  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const size_t MB = (size_t)BS * BS;
+  const int row = tid % BS, part = tid / BS;
+
+  for (int e = tid; e < MAT; e += 256) Z[e] = 0.0;
+  if (tid < BS) blv[tid] = 0.0;
+
+  {
+    const double gmax = build_node(X, bv, ch, K, first, tid);
+    publish_gmax(gmax, red, ch.gn_part, first, tid);
+  }
+  for (int k = 0; k < n_int; ++k) {
+    const int node = first + k;
+    fill_coupling_coef(cL, cR, K, node, tid);
+    __syncthreads();                                   // node complete in X / bv, tables visible
+    chol80(X, tid, numeric_err);
+    // y = U^T b~, z = U y (three partial sums per row)
+    if (tid < 3 * BS) {
+      double yy = 0.0;
+      const int c1 = min(27 * part + 27, row + 1);
+      for (int cc = 27 * part; cc < c1; ++cc) yy += X[cc * LD + row] * bv[cc];
+      ysc[tid] = yy;
+    }
+    __syncthreads();
+    if (tid < BS) yv[tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    __syncthreads();
+    if (tid < 3 * BS) {
+      double z = 0.0;
+      const int c1 = min(27 * part + 27, BS);
+      for (int cc = max(27 * part, row); cc < c1; ++cc) z += X[row * LD + cc] * yv[cc];
+      ysc[tid] = z;
+    }
+    __syncthreads();
+    if (tid < BS) {
+      const double z = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+      zv[tid] = z;
+      ch.b[(size_t)node * BS + tid] = z;
+    }
+    if (hasL) {
+      // ---- W = U^T F_k into Y
+      if (k == 0) {
+        // F_0 = E_l(node): rows (ii, p) of the node, columns (jj, p) of L, <= 3 terms per entry of W
+        for (int e = tid; e < BS * BS; e += 256) {
+          const int r = e / BS, cc = e % BS;
+          double v = 0.0;
+          if (cc < 3 * NP) {
+            const int cj = cc / NP, p = cc % NP;
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+              const int rw = ii * NP + p;
+              if (ii <= cj && rw <= r) v += X[rw * LD + r] * cL[(ii * 3 + cj) * NP + p];
+            }
+          }
+          Y[r * LD + cc] = v;
+        }
+        __syncthreads();
+      } else {
+        d4 w[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int t = wave + 4 * q;
+          if (t < NT * NT) w[q] = tile_ut_f(X, Y, t / NT, t % NT, li, lk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int t = wave + 4 * q;
+          if (t < NT * NT) tile_store(Y, t / NT, t % NT, w[q], li, lk);
+        }
+        __syncthreads();
+      }
+      // ---- left separator: D_L -= W^T W (registers, whole run), b_L -= W^T y
+      if (wave == 0) syrk_acc<0>(Y, Z, li, lk);
+      else if (wave == 1) syrk_acc<1>(Y, Z, li, lk);
+      else if (wave == 2) syrk_acc<2>(Y, Z, li, lk);
+      else syrk_acc<3>(Y, Z, li, lk);
+      if (tid < 3 * BS) {
+        double s = 0.0;
+        const int r1 = min(27 * part + 27, BS);
+        for (int r = 27 * part; r < r1; ++r) s += Y[r * LD + row] * yv[r];
+        ysc[tid] = s;
+      }
+      __syncthreads();
+      if (tid < BS) blv[tid] += ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+      // ---- T = U W in place
+      {
+        d4 w[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int t = wave + 4 * q;
+          if (t < NT * NT) w[q] = tile_u_w(X, Y, t / NT, t % NT, li, lk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int t = wave + 4 * q;
+          if (t < NT * NT) tile_store(Y, t / NT, t % NT, w[q], li, lk);
+        }
+      }
+    }
+    // ---- G = U U^T in place (lower tiles computed, mirrored on the way back)
+    {
+      d4 gq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        if (t < 15) gq[q] = tile_u_ut(X, c_tri_i[t], c_tri_j[t], li, lk);
+      }
+      __syncthreads();                                 // every read of U (and of W) is done
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        if (t < 15) {
+          const int ib = c_tri_i[t], jb = c_tri_j[t];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            X[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = gq[q][rr];
+            if (ib != jb) X[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = gq[q][rr];
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // G in X, T in Y
+    // ---- what the back-substitution needs: G_k, T_k^T (its lanes run along a COLUMN of T), z_k (stored above)
+    store_mat(ch.D + node * MB, X, tid);
+    if (hasL) {
+      double* Tg = ch.Wl + node * MB;
+      for (int e = tid; e < BS * BS; e += 256) Tg[e] = Y[(e % BS) * LD + e / BS];
+    }
+    const bool to_sep = k + 1 == n_int;
+    if (to_sep && !hasR) break;                        // last node of the chain
+    const int next = node + 1;
+    __syncthreads();                                   // the stores above have read X and Y
+    // ---- next node: -E^T G E (rows (a, p) x all columns, in registers), F' = -E^T T, b' correction
+    // pass 1: X <- G E (columns (jb, p)), in place.  item (row r, state p)
+#pragma unroll
+    for (int mq = 0; mq < 8; ++mq) {
+      const int q = tid + 256 * mq;
+      if (q < BS * NP) {
+        const int r = q / NP, p = q % NP;
+        const double g0 = X[r * LD + p], g1 = X[r * LD + NP + p], g2 = X[r * LD + 2 * NP + p];
+        X[r * LD + p] = g0 * cR[(0 * 3 + 0) * NP + p] + g1 * cR[(0 * 3 + 1) * NP + p] + g2 * cR[(0 * 3 + 2) * NP + p];
+        X[r * LD + NP + p] = g1 * cR[(1 * 3 + 1) * NP + p] + g2 * cR[(1 * 3 + 2) * NP + p];
+        X[r * LD + 2 * NP + p] = g2 * cR[(2 * 3 + 2) * NP + p];
+      }
+    }
+    __syncthreads();
+    // pass 2: dv = -E^T (G E); F' = -E^T T in place.  item (state p, column cc): the three frame rows of p
+    double dv[8][3];
+#pragma unroll
+    for (int mq = 0; mq < 8; ++mq) {
+      const int q = tid + 256 * mq;
+      if (q < NP * BS) {
+        const int p = q / BS, cc = q % BS;
+        const double c00 = cR[(0 * 3 + 0) * NP + p], c01 = cR[(0 * 3 + 1) * NP + p], c02 = cR[(0 * 3 + 2) * NP + p];
+        const double c11 = cR[(1 * 3 + 1) * NP + p], c12 = cR[(1 * 3 + 2) * NP + p], c22 = cR[(2 * 3 + 2) * NP + p];
+        const double t0 = X[p * LD + cc], t1 = X[(NP + p) * LD + cc], t2 = X[(2 * NP + p) * LD + cc];
+        dv[mq][0] = -(c00 * t0 + c01 * t1 + c02 * t2);
+        dv[mq][1] = -(c11 * t1 + c12 * t2);
+        dv[mq][2] = -(c22 * t2);
+        if (hasL) {
+          const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
+          Y[p * LD + cc] = -(c00 * f0 + c01 * f1 + c02 * f2);
+          Y[(NP + p) * LD + cc] = -(c11 * f1 + c12 * f2);
+          Y[(2 * NP + p) * LD + cc] = -(c22 * f2);
+        }
+      }
+    }
+    if (hasL)
+      for (int e = tid; e < 5 * BS; e += 256) Y[(3 * NP + e / BS) * LD + e % BS] = 0.0;   // padding rows couple to nothing
+    double bcorr = 0.0;                                // (E^T z)[(ja, pa)]
+    if (tid < 3 * NP) {
+      const int ja = tid / NP, pa = tid % NP;
+      for (int j1 = ja; j1 < 3; ++j1) bcorr += cR[(ja * 3 + j1) * NP + pa] * zv[j1 * NP + pa];
+    }
+    __syncthreads();                                   // pass-2 reads of X done
+    {
+      const double gmax = build_node(X, bv, ch, K, next, tid);
+      publish_gmax(gmax, red, ch.gn_part, next, tid);  // (barrier inside: node and bv complete)
+    }
+#pragma unroll
+    for (int mq = 0; mq < 8; ++mq) {
+      const int q = tid + 256 * mq;
+      if (q < NP * BS) {
+        const int p = q / BS, cc = q % BS;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) X[(a * NP + p) * LD + cc] += dv[mq][a];
+      }
+    }
+    if (tid < 3 * NP) bv[tid] -= bcorr;
+    if (to_sep) {                                      // the "next node" is the right separator
+      __syncthreads();
+      store_mat(sp.D + (size_t)c * MB, X, tid);
+      if (tid < BS) sp.b[(size_t)c * BS + tid] = bv[tid];
+      if (hasL) store_mat(sp.Cpl + (size_t)(c - 1) * MB, Y, tid);     // block(R, L): rows R, columns L
+      break;
+    }
+  }
+  if (hasL) {
+    __syncthreads();
+    store_mat(sp.AL + (size_t)(c - 1) * MB, Z, tid);   // (lower tiles are meaningful)
+    if (tid < BS) sp.bl[(size_t)(c - 1) * BS + tid] = blv[tid];
+  }
+}
+
+// ================================================================================================================
+// Second form of the sweep.  Per node the work splits into a SERIAL part (all four waves) and a PARALLEL part:
+//   serial   : G_k = U_k U_k^T -> HBM;  D~_k+1 = D_k+1 - E^T G_k E  (the next node's H / g / x were requested before G)
+//   parallel : wave 0 factors D~_k+1 ALONE (one-wave blocked Cholesky: no workgroup barrier on the pivot chain),
+//              waves 1..3 do the spike algebra of node k meanwhile: W = U_k^T F_k, D_L -= W^T W, T_k = U_k W -> HBM,
+//              F_k+1 = -E^T T_k, each wave on its own 16-column strips (two 3-wave LDS barriers per node for W^T W).
+// The right-hand side rides along as COLUMN 79 of the spike (the left separator has 75 unknowns, columns 75..79 are free):
+// column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1 = the next node's b~), and row 79
+// of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases, no extra barriers.
+// LDS: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 159.9 KB, one workgroup per CU.
+constexpr int SW2_VEC = 18 * NP + BS + 8 + 8;   // cL cR | bv | red | sync
+static constexpr size_t kSweep2Lds = (3 * MAT + SW2_VEC) * sizeof(double);
+
+// The value of x, made opaque to the optimiser: address arithmetic derived from it cannot be hoisted out of the node loop
+// (hoisted, the hundreds of per-tile LDS / HBM addresses of this kernel end up spilled to scratch and are reloaded one by
+// one in front of the loads that need them).
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+template <class T>
+__device__ __forceinline__ T* opaque_ptr(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// NB tile products C(q) (-)= A(q) B(q)^T style updates of chol80's trailing phase, batched: every LDS operand of the
+// batch is requested before the first matrix-core instruction and the NB accumulator chains interleave, so one wave alone
+// keeps its matrix core busy (tile by tile, each product would wait ~200 cycles for its operands and ~70 per dependent
+// MFMA).  code = 16 ti + tj; ti <= kb marks a tile of U (first written when ti == kb).
+template <int NB>
+__device__ __forceinline__ void trail_batch(double* Lm, int kb, const uint8_t* codes, int li, int lk) {
+  d4 a[NB];
+  double av[NB][4], bw[NB][4];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int ti = codes[q] >> 4, tj = codes[q] & 15;
+    const double* A = Lm + (ti * 16) * LD + kb * 16;
+    const double* B = Lm + (tj * 16) * LD + kb * 16;
+    const double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      av[q][s] = A[li * LD + 4 * s + lk];
+      bw[q][s] = B[li * LD + 4 * s + lk];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) a[q][rr] = ti != kb ? Cc[(lk + 4 * rr) * LD + li] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) a[q] = mfma(-av[q][s], bw[q][s], a[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int ti = codes[q] >> 4, tj = codes[q] & 15;
+    double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+  }
+}
+
+// Blocked Cholesky of the 80x80 matrix in LDS by ONE wave (same result layout as chol80: U = L^-T in the upper tiles).
+__device__ __forceinline__ void chol80_one_wave(double* Lm, int lane, int* err) {
+  const int li = lane & 15, lk = lane >> 4;
+  chol16_inv(Lm, lane, err);
+#pragma unroll 1
+  for (int kb = 0; kb < NT; ++kb) {
+    {  // panel: tile(t, kb) <- tile(t, kb) U_kk for the four t != kb, as one batch
+      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+      double bq[4], av[4][4];
+      d4 acc[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = q + (q >= kb ? 1 : 0);
+        const double* A = Lm + (t * 16) * LD + kb * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
+        acc[q] = d4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = q + (q >= kb ? 1 : 0);
+        double* A = Lm + (t * 16) * LD + kb * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
+      }
+    }
+    if (kb == NT - 1) break;
+    {                                         // next diagonal tile, then its 16-pivot chain
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      chol16_inv_acc(Cc, a, lane, err);
+    }
+    // the other trailing tiles (U tiles included), four at a time: 13 = 4+4+4+1, 11 = 4+4+3, 8 = 4+4, 4
+    const uint8_t* codes = c_trail[kb];
+    const int ntask = c_trail_n[kb];
+    int q0 = 0;
+#pragma unroll 1
+    for (; q0 + 4 <= ntask; q0 += 4) trail_batch<4>(Lm, kb, codes + q0, li, lk);
+    if (ntask - q0 == 3) trail_batch<3>(Lm, kb, codes + q0, li, lk);
+    else if (ntask - q0 == 1) trail_batch<1>(Lm, kb, codes + q0, li, lk);
+  }
+}
+
+// Barrier among n waves of the workgroup that share the LDS counter cnt (the other waves are busy elsewhere and must not
+// be waited for, so s_barrier cannot be used): every participant adds one and waits for the n-th arrival of this round.
+__device__ __forceinline__ void sub_barrier(int* cnt, int& target, int n, int lane) {
+  target += n;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// chol80 by a PAIR of waves: role 0 runs the five 16-pivot chains with the look-ahead update of the next diagonal tile
+// (exactly wave 0 of chol80), role 1 does every other panel and trailing tile, batched four at a time.
+__device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int* err, int* cnt, int& target) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (role == 0) chol16_inv(Lm, lane, err);
+  sub_barrier(cnt, target, 2, lane);
+#pragma unroll 1
+  for (int kb = 0; kb < NT; ++kb) {
+    {  // panel: tile(t, kb) <- tile(t, kb) U_kk: role 0 the tile its look-ahead needs next, role 1 the other three
+      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+      double bq[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
+      if (role == 0) {
+        double* A = Lm + (c_panel[kb][0] * 16) * LD + kb * 16;
+        double av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bq[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+      } else {
+        double av[3][4];
+        d4 acc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const double* A = Lm + (c_panel[kb][q + 1] * 16) * LD + kb * 16;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
+          acc[q] = d4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          double* A = Lm + (c_panel[kb][q + 1] * 16) * LD + kb * 16;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
+        }
+      }
+    }
+    sub_barrier(cnt, target, 2, lane);
+    if (kb == NT - 1) break;
+    if (role == 0) {                          // next diagonal tile, then its 16-pivot chain
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      chol16_inv_acc(Cc, a, lane, err);
+    } else {                                  // the other trailing tiles (U tiles included): 13 | 11 | 8 | 4
+      const uint8_t* codes = c_trail[kb];
+      const int ntask = c_trail_n[kb];
+      int q0 = 0;
+#pragma unroll 1
+      for (; q0 + 4 <= ntask; q0 += 4) trail_batch<4>(Lm, kb, codes + q0, li, lk);
+      if (ntask - q0 == 3) trail_batch<3>(Lm, kb, codes + q0, li, lk);
+      else if (ntask - q0 == 1) trail_batch<1>(Lm, kb, codes + q0, li, lk);
+    }
+    sub_barrier(cnt, target, 2, lane);
+  }
+}
+
+// W(:, strips) = U^T F(:, strips), in place in Y, for NS 16-column strips of one wave: W(ib, jb) = sum_{kb <= ib}
+// U(kb, ib)^T F(kb, jb).  k loop outermost: the U operand of a k-step is shared by the NS strips, the F operand by the row
+// tiles ib >= kb, and the NS (5 - kb) accumulator chains of a step are independent.
+template <int NS>
+__device__ __forceinline__ void strips_ut_f(const double* U, double* Y, const int (&jbs)[NS], int li, int lk) {
+  d4 acc[NS][NT];
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) acc[j][ib] = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int kb = 0; kb < NT; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = 16 * kb + 4 * s + lk;
+      double b[NS], a[NT];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) b[j] = Y[k * LD + jbs[j] * 16 + li];
+#pragma unroll
+      for (int ib = kb; ib < NT; ++ib) a[ib] = U[k * LD + ib * 16 + li];
+#pragma unroll
+      for (int ib = kb; ib < NT; ++ib)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[j], acc[j][ib], li, lk);
+}
+// T(:, strips) = U W(:, strips), in place: T(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb)
+template <int NS>
+__device__ __forceinline__ void strips_u_w(const double* U, double* Y, const int (&jbs)[NS], int li, int lk) {
+  d4 acc[NS][NT];
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) acc[j][ib] = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int kb = 0; kb < NT; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = 16 * kb + 4 * s + lk;
+      double b[NS], a[NT];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) b[j] = Y[k * LD + jbs[j] * 16 + li];
+#pragma unroll
+      for (int ib = 0; ib <= kb; ++ib) a[ib] = U[(ib * 16 + li) * LD + k];
+#pragma unroll
+      for (int ib = 0; ib <= kb; ++ib)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[j], acc[j][ib], li, lk);
+}
+
+// -(W^T W) accumulated into the left separator's update in HBM (L2-resident, owned by this workgroup): NT tiles of one
+// wave, tile q = (IB(q), JB(q)); every k-step reads NV operands W[k][16 c + li] once for all of the wave's tiles.
+template <int SET>
+struct SyrkSet {   // the 15 lower tiles over two waves.  SET 0: rows 4 and 3 (9 tiles) | SET 1: rows 2, 1, 0 (6 tiles)
+  static constexpr int nt = SET == 0 ? 9 : 6;
+  static constexpr int nv = SET == 0 ? 5 : 3;
+  static constexpr int ib(int q) { return SET == 0 ? (q < 5 ? 4 : 3) : (q < 3 ? 2 : (q < 5 ? 1 : 0)); }
+  static constexpr int jb(int q) { return SET == 0 ? (q < 5 ? q : q - 5) : (q < 3 ? q : (q < 5 ? q - 3 : 0)); }
+};
+template <int SET>
+__device__ __forceinline__ void syrk_load(d4 (&acc)[9], const double* __restrict__ Ag, bool load, int li, int lk) {
+  using T = SyrkSet<SET>;
+  const double* base = Ag + lk * BS + li;
+#pragma unroll
+  for (int q = 0; q < T::nt; ++q) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = load ? base[(T::ib(q) * 16 + 4 * rr) * BS + T::jb(q) * 16] : 0.0;
+  }
+}
+template <int SET>
+__device__ __forceinline__ void syrk_run(d4 (&acc)[9], const double* W, double* __restrict__ Ag, int li, int lk) {
+  using T = SyrkSet<SET>;
+  const double* p = W + lk * LD + li;
+  double v0[T::nv], v1[T::nv];
+#pragma unroll
+  for (int cidx = 0; cidx < T::nv; ++cidx) v0[cidx] = p[cidx * 16];
+#pragma unroll
+  for (int s = 0; s < BS / 4; s += 2) {      // operands of step s + 1 requested before the matrix-core work of step s
+#pragma unroll
+    for (int cidx = 0; cidx < T::nv; ++cidx) v1[cidx] = p[(4 * (s + 1)) * LD + cidx * 16];
+#pragma unroll
+    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v0[T::ib(q)], v0[T::jb(q)], acc[q]);
+    if (s + 2 < BS / 4) {
+#pragma unroll
+      for (int cidx = 0; cidx < T::nv; ++cidx) v0[cidx] = p[(4 * (s + 2)) * LD + cidx * 16];
+    }
+#pragma unroll
+    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v1[T::ib(q)], v1[T::jb(q)], acc[q]);
+  }
+  double* base = Ag + lk * BS + li;
+#pragma unroll
+  for (int q = 0; q < T::nt; ++q) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) base[(T::ib(q) * 16 + 4 * rr) * BS + T::jb(q) * 16] = acc[q][rr];
+  }
+}
+
+// G = U U^T: the 15 lower tiles dealt to the waves at compile time (tile t = WAVE + 4 q), so a wave's products are
+// straight-line code whose operand reads and matrix-core chains interleave.
+template <int WAVE>
+__device__ __forceinline__ void gram_tiles(const double* U, double* G, int li, int lk) {
+  constexpr int8_t TI[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+  constexpr int8_t TJ[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+  constexpr int nq = WAVE < 3 ? 4 : 3;
+  d4 g[nq];
+#pragma unroll
+  for (int q = 0; q < nq; ++q) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int ib = TI[WAVE + 4 * q], jb = TJ[WAVE + 4 * q];
+    g[q] = tile_u_ut(U, ib, jb, li, lk);
+  }
+#pragma unroll
+  for (int q = 0; q < nq; ++q) {
+    const int ib = TI[WAVE + 4 * q], jb = TJ[WAVE + 4 * q];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      G[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = g[q][rr];
+      if (ib != jb) G[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = g[q][rr];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+               int m, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
+  double* Xn = Xc + MAT;                               // G_k -> stencil workspace -> D~_k+1 -> U_k+1
+  double* Y = Xn + MAT;                                // spike: F_k -> W -> T_k -> F_k+1; column 79 = right-hand side
+  double* cL = Y + MAT;                                // coupling tables of the current node
+  double* cR = cL + 9 * NP;
+  double* bv = cR + 9 * NP;                            // [80] right-hand side of the node built last
+  double* red = bv + BS;                               // [8]
+  int* sync = reinterpret_cast<int*>(red + 8);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const FteConst& K = *cst;
+  const int c = blockIdx.x;
+  const int first = c * m;
+  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
+  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const size_t MB = (size_t)BS * BS;
+  // stencil items of this thread: state sp_, rows / columns sc0 + 10 j
+  const int sp_ = tid % NP, sc0 = tid / NP;
+  const bool s_act = tid < 10 * NP;
+  int t01 = 0, t23 = 0, t123 = 0;           // rounds of the three wave-subset barriers (sync[0], [1], [2])
+#define SW_STAMP(i) do { if (ch.dbg && (long long)blockIdx.x == ch.dbg[29] && (long long)k == ch.dbg[30] && lane == 0) ch.dbg[i] = (long long)wall_clock64(); } while (0)
+  if (tid < 3) sync[tid] = 0;
+
+  {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
+    NodeFetch f;
+    build_fetch(f, ch, K, first, tid);
+    fill_coupling_coef(cL, cR, K, first, tid);
+    for (int e = tid; e < MAT; e += 256) Y[e] = 0.0;
+    const double gmax = build_finish(Xc, bv, f, K, first, tid);
+    publish_gmax(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
+    if (hasL)
+      for (int e = tid; e < 9 * NP; e += 256) {
+        const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
+        if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
+      }
+    if (tid < BS) Y[tid * LD + (BS - 1)] = bv[tid];
+    __syncthreads();
+    if (wave < 2) chol80_pair(Xc, wave, lane, numeric_err, sync, t01);
+    __syncthreads();
+  }
+
+#pragma unroll 1
+  for (int k = 0; k < n_int; ++k) {
+    const int node = first + k, next = node + 1;
+    const bool last = k + 1 == n_int;
+    const bool has_next = !last || hasR;
+    // ================= serial part: G_k, then the next node =================
+    NodeFetch f;
+    if (has_next) build_fetch(f, ch, K, next, tid);
+    if (wave == 0) SW_STAMP(0);
+    if (k > 0) fill_coupling_coef(cL, cR, K, node, tid);
+    {
+      const int gi = opaque(li), gk = opaque(lk);
+      if (wave == 0) gram_tiles<0>(Xc, Xn, gi, gk);
+      else if (wave == 1) gram_tiles<1>(Xc, Xn, gi, gk);
+      else if (wave == 2) gram_tiles<2>(Xc, Xn, gi, gk);
+      else gram_tiles<3>(Xc, Xn, gi, gk);
+    }
+    __syncthreads();                                   // G in Xn, tables of this node visible
+    if (wave == 0) SW_STAMP(1);
+    store_mat(ch.D + node * MB, Xn, tid);
+    if (has_next) {
+      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+      if (s_act) {
+        c00 = cR[(0 * 3 + 0) * NP + sp_];  c01 = cR[(0 * 3 + 1) * NP + sp_];  c02 = cR[(0 * 3 + 2) * NP + sp_];
+        c11 = cR[(1 * 3 + 1) * NP + sp_];  c12 = cR[(1 * 3 + 2) * NP + sp_];  c22 = cR[(2 * 3 + 2) * NP + sp_];
+      }
+      __syncthreads();                                 // the store above has read Xn
+      if (s_act) {                                     // pass 1: Xn <- G E, in place (rows sc0 + 10 j, state sp_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double* rowp = Xn + (sc0 + 10 * j) * LD + sp_;
+          const double g0 = rowp[0], g1 = rowp[NP], g2 = rowp[2 * NP];
+          rowp[0] = g0 * c00 + g1 * c01 + g2 * c02;
+          rowp[NP] = g1 * c11 + g2 * c12;
+          rowp[2 * NP] = g2 * c22;
+        }
+      }
+      __syncthreads();
+      double dv[8][3];
+      if (wave == 0) SW_STAMP(2);
+      if (s_act) {                                     // pass 2: dv = -E^T (G E) (columns sc0 + 10 j, state sp_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double* colp = Xn + sp_ * LD + sc0 + 10 * j;
+          const double t0 = colp[0], t1 = colp[NP * LD], t2 = colp[2 * NP * LD];
+          dv[j][0] = -(c00 * t0 + c01 * t1 + c02 * t2);
+          dv[j][1] = -(c11 * t1 + c12 * t2);
+          dv[j][2] = -(c22 * t2);
+        }
+      }
+      __syncthreads();                                 // pass-2 reads done: Xn may be rebuilt
+      if (wave == 0) SW_STAMP(3);
+      const double gmax = build_finish(Xn, bv, f, K, next, tid);
+      publish_gmax(gmax, red, ch.gn_part, next, tid);  // (barrier inside)
+      if (s_act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double* colp = Xn + sp_ * LD + sc0 + 10 * j;
+          colp[0] += dv[j][0];
+          colp[NP * LD] += dv[j][1];
+          colp[2 * NP * LD] += dv[j][2];
+        }
+      }
+    }
+    __syncthreads();
+    // ================= parallel part =================
+    // waves 0, 1: blocked Cholesky of the next node (pivot chains | panel and trailing tiles)
+    // waves 2, 3: spike algebra of this node on their 16-column strips; wave 1 joins for the final stores / stencil
+    if (wave < 2) {
+      if (!last) chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01);
+      if (wave == 0) SW_STAMP(5);
+    } else {
+      const int li = opaque(lane & 15), lk = opaque(lane >> 4);
+      if (hasL) {
+        // the left separator's update so far (HBM / L2, owned by this workgroup): requested now, needed after W
+        d4 accL[9];
+        double* Ag = opaque_ptr(sp.AL + (size_t)(c - 1) * MB);
+        if (wave == 2) {
+          syrk_load<1>(accL, Ag, k > 0, li, lk);
+          const int jbs[3] = {0, 1, 4};
+          strips_ut_f<3>(Xc, Y, jbs, li, lk);
+        } else {
+          syrk_load<0>(accL, Ag, k > 0, li, lk);
+          const int jbs[2] = {2, 3};
+          strips_ut_f<2>(Xc, Y, jbs, li, lk);
+        }
+        SW_STAMP(8 + 8 * (wave - 2));
+        sub_barrier(sync + 1, t23, 2, lane);           // every strip of W is in Y
+        SW_STAMP(9 + 8 * (wave - 2));
+        if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
+        else syrk_run<0>(accL, Y, Ag, li, lk);
+        SW_STAMP(10 + 8 * (wave - 2));
+        sub_barrier(sync + 1, t23, 2, lane);           // every read of W is done
+        SW_STAMP(11 + 8 * (wave - 2));
+        if (wave == 2) {
+          const int jbs[3] = {0, 1, 4};
+          strips_u_w<3>(Xc, Y, jbs, li, lk);
+        } else {
+          const int jbs[2] = {2, 3};
+          strips_u_w<2>(Xc, Y, jbs, li, lk);
+        }
+        SW_STAMP(12 + 8 * (wave - 2));
+      } else if (wave == 2) {                          // first run: only the right-hand side column is alive
+        const int jbs[1] = {4};
+        strips_ut_f<1>(Xc, Y, jbs, li, lk);
+        strips_u_w<1>(Xc, Y, jbs, li, lk);
+      }
+    }
+    if (wave >= 1) {
+      // ---- T_k is complete in Y: T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then
+      //      F_k+1 = -E^T T_k in place, column 79 += the next node's right-hand side.  Strips {0,1} | {2,3} | {4}.
+      if (wave == 1) SW_STAMP(20);
+      sub_barrier(sync + 2, t123, 3, lane);
+      if (wave == 1) SW_STAMP(21);
+      const int li = opaque(lane & 15), lk = opaque(lane >> 4);
+      const int w = wave - 1;
+      const int jb0 = 2 * w, njb = w == 2 ? 1 : 2;
+      if (hasL || w == 2) {
+        if (hasL) {
+          double* Tg = ch.Wl + node * MB;
+          for (int sidx = 0; sidx < njb; ++sidx) {
+            const int cbase = 16 * (jb0 + sidx);
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+              const int cc = cbase + j;
+              Tg[(size_t)cc * BS + lane] = Y[lane * LD + cc];
+              if (lane < 16) Tg[(size_t)cc * BS + 64 + lane] = Y[(64 + lane) * LD + cc];
+            }
+          }
+        }
+        if (w == 2) {
+          ch.b[(size_t)node * BS + lane] = Y[lane * LD + (BS - 1)];
+          if (lane < 16) ch.b[(size_t)node * BS + 64 + lane] = Y[(64 + lane) * LD + (BS - 1)];
+        }
+        if (has_next) {
+          for (int sidx = 0; sidx < njb; ++sidx) {
+            const int cc = 16 * (jb0 + sidx) + li;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+              const int p = lk + 4 * j;
+              if (p < NP) {
+                const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
+                const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
+                const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
+                double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
+                if (cc == BS - 1) {
+                  o0 += bv[p];
+                  o1 += bv[NP + p];
+                  o2 += bv[2 * NP + p];
+                }
+                Y[p * LD + cc] = o0;
+                Y[(NP + p) * LD + cc] = o1;
+                Y[(2 * NP + p) * LD + cc] = o2;
+              }
+            }
+            Y[(3 * NP + lk) * LD + cc] = 0.0;          // padding rows 75..78, 79: couple to nothing
+            if (lk == 0) Y[(BS - 1) * LD + cc] = 0.0;
+          }
+        }
+      }
+      if (wave == 1) SW_STAMP(22);
+    }
+    __syncthreads();
+    if (wave == 0) SW_STAMP(27);
+    if (last && hasR) {                                // the node built last is the right separator
+      store_mat(sp.D + (size_t)c * MB, Xn, tid);
+      if (tid < BS) sp.b[(size_t)c * BS + tid] = Y[tid * LD + (BS - 1)];
+      if (hasL) {
+        double* Cg = sp.Cpl + (size_t)(c - 1) * MB;    // block(R, L): rows R, columns L
+        for (int e = tid; e < BS * BS; e += 256) {
+          const int r = e / BS, cc = e % BS;
+          Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
+        }
+      }
+    }
+    double* tmp = Xc;
+    Xc = Xn;
+    Xn = tmp;
+  }
+}
+
+// Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  First form of the sweep:
+// b -= bl.  Second form: the right-hand side rides as column 79 of the spike, so row 79 of AL holds -(sum W^T y) and
+// rows / columns >= 75 of AL are not part of the Schur update.
+__global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __restrict__ status, int rhs_row) {
+  if (status && *status != 0) return;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const size_t MB = (size_t)BS * BS;
+  double* D = sp.D + q * MB;
+  const double* A = sp.AL + q * MB;
+  for (int e = tid; e < BS * BS; e += 256) {
+    const int r = e / BS, cc = e % BS;
+    if ((cc >> 4) <= (r >> 4) && (!rhs_row || (r < 3 * NP && cc < 3 * NP))) D[e] += A[e];
+  }
+  if (tid < BS) {
+    if (rhs_row) {
+      if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] += A[(size_t)(BS - 1) * BS + tid];
+    } else {
+      sp.b[(size_t)q * BS + tid] -= sp.bl[(size_t)q * BS + tid];
+    }
+  }
+}
+
+// One workgroup per run, right to left: x_k = z_k - G_k (E_r(k) x_k+1) - T_k x_L.  G_k is symmetric and T_k is stored
+// transposed, so thread (column r, third of the rows) reads consecutive addresses along a wave - no LDS staging; the next
+// node's operands are requested before the current node's sums are reduced.
+__global__ void __launch_bounds__(256)
+k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
+                int n_chunks) {
+  if (status && *status != 0) return;
+  __shared__ double xn[BS], xl[BS], vv[BS], ysc[3 * BS], cL[9 * NP], cR[9 * NP];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x, first = c * m;
+  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
+  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const size_t MB = (size_t)BS * BS;
+  const int col = tid % BS, part = tid / BS, c0 = 27 * part, nc = part < 2 ? 27 : 26;
+  if (tid < BS) {
+    xl[tid] = hasL ? sp.b[(size_t)(c - 1) * BS + tid] : 0.0;
+    const double xr = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
+    xn[tid] = xr;
+    if (hasR) ch.b[(size_t)(first + n_int) * BS + tid] = xr;      // the separator's solution joins the chain's vector
+  }
+  double g[27], t[27];
+  auto fetch = [&](int node) {
+    if (tid < 3 * BS) {
+      const double* G = ch.D + node * MB;
+      const double* Tt = ch.Wl + node * MB;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        g[k] = k < nc ? G[(size_t)(c0 + k) * BS + col] : 0.0;
+        t[k] = (hasL && k < nc) ? Tt[(size_t)(c0 + k) * BS + col] : 0.0;
+      }
+    }
+  };
+  fetch(first + n_int - 1);
+  for (int k = n_int - 1; k >= 0; --k) {
+    const int node = first + k;
+    fill_coupling_coef(cL, cR, *cst, node, tid);
+    const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
+    __syncthreads();                                   // tables, xn of the previous round
+    if (tid < BS) {
+      double v = 0.0;
+      if (tid < 3 * NP) {
+        const int a = tid / NP, p = tid % NP;
+        for (int ii = 0; ii <= a; ++ii) v += cR[(ii * 3 + a) * NP + p] * xn[ii * NP + p];   // (E_r x_k+1)[(a, p)]
+      }
+      vv[tid] = v;
+    }
+    __syncthreads();
+    if (tid < 3 * BS) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 27; ++kk) {
+        const int cc = c0 + (kk < nc ? kk : 0);
+        s0 += g[kk] * vv[cc];
+        s1 += t[kk] * xl[cc];
+      }
+      ysc[tid] = s0 + s1;
+    }
+    if (k > 0) fetch(node - 1);
+    __syncthreads();
+    if (tid < BS) {
+      const double x = zi - ((ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid]);
+      xn[tid] = x;
+      ch.b[(size_t)node * BS + tid] = x;
+    }
+  }
+}
+
+int chunk_set_func_attributes() {
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep2),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweep2Lds));
+  return ACINO_OK;
+}
+
+int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
+                 const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
+                 Profiler* prof) {
+  static const bool v1 = getenv("ACINO_SWEEP_V1") != nullptr;     // (debug: the first, fully serial form of the sweep)
+  {
+    ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
+    if (v1)
+      hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status,
+                         pl.m, pl.n_chunks);
+    else
+      hipLaunchKernelGGL(k_chunk_sweep2, dim3(pl.n_chunks), dim3(256), kSweep2Lds, s, ch, sp, d_c, d_numeric_err,
+                         d_status, pl.m, pl.n_chunks);
+  }
+  ACINO_LAUNCH_CHECK();
+  if (pl.n_sep == 0) return ACINO_OK;
+  {
+    ProfSpan span(prof, PC_SEP_COMBINE, s, pl.n_sep);
+    hipLaunchKernelGGL(k_sep_combine, dim3(pl.n_sep), dim3(256), 0, s, sp, d_status, v1 ? 0 : 1);
+  }
+  ACINO_LAUNCH_CHECK();
+  return bcr_reduce(sepch, sepsch, d_c, d_numeric_err, d_status, s, prof);
+}
+
+int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
+                  const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
+                  Profiler* prof) {
+  if (pl.n_sep > 0) {
+    int rc = bcr_backsub(sepch, sepsch, d_c, d_status, s, prof, d_numeric_err);
+    if (rc) return rc;
+  }
+  {
+    ProfSpan span(prof, PC_CHUNK_BACKSUB, s, pl.n_nodes - pl.n_sep);
+    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(256), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks);
+  }
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+
+}  // namespace acino

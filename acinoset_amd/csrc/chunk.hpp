@@ -1,0 +1,37 @@
+// Chunked substructuring of the block-tridiagonal Gauss-Newton chain (chunk.hip): host-side plan and entry points.
+#pragma once
+#include "bcr.hpp"
+
+namespace acino {
+
+// The chain of n_nodes super-blocks is cut into n_chunks runs of m consecutive nodes.  The LAST node of every run but
+// the final one is a SEPARATOR; the others are interior nodes, eliminated in order by one workgroup per run with all
+// operands resident in LDS.  The n_sep = n_chunks - 1 separators form a block-tridiagonal chain with dense couplings
+// that the block cyclic reduction (bcr.hip) solves.
+struct ChunkPlan {
+  int n_nodes = 0, m = 0, n_chunks = 0, n_sep = 0;
+  bool active() const { return n_chunks > 0; }
+  // chunk_nodes: nodes per run incl. its separator (>= 2); 0 = automatic; < 0 = no chunking (plain BCR)
+  void build(int nodes, int chunk_nodes);
+};
+
+// Separator-side buffers written by the sweep (device views, [n_sep] each).
+struct SepView {
+  double* D;    // [80][80] built node - (right end of the run on its left)          -> + AL by k_sep_combine
+  double* Cpl;  // [80][80] block(separator q + 1, separator q)
+  double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles   (aliases the chain's Wr)
+  double* b;    // [80]
+  double* bl;   // [80]     sum over the run on its right of F^T z
+};
+
+int chunk_set_func_attributes();
+// forward: sweep of every run + separator assembly + reduction of the separator chain
+int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
+                 const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
+                 Profiler* prof);
+// backward: separator chain back-substitution, then every run from its right end to its left end; x -> ch.b
+int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
+                  const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
+                  Profiler* prof);
+
+}  // namespace acino

@@ -5,6 +5,7 @@
 #include <new>
 
 #include "bcr.hpp"
+#include "chunk.hpp"
 
 namespace acino {
 
@@ -24,6 +25,8 @@ struct Buffers {
   int* numeric_err;
   int* sched;         // elim (3/entry), remain (4/entry), tail (4/entry), dropped-coupling pairs (2/entry), tail counter
   double* trunc_eps2; // [n_pairs + 1]
+  double* sep_bl;     // [n_sep][80] (chunked solver)
+  double* refine_buf; // [3][n_isolated][80] (incomplete reduction with refinement sweeps)
 };
 
 }  // namespace acino
@@ -32,8 +35,12 @@ struct acino_fte_ctx {
   double lam0;
   acino::FteConst h;
   acino::Buffers b;
-  acino::BcrChain chain;
-  acino::BcrSchedule sched;
+  acino::BcrChain chain;         // the chain of 3-frame nodes
+  acino::BcrSchedule sched;      // reduction schedule of `chain`, or - chunked solver - of the separator chain
+  acino::ChunkPlan plan;         // chunked solver (csrc/chunk.hip); inactive: block cyclic reduction over `chain`
+  acino::BcrChain sepchain;      // chunked solver: the runs' separators
+  acino::SepView sep;
+  int n_trunc = 0;               // dropped couplings of an incomplete reduction (of whichever chain `sched` reduces)
   const double* d_det;
   int n_blk_asm, n_blk_trial;
   size_t ws_bytes;
@@ -66,9 +73,24 @@ struct Carver {
   }
 };
 
-static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChain* ch, size_t sched_ints, size_t n_pairs) {
+static bool use_chunks(const acino_fte_params* p) { return !p->pin_left && !p->pin_right && p->chunk_nodes >= 0; }
+
+// Host-side layout of a context: the chunk plan and the reduction schedule (of the separator chain when chunked).
+struct Layout {
+  ChunkPlan plan;
+  BcrSchedule sched;
+  void build(const acino_fte_params* p) {
+    plan.build(chain_nodes(p), use_chunks(p) ? p->chunk_nodes : -1);
+    if (plan.active()) sched.build(plan.n_sep, false, false, p->bcr_levels, p->refine_sweeps);
+    else sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps);
+  }
+};
+
+static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChain* ch, const Layout& lay, BcrChain* sepch = nullptr) {
   Carver c{base, 0};
   const size_t N = p->n_frames, T = chain_nodes(p);
+  const size_t sched_ints = lay.sched.ints(), n_pairs = lay.sched.pairs.size() / 2;
+  const bool chunked = lay.plan.active();
   Buffers b;
   b.cst = c.take<FteConst>(1);
   b.state = c.take<acino_fte_state>(1);
@@ -85,13 +107,15 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.numeric_err = b.nbehind + 1;
   b.sched = c.take<int>(sched_ints);
   b.trunc_eps2 = c.take<double>(n_pairs + 1);
+  b.refine_buf = nullptr;
+  if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
   BcrChain chn;
   chn.n_nodes = (int)T;
-  chn.D = c.take<double>(T * BS * BS);
-  chn.U = c.take<double>(T * BS * BS);
-  chn.Cpl = c.take<double>(T * BS * BS);
-  chn.Wl = c.take<double>(T * BS * BS);
-  chn.Wr = c.take<double>(T * BS * BS);
+  chn.D = c.take<double>(T * BS * BS);                       // chunked: G_k of the interior nodes
+  chn.U = chunked ? nullptr : c.take<double>(T * BS * BS);
+  chn.Cpl = chunked ? nullptr : c.take<double>(T * BS * BS);
+  chn.Wl = c.take<double>(T * BS * BS);                      // chunked: T_k^T of the interior nodes
+  chn.Wr = chunked ? nullptr : c.take<double>(T * BS * BS);
   chn.b = c.take<double>(T * BS);
   chn.d_elim = nullptr;
   chn.d_remain = nullptr;
@@ -107,8 +131,26 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.g0 = b.g[0]; chn.g1 = b.g[1];
   chn.H0 = b.H[0]; chn.H1 = b.H[1];
   chn.gn_part = b.gn_part;
+  BcrChain sc = chn;
+  b.sep_bl = nullptr;
+  if (chunked) {
+    const size_t S = lay.plan.n_sep > 0 ? lay.plan.n_sep : 1;
+    sc.n_nodes = lay.plan.n_sep;
+    sc.D = c.take<double>(S * BS * BS);
+    sc.U = c.take<double>(S * BS * BS);
+    sc.Cpl = c.take<double>(S * BS * BS);
+    sc.Wl = c.take<double>(S * BS * BS);
+    sc.Wr = c.take<double>(S * BS * BS);
+    sc.b = c.take<double>(S * BS);
+    b.sep_bl = c.take<double>(S * BS);
+    sc.implicit_couplings = 0;      // dense couplings, plain (non-fused) kernels
+    sc.st = nullptr;
+    sc.x0 = sc.x1 = sc.g0 = sc.g1 = sc.H0 = sc.H1 = nullptr;
+    sc.gn_part = nullptr;
+  }
   if (out) *out = b;
   if (ch) *ch = chn;
+  if (sepch) *sepch = sc;
   return c.off;
 }
 
@@ -183,6 +225,7 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
          int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control,
          const double* __restrict__ trunc_eps2, int n_trunc) {
   if (st->status != 0) return;
+  int* numeric_err_rw = const_cast<int*>(numeric_err);
   // the four reductions run together: strided per-thread partials, one shuffle tree per wave, the sixteen waves
   // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
   // HBM round trips (one per stride), so the stride count is what it costs - 4 instead of 14 for 10 000 frames
@@ -191,7 +234,7 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
   // thread 0 will run the controller: its operands are requested now, beside the reductions
   acino_fte_state S;
   LmTol T{0, 0, 0, 0, 0};
-  int ne = 0, nb = 0;
+  int ne = 0, nb = 0, n_ref = 0;
   double e2 = 0.0, ttol = 0.0;
   if (threadIdx.x == 0) {
     S = *st;
@@ -199,6 +242,7 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     ne = *numeric_err;
     nb = *nbehind;
     ttol = cst->trunc_tol;
+    n_ref = cst->refine_sweeps;
     if (with_step)                       // incomplete reduction: the largest dropped coupling of this step's solve
       for (int i = 0; i < n_trunc; ++i) e2 = fmax(e2, trunc_eps2[i]);
   }
@@ -242,8 +286,19 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     *nbehind = 0;
     if (with_step && n_trunc > 0) {
       S.trunc_eps = sqrt(e2);
-      if (!(S.trunc_eps <= ttol)) ne |= 4;           // (also catches NaN)
-      if (fused_control < 0) st->trunc_eps = S.trunc_eps;
+      // what the step's relative error is bounded by: eps itself for the plain truncated solve, (2 eps)^(r+1) after r
+      // block-Jacobi sweeps over the dropped couplings (bcr.hip k_bcr_refine)
+      double bound = S.trunc_eps;
+      if (n_ref > 0) {
+        bound = 1.0;
+        for (int q = 0; q <= n_ref; ++q) bound *= 2.0 * S.trunc_eps;
+      }
+      if (!(bound <= ttol)) ne |= 4;                 // (also catches NaN)
+      if (fused_control < 0) {
+        // split-control path (window / separator drivers): k_control reads the DEVICE flag, so the refusal must be there
+        st->trunc_eps = S.trunc_eps;
+        if (ne & 4) atomicOr(numeric_err_rw, 4);
+      }
     }
     if (fused_control >= 0) {
       lm_control_local(T, S, tot, ne, fused_control);
@@ -485,6 +540,7 @@ static int fill_const(const acino_fte_params* p, const double* h_cams, FteConst*
   c->clamp_lambda = p->clamp_lambda;
   c->precision = p->precision;
   c->trunc_tol = p->trunc_tol > 0.0 ? p->trunc_tol : 1e-10;
+  c->refine_sweeps = p->refine_sweeps;
   c->own_lo = p->own_count > 0 ? p->own_first : 0;
   c->own_hi = p->own_count > 0 ? p->own_first + p->own_count : p->n_frames;
   memcpy(c->cams, h_cams, sizeof(double) * ACINO_CAM_STRIDE * p->n_cams);
@@ -501,6 +557,8 @@ static int validate(const acino_fte_params* p) {
   ACINO_REQUIRE(p->clip_len >= 0, "clip_len");
   ACINO_REQUIRE(p->precision >= ACINO_PREC_F64 && p->precision <= ACINO_PREC_BF16_RES, "precision");
   ACINO_REQUIRE(p->bcr_levels >= 0 && p->trunc_tol >= 0.0, "bcr_levels, trunc_tol");
+  ACINO_REQUIRE(p->chunk_nodes >= -1 && p->chunk_nodes != 1, "chunk_nodes: -1 (off), 0 (automatic) or >= 2");
+  ACINO_REQUIRE(p->refine_sweeps >= 0 && p->refine_sweeps <= 64, "refine_sweeps in 0..64");
   ACINO_REQUIRE(p->own_count >= 0 && (p->own_count == 0 || (p->own_first >= 0 && p->own_first + p->own_count <= p->n_frames &&
                                                            !p->pin_left && !p->pin_right && p->clip_len == 0)),
                 "own range must lie inside the window (and windows have no pinned separators / clips)");
@@ -534,7 +592,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1024), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
                        b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
-                       with_step ? 1 : 0, b.cst, b.numeric_err, fused_control, b.trunc_eps2, ctx->chain.n_pairs);
+                       with_step ? 1 : 0, b.cst, b.numeric_err, fused_control, b.trunc_eps2, ctx->n_trunc);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
@@ -544,9 +602,9 @@ extern "C" {
 
 size_t acino_fte_workspace_bytes(const acino_fte_params* p) {
   if (!p || p->n_frames < 1) return 0;
-  BcrSchedule sch;
-  sch.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels);
-  return carve(p, nullptr, nullptr, nullptr, sch.ints(), sch.pairs.size() / 2) + 256;
+  Layout lay;
+  lay.build(p);
+  return carve(p, nullptr, nullptr, nullptr, lay) + 256;
 }
 
 int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det, const double* d_cams24,
@@ -564,9 +622,11 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     return ACINO_ERR_INVALID_ARG;
   }
   ctx->lam0 = p->lam0;
-  ctx->sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels);
-  const size_t sched_ints = ctx->sched.ints();
-  const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, sched_ints, ctx->sched.pairs.size() / 2);
+  Layout lay;
+  lay.build(p);
+  const size_t need = carve(p, (char*)d_workspace, &ctx->b, &ctx->chain, lay, &ctx->sepchain);
+  ctx->plan = lay.plan;
+  ctx->sched = std::move(lay.sched);
   if (need > workspace_bytes) {
     set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     delete ctx;
@@ -612,25 +672,52 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     delete ctx;
     return ACINO_ERR_HIP;
   }
-  ctx->chain.d_elim = ctx->b.sched;
-  ctx->chain.d_remain = ctx->b.sched + ctx->sched.elim.size();
-  if (!ctx->sched.tail.empty() && !p->shared_gpu) {
-    ctx->chain.d_tail = ctx->chain.d_remain + ctx->sched.remain.size();
-    ctx->chain.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() +
-                        ctx->sched.pairs.size();
+  {
+    BcrChain& rc = ctx->plan.active() ? ctx->sepchain : ctx->chain;   // the chain the schedule reduces
+    rc.d_elim = ctx->b.sched;
+    rc.d_remain = ctx->b.sched + ctx->sched.elim.size();
+    if (!ctx->sched.tail.empty() && !p->shared_gpu) {
+      rc.d_tail = rc.d_remain + ctx->sched.remain.size();
+      rc.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() +
+                  ctx->sched.pairs.size();
+    }
+    if (!ctx->sched.pairs.empty()) {
+      rc.d_pairs = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
+      rc.n_pairs = (int)(ctx->sched.pairs.size() / 2);
+    }
+    ctx->n_trunc = rc.n_pairs;
+    rc.refine_buf = ctx->b.refine_buf;
   }
-  if (!ctx->sched.pairs.empty()) {
-    ctx->chain.d_pairs = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
-    ctx->chain.n_pairs = (int)(ctx->sched.pairs.size() / 2);
-  }
+  if (ctx->plan.active())
+    ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, ctx->sepchain.Wr, ctx->sepchain.b, ctx->b.sep_bl};
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
   rc = bcr_set_func_attributes();
+  if (!rc) rc = chunk_set_func_attributes();
   if (rc) {
     delete ctx;
     return rc;
   }
   *out = ctx;
+  return ACINO_OK;
+}
+
+// The linear solver's layout for these parameters: out[0] = nodes per run (0: block cyclic reduction over the whole chain),
+// out[1] = runs, out[2] = separators, out[3] = reduction levels of the chain that is reduced (separators or whole chain)
+// when nothing is truncated.
+int acino_fte_plan(const acino_fte_params* p, int32_t* out) {
+  ACINO_REQUIRE(p && out, "null");
+  int rc = validate(p);
+  if (rc) return rc;
+  acino_fte_params q = *p;
+  q.bcr_levels = 0;
+  q.refine_sweeps = 0;
+  Layout lay;
+  lay.build(&q);
+  out[0] = lay.plan.m;
+  out[1] = lay.plan.n_chunks;
+  out[2] = lay.plan.n_sep;
+  out[3] = (int32_t)lay.sched.levels.size();
   return ACINO_OK;
 }
 
@@ -759,7 +846,10 @@ int acino_fte_reduce_local(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
   hipStream_t s = (hipStream_t)stream;
   const Buffers& b = ctx->b;
-  // the damped system is built inside the level-0 BCR kernels (no separate set-up launch)
+  // the damped system is built inside the level-0 kernels (no separate set-up launch)
+  if (ctx->plan.active())
+    return chunk_reduce(ctx->chain, ctx->plan, ctx->sep, ctx->sepchain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s,
+                        &ctx->prof);
   return bcr_reduce(ctx->chain, ctx->sched, b.cst, b.numeric_err, &b.state->status, s, &ctx->prof);
 }
 
@@ -887,6 +977,9 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
                        d_sep_x + (size_t)rank * BS);
     ACINO_LAUNCH_CHECK();
   }
+  if (ctx->plan.active())
+    return chunk_backsub(ctx->chain, ctx->plan, ctx->sep, ctx->sepchain, ctx->sched, ctx->b.cst, ctx->b.numeric_err,
+                         &ctx->b.state->status, s, &ctx->prof);
   return bcr_backsub(ctx->chain, ctx->sched, ctx->b.cst, &ctx->b.state->status, s, &ctx->prof, ctx->b.numeric_err);
 }
 
@@ -1146,10 +1239,36 @@ int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_p
   return ACINO_OK;
 }
 
-// Debug: phase timestamps (100 MHz wall clock) of workgroup 0 of every k_bcr_elim launch go to d_dbg[16].
+// Debug: phase timestamps (100 MHz wall clock) of workgroup d_dbg[29] of the k_bcr_elim launch at level d_dbg[30] go to
+// d_dbg[0..28] (a caller buffer of 32 entries).
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
   ACINO_REQUIRE(ctx, "null");
   ctx->chain.dbg = d_dbg;
+  return ACINO_OK;
+}
+
+// Debug / test aid: copies an internal buffer to d_out (at most n doubles).  what: 0 chain.b (step per node), 1 sep.D,
+// 2 sep.b, 3 sep.Cpl, 4 sep.AL, 5 sep.bl, 6 chain.D (G of the interior nodes), 7 chain.Wl (T^T of the interior nodes).
+int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream) {
+  ACINO_REQUIRE(ctx && d_out && n >= 0, "args");
+  const size_t MB = (size_t)BS * BS;
+  const size_t T = ctx->chain.n_nodes, S = ctx->plan.active() ? (size_t)ctx->plan.n_sep : 0;
+  const double* src = nullptr;
+  size_t cnt = 0;
+  switch (what) {
+    case 0: src = ctx->chain.b; cnt = T * BS; break;
+    case 1: src = ctx->sepchain.D; cnt = S * MB; break;
+    case 2: src = ctx->sepchain.b; cnt = S * BS; break;
+    case 3: src = ctx->sepchain.Cpl; cnt = S * MB; break;
+    case 4: src = ctx->sepchain.Wr; cnt = S * MB; break;
+    case 5: src = ctx->b.sep_bl; cnt = S * BS; break;
+    case 6: src = ctx->chain.D; cnt = T * MB; break;
+    case 7: src = ctx->chain.Wl; cnt = T * MB; break;
+    default: ACINO_REQUIRE(false, "what");
+  }
+  if ((size_t)n < cnt) cnt = (size_t)n;
+  if (cnt == 0 || !src) return ACINO_OK;
+  ACINO_HIP_CHECK(hipMemcpyAsync(d_out, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return ACINO_OK;
 }
 

@@ -40,6 +40,8 @@ struct FteConst {
   int64_t clip_len;        // > 0: independent clips of this many frames laid end to end (no coupling across clips)
   int32_t own_lo, own_hi;  // local frames [own_lo, own_hi) count towards cost / pred / step / gradient norms (window sharding)
   double trunc_tol;        // incomplete reduction: largest admissible eps of a dropped coupling (status 7 above it)
+  int32_t refine_sweeps;   // block-Jacobi sweeps after the truncated solve: the admissible quantity becomes (2 eps)^(r+1)
+  int32_t pad2;
   Cam cams[ACINO_MAX_CAMS];
 };
 
@@ -67,9 +69,10 @@ __host__ __device__ inline double band_coef_clip(int64_t n, int k, int64_t ng, i
 // Per-kernel-class HIP-event profiler (bench.py's live roofline measurement).  Events are recorded on
 // the stream the kernels are launched on; nothing is recorded unless enabled.
 // one class per kernel: {elim, elim_deep, update0, update, update_deep, backsub0, backsub, trial, assemble, totals,
-// control, backsub_tail, trunc_check}; `units` = chain nodes (BCR kernels) or frames (trial / assemble) the launch processed
+// control, backsub_tail, trunc_check, chunk_sweep, sep_combine, chunk_backsub, refine}; `units` = chain nodes (BCR kernels) or frames (trial / assemble) the launch processed
 enum ProfClass { PC_ELIM = 0, PC_ELIM_DEEP, PC_UPDATE0, PC_UPDATE, PC_UPDATE_DEEP, PC_BACKSUB0, PC_BACKSUB, PC_TRIAL,
-                 PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_BACKSUB_TAIL, PC_TRUNC_CHECK, PC_COUNT };
+                 PC_ASSEMBLE, PC_TOTALS, PC_CONTROL, PC_BACKSUB_TAIL, PC_TRUNC_CHECK, PC_CHUNK_SWEEP, PC_SEP_COMBINE,
+                 PC_CHUNK_BACKSUB, PC_REFINE, PC_COUNT };
 static_assert(PC_COUNT == ACINO_PROF_CLASSES, "profiler classes");
 struct Profiler {
   bool on = false;

@@ -54,7 +54,7 @@ def bounds45():
 def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, redesc=REDESC, lam0=1e-3,
                 ftol=1e-10, xtol=1e-10, gtol=1e-8, n_global=None, n_offset=0, pin_left=False, pin_right=False,
                 lam_max=1e16, clamp_lambda=False, shared_gpu=False, clip_len=0, precision="f64", bcr_levels=0,
-                trunc_tol=1e-10, own_first=0, own_count=0):
+                trunc_tol=1e-10, own_first=0, own_count=0, chunk_nodes=0, refine_sweeps=0):
     p = FteParams()
     p.n_frames, p.n_cams = int(n_frames), int(n_cams)
     p.n_global = int(n_frames if n_global is None else n_global)
@@ -83,15 +83,26 @@ def make_params(n_frames, n_cams, Ts, dlc_thresh=0.5, r_meas=R_MEAS, Q=None, red
     p.precision = PRECISIONS[precision]
     p.bcr_levels, p.trunc_tol = int(bcr_levels), float(trunc_tol)
     p.own_first, p.own_count = int(own_first), int(own_count)
+    p.chunk_nodes, p.refine_sweeps = int(chunk_nodes), int(refine_sweeps)
     return p
 
 
-def auto_bcr_levels(n_frames, min_distance_frames=384):
-    """Smallest K with 3 * 2^K >= min_distance_frames, or 0 (complete reduction) when the chain has no level beyond it."""
-    K = 0
-    while 3 * 2 ** K < min_distance_frames:
+def solver_plan(params):
+    """Layout the library chooses for these parameters (acino_fte_plan): nodes per run of the chunked solver (0: block
+    cyclic reduction over the whole chain), runs, separators, reduction levels of the reduced chain."""
+    out = (C.c_int32 * 4)()
+    check(lib().acino_fte_plan(C.byref(params), out))
+    return dict(m=int(out[0]), n_chunks=int(out[1]), n_sep=int(out[2]), levels=int(out[3]))
+
+
+def auto_bcr_levels(params, min_distance_frames=384):
+    """Smallest K >= 1 after which the nodes that remain are >= min_distance_frames apart (3 * m * 2^K frames, m = nodes
+    per run of the chunked solver, 1 without it), or 0 (complete reduction) when the chain has no level beyond it."""
+    plan = solver_plan(params)
+    K = 1
+    while 3 * max(plan["m"], 1) * 2 ** K < min_distance_frames:
         K += 1
-    return K if (n_frames + 2) // 3 > 2 ** (K + 1) else 0
+    return K if K < plan["levels"] else 0
 
 
 class FTEContext:
@@ -109,11 +120,18 @@ class FTEContext:
         self.cams = torch.as_tensor(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
         if self.cams.shape[0] != self.C:
             raise ValueError("camera count mismatch between det and the rig")
-        if kw.get("bcr_levels") == "auto":
-            # incomplete reduction where the chain is long enough to have levels beyond a node distance of 384 frames
-            # (eps ~1e-11 on the benchmark sequence; verified on the device every iteration, status 7 otherwise)
-            kw = dict(kw, bcr_levels=auto_bcr_levels(self.N))
+        auto = kw.get("bcr_levels") == "auto"
+        if auto:
+            # incomplete reduction where the chain is long enough to have levels beyond a node distance of
+            # `trunc_distance` frames (384: eps ~1e-11 on the benchmark sequence; verified on the device every iteration,
+            # status 7 otherwise)
+            kw = dict(kw, bcr_levels=0)
+        dist = kw.pop("trunc_distance", 384)
         self.params = make_params(self.N, self.C, Ts, **kw)
+        if auto:
+            self.params.bcr_levels = auto_bcr_levels(self.params, dist)
+            if self.params.bcr_levels == 0:
+                self.params.refine_sweeps = 0
         nbytes = lib().acino_fte_workspace_bytes(C.byref(self.params))
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         if os.environ.get("ACINO_POISON_WORKSPACE"):      # debug: every read-before-write of the workspace becomes a NaN
@@ -181,11 +199,12 @@ class FTEContext:
         return x, pos, dx, ddx
 
     PROF_CLASSES = ("elim", "elim_deep", "update0", "update", "update_deep", "backsub0", "backsub", "trial", "assemble",
-                    "totals", "control", "backsub_tail", "trunc_check")
+                    "totals", "control", "backsub_tail", "trunc_check", "chunk_sweep", "sep_combine", "chunk_backsub", "refine")
     PROF_KERNELS = dict(elim="k_bcr_elim", elim_deep="k_bcr_elim_deep", update0="k_bcr_update0", update="k_bcr_update",
                         update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
                         backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true, 0>", totals="k_totals", control="k_control",
-                        trunc_check="k_bcr_trunc_check")
+                        trunc_check="k_bcr_trunc_check", chunk_sweep="k_chunk_sweep", sep_combine="k_sep_combine",
+                        chunk_backsub="k_chunk_backsub", refine="k_bcr_refine")
 
     def profile_begin(self):
         check(lib().acino_fte_profile_begin(self._h))
@@ -301,9 +320,8 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
     if np.any(x0[:, inactive] != 0):
         raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
-    if kw.get("bcr_levels") == "auto":
-        kw = dict(kw, bcr_levels=auto_bcr_levels(int(det.shape[0])))
     ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+    kw.pop("trunc_distance", None)
     try:
         ctx.set_x(x0[:, ACTIVE])
         info = ctx.solve(max_iter)
@@ -312,9 +330,12 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
             # incomplete reduction whose dropped couplings exceeded trunc_tol: the rejected step was never applied.
             # Continue from the current iterate with one more level (a complete reduction once the chain is exhausted).
             done = info["iter"]
-            kw = dict(kw, bcr_levels=kw.get("bcr_levels", 0) + 1)
-            if 3 * 2 ** kw["bcr_levels"] >= det.shape[0]:
-                kw["bcr_levels"] = 0
+            levels = int(ctx.params.bcr_levels) + 1
+            if levels >= solver_plan(ctx.params)["levels"]:
+                levels = 0
+            kw = dict(kw, bcr_levels=levels)
+            if levels == 0:
+                kw["refine_sweeps"] = 0
             ctx.close()
             ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
             ctx.set_x(x)

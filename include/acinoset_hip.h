@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ACINO_ABI_VERSION 1
+#define ACINO_ABI_VERSION 2   /* 2: acino_fte_params grew (chunk_nodes, refine_sweeps), 17 profiler classes, status 5-7 / numeric_err bit mask, d_dbg[32] */
 
 typedef enum acino_status {
   ACINO_OK = 0,
@@ -168,6 +168,16 @@ typedef struct acino_fte_params {
                             * [own_first, own_first + own_count) are owned: the whole window is assembled and solved
                             * (frames outside it keep delta = 0), but cost, predicted reduction, step and gradient norms
                             * count owned frames only.  own_count = 0 (default): every frame is owned. */
+  int32_t chunk_nodes;     /* linear solver of single-GPU contexts (no pinned separators).  0 (default): chunked
+                            * substructuring (csrc/chunk.hip) - the chain of 3-frame nodes is cut into runs of an
+                            * automatically chosen length, one workgroup eliminates the interior nodes of a run in order
+                            * with every operand in LDS, block cyclic reduction solves the chain of the runs' separators.
+                            * m >= 2: the same with m nodes per run (m - 1 interior + 1 separator).  -1: block cyclic
+                            * reduction over the whole chain (the round-1/2 solver).  With chunking, bcr_levels counts
+                            * reduction levels of the SEPARATOR chain. */
+  int32_t refine_sweeps;   /* incomplete reduction (bcr_levels > 0): block-Jacobi sweeps that re-introduce the dropped
+                            * couplings after the truncated solve (0 = none).  r sweeps leave a relative energy-norm error
+                            * <= (2 eps)^(r+1) / (1 - 2 eps); that bound - not eps itself - is what trunc_tol is compared with. */
 } acino_fte_params;
 #define ACINO_PREC_F64 0
 #define ACINO_PREC_BF16_ROWS 1
@@ -201,6 +211,11 @@ size_t acino_fte_workspace_bytes(const acino_fte_params* p);
 int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const double* d_det,
                      const double* d_cams24, void* d_workspace, size_t workspace_bytes, void* stream);
 int acino_fte_destroy(acino_fte_ctx* ctx);
+/* Layout the linear solver chooses for these parameters: out[0] = nodes per run of the chunked solver (0: block cyclic
+ * reduction over the whole chain), out[1] = runs, out[2] = separators, out[3] = reduction levels of the reduced chain
+ * (the separators, or the whole chain) when nothing is truncated.  A caller that wants an incomplete reduction picks
+ * bcr_levels from the node distance it implies: 3 * max(out[0], 1) * 2^bcr_levels frames. */
+int acino_fte_plan(const acino_fte_params* p, int32_t* out);
 /* Loads the initial iterate (d_x0[N][25], clipped to the bounds), restarts the LM controller and evaluates
  * cost / gradient / Gauss-Newton blocks.  = load_x + eval(0) + control(NULL, init=1). */
 int acino_fte_set_x(acino_fte_ctx* ctx, const double* d_x0, void* stream);
@@ -237,11 +252,17 @@ int acino_fte_cost(acino_fte_ctx* ctx, const double* d_x, double* d_cost, void* 
 int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* stream);
 /* Live per-kernel timing for bench.py: HIP events recorded on the launch stream around every kernel between
  * begin and end.  end synchronises and returns, per class {elim, elim_deep, update0, update, update_deep, backsub0,
- * backsub, trial, assemble, totals, control, backsub_tail, trunc_check} (one class per kernel), the summed event time in ms, the launch
+ * backsub, trial, assemble, totals, control, backsub_tail, trunc_check, chunk_sweep, sep_combine, chunk_backsub, refine} (one class per kernel), the summed event time in ms, the launch
  * count and the work units (chain nodes for the block-reduction kernels, frames for trial/assemble; may be NULL). */
-#define ACINO_PROF_CLASSES 13
+#define ACINO_PROF_CLASSES 17
 int acino_fte_profile_begin(acino_fte_ctx* ctx);
-/* Debug aid: phase timestamps (wall_clock64 ticks) of workgroup 0 of the elimination kernel -> d_dbg[16]; NULL disables. */
+/* Test aid: copies an internal buffer of the linear solver to d_out (at most n doubles).  what: 0 = the solution vector
+ * per 3-frame node [n_nodes][80] (after acino_fte_backsub_local), 1..5 = separator-side buffers of the chunked solver
+ * (D, b, coupling blocks, left-run contributions), 6 / 7 = G_k and T_k^T of the interior nodes. */
+int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream);
+/* Debug aid: phase timestamps (wall_clock64 ticks) of ONE workgroup of the elimination kernel -> d_dbg[0..28] of a
+ * caller buffer of 32 entries; the caller sets d_dbg[29] = workgroup index and d_dbg[30] = reduction level to stamp
+ * (read by every launch while enabled).  NULL disables. */
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);
 int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, int64_t* units_by_class,
                           void* stream);

@@ -1,0 +1,34 @@
+"""Phase stamps (100 MHz wall clock) of one workgroup / one node of the chunk sweep.  usage: sweep_stamps.py [wg] [k]"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from acinoset_amd import fte, synth
+from acinoset_amd._lib import check, lib, ptr, stream_ptr
+wg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+kk = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+seq = synth.make_sequence(10000, "loop")
+rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+det = torch.as_tensor(seq["det"], device="cuda")
+x0 = fte.triangulation_init(det, *rig, 0.5)[:, fte.ACTIVE]
+c = fte.FTEContext(det, *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+c.set_x(x0)
+for _ in range(3):
+    c.step()
+dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
+dbg[29] = wg
+dbg[30] = kk
+check(lib().acino_fte_debug_stamps(c._h, ptr(dbg)))
+c.step()
+torch.cuda.synchronize()
+d = dbg.cpu().numpy()
+check(lib().acino_fte_debug_stamps(c._h, None))
+c.close()
+t0 = d[0]
+names = {0: "iter start", 1: "G in LDS", 2: "G stored + pass 1", 3: "pass 2", 4: "node built (parallel part starts)", 5: "wave0: chol80 done",
+         8: "w2: W strips", 9: "w2: barrier 1", 10: "w2: syrk", 11: "w2: barrier 2", 12: "w2: T strips",
+         16: "w3: W strips", 17: "w3: barrier 1", 18: "w3: syrk", 19: "w3: barrier 2", 20: "w1: at tail barrier", 21: "w1: tail barrier passed",
+         22: "w1: tail done", 27: "end of node"}
+for i in sorted(names, key=lambda i: d[i]):
+    if d[i]:
+        print(f"{(d[i] - t0) / 100.0:8.2f} us  {names[i]}")
