@@ -966,7 +966,7 @@ k_bcr_trunc_check(BcrChain ch, const int* __restrict__ status) {
 // to_chain: the new iterate also goes to ch.b (only legal when src != nullptr: nobody reads ch.b then).
 __global__ void __launch_bounds__(256)
 k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* __restrict__ src, double* __restrict__ dst,
-             double* __restrict__ x0, int to_chain, const int* __restrict__ status) {
+             double* __restrict__ x0, int to_chain, double* __restrict__ norms, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Ml = reinterpret_cast<double*>(smem_raw);
@@ -1019,10 +1019,16 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
   }
   __syncthreads();
   const int row = tid % BS, pr = tid / BS, k0 = 27 * pr, k1 = min(k0 + 27, BS);
-  if (tid < 3 * BS) {             // t = block(j, l) x_l + block(j, r) x_r
-    double s = 0.0;
-    for (int k = k0; k < k1; ++k) s += Ml[row * LD + k] * xl[k] + Mr[k * LD + row] * xr[k];
-    part[tid] = s;
+  if (tid < 3 * BS) {             // t = block(j, l) x_l + block(j, r) x_r  (fixed trip count: the LDS reads pipeline)
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const int k = k0 + (k0 + q < k1 ? q : 0);
+      const double w = k0 + q < k1 ? 1.0 : 0.0;
+      s0 += w * Ml[row * LD + k] * xl[k];
+      s1 += w * Mr[k * LD + row] * xr[k];
+    }
+    part[tid] = s0 + s1;
   }
   __syncthreads();
   if (tid < BS) tv[tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];
@@ -1030,7 +1036,12 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
   if (tid < 3 * BS) {             // w = U^T t  (U upper triangular: rows <= column)
     double s = 0.0;
     const int c1 = min(k1, row + 1);
-    for (int k = k0; k < c1; ++k) s += Mu[k * LD + row] * tv[k];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const bool on = k0 + q < c1;
+      const int k = k0 + (on ? q : 0);
+      s += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+    }
     part[tid] = s;
   }
   __syncthreads();
@@ -1038,14 +1049,40 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
   __syncthreads();
   if (tid < 3 * BS) {             // d = U w
     double s = 0.0;
-    for (int k = max(k0, row); k < k1; ++k) s += Mu[row * LD + k] * xl[k];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const bool on = k0 + q >= row && k0 + q < k1;
+      const int k = on ? k0 + q : row;
+      s += (on ? 1.0 : 0.0) * Mu[row * LD + k] * xl[k];
+    }
     part[tid] = s;
   }
   __syncthreads();
+  double dabs = 0.0, xabs = 0.0;
   if (tid < BS) {
     const double x = xj0 - ((part[tid] + part[BS + tid]) + part[2 * BS + tid]);
     dst[(size_t)p * BS + tid] = x;
     if (to_chain) ch.b[(size_t)j * BS + tid] = x;
+    // size of this sweep's update of the node (against its own previous value) and of the solution
+    const double xprev = src ? src[(size_t)p * BS + tid] : xj0;
+    dabs = fabs(x - xprev);
+    xabs = fabs(x);
+  }
+  if (norms) {                    // (waves 0 and 1 hold the 80 rows)
+    for (int off = 32; off > 0; off >>= 1) {
+      dabs = fmax(dabs, __shfl_down(dabs, off, 64));
+      xabs = fmax(xabs, __shfl_down(xabs, off, 64));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0 && tid < 128) {
+      part[2 * (tid >> 6)] = dabs;
+      part[2 * (tid >> 6) + 1] = xabs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      norms[p] = fmax(part[0], part[2]);
+      norms[n_iso + p] = fmax(part[1], part[3]);
+    }
   }
 }
 __global__ void k_bcr_refine_copy(BcrChain ch, const int* __restrict__ iso, const double* __restrict__ src,
@@ -1272,7 +1309,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     }
     ++level;
   }
-  if (!sch.pairs.empty() && ch.d_pairs && ch.trunc_eps2) {
+  if (!sch.pairs.empty() && ch.d_pairs && ch.trunc_eps2 && sch.refine == 0) {
     ProfSpan sp(prof, PC_TRUNC_CHECK, s, (long long)sch.pairs.size() / 2);
     hipLaunchKernelGGL(k_bcr_trunc_check, dim3((unsigned)(sch.pairs.size() / 2)), dim3(256), kTruncCheckLds, s, ch,
                        d_status);
@@ -1298,8 +1335,13 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     for (int sw = 0; sw < sch.refine; ++sw) {
       const bool last = sw + 1 == sch.refine;
       ProfSpan sp(prof, PC_REFINE, s, lv.n_elim);
+      // the last two sweeps record max |update| (and max |x|) per node: k_totals turns them into the bound on the error
+      // trunc_eps2 layout with refinement, n = isolated nodes: [0, n) |update| and [n, 2n) |x| of the last sweep,
+      // [2n, 3n) |update| and [3n, 4n) |x| of the sweep before it
+      double* norms = last ? ch.trunc_eps2 : (sw + 2 == sch.refine ? ch.trunc_eps2 + 2 * (size_t)lv.n_elim : (double*)nullptr);
       hipLaunchKernelGGL(k_bcr_refine, dim3(lv.n_elim), dim3(256), kBacksubTailLds, s, ch, iso, lv.n_elim,
-                         sw == 0 ? (const double*)nullptr : it[(sw - 1) & 1], it[sw & 1], x0, (last && sw > 0) ? 1 : 0, d_status);
+                         sw == 0 ? (const double*)nullptr : it[(sw - 1) & 1], it[sw & 1], x0, (last && sw > 0) ? 1 : 0, norms,
+                         d_status);
       ACINO_LAUNCH_CHECK();
     }
     if (sch.refine == 1) {      // (a single sweep reads its neighbours from ch.b: the result goes there afterwards)

@@ -691,7 +691,7 @@ __device__ __forceinline__ void gram_tiles(const double* U, double* G, int li, i
 
 __global__ void __launch_bounds__(256)
 k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
-               int m, int n_chunks) {
+               int m, int n_chunks, int skip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
@@ -753,7 +753,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     }
     __syncthreads();                                   // G in Xn, tables of this node visible
     if (wave == 0) SW_STAMP(1);
-    store_mat(ch.D + node * MB, Xn, tid);
+    if (!(skip & 16)) store_mat(ch.D + node * MB, Xn, tid);
     if (has_next) {
       double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
       if (s_act) {
@@ -803,7 +803,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     // waves 0, 1: blocked Cholesky of the next node (pivot chains | panel and trailing tiles)
     // waves 2, 3: spike algebra of this node on their 16-column strips; wave 1 joins for the final stores / stencil
     if (wave < 2) {
-      if (!last) chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01);
+      if (!last && !(skip & 1)) chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01);
       if (wave == 0) SW_STAMP(5);
     } else {
       const int li = opaque(lane & 15), lk = opaque(lane >> 4);
@@ -812,19 +812,21 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         d4 accL[9];
         double* Ag = opaque_ptr(sp.AL + (size_t)(c - 1) * MB);
         if (wave == 2) {
-          syrk_load<1>(accL, Ag, k > 0, li, lk);
+          if (!(skip & 2)) syrk_load<1>(accL, Ag, k > 0, li, lk);
           const int jbs[3] = {0, 1, 4};
           strips_ut_f<3>(Xc, Y, jbs, li, lk);
         } else {
-          syrk_load<0>(accL, Ag, k > 0, li, lk);
+          if (!(skip & 2)) syrk_load<0>(accL, Ag, k > 0, li, lk);
           const int jbs[2] = {2, 3};
           strips_ut_f<2>(Xc, Y, jbs, li, lk);
         }
         SW_STAMP(8 + 8 * (wave - 2));
         sub_barrier(sync + 1, t23, 2, lane);           // every strip of W is in Y
         SW_STAMP(9 + 8 * (wave - 2));
-        if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
-        else syrk_run<0>(accL, Y, Ag, li, lk);
+        if (!(skip & 2)) {
+          if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
+          else syrk_run<0>(accL, Y, Ag, li, lk);
+        }
         SW_STAMP(10 + 8 * (wave - 2));
         sub_barrier(sync + 1, t23, 2, lane);           // every read of W is done
         SW_STAMP(11 + 8 * (wave - 2));
@@ -852,7 +854,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       const int w = wave - 1;
       const int jb0 = 2 * w, njb = w == 2 ? 1 : 2;
       if (hasL || w == 2) {
-        if (hasL) {
+        if (hasL && !(skip & 4)) {
           double* Tg = ch.Wl + node * MB;
           for (int sidx = 0; sidx < njb; ++sidx) {
             const int cbase = 16 * (jb0 + sidx);
@@ -864,7 +866,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
             }
           }
         }
-        if (w == 2) {
+        if (w == 2 && !(skip & 8)) {
           ch.b[(size_t)node * BS + lane] = Y[lane * LD + (BS - 1)];
           if (lane < 16) ch.b[(size_t)node * BS + 64 + lane] = Y[(64 + lane) * LD + (BS - 1)];
         }
@@ -1023,7 +1025,7 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
                          pl.m, pl.n_chunks);
     else
       hipLaunchKernelGGL(k_chunk_sweep2, dim3(pl.n_chunks), dim3(256), kSweep2Lds, s, ch, sp, d_c, d_numeric_err,
-                         d_status, pl.m, pl.n_chunks);
+                         d_status, pl.m, pl.n_chunks, getenv("ACINO_SWEEP_SKIP") ? atoi(getenv("ACINO_SWEEP_SKIP")) : 0);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;

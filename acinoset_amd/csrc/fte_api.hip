@@ -106,7 +106,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.nbehind = c.take<int>(4);
   b.numeric_err = b.nbehind + 1;
   b.sched = c.take<int>(sched_ints);
-  b.trunc_eps2 = c.take<double>(n_pairs + 1);
+  b.trunc_eps2 = c.take<double>(4 * (n_pairs + 1) + 1);   // (refinement: four [n_isolated] arrays of sweep norms)
   b.refine_buf = nullptr;
   if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
   BcrChain chn;
@@ -230,12 +230,12 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
   // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
   // HBM round trips (one per stride), so the stride count is what it costs - 4 instead of 14 for 10 000 frames
   constexpr int NW = 16;
-  __shared__ double sh[NW][4];
+  __shared__ double sh[NW][8];
   // thread 0 will run the controller: its operands are requested now, beside the reductions
   acino_fte_state S;
   LmTol T{0, 0, 0, 0, 0};
   int ne = 0, nb = 0, n_ref = 0;
-  double e2 = 0.0, ttol = 0.0;
+  double e2 = 0.0, ttol = 0.0, r_d1 = 0.0, r_d0 = 0.0, r_x = 0.0;
   if (threadIdx.x == 0) {
     S = *st;
     T = LmTol{cst->gtol, cst->ftol, cst->xtol, cst->lam_max, cst->clamp_lambda};
@@ -243,10 +243,22 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     nb = *nbehind;
     ttol = cst->trunc_tol;
     n_ref = cst->refine_sweeps;
-    if (with_step)                       // incomplete reduction: the largest dropped coupling of this step's solve
-      for (int i = 0; i < n_trunc; ++i) e2 = fmax(e2, trunc_eps2[i]);
   }
   double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
+  // incomplete reduction: plain truncation -> the largest dropped coupling (eps^2) of this step's solve; with refinement
+  // sweeps -> max |update| of the last sweep (r_d1) and of the one before (r_d0), max |x| (r_x); strided like the sums
+  if (with_step && n_trunc > 0) {
+    if (cst->refine_sweeps > 0) {
+      const int n_iso = n_trunc + 1;
+      for (int i = threadIdx.x; i < n_iso; i += 64 * NW) {
+        r_d1 = fmax(r_d1, trunc_eps2[i]);
+        r_x = fmax(r_x, trunc_eps2[n_iso + i]);
+        r_d0 = fmax(r_d0, trunc_eps2[2 * n_iso + i]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < n_trunc; i += 64 * NW) e2 = fmax(e2, trunc_eps2[i]);
+    }
+  }
   for (int i = threadIdx.x; i < n_cost; i += 64 * NW) c += cost_part[i];
   if (with_step) {
     for (int i = threadIdx.x; i < n_trial; i += 64 * NW) {
@@ -260,6 +272,10 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     p += __shfl_down(p, off, 64);
     s = fmax(s, __shfl_down(s, off, 64));
     g = fmax(g, __shfl_down(g, off, 64));
+    e2 = fmax(e2, __shfl_down(e2, off, 64));
+    r_d1 = fmax(r_d1, __shfl_down(r_d1, off, 64));
+    r_d0 = fmax(r_d0, __shfl_down(r_d0, off, 64));
+    r_x = fmax(r_x, __shfl_down(r_x, off, 64));
   }
   if ((threadIdx.x & 63) == 0) {
     double* w = sh[threadIdx.x >> 6];
@@ -267,6 +283,10 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     w[1] = p;
     w[2] = s;
     w[3] = g;
+    w[4] = e2;
+    w[5] = r_d1;
+    w[6] = r_d0;
+    w[7] = r_x;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -279,19 +299,28 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
       p += sh[w][1];
       s = fmax(s, sh[w][2]);
       g = fmax(g, sh[w][3]);
+      e2 = fmax(e2, sh[w][4]);
+      r_d1 = fmax(r_d1, sh[w][5]);
+      r_d0 = fmax(r_d0, sh[w][6]);
+      r_x = fmax(r_x, sh[w][7]);
     }
     const double tot[8] = {c, p, s, g, (double)nb, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 8; ++q) totals[q] = tot[q];
     *nbehind = 0;
     if (with_step && n_trunc > 0) {
-      S.trunc_eps = sqrt(e2);
-      // what the step's relative error is bounded by: eps itself for the plain truncated solve, (2 eps)^(r+1) after r
-      // block-Jacobi sweeps over the dropped couplings (bcr.hip k_bcr_refine)
-      double bound = S.trunc_eps;
+      // what the step's relative error is bounded by.  Plain truncation: eps, the measured size of the dropped couplings.
+      // With r block-Jacobi sweeps over them (bcr.hip k_bcr_refine): the iteration contracts by rho <= 2 eps per sweep, so
+      // the error left after the last sweep is <= rho / (1 - rho) |last update|; rho is measured as the ratio of the last
+      // two updates (one sweep only: rho = 1/2 assumed), and a rho above 1/2 refuses the step.
+      double bound;
       if (n_ref > 0) {
-        bound = 1.0;
-        for (int q = 0; q <= n_ref; ++q) bound *= 2.0 * S.trunc_eps;
+        const double rho = n_ref >= 2 ? (r_d0 > 0.0 ? r_d1 / r_d0 : 0.0) : 0.5;
+        bound = (rho <= 0.5 && r_x > 0.0) ? rho / (1.0 - rho) * r_d1 / r_x : (r_d1 == 0.0 ? 0.0 : 1.0);
+        S.trunc_eps = bound;
+      } else {
+        S.trunc_eps = sqrt(e2);
+        bound = S.trunc_eps;
       }
       if (!(bound <= ttol)) ne |= 4;                 // (also catches NaN)
       if (fused_control < 0) {
@@ -665,7 +694,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   if (e == hipSuccess && !ctx->sched.pairs.empty())
     e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size(),
                        ctx->sched.pairs.data(), sizeof(int) * ctx->sched.pairs.size(), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (ctx->sched.pairs.size() / 2 + 1), s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     set_error("context upload failed: %s", hipGetErrorString(e));

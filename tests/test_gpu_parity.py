@@ -331,7 +331,8 @@ def test_gpu_lm_ends_at_a_stationary_point_of_the_reference_objective(mods, gold
     # (b) the end point
     res, info = fte.fte_solve(det[..., :2], det[..., 2], g["K"], g["D"], g["R"], g["t"], Ts, x0=g["init_x"],
                               dlc_thresh=float(g["dlc_thresh"]), max_iter=400, ftol=1e-15, xtol=1e-13, gtol=1e-9)
-    assert info["status_name"] in ("ftol", "xtol", "gtol"), info
+    # (ftol = 1e-15 is below the resolution of the fp64 cost sum: "no damping gives descent any more" is the same end)
+    assert info["status_name"] in ("ftol", "xtol", "gtol", "lambda_overflow"), info
     xg = np.asarray(res["x"])
     # (observed: 1121.23161 on the GPU against 1121.23207 - after the common start, rounding decides between accept and
     #  reject somewhere and the two runs settle 1.5e-3 apart in the same flat valley, both stationary)
@@ -374,7 +375,8 @@ def test_config3_exact_size_against_committed_oracle_solution(mods, golden_dir):
     x0 = fte.nose_line_init(det, *rig, 0.5)
     assert np.abs(x0[[0, -1], :3] - g["x0_line"]).max() < 1e-8 and abs(x0[0, 31] - float(g["psi0"])) < 1e-9
     res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x0, max_iter=200)
-    assert info["status_name"] in ("ftol", "xtol", "gtol"), info
+    # (ftol = 1e-15 is below the resolution of the fp64 cost sum: "no damping gives descent any more" is the same end)
+    assert info["status_name"] in ("ftol", "xtol", "gtol", "lambda_overflow"), info
     want_cost = float(g["cost"])
     assert abs(info["cost"] - want_cost) < 1e-11 * abs(want_cost), (info["cost"], want_cost)
     assert abs(info["iter"] - int(g["iterations"])) <= 1, (info["iter"], int(g["iterations"]))
@@ -975,32 +977,40 @@ def test_config5_bf16_rows_solve_lands_on_the_fp64_solution(mods):
     assert truth.max() < 0.1
 
 
-def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods):
+@pytest.mark.parametrize("solver", ["whole_chain", "chunked", "chunked_refined"])
+def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods, solver):
     """acino_fte_params::bcr_levels: after K levels the couplings between the remaining nodes are dropped; their
     normalised size eps is MEASURED every iteration (state.trunc_eps).  With eps below trunc_tol the LM trajectory is the
     complete reduction's to ~eps; with eps above it the step is refused (status 7) and fte_solve continues with more
-    levels - never an unverified step."""
+    levels - never an unverified step.  Three forms: block cyclic reduction over the whole chain (K counts levels of the
+    3-frame nodes), the chunked solver (K counts levels of the separator chain, 12 frames apart here), and the chunked
+    solver with block-Jacobi sweeps over the dropped couplings (refine_sweeps): fewer levels, the same verified accuracy -
+    there trunc_eps is the bound rho / (1 - rho) |last update| / |x| from the measured contraction of the sweeps."""
     calib, fte, synth = mods
     n = 1537
     seq = synth.make_sequence(n, "loop")
     x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(11).normal(0, 0.02, (n, 25))
+    good, bad = {"whole_chain": (dict(chunk_nodes=-1, bcr_levels=7), dict(chunk_nodes=-1, bcr_levels=3)),
+                 "chunked": (dict(chunk_nodes=4, bcr_levels=5), dict(chunk_nodes=4, bcr_levels=1)),
+                 "chunked_refined": (dict(chunk_nodes=4, bcr_levels=3, refine_sweeps=4),
+                                     dict(chunk_nodes=4, bcr_levels=1, refine_sweeps=1))}[solver]
     runs = {}
-    for K in (0, 7):
-        c = _ctx(fte, seq, ftol=0.0, xtol=0.0, gtol=0.0, bcr_levels=K)
+    for tag, kw in (("full", dict(chunk_nodes=good["chunk_nodes"])), ("trunc", good)):
+        c = _ctx(fte, seq, ftol=0.0, xtol=0.0, gtol=0.0, **kw)
         c.set_x(x0)
         eps = []
         for _ in range(10):
             c.step()
             eps.append(c.state()["trunc_eps"])
-        runs[K] = (c.result()[0].cpu().numpy(), c.state(), eps)
+        runs[tag] = (c.result()[0].cpu().numpy(), c.state(), eps)
         c.close()
-    (x_full, st_full, e_full), (x_tr, st_tr, e_tr) = runs[0], runs[7]
+    (x_full, st_full, e_full), (x_tr, st_tr, e_tr) = runs["full"], runs["trunc"]
     assert max(e_full) == 0.0 and 0.0 < max(e_tr) < 1e-10, (e_full, e_tr)
     assert st_tr["status"] == 0 and st_tr["accepted"] == st_full["accepted"]
     assert abs(st_tr["cost"] - st_full["cost"]) < 1e-9 * abs(st_full["cost"])
     assert np.abs(x_tr - x_full).max() < 1e-7
     # too few levels: nodes 24 frames apart are still coupled at the 1e-2 level - the step is refused, not returned
-    c = _ctx(fte, seq, bcr_levels=3)
+    c = _ctx(fte, seq, **bad)
     c.set_x(x0)
     c.step()
     st = c.state()
@@ -1013,9 +1023,9 @@ def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods):
     x45 = np.clip(x45, lo, hi)
     det = seq["det"]
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
-    ref, iref = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60)
-    got, igot = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, bcr_levels=3)
-    assert igot["status_name"] in ("ftol", "xtol", "gtol") and igot.get("bcr_levels", 3) != 3
+    ref, iref = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, chunk_nodes=good["chunk_nodes"])
+    got, igot = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, **bad)
+    assert igot["status_name"] in ("ftol", "xtol", "gtol") and igot.get("bcr_levels", bad["bcr_levels"]) != bad["bcr_levels"]
     # (the restarted controller begins again at lam0, so the two runs stop at slightly different points of the same basin)
     assert np.abs(got["positions"] - ref["positions"]).max() < 1e-3 and abs(igot["cost"] - iref["cost"]) < 1e-6 * abs(iref["cost"])
     with pytest.raises(ValueError):
