@@ -320,6 +320,7 @@ class HipWindowBackend:
     """One rank's window on this process's GPU: thin calls into the C ABI (single-GPU context with an owned range)."""
 
     def __init__(self, det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global, n_offset, own_first, own_count, **kw):
+        kw.setdefault("bcr_levels", 0)      # (complete reduction unless the caller asks: a refused step needs every rank's consent)
         self.ctx = fte.FTEContext(det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=n_offset,
                                   own_first=own_first, own_count=own_count, **kw)
         self.device = self.ctx.device

@@ -102,7 +102,7 @@ def auto_bcr_levels(params, min_distance_frames=384):
     K = 1
     while 3 * max(plan["m"], 1) * 2 ** K < min_distance_frames:
         K += 1
-    return K if K < plan["levels"] else 0
+    return K if K <= plan["levels"] - 2 else 0      # (worth it from two saved levels on)
 
 
 class FTEContext:
@@ -120,20 +120,38 @@ class FTEContext:
         self.cams = torch.as_tensor(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
         if self.cams.shape[0] != self.C:
             raise ValueError("camera count mismatch between det and the rig")
+        self._kw = dict(kw)
+        self._graph = False
+        self._create()
+
+    # Linear-solver defaults of a single-GPU context (no pinned separators): chunked substructuring, the separator chain
+    # reduced until the remaining nodes are >= TRUNC_DISTANCE frames apart, their dropped couplings re-introduced by
+    # REFINE_SWEEPS block-Jacobi sweeps - verified on the device every iteration (state["trunc_eps"] <= trunc_tol, status 7
+    # "truncation" otherwise, on which solve() continues with one more level).  bcr_levels = 0 asks for the complete
+    # reduction, chunk_nodes = -1 for block cyclic reduction over the whole chain (the round-1/2 solver).
+    TRUNC_DISTANCE = 160
+    REFINE_SWEEPS = 3
+    TRUNC_TOL = 1e-12
+
+    def _create(self):
+        kw = dict(self._kw)
+        pinned = bool(kw.get("pin_left")) or bool(kw.get("pin_right"))
+        if "bcr_levels" not in kw and not pinned:
+            kw["bcr_levels"] = "auto"
+            kw.setdefault("trunc_distance", self.TRUNC_DISTANCE)
+            kw.setdefault("refine_sweeps", self.REFINE_SWEEPS)
+            kw.setdefault("trunc_tol", self.TRUNC_TOL)
         auto = kw.get("bcr_levels") == "auto"
         if auto:
-            # incomplete reduction where the chain is long enough to have levels beyond a node distance of
-            # `trunc_distance` frames (384: eps ~1e-11 on the benchmark sequence; verified on the device every iteration,
-            # status 7 otherwise)
-            kw = dict(kw, bcr_levels=0)
+            kw["bcr_levels"] = 0
         dist = kw.pop("trunc_distance", 384)
-        self.params = make_params(self.N, self.C, Ts, **kw)
+        self.params = make_params(self.N, self.C, self.Ts, **kw)
         if auto:
             self.params.bcr_levels = auto_bcr_levels(self.params, dist)
-            if self.params.bcr_levels == 0:
-                self.params.refine_sweeps = 0
+        if self.params.bcr_levels == 0:
+            self.params.refine_sweeps = 0
         nbytes = lib().acino_fte_workspace_bytes(C.byref(self.params))
-        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         if os.environ.get("ACINO_POISON_WORKSPACE"):      # debug: every read-before-write of the workspace becomes a NaN
             self.workspace.view(torch.float64)[: (nbytes + 256) // 8].fill_(float("nan"))
         base = self.workspace.data_ptr()
@@ -141,6 +159,23 @@ class FTEContext:
         self._h = C.c_void_p()
         check(lib().acino_fte_create(C.byref(self._h), C.byref(self.params), ptr(self.det), ptr(self.cams),
                                      C.c_void_p(self._ws_ptr), nbytes, stream_ptr()))
+        if self._graph:
+            check(lib().acino_fte_enable_graph(self._h, 1))
+
+    def _escalate(self):
+        """After status 7 (the truncated solve's verified error bound exceeded trunc_tol; the refused step was never
+        applied): the same problem with one more reduction level (the complete reduction once the chain is exhausted),
+        restarted from the current iterate."""
+        x = self.result()[0]
+        levels = int(self.params.bcr_levels) + 1
+        if levels >= solver_plan(self.params)["levels"]:
+            levels = 0
+        self.close()
+        self._kw = dict(self._kw, bcr_levels=levels)
+        self._kw.pop("trunc_distance", None)
+        self._create()
+        check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
+        return levels
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -170,6 +205,7 @@ class FTEContext:
 
     def enable_graph(self, on=True):
         """Replay the LM step as a hipGraph (takes effect on a non-default stream)."""
+        self._graph = bool(on)
         check(lib().acino_fte_enable_graph(self._h, int(bool(on))))
 
     def graphs_active(self):
@@ -180,9 +216,19 @@ class FTEContext:
         check(lib().acino_fte_step(self._h, stream_ptr()))
 
     def solve(self, max_iter):
+        """Up to max_iter LM iterations.  A step the truncated linear solve could not verify (status 7) is never applied:
+        the context is rebuilt with one more reduction level and the solve continues from the current iterate."""
         st = FteState()
-        check(lib().acino_fte_solve(self._h, int(max_iter), C.byref(st), stream_ptr()))
-        return st.as_dict()
+        done = 0
+        while True:
+            check(lib().acino_fte_solve(self._h, max(int(max_iter) - done, 1), C.byref(st), stream_ptr()))
+            info = st.as_dict()
+            info["iter"] += done
+            if info["status"] != 7:
+                info["bcr_levels"] = int(self.params.bcr_levels)
+                return info
+            done = info["iter"]
+            self._escalate()
 
     def state(self):
         st = FteState()
@@ -326,23 +372,6 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
         ctx.set_x(x0[:, ACTIVE])
         info = ctx.solve(max_iter)
         x, pos, dx, ddx = ctx.result()
-        while info["status"] == 7:
-            # incomplete reduction whose dropped couplings exceeded trunc_tol: the rejected step was never applied.
-            # Continue from the current iterate with one more level (a complete reduction once the chain is exhausted).
-            done = info["iter"]
-            levels = int(ctx.params.bcr_levels) + 1
-            if levels >= solver_plan(ctx.params)["levels"]:
-                levels = 0
-            kw = dict(kw, bcr_levels=levels)
-            if levels == 0:
-                kw["refine_sweeps"] = 0
-            ctx.close()
-            ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
-            ctx.set_x(x)
-            info = ctx.solve(max(max_iter - done, 1))
-            info["iter"] += done
-            info["bcr_levels"] = kw["bcr_levels"]
-            x, pos, dx, ddx = ctx.result()
     finally:
         ctx.close()
     if info["status"] == 5:
@@ -398,13 +427,13 @@ def fte_solve_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, x0s=None, dlc_thresh=0
     try:
         ctx.set_x(x0_all[:, ACTIVE])
         info = ctx.solve(max_iter)
-        if polish and kw.get("precision", "f64") != "f64" and info["status"] in (1, 2, 3, 4):
+        if polish and kw.get("precision", "f64") != "f64" and info["status"] in (0, 1, 2, 3, 4):
             # mixed-precision solve finished - by a stopping test or because no damping gives descent any more against
             # the fp64-summed cost (lambda overflow: the natural end of an inexact gradient) - : a few fp64 iterations
             # from its end point (same controller; damping kept, or back to lam0 after an overflow)
             n_mixed = info["iter"]
             ctx.set_precision("f64")
-            info = ctx.solve(max(max_iter - n_mixed, 1))
+            info = ctx.solve(max(max_iter - n_mixed, 5))      # (a mixed solve that ran out of iterations is polished too)
             info["iter_mixed"] = n_mixed
         x, pos, _dx, _ddx = ctx.result()
         if info["status"] == 5:

@@ -29,16 +29,19 @@ N_CAMS = 6
 ALG_FLOPS = {"assemble": 218.0e3,   # FK 1.1k + projection 7.8k + Jacobians 14.4k + chain 16.7k + weights 10k + J^T W J 156k + J^T r 12k
              "elim": 52.0e3,        # block Cholesky 25^3/3 + three 25x25 triangular solves
              "update": 187.5e3,     # six 2*25^3 trailing GEMM updates of the banded factorisation
+             "factor": 239.5e3,     # elim + update: what the chunk sweep does for its interior nodes in one kernel
              "backsub": 10.0e3}     # forward/backward substitution
-# every phase of the block-cyclic reduction is carried by several kernels (level 0 has its own sparse-coupling forms, the
-# narrow levels their own latency-oriented kernels); a kernel's share of the phase = the chain nodes it processed
+# every phase of the factorisation is carried by several kernels (the chunk sweep for the interior nodes of the runs; the
+# block cyclic reduction of the separator chain with its wide / narrow level kernels); a kernel's algorithmic work = the
+# chain nodes it processed x 3 frames x the phase's flops per frame
 PHASE_OF = {"elim": "elim", "elim_deep": "elim", "update0": "update", "update": "update", "update_deep": "update",
-            "backsub0": "backsub", "backsub": "backsub", "backsub_tail": "backsub", "assemble": "assemble"}
+            "backsub0": "backsub", "backsub": "backsub", "backsub_tail": "backsub", "assemble": "assemble",
+            "chunk_sweep": "factor", "chunk_backsub": "backsub", "refine": "backsub"}
 ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0
-PROFILE_DIR = "round2_final"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
+PROFILE_DIR = "round3"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
 
 
 def _log(msg):
@@ -302,8 +305,11 @@ def main():
                     help="N > 1: overlapping windows (two all-gathers per step, step exact to the decay over --halo frames) or "
                          "exact separator system (one all-reduce + two all-gathers)")
     ap.add_argument("--halo", type=int, default=192, help="--shard windows: frames of overlap on either side")
-    ap.add_argument("--bcr-levels", type=int, default=0,
-                    help="incomplete block cyclic reduction after this many levels (0 = complete; single GPU only)")
+    ap.add_argument("--bcr-levels", type=int, default=None,
+                    help="reduction levels before the remaining nodes are solved on their own + refined (default: the library's "
+                         "automatic choice, FTEContext.TRUNC_DISTANCE; 0 = complete reduction; single GPU only)")
+    ap.add_argument("--refine-sweeps", type=int, default=None, help="block-Jacobi sweeps over the dropped couplings")
+    ap.add_argument("--chunk-nodes", type=int, default=0, help="nodes per run of the chunked solver (0 auto, -1 whole-chain BCR)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -344,13 +350,20 @@ def main():
     windows = world > 1 and args.shard == "windows"
     common = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,                           # never stops: every step is full work
                   shared_gpu="ACINO_FORCE_DEVICE" in os.environ)                             # (ranks sharing one GPU: functional runs only)
+    solver_kw = {}
+    if world == 1:
+        solver_kw["chunk_nodes"] = args.chunk_nodes
+        if args.bcr_levels is not None:
+            solver_kw["bcr_levels"] = args.bcr_levels
+        if args.refine_sweeps is not None:
+            solver_kw["refine_sweeps"] = args.refine_sweeps
     if windows:
         solver, (w0, w1, n0, n1) = adist.make_windowed(torch.as_tensor(det), *rig, seq["Ts"], rank, world, halo=args.halo, **common)
         x0_local = torch.as_tensor(x0_full[w0:w1][:, fte.ACTIVE])
         ctx = solver.ctx
     else:
         solver, (n0, n1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world, **common,
-                                              **({"bcr_levels": args.bcr_levels} if args.bcr_levels and world == 1 else {}))
+                                              **solver_kw)
         x0_local = torch.as_tensor(x0_full[n0:n1][:, fte.ACTIVE])
         ctx = solver.b.ctx
 
@@ -410,8 +423,8 @@ def main():
         launches = max(prof[dom]["launches"], 1)
         avg_ms = prof[dom]["ms"] / launches
         phase = PHASE_OF[dom]
-        phase_units = sum(prof[k]["units"] for k in PHASE_OF if PHASE_OF[k] == phase)
-        share = prof[dom]["units"] / max(phase_units, 1)             # of the phase's nodes (frames for assemble)
+        total_units = (n_loc if phase == "assemble" else (n_loc + 2) // 3) * args.steps
+        share = prof[dom]["units"] / max(total_units, 1)             # of the chain's nodes (frames for assemble)
         flops_per_launch = ALG_FLOPS[phase] * n_loc * args.steps * share / launches
         achieved = flops_per_launch / (max(avg_ms, 1e-9) * 1e-3) / 1e12
         gpu_ms_step = sum(v["ms"] for v in prof.values()) / args.steps
@@ -430,7 +443,7 @@ def main():
             if tj.get("build_id") != bid or mj.get("build_id") != bid:
                 pmc_note = (f"profiles/{PROFILE_DIR} was measured on build {tj.get('build_id')}, this library is {bid}: "
                             "traffic / pmc not quoted")
-            elif args.frames == N_FRAMES and world == 1 and not args.bcr_levels:
+            elif args.frames == N_FRAMES and world == 1:
                 traffic = tj["kernels"]["acino::" + kname]["bytes_per_launch"]
                 mk = mj["kernels"]["acino::" + kname]
                 mfma = dict(mfma_f64_flops_executed_per_launch=mk["mfma_f64_flops_per_launch"],

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= declared
-    assert lib.acino_abi_version() == 1
+    assert lib.acino_abi_version() == _lib.ABI_VERSION == 2     # (2: acino_fte_params grew, 17 profiler classes - include/acinoset_hip.h)
     assert lib.acino_sizeof_fte_params() == C.sizeof(_lib.FteParams)
     assert lib.acino_sizeof_fte_state() == C.sizeof(_lib.FteState)
 
@@ -125,7 +125,15 @@ def test_window_plan_and_params_host_logic():
     assert fte.make_params(100, 6, 1 / 120).precision == 0 and fte.PRECISIONS["bf16_residuals"] == 2
     with pytest.raises(ValueError):
         fte.make_params(100, 6, 1 / 120, precision="fp8")
-    assert fte.auto_bcr_levels(10000) == 7 and fte.auto_bcr_levels(1000) == 7 and fte.auto_bcr_levels(700) == 0
+    # the solver layout (acino_fte_plan is host logic: no device call) and the automatic truncation depth derived from it
+    mk = lambda n, **kw: fte.make_params(n, 6, 1 / 120, **kw)
+    assert fte.solver_plan(mk(10000)) == dict(m=14, n_chunks=239, n_sep=238, levels=8)
+    assert fte.solver_plan(mk(10000, chunk_nodes=-1)) == dict(m=0, n_chunks=0, n_sep=0, levels=12)
+    assert fte.solver_plan(mk(9999, pin_right=True, n_global=20000))["m"] == 0        # sharded contexts: whole-chain reduction
+    assert fte.solver_plan(mk(9, chunk_nodes=5)) == dict(m=5, n_chunks=1, n_sep=0, levels=0)
+    assert fte.auto_bcr_levels(mk(10000), 160) == 2 and fte.auto_bcr_levels(mk(10000), 384) == 4      # 42 * 2^K frames
+    assert fte.auto_bcr_levels(mk(10000, chunk_nodes=-1), 384) == 7 and fte.auto_bcr_levels(mk(700, chunk_nodes=-1), 384) == 0
+    assert fte.auto_bcr_levels(mk(300), 160) == 0                                        # chain too short to truncate
 
 
 def test_build_id_matches_sources_and_cpu_baseline_worker(tmp_path):
