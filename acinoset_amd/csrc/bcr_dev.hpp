@@ -52,13 +52,17 @@ static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain&
     }
   }
 }
+// qw / lo / hi: the per-state weight and bound tables (K.q_w, K.lo, K.hi, or a copy of them in LDS)
 static __device__ __forceinline__ double build_finish(double* Dm, double* bv, const NodeFetch& f, const FteConst& K, int t,
-                                                      int tid) {
+                                                      int tid, const double* qw, const double* lo, const double* hi,
+                                                      long long* dbg = nullptr) {
   const bool sep_left = K.pin_left && t == 0;
   const int fbase = 3 * (t - K.pin_left);
   // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
   for (int e = tid; e < BS * LD; e += 256) Dm[e] = 0.0;
+  if (dbg && tid == 0) dbg[24] = (long long)wall_clock64();
   __syncthreads();
+  if (dbg && tid == 0) dbg[25] = (long long)wall_clock64();
   if (!sep_left) {
     if (tid < BS) {
       const int nfr = fbase + tid / NP;
@@ -67,12 +71,13 @@ static __device__ __forceinline__ double build_finish(double* Dm, double* bv, co
       const int q = tid - BS, pr = q / NP, p = q % NP;          // frame pairs (0,1), (0,2), (1,2)
       const int ii = pr == 2 ? 1 : 0, jj = pr == 0 ? 1 : 2;
       if (fbase + jj < K.n_frames) {
-        const double v = 2.0 * K.q_w[p] * band_coef_clip(K.n_offset + fbase + ii, jj - ii, K.n_global, K.clip_len);
+        const double v = 2.0 * qw[p] * band_coef_clip(K.n_offset + fbase + ii, jj - ii, K.n_global, K.clip_len);
         Dm[(ii * NP + p) * LD + jj * NP + p] = v;
         Dm[(jj * NP + p) * LD + ii * NP + p] = v;
       }
     }
   }
+  if (dbg && tid == 0) dbg[26] = (long long)wall_clock64();
   // (3) drop the H blocks in (their targets are disjoint from the entries written in (2))
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -82,7 +87,9 @@ static __device__ __forceinline__ double build_finish(double* Dm, double* bv, co
       if (fbase + ii < K.n_frames) Dm[(ii * NP + p) * LD + ii * NP + pc] = f.hv[k];
     }
   }
+  if (dbg && tid == 0) dbg[28] = (long long)wall_clock64();
   __syncthreads();
+  if (dbg && tid == 0) dbg[31] = (long long)wall_clock64();
   // (4) Marquardt damping and pinning of the diagonal, right-hand side, projected-gradient norm
   double gmax = 0.0;
   if (tid < BS) {
@@ -91,7 +98,7 @@ static __device__ __forceinline__ double build_finish(double* Dm, double* bv, co
       const int p = tid % NP;
       double d = Dm[tid * LD + tid];
       const double gtol = GRAD_ZERO_REL * d;
-      const bool fixed = (f.xv <= K.lo[p] && f.gv > gtol) || (f.xv >= K.hi[p] && f.gv < -gtol);
+      const bool fixed = (f.xv <= lo[p] && f.gv > gtol) || (f.xv >= hi[p] && f.gv < -gtol);
       d = d + f.lam * fmax(d, DIAG_FLOOR);
       if (fixed) d *= FIX_SCALE;
       Dm[tid * LD + tid] = d;
@@ -106,7 +113,7 @@ static __device__ __forceinline__ double build_finish(double* Dm, double* bv, co
 static __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, const FteConst& K, int t, int tid) {
   NodeFetch f;
   build_fetch(f, ch, K, t, tid);
-  return build_finish(Dm, bv, f, K, t, tid);
+  return build_finish(Dm, bv, f, K, t, tid, K.q_w, K.lo, K.hi);
 }
 
 // max over the workgroup -> gn_part[node]
@@ -123,7 +130,9 @@ static __device__ void publish_gmax(double gmax, double* red, double* gn_part, i
 //   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
 // coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
 // right: columns in node i+1).  450 doubles, filled once per workgroup.
-static __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
+static __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid,
+                                          const double* qw = nullptr) {
+  if (!qw) qw = K.q_w;
   const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
   const int64_t f_i = K.n_offset + (int64_t)loc_i;
   for (int e = tid; e < 2 * 9 * NP; e += 256) {
@@ -136,7 +145,7 @@ static __device__ void fill_coupling_coef(double* coefL, double* coefR, const Ft
       // frames) is an identity row of the chain and must not be coupled, whatever the global band says there.
       const int hi = side == 0 ? loc_i + ii : loc_i + 3 + ii;
       if (hi < K.n_frames)
-        v = 2.0 * K.q_w[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
+        v = 2.0 * qw[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
                                               : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
     }
     (side == 0 ? coefL : coefR)[q] = v;

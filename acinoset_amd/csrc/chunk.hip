@@ -362,7 +362,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
 // column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1 = the next node's b~), and row 79
 // of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases, no extra barriers.
 // LDS: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 159.9 KB, one workgroup per CU.
-constexpr int SW2_VEC = 18 * NP + BS + 8 + 8;   // cL cR | bv | red | sync
+constexpr int SW2_VEC = 18 * NP + BS + 8 + 8 + 3 * NP;   // cL cR | bv | red | sync | kq klo khi
 static constexpr size_t kSweep2Lds = (3 * MAT + SW2_VEC) * sizeof(double);
 
 // The value of x, made opaque to the optimiser: address arithmetic derived from it cannot be hoisted out of the node loop
@@ -482,12 +482,91 @@ __device__ __forceinline__ void sub_barrier(int* cnt, int& target, int n, int la
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Trailing phase of step KB of the blocked Cholesky by ONE wave: every tile product is C(ti, tj) -= P(ti) P(tj)^T with
+// P(t) = tile (t, KB) (the panel output; P(KB) = U_kk for the tiles of U), and both operands of a product are read with the
+// SAME lane pattern - so the five P tiles are read once into registers (20 doubles) and serve all 13 / 11 / 8 / 4 products
+// of the step, whose addresses are compile-time constants.  The tiles the next pivot chain needs come first.
+template <int KB>
+struct TrailList {
+  int ti[13], tj[13], n;
+  constexpr TrailList() : ti{}, tj{}, n(0) {
+    for (int r = KB + 2; r < NT; ++r)
+      for (int c = KB + 1; c <= r; ++c) {
+        ti[n] = r;
+        tj[n] = c;
+        ++n;
+      }
+    for (int r = 0; r <= KB; ++r)
+      for (int c = KB + 1; c < NT; ++c) {
+        ti[n] = r;
+        tj[n] = c;
+        ++n;
+      }
+  }
+};
+template <int KB>
+__device__ __forceinline__ void trail_step(double* Lm, int li, int lk) {
+  double P[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P[t][s] = Lm[(t * 16 + li) * LD + KB * 16 + 4 * s + lk];
+  // the products of the step as a compile-time list (ti, tj): lower part first - rows KB+2 .. 4, row KB+2 feeds the next
+  // look-ahead (the look-ahead tile (KB+1, KB+1) itself is the chain wave's) -, then the tiles of U (ti <= KB < tj, first
+  // written at ti == KB); processed four at a time with their accumulator chains interleaved
+  constexpr TrailList<KB> TL{};
+  constexpr int NTOT = TL.n;
+  auto tile_of = [&](int q, int& ti, int& tj) {
+    ti = TL.ti[q];
+    tj = TL.tj[q];
+  };
+#pragma unroll
+  for (int q0 = 0; q0 < NTOT; q0 += 4) {
+    d4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q0 + q < NTOT) {
+        int ti = 0, tj = 0;
+        tile_of(q0 + q, ti, tj);
+        const double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a[q][rr] = ti == KB ? 0.0 : Cc[(lk + 4 * rr) * LD + li];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q0 + q < NTOT) {
+          int ti = 0, tj = 0;
+          tile_of(q0 + q, ti, tj);
+          a[q] = mfma(-P[ti][s], P[tj][s], a[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q0 + q < NTOT) {
+        int ti = 0, tj = 0;
+        tile_of(q0 + q, ti, tj);
+        double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+      }
+    }
+  }
+}
+
 // chol80 by a PAIR of waves: role 0 runs the five 16-pivot chains with the look-ahead update of the next diagonal tile
 // (exactly wave 0 of chol80), role 1 does every other panel and trailing tile, batched four at a time.
-__device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int* err, int* cnt, int& target) {
+__device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int* err, int* cnt, int& target, int& posted,
+                                            long long* dbg = nullptr) {
   const int li = lane & 15, lk = lane >> 4;
+#define CH_STAMP(i) do { if (dbg && lane == 0) dbg[i] = (long long)wall_clock64(); } while (0)
   if (role == 0) chol16_inv(Lm, lane, err);
+  CH_STAMP(32 + 16 * role);
   sub_barrier(cnt, target, 2, lane);
+  CH_STAMP(33 + 16 * role);
 #pragma unroll 1
   for (int kb = 0; kb < NT; ++kb) {
     {  // panel: tile(t, kb) <- tile(t, kb) U_kk: role 0 the tile its look-ahead needs next, role 1 the other three
@@ -528,8 +607,22 @@ __device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int*
         }
       }
     }
-    sub_barrier(cnt, target, 2, lane);
-    if (kb == NT - 1) break;
+    CH_STAMP(34 + 16 * role + 3 * kb);
+    if (kb == NT - 1) {
+      sub_barrier(cnt, target, 2, lane);
+      break;
+    }
+    // role 0 goes straight on with the look-ahead (it needs only its own panel tile); role 1's trailing products also
+    // read that tile: one-way flag cnt[3] (monotonic: `posted` panel tiles so far)
+    ++posted;
+    if (role == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(cnt + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      while (__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < posted) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    CH_STAMP(35 + 16 * role + 3 * kb);
     if (role == 0) {                          // next diagonal tile, then its 16-pivot chain
       double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
       const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
@@ -543,16 +636,15 @@ __device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int*
       for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
       chol16_inv_acc(Cc, a, lane, err);
     } else {                                  // the other trailing tiles (U tiles included): 13 | 11 | 8 | 4
-      const uint8_t* codes = c_trail[kb];
-      const int ntask = c_trail_n[kb];
-      int q0 = 0;
-#pragma unroll 1
-      for (; q0 + 4 <= ntask; q0 += 4) trail_batch<4>(Lm, kb, codes + q0, li, lk);
-      if (ntask - q0 == 3) trail_batch<3>(Lm, kb, codes + q0, li, lk);
-      else if (ntask - q0 == 1) trail_batch<1>(Lm, kb, codes + q0, li, lk);
+      if (kb == 0) trail_step<0>(Lm, li, lk);
+      else if (kb == 1) trail_step<1>(Lm, li, lk);
+      else if (kb == 2) trail_step<2>(Lm, li, lk);
+      else trail_step<3>(Lm, li, lk);
     }
+    CH_STAMP(36 + 16 * role + 3 * kb);
     sub_barrier(cnt, target, 2, lane);
   }
+#undef CH_STAMP
 }
 
 // W(:, strips) = U^T F(:, strips), in place in Y, for NS 16-column strips of one wave: W(ib, jb) = sum_{kb <= ib}
@@ -586,10 +678,11 @@ __device__ __forceinline__ void strips_ut_f(const double* U, double* Y, const in
 #pragma unroll
     for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[j], acc[j][ib], li, lk);
 }
-// T(:, strips) = U W(:, strips), in place: T(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb)
+// T(:, strips) = U W(:, strips): T(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb); accumulators out (the caller stores them
+// once nobody reads W any more)
 template <int NS>
-__device__ __forceinline__ void strips_u_w(const double* U, double* Y, const int (&jbs)[NS], int li, int lk) {
-  d4 acc[NS][NT];
+__device__ __forceinline__ void strips_u_w_acc(const double* U, const double* Y, const int (&jbs)[NS], d4 (&acc)[NS][NT], int li,
+                                               int lk) {
 #pragma unroll
   for (int j = 0; j < NS; ++j)
 #pragma unroll
@@ -610,14 +703,8 @@ __device__ __forceinline__ void strips_u_w(const double* U, double* Y, const int
         for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
     }
   }
-#pragma unroll
-  for (int j = 0; j < NS; ++j)
-#pragma unroll
-    for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[j], acc[j][ib], li, lk);
 }
 
-// -(W^T W) accumulated into the left separator's update in HBM (L2-resident, owned by this workgroup): NT tiles of one
-// wave, tile q = (IB(q), JB(q)); every k-step reads NV operands W[k][16 c + li] once for all of the wave's tiles.
 template <int SET>
 struct SyrkSet {   // the 15 lower tiles over two waves.  SET 0: rows 4 and 3 (9 tiles) | SET 1: rows 2, 1, 0 (6 tiles)
   static constexpr int nt = SET == 0 ? 9 : 6;
@@ -702,6 +789,9 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
   double* bv = cR + 9 * NP;                            // [80] right-hand side of the node built last
   double* red = bv + BS;                               // [8]
   int* sync = reinterpret_cast<int*>(red + 8);
+  double* kq = red + 16;                               // [25] each: copies of K.q_w, K.lo, K.hi
+  double* klo = kq + NP;
+  double* khi = klo + NP;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const FteConst& K = *cst;
   const int c = blockIdx.x;
@@ -709,19 +799,25 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
   const bool hasL = c > 0, hasR = c + 1 < n_chunks;
   const int n_int = hasR ? m - 1 : ch.n_nodes - first;
   const size_t MB = (size_t)BS * BS;
-  // stencil items of this thread: state sp_, rows / columns sc0 + 10 j
-  const int sp_ = tid % NP, sc0 = tid / NP;
-  const bool s_act = tid < 10 * NP;
-  int t01 = 0, t23 = 0, t123 = 0;           // rounds of the three wave-subset barriers (sync[0], [1], [2])
-#define SW_STAMP(i) do { if (ch.dbg && (long long)blockIdx.x == ch.dbg[29] && (long long)k == ch.dbg[30] && lane == 0) ch.dbg[i] = (long long)wall_clock64(); } while (0)
-  if (tid < 3) sync[tid] = 0;
+  int t01 = 0, t23 = 0, tflag = 0;           // rounds of the three wave-subset barriers (sync[0], [1], [2])
+  // (debug stamps: workgroup dbg[29] writes wall-clock ticks of its phases at node dbg[30]; selectors read ONCE)
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[29]) ? ch.dbg : nullptr;
+  const int dbg_k = dbgp ? (int)ch.dbg[30] : -1;
+#define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) dbgp[i] = (long long)wall_clock64(); } while (0)
+  if (tid < 4) sync[tid] = 0;
+  if (tid < NP) {
+    kq[tid] = K.q_w[tid];
+    klo[tid] = K.lo[tid];
+    khi[tid] = K.hi[tid];
+  }
+  __syncthreads();
 
   {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
     NodeFetch f;
     build_fetch(f, ch, K, first, tid);
-    fill_coupling_coef(cL, cR, K, first, tid);
+    fill_coupling_coef(cL, cR, K, first, tid, kq);
     for (int e = tid; e < MAT; e += 256) Y[e] = 0.0;
-    const double gmax = build_finish(Xc, bv, f, K, first, tid);
+    const double gmax = build_finish(Xc, bv, f, K, first, tid, kq, klo, khi);
     publish_gmax(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
     if (hasL)
       for (int e = tid; e < 9 * NP; e += 256) {
@@ -730,7 +826,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       }
     if (tid < BS) Y[tid * LD + (BS - 1)] = bv[tid];
     __syncthreads();
-    if (wave < 2) chol80_pair(Xc, wave, lane, numeric_err, sync, t01);
+    if (wave < 2) chol80_pair(Xc, wave, lane, numeric_err, sync, t01, tflag);
     __syncthreads();
   }
 
@@ -740,10 +836,15 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     const bool last = k + 1 == n_int;
     const bool has_next = !last || hasR;
     // ================= serial part: G_k, then the next node =================
+    // (thread index made opaque per iteration: the index arithmetic of the build / stencil phases is recomputed instead of
+    //  being hoisted out of the node loop and spilled - a scratch reload behind the 51 KB store of G waits for that store)
+    const int tid_ = opaque(tid);
+    const int sp_ = tid_ % NP, sc0 = tid_ / NP;
+    const bool s_act = tid_ < 10 * NP;
     NodeFetch f;
-    if (has_next) build_fetch(f, ch, K, next, tid);
+    if (has_next) build_fetch(f, ch, K, next, tid_);
     if (wave == 0) SW_STAMP(0);
-    if (k > 0) fill_coupling_coef(cL, cR, K, node, tid);
+    if (k > 0) fill_coupling_coef(cL, cR, K, node, tid_, kq);
     {
       const int gi = opaque(li), gk = opaque(lk);
       if (wave == 0) gram_tiles<0>(Xc, Xn, gi, gk);
@@ -753,7 +854,15 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     }
     __syncthreads();                                   // G in Xn, tables of this node visible
     if (wave == 0) SW_STAMP(1);
-    if (!(skip & 16)) store_mat(ch.D + node * MB, Xn, tid);
+    if (has_next) {
+      // the next node's H / g / x were requested at the top of the iteration and have arrived; pin them down HERE: behind
+      // the 51 KB store of G the wait for them would be a wait for the stores as well (one counter for loads and stores)
+      // ("+v": the values leave the asm as NEW definitions, so no later use is tied to the loads' counter any more)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(f.hv[q]));
+      asm volatile("" : "+v"(f.xv), "+v"(f.gv), "+v"(f.lam));
+    }
+    if (!(skip & 16)) store_mat(ch.D + node * MB, Xn, tid_);
     if (has_next) {
       double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
       if (s_act) {
@@ -786,8 +895,11 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       }
       __syncthreads();                                 // pass-2 reads done: Xn may be rebuilt
       if (wave == 0) SW_STAMP(3);
-      const double gmax = build_finish(Xn, bv, f, K, next, tid);
-      publish_gmax(gmax, red, ch.gn_part, next, tid);  // (barrier inside)
+      const double gmax = build_finish(Xn, bv, f, K, next, tid_, kq, klo, khi,
+                                       (dbgp && k == dbg_k) ? dbgp : nullptr);
+      if (wave == 0) SW_STAMP(13);
+      publish_gmax(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
+      if (wave == 0) SW_STAMP(14);
       if (s_act) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -798,12 +910,16 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         }
       }
     }
+    if (wave == 0) SW_STAMP(15);
     __syncthreads();
+    if (wave == 0) SW_STAMP(4);
     // ================= parallel part =================
     // waves 0, 1: blocked Cholesky of the next node (pivot chains | panel and trailing tiles)
-    // waves 2, 3: spike algebra of this node on their 16-column strips; wave 1 joins for the final stores / stencil
+    // waves 2, 3: W = U_k^T F_k on their 16-column strips, then D_L -= W^T W
     if (wave < 2) {
-      if (!last && !(skip & 1)) chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01);
+      if (!last && !(skip & 1))
+        chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01, tflag,
+                    (dbgp && k == dbg_k) ? dbgp : nullptr);
       if (wave == 0) SW_STAMP(5);
     } else {
       const int li = opaque(lane & 15), lk = opaque(lane >> 4);
@@ -812,91 +928,100 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         d4 accL[9];
         double* Ag = opaque_ptr(sp.AL + (size_t)(c - 1) * MB);
         if (wave == 2) {
-          if (!(skip & 2)) syrk_load<1>(accL, Ag, k > 0, li, lk);
+          syrk_load<1>(accL, Ag, k > 0, li, lk);
           const int jbs[3] = {0, 1, 4};
           strips_ut_f<3>(Xc, Y, jbs, li, lk);
         } else {
-          if (!(skip & 2)) syrk_load<0>(accL, Ag, k > 0, li, lk);
+          syrk_load<0>(accL, Ag, k > 0, li, lk);
           const int jbs[2] = {2, 3};
           strips_ut_f<2>(Xc, Y, jbs, li, lk);
         }
         SW_STAMP(8 + 8 * (wave - 2));
         sub_barrier(sync + 1, t23, 2, lane);           // every strip of W is in Y
         SW_STAMP(9 + 8 * (wave - 2));
-        if (!(skip & 2)) {
-          if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
-          else syrk_run<0>(accL, Y, Ag, li, lk);
-        }
+        if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
+        else syrk_run<0>(accL, Y, Ag, li, lk);
         SW_STAMP(10 + 8 * (wave - 2));
-        sub_barrier(sync + 1, t23, 2, lane);           // every read of W is done
-        SW_STAMP(11 + 8 * (wave - 2));
-        if (wave == 2) {
-          const int jbs[3] = {0, 1, 4};
-          strips_u_w<3>(Xc, Y, jbs, li, lk);
-        } else {
-          const int jbs[2] = {2, 3};
-          strips_u_w<2>(Xc, Y, jbs, li, lk);
-        }
-        SW_STAMP(12 + 8 * (wave - 2));
       } else if (wave == 2) {                          // first run: only the right-hand side column is alive
         const int jbs[1] = {4};
         strips_ut_f<1>(Xc, Y, jbs, li, lk);
-        strips_u_w<1>(Xc, Y, jbs, li, lk);
       }
     }
-    if (wave >= 1) {
-      // ---- T_k is complete in Y: T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then
-      //      F_k+1 = -E^T T_k in place, column 79 += the next node's right-hand side.  Strips {0,1} | {2,3} | {4}.
-      if (wave == 1) SW_STAMP(20);
-      sub_barrier(sync + 2, t123, 3, lane);
-      if (wave == 1) SW_STAMP(21);
+    __syncthreads();                                   // next node factored; W complete and no longer needed by W^T W
+    if (wave == 0) SW_STAMP(6);
+    {
+      // ---- T = U_k W, all four waves: wave w takes strip w, strip 4 (11 columns + the right-hand side) is dealt by row
+      //      tile: (0,4) | (1,4) | (2,4), (4,4) | (3,4).  Results wait in registers until every read of W is done.
       const int li = opaque(lane & 15), lk = opaque(lane >> 4);
-      const int w = wave - 1;
-      const int jb0 = 2 * w, njb = w == 2 ? 1 : 2;
-      if (hasL || w == 2) {
-        if (hasL && !(skip & 4)) {
-          double* Tg = ch.Wl + node * MB;
-          for (int sidx = 0; sidx < njb; ++sidx) {
-            const int cbase = 16 * (jb0 + sidx);
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-              const int cc = cbase + j;
-              Tg[(size_t)cc * BS + lane] = Y[lane * LD + cc];
-              if (lane < 16) Tg[(size_t)cc * BS + 64 + lane] = Y[(64 + lane) * LD + cc];
-            }
-          }
-        }
-        if (w == 2 && !(skip & 8)) {
-          ch.b[(size_t)node * BS + lane] = Y[lane * LD + (BS - 1)];
-          if (lane < 16) ch.b[(size_t)node * BS + 64 + lane] = Y[(64 + lane) * LD + (BS - 1)];
-        }
-        if (has_next) {
-          for (int sidx = 0; sidx < njb; ++sidx) {
-            const int cc = 16 * (jb0 + sidx) + li;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-              const int p = lk + 4 * j;
-              if (p < NP) {
-                const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
-                const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
-                const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
-                double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
-                if (cc == BS - 1) {
-                  o0 += bv[p];
-                  o1 += bv[NP + p];
-                  o2 += bv[2 * NP + p];
-                }
-                Y[p * LD + cc] = o0;
-                Y[(NP + p) * LD + cc] = o1;
-                Y[(2 * NP + p) * LD + cc] = o2;
-              }
-            }
-            Y[(3 * NP + lk) * LD + cc] = 0.0;          // padding rows 75..78, 79: couple to nothing
-            if (lk == 0) Y[(BS - 1) * LD + cc] = 0.0;
-          }
-        }
+      d4 town[1][NT], tx0 = {0, 0, 0, 0}, tx1 = {0, 0, 0, 0};
+      const int jbs[1] = {hasL ? wave : 4};
+      const bool own = hasL || wave == 2;
+      if (own) strips_u_w_acc<1>(Xc, Y, jbs, town, li, lk);
+      if (hasL) {
+        if (wave == 0) tx0 = tile_u_w(Xc, Y, 0, 4, li, lk);
+        else if (wave == 1) tx0 = tile_u_w(Xc, Y, 1, 4, li, lk);
+        else if (wave == 2) {
+          tx0 = tile_u_w(Xc, Y, 2, 4, li, lk);
+          tx1 = tile_u_w(Xc, Y, 4, 4, li, lk);
+        } else tx0 = tile_u_w(Xc, Y, 3, 4, li, lk);
       }
-      if (wave == 1) SW_STAMP(22);
+      __syncthreads();
+      if (own) {
+#pragma unroll
+        for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[0], town[0][ib], li, lk);
+      }
+      if (hasL) {
+        tile_store(Y, wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 2 : 3)), 4, tx0, li, lk);
+        if (wave == 2) tile_store(Y, 4, 4, tx1, li, lk);
+      }
+    }
+    __syncthreads();                                   // T_k complete in Y
+    if (wave == 0) SW_STAMP(7);
+    {
+      // ---- T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then F_k+1 = -E^T T_k in place,
+      //      column 79 += the next node's right-hand side.  20 columns per wave (first run: column 79 only).
+      const int c_lo = hasL ? 20 * wave : BS - 1, c_hi = hasL ? c_lo + 20 : (wave == 3 ? BS : BS - 1);
+      if (hasL && !(skip & 4)) {
+        double* Tg = ch.Wl + node * MB;
+        // (all 25 LDS reads of the wave first, then the stores)
+        double v0[20], v1[5];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) v0[j] = Y[lane * LD + c_lo + j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v1[j] = Y[(64 + (lane & 15)) * LD + c_lo + 5 * (lane >> 4) + j];   // rows 64..79: 4 x 5 columns
+#pragma unroll
+        for (int j = 0; j < 20; ++j) Tg[(size_t)(c_lo + j) * BS + lane] = v0[j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) Tg[(size_t)(c_lo + 5 * (lane >> 4) + j) * BS + 64 + (lane & 15)] = v1[j];
+      }
+      if (wave == 3) {
+        ch.b[(size_t)node * BS + lane] = Y[lane * LD + (BS - 1)];
+        if (lane < 16) ch.b[(size_t)node * BS + 64 + lane] = Y[(64 + lane) * LD + (BS - 1)];
+      }
+      if (has_next) {
+        // lane = (state p, column group): the six stencil coefficients of p are read once, rows p, 25 + p, 50 + p of the
+        // lane's columns are rewritten in place
+        const int ncol = c_hi - c_lo, p = lane % NP, cg = lane / NP;        // cg 0, 1 (lanes 50..63 idle)
+        if (cg < 2 && ncol > 0) {
+          const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
+          const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
+          const double b0 = bv[p], b1 = bv[NP + p], b2 = bv[2 * NP + p];
+          for (int cc = c_lo + cg; cc < c_hi; cc += 2) {
+            const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
+            double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
+            if (cc == BS - 1) {
+              o0 += b0;
+              o1 += b1;
+              o2 += b2;
+            }
+            Y[p * LD + cc] = o0;
+            Y[(NP + p) * LD + cc] = o1;
+            Y[(2 * NP + p) * LD + cc] = o2;
+          }
+        }
+        if (lane < ncol)
+          for (int r = 3 * NP; r < BS; ++r) Y[r * LD + c_lo + lane] = 0.0;     // padding rows couple to nothing
+      }
     }
     __syncthreads();
     if (wave == 0) SW_STAMP(27);

@@ -261,7 +261,7 @@ int acino_fte_profile_begin(acino_fte_ctx* ctx);
  * (D, b, coupling blocks, left-run contributions), 6 / 7 = G_k and T_k^T of the interior nodes. */
 int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream);
 /* Debug aid: phase timestamps (wall_clock64 ticks) of ONE workgroup of the elimination kernel -> d_dbg[0..28] of a
- * caller buffer of 32 entries; the caller sets d_dbg[29] = workgroup index and d_dbg[30] = reduction level to stamp
+ * caller buffer of 64 entries (the chunk sweep stamps up to [63]); the caller sets d_dbg[29] = workgroup index and d_dbg[30] = reduction level to stamp
  * (read by every launch while enabled).  NULL disables. */
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);
 int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, int64_t* units_by_class,

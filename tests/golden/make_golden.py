@@ -442,6 +442,51 @@ def gen_fte_stationary():
           "bound-active", int(fixed.sum()))
 
 
+def gen_fte_lbfgs():
+    """fte_lbfgs.npz: a THIRD-PARTY quasi-Newton optimiser on the reference's NLP (row a-10: the reference hands its model
+    to IPOPT with hessian_approximation = limited-memory, all_optimizations.py:503-522; IPOPT cannot run here).
+
+    scipy.optimize.minimize(method="L-BFGS-B") minimises the reduced objective over the N x 25 active states inside the
+    21 boxes recovered from the reference's inequality rules, from the reference's own init_x.  Function and gradient come
+    from oracle.fte.FTEProblem.evaluate - pinned to the reference's model text at five iterates (fte_model.npz, 1e-10) and
+    its gradient to central differences of that text (fte_stationary.npz) -; the END POINT is then evaluated by the
+    reference's own objective text with every equality re-solved (_feasible_objective), as x* of fte_stationary.npz was."""
+    from scipy.optimize import minimize
+    ctx = _fte_model_setup()
+    out, N = ctx["out"], ctx["N"]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fk as ofk, fte as ofte
+    s, e = ctx["start_frame"], ctx["end_frame"]
+    det = out["det"][s:e]
+    prob = ofte.FTEProblem(det[..., :2], det[..., 2], out["K"], out["D"], out["R"], out["t"], 1.0 / float(out["fps"]),
+                           dlc_thresh=float(out["dlc_thresh"]))
+    X0 = out["init_x"].copy()
+    act = np.asarray(ofk.ACTIVE)
+    x0 = np.clip(X0[:, act], prob.lo, prob.hi)
+    nfev = [0]
+
+    def fun(v):
+        nfev[0] += 1
+        F, g, _H, _nb = prob.evaluate(v.reshape(N, len(act)))
+        return F, g.reshape(-1)
+
+    bounds = [(None if not np.isfinite(lo) else float(lo), None if not np.isfinite(hi) else float(hi))
+              for _ in range(N) for lo, hi in zip(prob.lo, prob.hi)]
+    res = minimize(fun, x0.reshape(-1), jac=True, method="L-BFGS-B", bounds=bounds,
+                   options=dict(maxiter=50000, maxfun=500000, ftol=1e-16, gtol=1e-9, maxcor=30))
+    xl = res.x.reshape(N, len(act))
+    Xl = X0.copy()
+    Xl[:, act] = xl
+    obj_ref, worst = _feasible_objective(ctx, Xl)
+    F, g, _H, _nb = prob.evaluate(xl)
+    fixed = ((xl <= prob.lo) & (g > 0)) | ((xl >= prob.hi) & (g < 0))
+    np.savez_compressed(os.path.join(OUT, "fte_lbfgs.npz"), x_lbfgs=Xl, cost_oracle=F, obj_ref_lbfgs=obj_ref,
+                        max_eq_residual=worst, nit=res.nit, nfev=res.nfev, message=str(res.message),
+                        proj_grad_inf=np.abs(np.where(fixed, 0.0, g)).max(), bound_active=int(fixed.sum()))
+    print("fte_lbfgs.npz: L-BFGS-B", res.message, "nit", res.nit, "nfev", res.nfev, "cost", F, "obj_ref", obj_ref,
+          "|proj grad|_inf", np.abs(np.where(fixed, 0.0, g)).max(), "bound-active", int(fixed.sum()))
+
+
 def gen_ekf():
     """The reference's OWN EKF + RTS-smoother text on two short synthetic clips (ekf_ref.npz).
 
@@ -610,8 +655,8 @@ def gen_dummy_scene():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: golden fixtures can only be regenerated in the build container"
     install_stubs()
-    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "fte_stationary", "ekf"]
+    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "fte_stationary", "fte_lbfgs", "ekf"]
     for name, fn in (("helpers", gen_ref_helpers), ("fk", gen_cheetah_fk), ("index", gen_index_path),
-                     ("fte_model", gen_fte_model), ("fte_stationary", gen_fte_stationary), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
+                     ("fte_model", gen_fte_model), ("fte_stationary", gen_fte_stationary), ("fte_lbfgs", gen_fte_lbfgs), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
         if name in parts:
             fn()
