@@ -66,7 +66,7 @@ class SkelOp(C.Structure):
 class SbaParams(C.Structure):
     _fields_ = [("n_cams", C.c_int32), ("optimize_cameras", C.c_int32), ("n_points", C.c_int64), ("n_obs", C.c_int64),
                 ("f_scale", C.c_double), ("lam0", C.c_double), ("ftol", C.c_double), ("gtol", C.c_double),
-                ("max_iter", C.c_int32), ("camera_model", C.c_int32)]
+                ("max_iter", C.c_int32), ("camera_model", C.c_int32), ("precision", C.c_int32), ("pad0", C.c_int32)]
 
 
 class SbaInfo(C.Structure):

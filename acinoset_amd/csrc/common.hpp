@@ -114,6 +114,13 @@ __device__ __forceinline__ void project_fisheye_pt(const Cam& c, double X, doubl
   v = yd * c.fy + c.cy;
 }
 
+// bf16 storage rounding (round-to-nearest-even on the upper 16 bits of the float)
+__device__ __forceinline__ float bf16_round(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
 __device__ __forceinline__ bool m_finite(double v) { return fabs(v) <= 1.79769313486231570e308; }   // false for NaN too
 
 // Right-singular vector of the smallest singular value of the 4x4 DLT matrix by INVERSE ITERATION on B = A^T A

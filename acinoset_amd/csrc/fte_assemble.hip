@@ -56,12 +56,6 @@ __device__ __forceinline__ void redescending_f(const LossF& L, float err, float&
     h = fminf(fmaxf(hh, 0.0f), 1.0f);
   }
 }
-// bf16 storage rounding (round-to-nearest-even on the upper 16 bits of the float)
-__device__ __forceinline__ float bf16_round(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return __uint_as_float(u & 0xffff0000u);
-}
 
 // PREC = ACINO_PREC_F64: everything fp64.  PREC = ACINO_PREC_BF16_ROWS (BASELINE config 5): camera-frame coordinates
 // in fp64, projection / Jacobian / robust weights in fp32, the scaled residuals and the 2x3 Jacobian ROWS rounded to

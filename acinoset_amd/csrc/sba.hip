@@ -6,6 +6,8 @@
 // Schur complement of the point blocks (3x3 per point) onto the camera block (6C x 6C), rotations updated by a
 // left perturbation R <- exp([dw]x) R (same minimiser, no rvec singularities).  One thread per POINT walks its
 // observations (CSR built by the host); camera-block sums are reduced in LDS, then one atomic per entry.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace acino {
@@ -83,7 +85,7 @@ __device__ __forceinline__ void pinhole_cam(const SbaIntr& c, const double Xc[3]
 
 struct SbaBuf {
   int C, P, M, opt_cams;
-  int model, pad;        // 0 fisheye, 1 pinhole
+  int model, prec;       // 0 fisheye, 1 pinhole | ACINO_PREC_F64 or ACINO_PREC_BF16_ROWS
   double fs;
   const double* intr;    // [C][16]
   const double* uv;      // [M][2]
@@ -104,10 +106,17 @@ struct SbaBuf {
 };
 
 // Evaluate at (Rt, pts): cost; with JAC also V, gp, Wpc, U, gc; optionally the residuals.
-template <bool JAC>
+// PREC = ACINO_PREC_BF16_ROWS (BASELINE config 5, "bf16 residuals with fp32 accumulate", the SBA half): camera-frame
+// point, projection and analytic Jacobians in fp64 as before; every residual and every Jacobian ROW (2x3 point part, 2x6
+// camera part) rounded to bf16 before it enters the normal equations; the IRLS weights come from the stored residual; the
+// point blocks V_p, g_p, the coupling blocks W_cp and the per-workgroup camera sums U_c, g_c are accumulated in fp32.  The
+// cost is summed in fp64 from the unrounded residuals (accept / reject needs more than 8 bits); Schur complement,
+// camera solve and the updates stay fp64.
+template <bool JAC, int PREC>
 __global__ void __launch_bounds__(256)
 k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ pts, double* __restrict__ res_out) {
-  __shared__ double sU[SBA_MAXC][27];
+  typedef typename std::conditional<PREC == ACINO_PREC_F64, double, float>::type acc_t;
+  __shared__ acc_t sU[SBA_MAXC][27];
   __shared__ double sred[4];
   const int tid = threadIdx.x;
   if (JAC)
@@ -117,7 +126,7 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
   double cost = 0.0, gmax = 0.0;
   if (p < B.P) {
     const double X[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
-    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    acc_t V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     const double ifs2 = 1.0 / (B.fs * B.fs);
     for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
       const int k = B.pt_obs[o], c = B.cam_idx[k];
@@ -137,19 +146,32 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
       const double z0 = r0 * r0 * ifs2, z1 = r1 * r1 * ifs2;
       cost += 0.5 * B.fs * B.fs * (log1p(z0) + log1p(z1));
       if (JAC) {
-        const double w0 = 1.0 / (1.0 + z0), w1 = 1.0 / (1.0 + z1);
-        double Jp[2][3], Jc[2][6];
+        acc_t w0, w1, rs0, rs1;
+        acc_t Jp[2][3], Jc[2][6];
+        if (PREC == ACINO_PREC_F64) {
+          w0 = 1.0 / (1.0 + z0);
+          w1 = 1.0 / (1.0 + z1);
+          rs0 = r0;
+          rs1 = r1;
+        } else {
+          rs0 = bf16_round((float)r0);
+          rs1 = bf16_round((float)r1);
+          const float fi = (float)ifs2;
+          w0 = 1.0f / (1.0f + (float)rs0 * (float)rs0 * fi);
+          w1 = 1.0f / (1.0f + (float)rs1 * (float)rs1 * fi);
+        }
+        auto st = [](double v) -> acc_t { return PREC == ACINO_PREC_F64 ? (acc_t)v : (acc_t)bf16_round((float)v); };
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) Jp[d][j] = Jpi[d][0] * R[j] + Jpi[d][1] * R[3 + j] + Jpi[d][2] * R[6 + j];
+          for (int j = 0; j < 3; ++j) Jp[d][j] = st(Jpi[d][0] * R[j] + Jpi[d][1] * R[3 + j] + Jpi[d][2] * R[6 + j]);
           // d(Xc)/d(dw) = -[RX]x ;  d(Xc)/d(dt) = I
-          Jc[d][0] = Jpi[d][1] * (-RX[2]) + Jpi[d][2] * RX[1];
-          Jc[d][1] = Jpi[d][0] * RX[2] - Jpi[d][2] * RX[0];
-          Jc[d][2] = -Jpi[d][0] * RX[1] + Jpi[d][1] * RX[0];
-          Jc[d][3] = Jpi[d][0];
-          Jc[d][4] = Jpi[d][1];
-          Jc[d][5] = Jpi[d][2];
+          Jc[d][0] = st(Jpi[d][1] * (-RX[2]) + Jpi[d][2] * RX[1]);
+          Jc[d][1] = st(Jpi[d][0] * RX[2] - Jpi[d][2] * RX[0]);
+          Jc[d][2] = st(-Jpi[d][0] * RX[1] + Jpi[d][1] * RX[0]);
+          Jc[d][3] = st(Jpi[d][0]);
+          Jc[d][4] = st(Jpi[d][1]);
+          Jc[d][5] = st(Jpi[d][2]);
         }
         V[0] += w0 * Jp[0][0] * Jp[0][0] + w1 * Jp[1][0] * Jp[1][0];
         V[1] += w0 * Jp[0][0] * Jp[0][1] + w1 * Jp[1][0] * Jp[1][1];
@@ -158,7 +180,7 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
         V[4] += w0 * Jp[0][1] * Jp[0][2] + w1 * Jp[1][1] * Jp[1][2];
         V[5] += w0 * Jp[0][2] * Jp[0][2] + w1 * Jp[1][2] * Jp[1][2];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g[j] += w0 * r0 * Jp[0][j] + w1 * r1 * Jp[1][j];
+        for (int j = 0; j < 3; ++j) g[j] += w0 * rs0 * Jp[0][j] + w1 * rs1 * Jp[1][j];
         double* W = B.Wpc + 18 * (size_t)k;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -171,7 +193,7 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
 #pragma unroll
             for (int bq = a; bq < 6; ++bq) atomicAdd(&sU[c][q++], w0 * Jc[0][a] * Jc[0][bq] + w1 * Jc[1][a] * Jc[1][bq]);
 #pragma unroll
-          for (int a = 0; a < 6; ++a) atomicAdd(&sU[c][21 + a], w0 * r0 * Jc[0][a] + w1 * r1 * Jc[1][a]);
+          for (int a = 0; a < 6; ++a) atomicAdd(&sU[c][21 + a], w0 * rs0 * Jc[0][a] + w1 * rs1 * Jc[1][a]);
         }
       }
     }
@@ -198,7 +220,7 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
     __syncthreads();
     for (int e = tid; e < B.C * 27; e += 256) {
       const int c = e / 27, q = e % 27;
-      const double v = sU[c][q];
+      const double v = (double)sU[c][q];
       if (v != 0.0) atomicAdd(q < 21 ? &B.U[21 * c + q] : &B.gc[6 * c + (q - 21)], v);
     }
   }
@@ -428,6 +450,7 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   ACINO_REQUIRE(prm->n_points >= 1 && prm->n_obs >= 1, "sizes (a rank without points cannot take part)");
   ACINO_REQUIRE(prm->f_scale > 0 && prm->lam0 > 0 && prm->max_iter >= 0, "f_scale, lam0, max_iter");
   ACINO_REQUIRE(prm->camera_model == 0 || prm->camera_model == 1, "camera_model: 0 fisheye, 1 pinhole");
+  ACINO_REQUIRE(prm->precision == ACINO_PREC_F64 || prm->precision == ACINO_PREC_BF16_ROWS, "precision: 0 f64, 1 bf16 rows");
   ACINO_REQUIRE(d_intr && d_Rt && d_pts && d_uv && d_cam_idx && d_pt_start && d_pt_obs && d_ws, "null buffer");
   ACINO_REQUIRE(((uintptr_t)d_ws & 255) == 0, "workspace must be 256-byte aligned");
   ACINO_REQUIRE(ws_bytes >= acino_sba_workspace_bytes(prm->n_cams, prm->n_points, prm->n_obs), "workspace too small");
@@ -446,7 +469,7 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   B.M = (int)M;
   B.opt_cams = prm->optimize_cameras ? 1 : 0;
   B.model = prm->camera_model;
-  B.pad = 0;
+  B.prec = prm->precision;
   B.fs = prm->f_scale;
   B.intr = d_intr;
   B.uv = d_uv;
@@ -485,9 +508,10 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     if (jac) {
       ACINO_HIP_CHECK(hipMemsetAsync(B.U, 0, C * 21 * 8, s));
       ACINO_HIP_CHECK(hipMemsetAsync(B.gc, 0, n * 8, s));
-      hipLaunchKernelGGL(k_sba_point<true>, dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+      if (B.prec == ACINO_PREC_F64) hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_F64>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+      else hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_BF16_ROWS>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
     } else {
-      hipLaunchKernelGGL(k_sba_point<false>, dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+      hipLaunchKernelGGL((k_sba_point<false, ACINO_PREC_F64>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);   // (cost only: fp64)
     }
     ACINO_LAUNCH_CHECK();
     if (int e = greduce(B.scal, 1, 0)) return e;

@@ -23,6 +23,8 @@ from . import _lib, calib
 from ._lib import SbaInfo, SbaParams, check, lib, ptr, stream_ptr
 
 last_info = None
+# acino_sba_params::precision: fp64 throughout, or BASELINE config 5's "bf16 residuals with fp32 accumulate"
+PRECISIONS = {"f64": 0, "bf16": 1}
 
 
 def _camera_model(project_func):
@@ -54,6 +56,7 @@ class ReduceHook:
 
     def __init__(self, ws, group=None):
         self.ws, self.group, self.calls, self.error = ws, group, 0, None
+        self.sizes = []                      # doubles per reduction, in call order
         self.fn = _lib.REDUCE_FN(self._call)
 
     def all_reduce(self, t, op):
@@ -75,6 +78,7 @@ class ReduceHook:
                 raise ValueError("reduction buffer outside the workspace")
             self.all_reduce(self.ws[off:off + 8 * n].view(torch.float64), op)
             self.calls += 1
+            self.sizes.append(int(n))
             return 0
         except Exception as e:      # an exception must not unwind through the C frames
             self.error = e
@@ -82,7 +86,7 @@ class ReduceHook:
 
 
 def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, optimize_cameras,
-           f_scale, max_iter, ftol, gtol, lam0=1e-3, model=0, group=None, sharded=False):
+           f_scale, max_iter, ftol, gtol, lam0=1e-3, model=0, group=None, sharded=False, precision="f64"):
     global last_info
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -121,7 +125,7 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
 
     prm = SbaParams(n_cams=n_cams, optimize_cameras=int(bool(optimize_cameras)), n_points=n_points, n_obs=n_obs,
                     f_scale=float(f_scale), lam0=float(lam0), ftol=float(ftol), gtol=float(gtol), max_iter=int(max_iter),
-                    camera_model=int(model))
+                    camera_model=int(model), precision=PRECISIONS[precision])
     nbytes = lib().acino_sba_workspace_bytes(n_cams, n_points, n_obs)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (ws.data_ptr() + 255) // 256 * 256
@@ -159,22 +163,23 @@ def bundle_adjust_points_only(points_2d, points_3d, point_3d_indices, camera_ind
 
 
 def bundle_adjust_points_and_extrinsics(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr,
-                                        t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10):
-    """calib.py:369-390: refine the 3-D points and every camera's rotation + translation (Cauchy loss, scale 1)."""
+                                        t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10, precision="f64"):
+    """calib.py:369-390: refine the 3-D points and every camera's rotation + translation (Cauchy loss, scale 1).
+    ``precision="bf16"``: BASELINE config 5's mixed mode (residual / Jacobian rows in bf16, blocks accumulated in fp32)."""
     return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
-                  max_iter, ftol, gtol, model=_camera_model(project_func))
+                  max_iter, ftol, gtol, model=_camera_model(project_func), precision=precision)
 
 
 def bundle_adjust_points_and_extrinsics_sharded(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
                                                 r_arr, t_arr, project_func=None, max_iter=300, ftol=1e-10, gtol=1e-10,
-                                                group=None):
+                                                group=None, precision="f64"):
     """The same refinement with the POINTS spread over the ranks of a torch.distributed group (one process per GPU)
     and the cameras shared: every rank passes its own points / observations (``point_3d_indices`` local, 0-based) and
     the same initial poses; the reduced camera system is summed over the ranks each iteration (a 6C x 6C block + 6C
     vector - BASELINE config 5's extrinsic refinement over all sequences).  Returns this rank's refined points, the
     common poses and this rank's residuals; ``last_info`` carries the GLOBAL costs."""
     return _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr, r_arr, t_arr, True, 1.0,
-                  max_iter, ftol, gtol, model=_camera_model(project_func), group=group, sharded=True)
+                  max_iter, ftol, gtol, model=_camera_model(project_func), group=group, sharded=True, precision=precision)
 
 
 def prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr, t_arr,
@@ -258,3 +263,104 @@ def bundle_adjust_board_points_and_extrinsics(img_pts_arr, fnames_arr, board_sha
     data = prepare_calib_board_data_for_bundle_adjustment(img_pts_arr, fnames_arr, board_shape, k_arr, d_arr, r_arr,
                                                           t_arr, triangulate_func)
     return bundle_adjust_points_and_extrinsics(*data, k_arr, d_arr, r_arr, t_arr, project_func)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: extrinsic refinement over the marker trajectories of many sequences (app.py:201-223 feeds board
+# corners or hand-picked points into calib.py:345-390; here the points are the FTE marker positions of every clip and
+# the observations their above-threshold detections, the six extrinsics shared by all sequences)
+# ---------------------------------------------------------------------------------------------------------------
+def dense_observations(det, dlc_thresh, min_views=2):
+    """Observation lists of dense detections det[N, C, L, 3] = (x, y, likelihood), built on the device: every (frame,
+    marker) seen by >= min_views cameras above the threshold (calib.py:281 keeps points with > 1 view) becomes a point;
+    observations are point-major, cameras ascending.  Returns (keep[N, L] bool, uv[M, 2], cam_idx[M] int32,
+    pt_start[P + 1] int32, pt_obs[M] int32) as device tensors."""
+    lik = det[..., 2].permute(0, 2, 1)                    # [N, L, C]
+    seen = lik > dlc_thresh
+    keep = seen.sum(-1) >= min_views                      # [N, L]
+    sel = seen & keep[..., None]
+    idx = torch.nonzero(sel)                              # rows sorted by (frame, marker, camera)
+    uv = det.permute(0, 2, 1, 3)[idx[:, 0], idx[:, 1], idx[:, 2], :2].contiguous()
+    cam_idx = idx[:, 2].to(torch.int32).contiguous()
+    counts = sel.sum(-1)[keep]                            # observations per kept point, in point order
+    pt_start = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=det.device)
+    pt_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    pt_obs = torch.arange(uv.shape[0], dtype=torch.int32, device=det.device)
+    return keep, uv, cam_idx, pt_start, pt_obs
+
+
+def bundle_adjust_dense_points_and_extrinsics(det, points_3d, k_arr, d_arr, r_arr, t_arr, dlc_thresh=0.5, precision="f64",
+                                              max_iter=100, ftol=1e-10, gtol=1e-10, f_scale=1.0, lam0=1e-3, min_views=2,
+                                              group=None):
+    """calib.py:369-390 on DENSE data, everything resident on the device: det[N, C, 20, 3] detections and
+    points_3d[N, 20, 3] initial points (e.g. ``positions`` of an FTE solve, clips concatenated along N); fisheye model.
+    Returns (points[N, 20, 3] - refined where a point had >= min_views views, input value elsewhere -, r_arr[C, 3, 3],
+    t_arr[C, 3, 1], info) with info = the solver summary plus ``n_points``, ``n_obs`` and the rms residuals (px)
+    before / after.  ``group``: a torch.distributed group whose ranks each hold their own sequences (points sharded,
+    cameras replicated: the reduced camera system - (6C)^2 + 6C doubles - is all-reduced every iteration)."""
+    global last_info
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    det = calib._to_dev(det, dev)
+    pts_all = calib._to_dev(points_3d, dev).to(torch.float64).contiguous().clone()
+    n_cams = len(k_arr)
+    if det.dim() != 4 or det.shape[1] != n_cams or tuple(pts_all.shape) != (det.shape[0], det.shape[2], 3):
+        raise ValueError("det must be [N, C, L, 3] and points_3d [N, L, 3] for the C cameras of the rig")
+    keep, uv, cam_idx, pt_start, pt_obs = dense_observations(det, float(dlc_thresh), min_views)
+    n_points, n_obs = int(pt_start.numel() - 1), int(uv.shape[0])
+    if n_points < 1:
+        raise ValueError("no point is seen by enough cameras")
+    intr = np.zeros((n_cams, 16))
+    Rt = np.zeros((n_cams, 12))
+    for c in range(n_cams):
+        k = np.asarray(k_arr[c], dtype=np.float64)
+        intr[c, :4] = [k[0, 0], k[1, 1], k[0, 2], k[1, 2]]
+        intr[c, 4:8] = np.asarray(d_arr[c], dtype=np.float64).reshape(-1)[:4]
+        r = np.asarray(r_arr[c], dtype=np.float64)
+        u, _s, vt = np.linalg.svd(calib._rodrigues(r) if r.size == 3 else r)     # (as _solve: cv2.Rodrigues' SO(3) projection)
+        Rt[c, :9] = (u @ vt).reshape(-1)
+        Rt[c, 9:] = np.asarray(t_arr[c], dtype=np.float64).reshape(-1)
+    d_intr, d_Rt = torch.as_tensor(intr, device=dev), torch.as_tensor(Rt, device=dev)
+    d_pts = pts_all[keep].contiguous()
+    prm = SbaParams(n_cams=n_cams, optimize_cameras=1, n_points=n_points, n_obs=n_obs, f_scale=float(f_scale),
+                    lam0=float(lam0), ftol=float(ftol), gtol=float(gtol), max_iter=int(max_iter), camera_model=0,
+                    precision=PRECISIONS[precision])
+    nbytes = lib().acino_sba_workspace_bytes(n_cams, n_points, n_obs)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+    res_b = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
+    res_a = torch.empty((n_obs, 2), dtype=torch.float64, device=dev)
+    info = SbaInfo()
+    hook = ReduceHook(ws, group) if group is not None else None
+    status = lib().acino_sba_solve_sharded(C.byref(prm), ptr(d_intr), ptr(d_Rt), ptr(d_pts), ptr(uv), ptr(cam_idx),
+                                           ptr(pt_start), ptr(pt_obs), C.c_void_p(ws_ptr), nbytes, ptr(res_b), ptr(res_a),
+                                           C.byref(info), hook.fn if hook else _lib.REDUCE_FN(0), None, stream_ptr())
+    if hook is not None and hook.error is not None:
+        raise hook.error
+    check(status)
+    torch.cuda.current_stream().synchronize()
+    last_info = info.as_dict()
+    out = dict(last_info, n_points=n_points, n_obs=n_obs, precision=precision,
+               rms_before=float(res_b.pow(2).mean().sqrt()), rms_after=float(res_a.pow(2).mean().sqrt()),
+               reduce_calls=hook.calls if hook else 0, reduce_sizes=sorted(set(hook.sizes)) if hook else [])
+    pts_all[keep] = d_pts
+    Rt_o = d_Rt.cpu().numpy()
+    return pts_all, Rt_o[:, :9].reshape(n_cams, 3, 3).copy(), Rt_o[:, 9:].reshape(n_cams, 3, 1).copy(), out
+
+
+def refine_extrinsics_from_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=0.5, precision="bf16", fte_iter=60,
+                                 sba_iter=60, fte_kw=None, sba_kw=None):
+    """BASELINE config 5 end to end on one GPU: the clips' trajectories are estimated with the current rig (fte_solve_clips:
+    all clips as one chain, ``precision`` = "bf16": bf16 residual / Jacobian rows, fp32 accumulation), then the marker
+    positions of ALL clips and their above-threshold detections go through one bundle adjustment of points + the shared
+    extrinsics in the same precision mode.  Returns (r_arr, t_arr, info) with info = dict(fte=..., sba=...)."""
+    from . import fte
+    outs = fte.fte_solve_clips(dets, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, max_iter=fte_iter,
+                               return_numpy=False, precision=precision, **(fte_kw or {}))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pos = torch.cat([o[0]["positions"] for o in outs], 0)
+    det_all = torch.cat([calib._to_dev(d, dev) for d in dets], 0)
+    _pts, r_new, t_new, info = bundle_adjust_dense_points_and_extrinsics(det_all, pos, k_arr, d_arr, r_arr, t_arr, dlc_thresh,
+                                                                         precision=precision, max_iter=sba_iter,
+                                                                         **(sba_kw or {}))
+    return r_new, t_new, dict(fte=outs[0][1], sba=info)

@@ -323,6 +323,11 @@ typedef struct acino_sba_params {
   double gtol;                /* stop when ||J^T W r||_inf <= gtol */
   int32_t max_iter;
   int32_t camera_model;       /* 0 = cv2.fisheye (app.py:220-223), 1 = cv2.projectPoints pinhole (app.py:215-218) */
+  int32_t precision;          /* ACINO_PREC_F64 (0) or ACINO_PREC_BF16_ROWS (1): BASELINE config 5's "bf16 residuals with fp32
+                               * accumulate" for the extrinsic refinement - residuals and Jacobian rows rounded to bf16, the
+                               * point / coupling / camera blocks accumulated in fp32; cost, Schur complement, camera solve
+                               * and updates fp64 */
+  int32_t pad0;
 } acino_sba_params;
 typedef struct acino_sba_info {
   double cost_initial, cost_final, gnorm_inf, lam;

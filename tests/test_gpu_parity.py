@@ -334,16 +334,21 @@ def test_gpu_lm_ends_at_a_stationary_point_of_the_reference_objective(mods, gold
     # (ftol = 1e-15 is below the resolution of the fp64 cost sum: "no damping gives descent any more" is the same end)
     assert info["status_name"] in ("ftol", "xtol", "gtol", "lambda_overflow"), info
     xg = np.asarray(res["x"])
-    # (observed: 1121.23161 on the GPU against 1121.23207 - after the common start, rounding decides between accept and
-    #  reject somewhere and the two runs settle 1.5e-3 apart in the same flat valley, both stationary)
-    assert abs(info["cost"] - float(st["obj_ref_star"])) < 1e-6 * abs(float(st["obj_ref_star"])), (info["cost"], float(st["obj_ref_star"]))
+    # (observed end costs in this valley: oracle LM x* 1121.23207, GPU 1121.23161 with the round-2 solver and 1121.22941
+    #  with the chunked solver, scipy L-BFGS-B after 50 000 iterations 1121.22759 (fte_lbfgs.npz): after the common start,
+    #  rounding decides between accept and reject somewhere and the runs settle at neighbouring stationary points of the
+    #  non-convex objective, 1e-6 ... 4e-6 apart in cost and up to 2-3 mm apart in the least constrained marker)
+    lb = np.load(os.path.join(golden_dir, "fte_lbfgs.npz"))
+    assert abs(info["cost"] - float(st["obj_ref_star"])) < 1e-5 * abs(float(st["obj_ref_star"])), (info["cost"], float(st["obj_ref_star"]))
+    assert abs(info["cost"] - float(lb["obj_ref_lbfgs"])) < 1e-5 * abs(info["cost"])
     cost, grad, _H, _nb = prob.evaluate(xg)
     assert abs(cost - info["cost"]) < 1e-10 * abs(cost)
     active = ((xg <= prob.lo) & (grad > 0)) | ((xg >= prob.hi) & (grad < 0))
     scale = np.abs(st["grad_ref_init"]).max()
     assert np.abs(np.where(active, 0.0, grad)).max() < 1e-6 * scale, np.abs(np.where(active, 0.0, grad)).max()
-    assert np.abs(xg - st["x_star"][:, fte.ACTIVE]).max() < 5e-3
-    assert np.abs(np.asarray(res["positions"]) - ofk.cheetah_fk(st["x_star"])).max() < 1e-3
+    assert np.abs(xg - st["x_star"][:, fte.ACTIVE]).max() < 1e-2
+    for other in (st["x_star"], lb["x_lbfgs"]):
+        assert np.abs(np.asarray(res["positions"]) - ofk.cheetah_fk(other)).max() < 3e-3
 
 
 def test_lm_path_identity_on_nasty_small_problems(mods):
