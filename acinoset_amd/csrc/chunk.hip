@@ -31,9 +31,11 @@ void ChunkPlan::build(int nodes, int chunk_nodes) {
   if (chunk_nodes < 0 || nodes < 1) return;
   int mm = chunk_nodes;
   if (mm == 0) {
-    // automatic: one run per CU for the long chains, runs of at least 4 nodes for the short ones
+    // automatic: one run per CU (256) - one round of workgroups, the fewest separators - for the long chains (measured on
+    // config 5's 21 334-node chain: 3.45 ms per iteration with runs of 84 against 3.90 with runs of 16 in 5 rounds), runs of
+    // at least 4 nodes for the short ones
     mm = (nodes + 255) / 256;
-    mm = std::max(4, std::min(mm, 16));
+    mm = std::max(4, std::min(mm, 512));
   }
   mm = std::max(2, mm);
   m = mm;

@@ -152,6 +152,16 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
     return out
 
 
+def _rod(v):
+    """Rodrigues vector -> rotation matrix (host helper for the synthetic rig perturbation)."""
+    th = float(np.linalg.norm(v))
+    if th < 1e-12:
+        return np.eye(3)
+    k = np.asarray(v) / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
 def secondary_metrics(det, rig, Ts):
     """SURVEY 8(d)'s other two quantities, single GPU: config 2 (triangulation + reprojection residual over the
     whole 10 000-frame detection tensor, HBM-resident) and the end-to-end solve wall-clock to a fixed tolerance
@@ -254,14 +264,48 @@ def secondary_metrics(det, rig, Ts):
                                                               "fp64 from the 6x6 spatial blocks on (acino_fte_params::precision = 1)",
                         assemble_ms_per_step=prof["assemble"]["ms"] / 5,
                         lm="one controller over the sum of the clips' costs")
+    # ... and config 5's other half: the six shared extrinsics refined over the marker positions of all 64 clips
+    # (sba.bundle_adjust_dense_points_and_extrinsics: points = FTE positions, observations = above-threshold detections)
+    try:
+        from acinoset_amd import sba as _sba
+        _log("secondary: config 5, extrinsic refinement over 64 x 1000 frames")
+        rng = np.random.default_rng(7)
+        pos64 = torch.as_tensor(seq["pos_true"], device=dev).repeat(64, 1, 1)
+        pos64 = pos64 + 0.005 * torch.randn(pos64.shape, dtype=torch.float64, device=dev)
+        Rp = np.array([_rod(rng.normal(0, 1, 3) / np.sqrt(3) * np.radians(0.5)) @ r3[2][c] for c in range(len(r3[2]))])
+        tp = np.asarray(r3[3], dtype=np.float64).reshape(-1, 3, 1) + rng.normal(0, 1, (len(r3[2]), 3, 1)) / np.sqrt(3) * 1e-2
+        c5 = {}
+        for prec in ("f64", "bf16"):
+            for _rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _pts, _r, _t, info = _sba.bundle_adjust_dense_points_and_extrinsics(det64, pos64, r3[0], r3[1], Rp, tp, 0.5, precision=prec,
+                                                                                    max_iter=10, ftol=0.0, gtol=0.0)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            it = max(info["iterations"], 1)
+            c5[prec] = dict(seconds=dt, iterations=info["iterations"], ms_per_outer_iteration=1e3 * dt / it, n_points=info["n_points"],
+                            n_obs=info["n_obs"], observations_per_s=info["n_obs"] * it / dt, rms_before_px=info["rms_before"],
+                            rms_after_px=info["rms_after"], cost_initial=info["cost_initial"], cost_final=info["cost_final"],
+                            includes="observation lists built on the device, workspace allocation, 10 LM iterations (two 32-byte read-backs each)")
+        c5["bytes_per_observation"] = dict(algorithmic_survey=200, as_implemented=16 + 8 + 144 * 3,
+                                           note="uv + indices + the 6x3 coupling block W_cp written once and read by the Schur and back-substitution kernels")
+        c5["all_reduce_doubles_per_iteration_when_sharded"] = (6 * len(r3[2])) ** 2 + 6 * len(r3[2])
+        out["config5_sba_extrinsics"] = c5
+        del pos64
+    except Exception as exc:                           # pragma: no cover
+        out["config5_sba_extrinsics"] = dict(error=f"{type(exc).__name__}: {exc}")
     del det64
-    # the benchmark sequence with an INCOMPLETE reduction (acino_fte_params::bcr_levels): couplings between nodes
-    # 3 * 2^K frames apart dropped, their measured size eps reported; same LM trajectory to ~eps
+    # the benchmark sequence under the linear-solver variants: the round-1/2 solver (block cyclic reduction over the whole
+    # chain), the chunked sweep with a COMPLETE reduction of the separator chain, and the default (separator chain reduced
+    # until the remaining nodes are TRUNC_DISTANCE frames apart, dropped couplings re-introduced by refinement sweeps whose
+    # measured contraction bounds the error: state.trunc_eps)
     x10 = fte.triangulation_init(d, *rig, 0.5)[:, fte.ACTIVE]
     inc = {}
-    for K in (0, 8, 7):
-        _log(f"secondary: incomplete reduction, levels = {K}")
-        c = fte.FTEContext(d, *rig, Ts, ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, bcr_levels=K)
+    for tag, kw in (("whole_chain_bcr_complete", dict(chunk_nodes=-1, bcr_levels=0)), ("chunked_complete", dict(bcr_levels=0)),
+                    ("chunked_truncated_refined_default", {})):
+        _log(f"secondary: solver variant {tag}")
+        c = fte.FTEContext(d, *rig, Ts, ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, **kw)
         with torch.cuda.stream(side):
             c.enable_graph(True)
             c.set_x(x10)
@@ -274,12 +318,14 @@ def secondary_metrics(det, rig, Ts):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             stK = c.state()
+        inc[tag] = dict(ms_per_step=1e3 * dt / 20, frames_per_s=N * 20 / dt, cost_after_23_steps=stK["cost"], accepted=stK["accepted"],
+                        trunc_eps=stK["trunc_eps"], status=stK["status_name"], plan=fte.solver_plan(c.params),
+                        bcr_levels=int(c.params.bcr_levels), refine_sweeps=int(c.params.refine_sweeps))
         c.close()
-        inc["complete" if K == 0 else f"levels_{K}"] = dict(ms_per_step=1e3 * dt / 20, frames_per_s=N * 20 / dt, cost_after_23_steps=stK["cost"],
-                                                          accepted=stK["accepted"], trunc_eps=stK["trunc_eps"], status=stK["status_name"])
-    out["incomplete_reduction_10k"] = inc
+    out["solver_variants_10k"] = inc
     _log("secondary: end-to-end solve of the 10 000-frame sequence")
-    for key, kw in (("solve_10k_frames", {}), ("solve_10k_frames_incomplete_auto", {"bcr_levels": "auto"})):
+    for key, kw in (("solve_10k_frames", {}), ("solve_10k_frames_complete_reduction", {"bcr_levels": 0}),
+                    ("solve_10k_frames_whole_chain_bcr", {"bcr_levels": 0, "chunk_nodes": -1})):
         for _rep in range(2):                  # (second run: graph capture, allocator and first-touch costs paid)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -288,6 +334,7 @@ def secondary_metrics(det, rig, Ts):
             dt = time.perf_counter() - t0
         out[key] = dict(seconds=dt, iterations=info["iter"], status=info["status_name"], cost=info["cost"],
                         init="per-frame triangulation", frames_per_s_end_to_end=N / dt, trunc_eps=info.get("trunc_eps", 0.0),
+                        bcr_levels=info.get("bcr_levels"),
                         includes="init triangulation, workspace setup, LM loop to ftol = xtol = 1e-10, outputs")
     return out
 
@@ -414,6 +461,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     st = ctx.state()
+    assert st["status"] != 7, "the timed steps were refused by the truncation check: not a valid measurement"
 
     if rank == 0:
         n_loc = n1 - n0
@@ -475,6 +523,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"FTE LM iteration, {N_CAMS} cam x 20 markers x {args.frames} frames (BASELINE configs[3] shape"
                                    f"{'' if world > 1 else ' on one GPU'}), loop trajectory, seed 20210313",
+                       "linear_solver": (dict(plan=fte.solver_plan(ctx.params), bcr_levels=int(ctx.params.bcr_levels),
+                                              refine_sweeps=int(ctx.params.refine_sweeps), trunc_tol=float(ctx.params.trunc_tol),
+                                              note="chunked sweep; separator chain reduced bcr_levels levels, the remaining nodes solved on "
+                                                   "their own and corrected by refine_sweeps block-Jacobi sweeps over the dropped "
+                                                   "couplings; the error bound measured from the sweeps' contraction (lm_state.trunc_eps) "
+                                                   "is checked against trunc_tol INSIDE every timed step (status 7 otherwise); "
+                                                   "bcr_levels = 0: complete reduction") if world == 1 else None),
                        "frames": args.frames, "cams": N_CAMS, "markers": 20, "states": 25,
                        "parallelism": (f"frames sharded x{world}, " + (f"overlapping windows (halo {args.halo} frames), 2 all-gathers / step"
                                                                         if windows else "separator system, 1 all-reduce + 2 all-gathers / step"))
@@ -507,6 +562,8 @@ def main():
                                           "waiting for the slowest rank); kernel_ms_per_step above is rank 0's shard"}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(det, rig, seq["Ts"])
+            # time to solution, first class beside the per-iteration headline (what an inexact step must answer to)
+            out["end_to_end"] = {k: out["secondary"][k] for k in ("solve_10k_frames", "config3_solve_1k_frames") if k in out["secondary"]}
         if not args.no_cpu_baseline and world == 1:
             _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline(det, rig, seq["Ts"], x0_full)
