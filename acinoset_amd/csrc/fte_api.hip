@@ -304,7 +304,7 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
       r_d0 = fmax(r_d0, sh[w][6]);
       r_x = fmax(r_x, sh[w][7]);
     }
-    const double tot[8] = {c, p, s, g, (double)nb, 0.0, 0.0, 0.0};
+    double tot[8] = {c, p, s, g, (double)nb, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 8; ++q) totals[q] = tot[q];
     *nbehind = 0;
@@ -329,6 +329,10 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
         if (ne & 4) atomicOr(numeric_err_rw, 4);
       }
     }
+    // slot 5: this rank's numeric flags (bit 0 pivot, 1 tail timeout, 2 truncation).  Sharded drivers combine it over the
+    // ranks (max) with the sums, so every rank's controller takes the same status in the same iteration
+    totals[5] = (double)ne;
+    tot[5] = (double)ne;
     if (fused_control >= 0) {
       lm_control_local(T, S, tot, ne, fused_control);
       *st = S;
@@ -395,7 +399,9 @@ __device__ void lm_control(const FteConst& K, acino_fte_state* st, const double*
                            int init) {
   acino_fte_state S = *st;
   const LmTol T{K.gtol, K.ftol, K.xtol, K.lam_max, K.clamp_lambda};
-  lm_control_local(T, S, totals, *numeric_err, init);
+  // the local flag and the flag that travelled with the (combined) sums: a failure on ANY rank stops every rank
+  const int flag = *numeric_err | (totals[5] > 0.0 ? (int)totals[5] : 0);
+  lm_control_local(T, S, totals, flag, init);
   *st = S;
 }
 
@@ -419,6 +425,7 @@ __global__ void k_control_gathered(const FteConst* __restrict__ cst, acino_fte_s
     tot[2] = fmax(tot[2], p[2]);
     tot[3] = fmax(tot[3], p[3]);
     tot[4] += p[4];
+    tot[5] = (double)((int)tot[5] | (p[5] > 0.0 ? (int)p[5] : 0));
   }
   lm_control(*cst, st, tot, numeric_err, init);
 }

@@ -152,7 +152,7 @@ class TorchComm:
 
 
 def combine_partials(gathered):
-    """[world, 8] local sums -> global {cost, pred, step_inf, gnorm_inf, n_behind, 0, 0, 0}; fixed (rank)
+    """[world, 8] local sums -> global {cost, pred, step_inf, gnorm_inf, n_behind, numeric flags, 0, 0}; fixed (rank)
     order, so every rank computes bit-identical totals."""
     total = torch.zeros(8, dtype=gathered.dtype, device=gathered.device)
     total[0] = gathered[:, 0].sum()
@@ -160,6 +160,7 @@ def combine_partials(gathered):
     total[2] = gathered[:, 2].max()
     total[3] = gathered[:, 3].max()
     total[4] = gathered[:, 4].sum()
+    total[5] = gathered[:, 5].max()      # numeric flags (pivot / sync timeout / truncation): any rank's failure is everyone's
     return total
 
 

@@ -1000,7 +1000,7 @@ def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods, sol
                  "chunked_refined": (dict(chunk_nodes=4, bcr_levels=3, refine_sweeps=4),
                                      dict(chunk_nodes=4, bcr_levels=1, refine_sweeps=1))}[solver]
     runs = {}
-    for tag, kw in (("full", dict(chunk_nodes=good["chunk_nodes"])), ("trunc", good)):
+    for tag, kw in (("full", dict(chunk_nodes=good["chunk_nodes"], bcr_levels=0)), ("trunc", good)):
         c = _ctx(fte, seq, ftol=0.0, xtol=0.0, gtol=0.0, **kw)
         c.set_x(x0)
         eps = []
@@ -1028,7 +1028,7 @@ def test_incomplete_reduction_is_verified_and_matches_the_complete_one(mods, sol
     x45 = np.clip(x45, lo, hi)
     det = seq["det"]
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
-    ref, iref = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, chunk_nodes=good["chunk_nodes"])
+    ref, iref = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, chunk_nodes=good["chunk_nodes"], bcr_levels=0)
     got, igot = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x45, max_iter=60, **bad)
     assert igot["status_name"] in ("ftol", "xtol", "gtol") and igot.get("bcr_levels", bad["bcr_levels"]) != bad["bcr_levels"]
     # (the restarted controller begins again at lam0, so the two runs stop at slightly different points of the same basin)
@@ -1130,6 +1130,35 @@ def test_overlapping_windows_converge_to_the_single_gpu_optimum(mods):
         assert st["iter"] <= st_ref["iter"] + 6
         for d, *_ in drv:
             d.ctx.close()
+
+
+def test_window_ranks_refuse_a_truncated_step_together(mods):
+    """A window context with an incomplete reduction whose error bound exceeds trunc_tol (here: made impossible to meet):
+    the refusal is taken on the split-control path (k_totals -> the flag travels in slot 5 of the partial sums -> every
+    rank's controller), so ALL ranks stop with status 7 in the same iteration - no rank applies an unverified step and no
+    rank is left waiting in a collective.  Two windows in lock step, only ONE of them truncates."""
+    calib, fte, synth = mods
+    from acinoset_amd import dist as adist
+    n = 1500
+    seq = synth.make_sequence(n, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = seq["q_true"][:, fte.ACTIVE] + np.random.default_rng(5).normal(0, 0.02, (n, 25))
+    lo, hi = fte.bounds45()
+    x0 = np.clip(x0, lo[fte.ACTIVE], hi[fte.ACTIVE])
+    det = torch.as_tensor(seq["det"])
+    box = _LockStepComm(2)
+    drv = []
+    for r in range(2):
+        kw = dict(bcr_levels=1, refine_sweeps=0, trunc_tol=1e-300, chunk_nodes=4) if r == 1 else {}
+        d, (w0, w1, n0, n1) = adist.make_windowed(det, *rig, seq["Ts"], r, 2, halo=96, comm=box.rank(r), shared_gpu=True, **kw)
+        drv.append((d, w0, w1))
+    box.run([lambda d=d, w0=w0, w1=w1: d.set_x(x0[w0:w1]) for d, w0, w1 in drv])
+    box.run([d.step for d, *_ in drv])
+    sts = [d.state() for d, *_ in drv]
+    assert [s["status"] for s in sts] == [7, 7] and all(s["accepted"] == 0 for s in sts), sts
+    assert sts[1]["trunc_eps"] > 0.0 and sts[0]["trunc_eps"] == 0.0
+    for d, *_ in drv:
+        d.ctx.close()
 
 
 @pytest.mark.parametrize("start", ["near", "line"])
