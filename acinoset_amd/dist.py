@@ -321,7 +321,6 @@ class HipWindowBackend:
     """One rank's window on this process's GPU: thin calls into the C ABI (single-GPU context with an owned range)."""
 
     def __init__(self, det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global, n_offset, own_first, own_count, **kw):
-        kw.setdefault("bcr_levels", 0)      # (complete reduction unless the caller asks: a refused step needs every rank's consent)
         self.ctx = fte.FTEContext(det_window, k_arr, d_arr, r_arr, t_arr, Ts, n_global=n_global, n_offset=n_offset,
                                   own_first=own_first, own_count=own_count, **kw)
         self.device = self.ctx.device
@@ -329,6 +328,22 @@ class HipWindowBackend:
 
     def new(self, *shape):
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def escalate(self):
+        """After a refused (status 7) step: this window with one more reduction level.  Returns the current iterate of the
+        whole window, which the driver loads again (every rank does the same in the same iteration: the refusal travels with
+        the partial sums)."""
+        n = self.ctx.N
+        x = torch.empty((n, N_ACTIVE), dtype=torch.float64, device=self.device)
+        self._c(lib().acino_fte_copy_frames, 0, 0, 0, n, ptr(x), stream_ptr())
+        levels = int(self.ctx.params.bcr_levels) + 1
+        if int(self.ctx.params.bcr_levels) == 0 or levels >= fte.solver_plan(self.ctx.params)["levels"]:
+            levels = 0
+        self.ctx.close()
+        self.ctx._kw = dict(self.ctx._kw, bcr_levels=levels)
+        self.ctx._kw.pop("trunc_distance", None)
+        self.ctx._create()
+        return x
 
     def _c(self, fn, *args):
         check(fn(self.ctx._h, *args))
@@ -475,10 +490,21 @@ class WindowedFTE:
         return self.b.state()
 
     def solve(self, max_iter, peek_every=8):
-        for it in range(max_iter):
+        it = 0
+        while it < max_iter:
             self.step()
-            if (it % peek_every) == peek_every - 1 and self.b.state()["status"] != 0:
-                break
+            it += 1
+            if (it % peek_every) == 0 or it == max_iter:
+                st = self.b.state()
+                if st["status"] == 7 and hasattr(self.b, "escalate"):
+                    # a rank's truncated solve could not verify its step: every rank has stopped (the flag travels with the
+                    # sums), nobody applied it; all continue with one more reduction level from the current iterate
+                    x = self.b.escalate()
+                    self._graphs = {}
+                    self.set_x(x)
+                    continue
+                if st["status"] != 0:
+                    break
         return self.b.state()
 
     def result_x(self):

@@ -348,8 +348,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / solve-to-tolerance extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
-    ap.add_argument("--shard", choices=("windows", "separators"), default="windows",
-                    help="N > 1: overlapping windows (two all-gathers per step, step exact to the decay over --halo frames) or "
+    ap.add_argument("--shard", choices=("both", "windows", "separators"), default="both",
+                    help="N > 1: 'both' (default) = the headline is the separator system - the north star's RCCL all-reduce on the "
+                         "temporal-coupling rows, exact step - and the overlapping-window driver is timed in the same run "
+                         "(drivers.windows); or one of: overlapping windows (two all-gathers per step, step exact to the decay over --halo frames) or "
                          "exact separator system (one all-reduce + two all-gathers)")
     ap.add_argument("--halo", type=int, default=192, help="--shard windows: frames of overlap on either side")
     ap.add_argument("--bcr-levels", type=int, default=None,
@@ -395,6 +397,50 @@ def main():
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     x0_full = fte.triangulation_init(det, *rig, 0.5)
     windows = world > 1 and args.shard == "windows"
+
+    def time_other_driver(kind):
+        """K timed steps of the driver that is NOT the headline of this run (same sequence, same start, same barrier /
+        synchronise bracket, max over ranks), with HIP-event times of its collectives."""
+        cm = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True, shared_gpu="ACINO_FORCE_DEVICE" in os.environ)
+        if kind == "windows":
+            sv, (w0_, w1_, a0, a1) = adist.make_windowed(torch.as_tensor(det), *rig, seq["Ts"], rank, world, halo=args.halo, **cm)
+            xl = torch.as_tensor(x0_full[w0_:w1_][:, fte.ACTIVE])
+        else:
+            sv, (a0, a1) = adist.make_sharded(torch.as_tensor(det), *rig, seq["Ts"], rank, world, **cm)
+            xl = torch.as_tensor(x0_full[a0:a1][:, fte.ACTIVE])
+        sd = torch.cuda.Stream()
+        sd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sd):
+            if not args.no_graph:
+                (sv if kind == "windows" else sv.b.ctx).enable_graph(True)
+            sv.set_x(xl)
+            for _ in range(args.warmup):
+                sv.step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                sv.step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0_
+            sv.collect_timing(True)
+            for _ in range(args.steps):
+                sv.step()
+            torch.cuda.synchronize()
+            coll_ = sv.timing_summary()
+            sv.collect_timing(False)
+            st_ = (sv.ctx if kind == "windows" else sv.b.ctx).state()
+        tm = torch.tensor([dt_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt_ = float(tm.item())
+        (sv.ctx if kind == "windows" else sv.b.ctx).close()
+        return dict(ms_per_step=1e3 * dt_ / args.steps, value=args.frames * args.steps / dt_, unit="frames/s", collectives_per_step=coll_,
+                    lm_state={k: st_[k] for k in ("cost", "iter", "accepted", "status_name", "trunc_eps")},
+                    what=("overlapping windows (halo %d frames): 2 all-gathers / step, step exact to the decay over the halo" % args.halo)
+                    if kind == "windows" else "separator system: 1 all-reduce on the separator rows + 2 all-gathers / step, exact step")
+
+    other = time_other_driver("windows") if (world > 1 and args.shard == "both") else None
     common = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,                           # never stops: every step is full work
                   shared_gpu="ACINO_FORCE_DEVICE" in os.environ)                             # (ranks sharing one GPU: functional runs only)
     solver_kw = {}
@@ -552,6 +598,7 @@ def main():
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},
         }
         if world > 1:
+            out["drivers"] = {"headline": "windows" if windows else "separators", "windows": other if not windows else None}
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
                                   "payload_bytes": ({"all_gather_edge_slabs": world * 2 * (args.halo + 3) * 25 * 8, "all_gather_scalars": world * 8 * 8}

@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64
 cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 # the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
-mkdir -p $R/profiles/round2_final && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round2_final/ 2>/dev/null
+mkdir -p $R/profiles/round3 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round3/ 2>/dev/null
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
