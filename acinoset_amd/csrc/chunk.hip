@@ -88,274 +88,8 @@ __device__ __forceinline__ void tile_store(double* M, int ib, int jb, const d4& 
   for (int rr = 0; rr < 4; ++rr) M[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = a[rr];
 }
 
-// accL(ib, jb) -= W(:, ib)^T W(:, jb) over the lower tiles, rows of tiles dealt to the waves as in k_bcr_update (one
-// LDS operand read feeds every tile of a row): wave 0: row 4 | 1: row 3 | 2: row 2 and (0,0) | 3: row 1
-template <int WAVE>
-__device__ __forceinline__ void syrk_acc(const double* W, double* Acc, int li, int lk) {
-  constexpr int nb = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 3 : 2));
-  constexpr int nt = WAVE == 0 ? 5 : (WAVE == 1 ? 4 : (WAVE == 2 ? 4 : 2));
-  d4 acc[nt];
-#pragma unroll
-  for (int q = 0; q < nt; ++q) {
-    const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
-    const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Acc[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li];
-  }
-  const double* p = W + lk * LD + li;
-#pragma unroll
-  for (int s = 0; s < BS / 4; ++s) {
-    double v[nb];
-#pragma unroll
-    for (int c = 0; c < nb; ++c) v[c] = p[(4 * s) * LD + c * 16];
-#pragma unroll
-    for (int q = 0; q < nt; ++q) {
-      const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
-      const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
-      acc[q] = mfma(-v[ib], v[jb], acc[q]);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < nt; ++q) {
-    const int ib = WAVE == 0 ? 4 : (WAVE == 1 ? 3 : (WAVE == 2 ? (q < 3 ? 2 : 0) : 1));
-    const int jb = WAVE == 2 ? (q < 3 ? q : 0) : q;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Acc[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = acc[q][rr];
-  }
-}
-
-constexpr int SW_VEC = 7 * BS + 8 + 18 * NP;   // bv yv zv blv ysc[3] | red | cL cR
-static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
-
-// One workgroup per run: forward elimination of its interior nodes, left to right.
-__global__ void __launch_bounds__(256)
-k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
-              int m, int n_chunks) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (status && *status != 0) return;
-  double* X = reinterpret_cast<double*>(smem_raw);   // D~_k -> factor (U in the upper tiles) -> G_k -> stencil workspace
-  double* Y = X + MAT;                                // F_k -> W -> T_k -> F_k+1
-  double* Z = Y + MAT;                                // -(sum_k W^T W), the left separator's Schur update
-  double* bv = Z + MAT;                               // [80] b~_k
-  double* yv = bv + BS;                               // [80] y
-  double* zv = yv + BS;                               // [80] z_k
-  double* blv = zv + BS;                              // [80] sum_k W^T y
-  double* ysc = blv + BS;                             // [3][80] partial sums of the mat-vecs
-  double* red = ysc + 3 * BS;                         // [8]
-  double* cL = red + 8;                               // coupling tables of the current node
-  double* cR = cL + 9 * NP;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const FteConst& K = *cst;
-  const int c = blockIdx.x;
-  const int first = c * m;
-  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
-  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
-  const size_t MB = (size_t)BS * BS;
-  const int row = tid % BS, part = tid / BS;
-
-  for (int e = tid; e < MAT; e += 256) Z[e] = 0.0;
-  if (tid < BS) blv[tid] = 0.0;
-
-  {
-    const double gmax = build_node(X, bv, ch, K, first, tid);
-    publish_gmax(gmax, red, ch.gn_part, first, tid);
-  }
-  for (int k = 0; k < n_int; ++k) {
-    const int node = first + k;
-    fill_coupling_coef(cL, cR, K, node, tid);
-    __syncthreads();                                   // node complete in X / bv, tables visible
-    chol80(X, tid, numeric_err);
-    // y = U^T b~, z = U y (three partial sums per row)
-    if (tid < 3 * BS) {
-      double yy = 0.0;
-      const int c1 = min(27 * part + 27, row + 1);
-      for (int cc = 27 * part; cc < c1; ++cc) yy += X[cc * LD + row] * bv[cc];
-      ysc[tid] = yy;
-    }
-    __syncthreads();
-    if (tid < BS) yv[tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
-    __syncthreads();
-    if (tid < 3 * BS) {
-      double z = 0.0;
-      const int c1 = min(27 * part + 27, BS);
-      for (int cc = max(27 * part, row); cc < c1; ++cc) z += X[row * LD + cc] * yv[cc];
-      ysc[tid] = z;
-    }
-    __syncthreads();
-    if (tid < BS) {
-      const double z = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
-      zv[tid] = z;
-      ch.b[(size_t)node * BS + tid] = z;
-    }
-    if (hasL) {
-      // ---- W = U^T F_k into Y
-      if (k == 0) {
-        // F_0 = E_l(node): rows (ii, p) of the node, columns (jj, p) of L, <= 3 terms per entry of W
-        for (int e = tid; e < BS * BS; e += 256) {
-          const int r = e / BS, cc = e % BS;
-          double v = 0.0;
-          if (cc < 3 * NP) {
-            const int cj = cc / NP, p = cc % NP;
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {
-              const int rw = ii * NP + p;
-              if (ii <= cj && rw <= r) v += X[rw * LD + r] * cL[(ii * 3 + cj) * NP + p];
-            }
-          }
-          Y[r * LD + cc] = v;
-        }
-        __syncthreads();
-      } else {
-        d4 w[7];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int t = wave + 4 * q;
-          if (t < NT * NT) w[q] = tile_ut_f(X, Y, t / NT, t % NT, li, lk);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int t = wave + 4 * q;
-          if (t < NT * NT) tile_store(Y, t / NT, t % NT, w[q], li, lk);
-        }
-        __syncthreads();
-      }
-      // ---- left separator: D_L -= W^T W (registers, whole run), b_L -= W^T y
-      if (wave == 0) syrk_acc<0>(Y, Z, li, lk);
-      else if (wave == 1) syrk_acc<1>(Y, Z, li, lk);
-      else if (wave == 2) syrk_acc<2>(Y, Z, li, lk);
-      else syrk_acc<3>(Y, Z, li, lk);
-      if (tid < 3 * BS) {
-        double s = 0.0;
-        const int r1 = min(27 * part + 27, BS);
-        for (int r = 27 * part; r < r1; ++r) s += Y[r * LD + row] * yv[r];
-        ysc[tid] = s;
-      }
-      __syncthreads();
-      if (tid < BS) blv[tid] += ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
-      // ---- T = U W in place
-      {
-        d4 w[7];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int t = wave + 4 * q;
-          if (t < NT * NT) w[q] = tile_u_w(X, Y, t / NT, t % NT, li, lk);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int t = wave + 4 * q;
-          if (t < NT * NT) tile_store(Y, t / NT, t % NT, w[q], li, lk);
-        }
-      }
-    }
-    // ---- G = U U^T in place (lower tiles computed, mirrored on the way back)
-    {
-      d4 gq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = wave + 4 * q;
-        if (t < 15) gq[q] = tile_u_ut(X, c_tri_i[t], c_tri_j[t], li, lk);
-      }
-      __syncthreads();                                 // every read of U (and of W) is done
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = wave + 4 * q;
-        if (t < 15) {
-          const int ib = c_tri_i[t], jb = c_tri_j[t];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            X[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = gq[q][rr];
-            if (ib != jb) X[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = gq[q][rr];
-          }
-        }
-      }
-    }
-    __syncthreads();                                   // G in X, T in Y
-    // ---- what the back-substitution needs: G_k, T_k^T (its lanes run along a COLUMN of T), z_k (stored above)
-    store_mat(ch.D + node * MB, X, tid);
-    if (hasL) {
-      double* Tg = ch.Wl + node * MB;
-      for (int e = tid; e < BS * BS; e += 256) Tg[e] = Y[(e % BS) * LD + e / BS];
-    }
-    const bool to_sep = k + 1 == n_int;
-    if (to_sep && !hasR) break;                        // last node of the chain
-    const int next = node + 1;
-    __syncthreads();                                   // the stores above have read X and Y
-    // ---- next node: -E^T G E (rows (a, p) x all columns, in registers), F' = -E^T T, b' correction
-    // pass 1: X <- G E (columns (jb, p)), in place.  item (row r, state p)
-#pragma unroll
-    for (int mq = 0; mq < 8; ++mq) {
-      const int q = tid + 256 * mq;
-      if (q < BS * NP) {
-        const int r = q / NP, p = q % NP;
-        const double g0 = X[r * LD + p], g1 = X[r * LD + NP + p], g2 = X[r * LD + 2 * NP + p];
-        X[r * LD + p] = g0 * cR[(0 * 3 + 0) * NP + p] + g1 * cR[(0 * 3 + 1) * NP + p] + g2 * cR[(0 * 3 + 2) * NP + p];
-        X[r * LD + NP + p] = g1 * cR[(1 * 3 + 1) * NP + p] + g2 * cR[(1 * 3 + 2) * NP + p];
-        X[r * LD + 2 * NP + p] = g2 * cR[(2 * 3 + 2) * NP + p];
-      }
-    }
-    __syncthreads();
-    // pass 2: dv = -E^T (G E); F' = -E^T T in place.  item (state p, column cc): the three frame rows of p
-    double dv[8][3];
-#pragma unroll
-    for (int mq = 0; mq < 8; ++mq) {
-      const int q = tid + 256 * mq;
-      if (q < NP * BS) {
-        const int p = q / BS, cc = q % BS;
-        const double c00 = cR[(0 * 3 + 0) * NP + p], c01 = cR[(0 * 3 + 1) * NP + p], c02 = cR[(0 * 3 + 2) * NP + p];
-        const double c11 = cR[(1 * 3 + 1) * NP + p], c12 = cR[(1 * 3 + 2) * NP + p], c22 = cR[(2 * 3 + 2) * NP + p];
-        const double t0 = X[p * LD + cc], t1 = X[(NP + p) * LD + cc], t2 = X[(2 * NP + p) * LD + cc];
-        dv[mq][0] = -(c00 * t0 + c01 * t1 + c02 * t2);
-        dv[mq][1] = -(c11 * t1 + c12 * t2);
-        dv[mq][2] = -(c22 * t2);
-        if (hasL) {
-          const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
-          Y[p * LD + cc] = -(c00 * f0 + c01 * f1 + c02 * f2);
-          Y[(NP + p) * LD + cc] = -(c11 * f1 + c12 * f2);
-          Y[(2 * NP + p) * LD + cc] = -(c22 * f2);
-        }
-      }
-    }
-    if (hasL)
-      for (int e = tid; e < 5 * BS; e += 256) Y[(3 * NP + e / BS) * LD + e % BS] = 0.0;   // padding rows couple to nothing
-    double bcorr = 0.0;                                // (E^T z)[(ja, pa)]
-    if (tid < 3 * NP) {
-      const int ja = tid / NP, pa = tid % NP;
-      for (int j1 = ja; j1 < 3; ++j1) bcorr += cR[(ja * 3 + j1) * NP + pa] * zv[j1 * NP + pa];
-    }
-    __syncthreads();                                   // pass-2 reads of X done
-    {
-      const double gmax = build_node(X, bv, ch, K, next, tid);
-      publish_gmax(gmax, red, ch.gn_part, next, tid);  // (barrier inside: node and bv complete)
-    }
-#pragma unroll
-    for (int mq = 0; mq < 8; ++mq) {
-      const int q = tid + 256 * mq;
-      if (q < NP * BS) {
-        const int p = q / BS, cc = q % BS;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) X[(a * NP + p) * LD + cc] += dv[mq][a];
-      }
-    }
-    if (tid < 3 * NP) bv[tid] -= bcorr;
-    if (to_sep) {                                      // the "next node" is the right separator
-      __syncthreads();
-      store_mat(sp.D + (size_t)c * MB, X, tid);
-      if (tid < BS) sp.b[(size_t)c * BS + tid] = bv[tid];
-      if (hasL) store_mat(sp.Cpl + (size_t)(c - 1) * MB, Y, tid);     // block(R, L): rows R, columns L
-      break;
-    }
-  }
-  if (hasL) {
-    __syncthreads();
-    store_mat(sp.AL + (size_t)(c - 1) * MB, Z, tid);   // (lower tiles are meaningful)
-    if (tid < BS) sp.bl[(size_t)(c - 1) * BS + tid] = blv[tid];
-  }
-}
-
 // ================================================================================================================
-// Second form of the sweep.  Per node the work splits into a SERIAL part (all four waves) and a PARALLEL part:
+// The sweep kernel.  Per node the work splits into a SERIAL part (all four waves) and a PARALLEL part:
 //   serial   : G_k = U_k U_k^T -> HBM;  D~_k+1 = D_k+1 - E^T G_k E  (the next node's H / g / x were requested before G)
 //   parallel : wave 0 factors D~_k+1 ALONE (one-wave blocked Cholesky: no workgroup barrier on the pivot chain),
 //              waves 1..3 do the spike algebra of node k meanwhile: W = U_k^T F_k, D_L -= W^T W, T_k = U_k W -> HBM,
@@ -364,8 +98,8 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
 // column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1 = the next node's b~), and row 79
 // of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases, no extra barriers.
 // LDS: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 159.9 KB, one workgroup per CU.
-constexpr int SW2_VEC = 18 * NP + BS + 8 + 8 + 3 * NP;   // cL cR | bv | red | sync | kq klo khi
-static constexpr size_t kSweep2Lds = (3 * MAT + SW2_VEC) * sizeof(double);
+constexpr int SW_VEC = 18 * NP + BS + 8 + 8 + 3 * NP;   // cL cR | bv | red | sync | kq klo khi
+static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
 
 // The value of x, made opaque to the optimiser: address arithmetic derived from it cannot be hoisted out of the node loop
 // (hoisted, the hundreds of per-tile LDS / HBM addresses of this kernel end up spilled to scratch and are reloaded one by
@@ -779,8 +513,8 @@ __device__ __forceinline__ void gram_tiles(const double* U, double* G, int li, i
 }
 
 __global__ void __launch_bounds__(256)
-k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
-               int m, int n_chunks, int skip) {
+k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+               int m, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
@@ -864,7 +598,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(f.hv[q]));
       asm volatile("" : "+v"(f.xv), "+v"(f.gv), "+v"(f.lam));
     }
-    if (!(skip & 16)) store_mat(ch.D + node * MB, Xn, tid_);
+    store_mat(ch.D + node * MB, Xn, tid_);
     if (has_next) {
       double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
       if (s_act) {
@@ -919,7 +653,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     // waves 0, 1: blocked Cholesky of the next node (pivot chains | panel and trailing tiles)
     // waves 2, 3: W = U_k^T F_k on their 16-column strips, then D_L -= W^T W
     if (wave < 2) {
-      if (!last && !(skip & 1))
+      if (!last)
         chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01, tflag,
                     (dbgp && k == dbg_k) ? dbgp : nullptr);
       if (wave == 0) SW_STAMP(5);
@@ -983,7 +717,7 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       // ---- T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then F_k+1 = -E^T T_k in place,
       //      column 79 += the next node's right-hand side.  20 columns per wave (first run: column 79 only).
       const int c_lo = hasL ? 20 * wave : BS - 1, c_hi = hasL ? c_lo + 20 : (wave == 3 ? BS : BS - 1);
-      if (hasL && !(skip & 4)) {
+      if (hasL) {
         double* Tg = ch.Wl + node * MB;
         // (all 25 LDS reads of the wave first, then the stores)
         double v0[20], v1[5];
@@ -1044,10 +778,10 @@ k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
   }
 }
 
-// Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  First form of the sweep:
-// b -= bl.  Second form: the right-hand side rides as column 79 of the spike, so row 79 of AL holds -(sum W^T y) and
-// rows / columns >= 75 of AL are not part of the Schur update.
-__global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __restrict__ status, int rhs_row) {
+// Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as
+// column 79 of the spike, so row 79 of AL holds -(sum W^T y) = the update of b, and rows / columns >= 75 of AL are not
+// part of the Schur update.
+__global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __restrict__ status) {
   if (status && *status != 0) return;
   const int q = blockIdx.x, tid = threadIdx.x;
   const size_t MB = (size_t)BS * BS;
@@ -1055,15 +789,9 @@ __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __re
   const double* A = sp.AL + q * MB;
   for (int e = tid; e < BS * BS; e += 256) {
     const int r = e / BS, cc = e % BS;
-    if ((cc >> 4) <= (r >> 4) && (!rhs_row || (r < 3 * NP && cc < 3 * NP))) D[e] += A[e];
+    if ((cc >> 4) <= (r >> 4) && r < 3 * NP && cc < 3 * NP) D[e] += A[e];
   }
-  if (tid < BS) {
-    if (rhs_row) {
-      if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] += A[(size_t)(BS - 1) * BS + tid];
-    } else {
-      sp.b[(size_t)q * BS + tid] -= sp.bl[(size_t)q * BS + tid];
-    }
-  }
+  if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] += A[(size_t)(BS - 1) * BS + tid];
 }
 
 // One workgroup per run, right to left: x_k = z_k - G_k (E_r(k) x_k+1) - T_k x_L.  G_k is symmetric and T_k is stored
@@ -1136,29 +864,22 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
 int chunk_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
-  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep2),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweep2Lds));
   return ACINO_OK;
 }
 
 int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
                  const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
                  Profiler* prof) {
-  static const bool v1 = getenv("ACINO_SWEEP_V1") != nullptr;     // (debug: the first, fully serial form of the sweep)
   {
     ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
-    if (v1)
-      hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status,
-                         pl.m, pl.n_chunks);
-    else
-      hipLaunchKernelGGL(k_chunk_sweep2, dim3(pl.n_chunks), dim3(256), kSweep2Lds, s, ch, sp, d_c, d_numeric_err,
-                         d_status, pl.m, pl.n_chunks, getenv("ACINO_SWEEP_SKIP") ? atoi(getenv("ACINO_SWEEP_SKIP")) : 0);
+    hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                       pl.n_chunks);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;
   {
     ProfSpan span(prof, PC_SEP_COMBINE, s, pl.n_sep);
-    hipLaunchKernelGGL(k_sep_combine, dim3(pl.n_sep), dim3(256), 0, s, sp, d_status, v1 ? 0 : 1);
+    hipLaunchKernelGGL(k_sep_combine, dim3(pl.n_sep), dim3(256), 0, s, sp, d_status);
   }
   ACINO_LAUNCH_CHECK();
   return bcr_reduce(sepch, sepsch, d_c, d_numeric_err, d_status, s, prof);

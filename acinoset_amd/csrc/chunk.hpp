@@ -19,9 +19,8 @@ struct ChunkPlan {
 struct SepView {
   double* D;    // [80][80] built node - (right end of the run on its left)          -> + AL by k_sep_combine
   double* Cpl;  // [80][80] block(separator q + 1, separator q)
-  double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles   (aliases the chain's Wr)
+  double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles; row 79: its update of b (aliases the chain's Wr)
   double* b;    // [80]
-  double* bl;   // [80]     sum over the run on its right of F^T z
 };
 
 int chunk_set_func_attributes();

@@ -725,7 +725,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     rc.refine_buf = ctx->b.refine_buf;
   }
   if (ctx->plan.active())
-    ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, ctx->sepchain.Wr, ctx->sepchain.b, ctx->b.sep_bl};
+    ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, ctx->sepchain.Wr, ctx->sepchain.b};
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
   rc = bcr_set_func_attributes();

@@ -120,3 +120,38 @@ def test_chunk_sweep_at_bench_size(mods):
         assert g[3] == 0 and g[1] == r[1]
         assert abs(g[0] - r[0]) <= 1e-10 * abs(r[0]), (it, g[0], r[0])
         assert np.abs(g[4] - r[4]).max() < 1e-8, (it, float(np.abs(g[4] - r[4]).max()))
+
+
+def test_chunk_sweep_random_chain_and_run_lengths(mods):
+    """25 seeded (frames, run length) pairs - chains of 1 ... 133 nodes, runs of 2 ... 14 nodes, partial last nodes, last
+    runs of every length: the step of ONE linear solve, node by node, against the whole-chain reduction; the same solve
+    repeated three times must not change a bit (the sweep's waves synchronise through LDS counters: a missing fence would
+    show up as run-to-run differences).  scripts/chunk_stress.py is the long form."""
+    import ctypes as C
+    calib, fte, synth = mods
+    from acinoset_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(2024)
+    for _ in range(25):
+        n = int(rng.integers(3, 400))
+        m = int(rng.choice([0, 2, 3, 4, 5, 7, 9, 14]))
+        seq = synth.make_sequence(n, "sprint" if n < 200 else "loop")
+        rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+        xa = _start(fte, seq, n, n + m)
+        T = (n + 2) // 3
+        got = {}
+        for tag, cn in (("bcr", -1), ("chunk", m)):
+            ctx = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, chunk_nodes=cn, bcr_levels=0)
+            ctx.set_x(xa)
+            runs = []
+            for _rep in range(3 if tag == "chunk" else 1):
+                check(lib().acino_fte_reduce_local(ctx._h, stream_ptr()))
+                check(lib().acino_fte_backsub_local(ctx._h, C.c_void_p(0), 0, 1, stream_ptr()))
+                buf = torch.zeros(T * 80, dtype=torch.float64, device="cuda")
+                check(lib().acino_fte_debug_read(ctx._h, 0, ptr(buf), T * 80, stream_ptr()))
+                torch.cuda.synchronize()
+                runs.append(buf.cpu().numpy().reshape(T, 80)[:, :75])
+            ctx.close()
+            assert all(np.array_equal(r, runs[0]) for r in runs[1:]), (n, m, "not reproducible")
+            got[tag] = runs[0]
+        d = np.abs(got["bcr"] - got["chunk"]).max() / np.abs(got["bcr"]).max()
+        assert d < 1e-8, (n, m, d)
