@@ -49,20 +49,54 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def probe_reference_cpu_path():
-    """SURVEY 8(d) "CPU baseline timing" (ii): is the reference's own CPU path (Pyomo + IPOPT, cv2) on this host?"""
+def probe_reference_cpu_path(det=None, rig=None, Ts=None, x0_full=None):
+    """SURVEY 8(d) "CPU baseline timing" (ii): is the reference's own CPU path (Pyomo + IPOPT, cv2) on this host?  Where
+    Pyomo and an ipopt binary exist, the repo's own Pyomo formulation of the FTE NLP (oracle/pyomo_model.py - validated
+    against the reference's model text through float stand-ins, tests/test_oracle_golden.py) is built and solved with the
+    reference's solver options at N = 100 and N = 1000 frames and the timings reported."""
     import importlib.util
     import shutil
     have = {m: importlib.util.find_spec(m) is not None for m in ("cv2", "pyomo")}
     have["ipopt"] = shutil.which("ipopt") is not None
     missing = [k for k, v in have.items() if not v]
-    if missing:
+    if not (have["pyomo"] and have["ipopt"]) or det is None:
         return dict(available=False, probe=have,
                     note="reference CPU path unavailable on this host (missing: " + ", ".join(missing) +
-                         "): the Pyomo/IPOPT FTE solve and the cv2 triangulation cannot be timed here; the baseline "
-                         "below is this repo's numpy/scipy oracle of the same LM iteration (kind = port)")
-    return dict(available=True, probe=have, note="pyomo, ipopt and cv2 are importable on this host (not timed: the "
-                "repo ships no Pyomo formulation; the oracle port below is the reported baseline)")
+                         "): the Pyomo/IPOPT FTE solve cannot be timed here (oracle/pyomo_model.py holds the formulation "
+                         "and runs where they exist); the baseline reported is this repo's numpy/scipy oracle of the same "
+                         "LM iteration (kind = port)")
+    out = dict(available=True, probe=have, runs=[])
+    from oracle import pyomo_model
+    for n in (100, 1000):
+        try:
+            out["runs"].append(pyomo_model.time_reference_cpu_path(det, rig, Ts, x0_full, n_frames=n))
+        except Exception as exc:                       # pragma: no cover
+            out["runs"].append(dict(frames=n, error=f"{type(exc).__name__}: {exc}"))
+            break
+    return out
+
+
+def _baseline_fingerprint(det_sample):
+    """What the CPU figure was measured ON and WITH, so that a change between rounds is attributable: sha256 of the
+    oracle sources in the timed loop, of the sample's bytes, and the host's CPU / numpy / scipy."""
+    import hashlib
+    import platform
+    import scipy
+    h = hashlib.sha256()
+    for f in ("cpu_baseline.py", "fte.py", "fk.py", "camera.py", "loss.py"):
+        h.update(open(os.path.join(ROOT, "oracle", f), "rb").read())
+    cpu = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:                                    # pragma: no cover
+        pass
+    return dict(oracle_sources_sha256=h.hexdigest()[:16],
+                sample_sha256=hashlib.sha256(np.ascontiguousarray(det_sample).tobytes()).hexdigest()[:16],
+                host_cpu=cpu or platform.processor(), nproc=os.cpu_count(), numpy=np.__version__, scipy=scipy.__version__,
+                python=platform.python_version())
 
 
 def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
@@ -92,10 +126,12 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
     c1 = (time.perf_counter() - t0) / reps
     if limiter is not None and hasattr(limiter, "restore_original_limits"):
         limiter.restore_original_limits()
-    out = dict(value=n / per_iter, unit="frames/s", cores=1, kind="port",
-               sample=f"{iters} LM iterations (+ initial evaluation) of the numpy/scipy oracle on the first {n} "
-                      f"frames of the same sequence, 1 thread, {dt:.1f} s",
-               reference_cpu_path=probe_reference_cpu_path(),
+    single = dict(value=n / per_iter, unit="frames/s", cores=1,
+                  sample=f"{iters} LM iterations (+ initial evaluation) of the numpy/scipy oracle on the first {n} "
+                         f"frames of the same sequence, 1 thread, {dt:.1f} s")
+    out = dict(value=single["value"], unit="frames/s", cores=1, kind="port", sample=single["sample"],
+               single_thread=single, fingerprint=_baseline_fingerprint(det[:n]),
+               reference_cpu_path=probe_reference_cpu_path(det, rig, Ts, x0_full),
                config1_single_frame_triangulation=dict(seconds_per_frame=c1, frames_per_s=1.0 / c1, cores=1,
                                                        what="oracle.index_path.pairwise_dense on 1 frame x 6 cameras x "
                                                             "20 keypoints (5 adjacent pairs, numpy SVD DLT), mean of "
@@ -138,7 +174,7 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
                 each.append(float(o.strip().splitlines()[-1]))
             wall = time.perf_counter() - t1
         slow = max(each)
-        out["all_cores"] = dict(value=n / (slow / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu,
+        out["all_cores"] = dict(value=n / (slow / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu, each_seconds=each,
                                 sample=f"the same {n} frames cut into {procs} contiguous blocks, one single-threaded "
                                        f"oracle process per block (python -m oracle.cpu_baseline), {iters} LM iterations "
                                        f"each, run together: slowest block {slow:.1f} s (wall incl. interpreter start "
@@ -149,6 +185,9 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
             if pr.poll() is None:
                 pr.kill()
         out["all_cores"] = dict(value=None, error=repr(exc), nproc=ncpu)
+    # the reported baseline is the host's BEST: every core busy (<= 32 processes), the 1-thread figure beside it
+    if out["all_cores"].get("value") and out["all_cores"]["value"] > out["value"]:
+        out.update(value=out["all_cores"]["value"], cores=out["all_cores"]["cores"], sample=out["all_cores"]["sample"])
     return out
 
 

@@ -24,5 +24,9 @@ upstream AcinoSet tree).  Pinning status:
   end point by central differences of that same text (fte_stationary.npz); the
   reduction by KAT-4 (integration / third-difference identities on the stored
   build.py runs).  I.e. the LM solution is a stationary point of the reference's
-  NLP; that IPOPT ends at the same one is not shown.
+  NLP; that IPOPT ends at the same one is not shown.  A third-party quasi-Newton
+  optimiser (scipy L-BFGS-B) on the same objective ends beside it (fte_lbfgs.npz).
+* ``pyomo_model``: this repo's own Pyomo formulation of that NLP (for bench.py's
+  conditional IPOPT timing where Pyomo exists); validated against the reference's
+  model text through the float stand-ins of tests/golden/_float_pyomo.py.
 """

@@ -233,6 +233,80 @@ def test_objective_matches_reference_model_text(golden_dir):
     assert prob.measurement_terms(g["case_x"][4][:, fk.ACTIVE], need_jac=False)[3] > 0
 
 
+def _complete_equalities(fp, m, X):
+    """Give the model's dependent variables the values its own equalities define at the states X [N, 45] (each equality
+    is affine with slope +-1 or +-Ts in the variable it defines), the free dx_1, ddx_1 at their optimum; returns the
+    worst equality residual afterwards."""
+    N, C, L, P = m._shape
+
+    def solve(comp, idx, var):
+        v0 = var.value = 0.0 if var.value is None else var.value
+        r0 = comp.rule(m, *idx).r
+        var.value = v0 + 1.0
+        slope = comp.rule(m, *idx).r - r0
+        var.value = v0 - r0 / slope
+
+    for n in range(1, N + 1):
+        for p in range(1, P + 1):
+            m.x[n, p].value = float(X[n - 1, p - 1])
+            m.dx[n, p].value = m.ddx[n, p].value = m.slack_model[n, p].value = 0.0
+    for p in range(1, P + 1):
+        for n in range(2, N + 1):
+            solve(m.integrate_p, (n, p), m.dx[n, p])
+        acc = (m.dx[3, p].value - m.dx[2, p].value) / m.Ts
+        m.ddx[1, p].value = m.ddx[2, p].value = acc
+        m.dx[1, p].value = m.dx[2, p].value - m.Ts * acc
+        for n in range(3, N + 1):
+            solve(m.integrate_v, (n, p), m.ddx[n, p])
+        for n in range(2, N + 1):
+            solve(m.constant_acc, (n, p), m.slack_model[n, p])
+    for n in range(1, N + 1):
+        for l in range(1, L + 1):
+            for d in (1, 2, 3):
+                solve(m.pose_constraint, (n, l, d), m.poses[n, l, d])
+            for c in range(1, C + 1):
+                for d in (1, 2):
+                    m.slack_meas[n, c, l, d].value = 0.0
+                    solve(m.measurement, (n, c, l, d), m.slack_meas[n, c, l, d])
+    worst = 0.0
+    for name in ("pose_constraint", "integrate_p", "integrate_v", "constant_acc", "measurement"):
+        for v in getattr(m, name).evaluate(m).values():
+            if v is not fp.Constraint.Skip:
+                worst = max(worst, abs(v.r))
+    return worst
+
+
+def test_own_pyomo_formulation_reproduces_the_reference_model_text(golden_dir):
+    """oracle/pyomo_model.py - the formulation bench.py times through IPOPT where Pyomo exists - built against the float
+    stand-ins: same variable blocks and equality counts as the reference's model, and at the five recorded iterates its
+    objective, slacks and derivatives equal what the reference's own model text gave (fte_model.npz)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import _float_pyomo as fp
+    from oracle import pyomo_model
+    g = _g(golden_dir, "fte_model.npz")
+    m = pyomo_model.build_fte_model(fp, g["meas"], g["det"][int(g["start_frame"]):int(g["end_frame"]), ..., 2], g["K"], g["D"],
+                                    g["R"], g["t"], 1.0 / float(g["fps"]), g["init_x"], dlc_thresh=float(g["dlc_thresh"]),
+                                    r_meas=float(g["R_meas"]), Q=g["Q"], redesc=tuple(g["redesc"]))
+    N, C, L, P = m._shape
+    assert (N, C, L, P) == (6, 3, 20, 45)
+    n_eq = {k: sum(v is not fp.Constraint.Skip for v in getattr(m, k).data.values())
+            for k in ("pose_constraint", "integrate_p", "integrate_v", "constant_acc", "measurement")}
+    assert n_eq == dict(pose_constraint=N * L * 3, integrate_p=(N - 1) * P, integrate_v=(N - 1) * P,
+                        constant_acc=(N - 1) * P, measurement=N * C * L * 2)
+    # start values (:333-355): x = init_x, poses = FK(init_x), everything else 0
+    assert max(abs(m.poses[n, l, d].value - g["init_poses"][n - 1, l - 1, d - 1])
+               for n in m.N for l in m.L for d in m.D3) < 1e-13
+    for X, want, slack, dx, ddx in zip(g["case_x"], g["case_obj"], g["case_slack_model"], g["case_dx"], g["case_ddx"]):
+        assert _complete_equalities(fp, m, X) < 1e-9
+        got = m.obj.value(m)
+        assert abs(got - want) < 1e-10 * abs(want), (got, want)
+        val = lambda v: np.array([[v[n, p].value for p in m.P] for n in m.N])
+        assert np.abs(val(m.slack_model) - slack).max() < 1e-9 * max(1.0, np.abs(slack).max())
+        assert np.abs(val(m.dx) - dx).max() < 1e-9 * max(1.0, np.abs(dx).max())
+        assert np.abs(val(m.ddx) - ddx).max() < 1e-9 * max(1.0, np.abs(ddx).max())
+
+
 def test_lm_fixed_point_is_stationary_for_the_reference_objective(golden_dir):
     """Row a-10 (the IPOPT call): IPOPT itself cannot run here, so its end state stays unpinned - but the point the
     projected LM converges to is pinned as a first-order stationary point of the REFERENCE's own objective.
