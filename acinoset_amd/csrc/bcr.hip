@@ -140,7 +140,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
     for (int q = 0; q < 4; ++q) {
       const int t = wave + 4 * q;
       if (t < 15) {
-        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        const int ib = tri_i(t), jb = tri_j(t);
         const double* pa = Lm + (ib * 16 + li) * LD + ib * 16 + lk;   // U(ib, k >= ib)[i][kk]
         const double* pb = Lm + (jb * 16 + li) * LD + ib * 16 + lk;   // U(jb, k >= ib)[j][kk]
         d4 acc = {0, 0, 0, 0};
@@ -524,7 +524,7 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
     for (int q = 0; q < 4; ++q) {    // this wave's output tiles of D_j, requested first, consumed last
       const int t = sub + S * (wave + 4 * q);
       if (t < 15) {
-        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        const int ib = tri_i(t), jb = tri_j(t);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) dt[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
       }
@@ -537,7 +537,7 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
     for (int q = 0; q < 4; ++q) {
       const int t = sub + S * (wave + 4 * q);
       if (t < 15) {
-        const int ib = c_tri_i[t], jb = c_tri_j[t];
+        const int ib = tri_i(t), jb = tri_j(t);
         d4 a = {0, 0, 0, 0};
         a = mma_seq<BS / 4, true>(a, Wb + lk * LD + ib * 16 + li, 4 * LD, Wb + lk * LD + jb * 16 + li, 4 * LD);
         if (both) a = mma_seq<BS / 4, true>(a, Wb2 + lk * LD + ib * 16 + li, 4 * LD, Wb2 + lk * LD + jb * 16 + li, 4 * LD);

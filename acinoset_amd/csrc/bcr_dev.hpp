@@ -6,9 +6,12 @@
 
 namespace acino {
 
-// lower-triangular tile enumeration t -> (ib, jb)
-static __constant__ int8_t c_tri_i[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
-static __constant__ int8_t c_tri_j[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+// lower-triangular tile enumeration t -> (ib, jb), t = ib (ib + 1) / 2 + jb  (arithmetic, not a table: see dense80.hpp)
+__device__ __forceinline__ int tri_i(int t) { return (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10); }
+__device__ __forceinline__ int tri_j(int t) {
+  const int i = tri_i(t);
+  return t - (i * (i + 1)) / 2;
+}
 
 // Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
 // assembly's H/g (no set-up pass through HBM): D = H_gn + lam*diag(H_gn), bound-active variables
@@ -21,6 +24,8 @@ struct NodeFetch {
   double xv, gv, lam;
   bool row_live;
 };
+// (NTH = threads of the workgroup: 256, or 512 in the eight-wave chunk sweep)
+template <int NTH = 256>
 static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain& ch, const FteConst& K, int t, int tid) {
   const int cur = ch.st->cur;
   const double* x = cur ? ch.x1 : ch.x0;
@@ -32,8 +37,8 @@ static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain&
   // the three 25x25 Gauss-Newton blocks (<= 8 entries per thread) and, for the 75 row-owner threads, the state and
   // gradient entry of their row
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = tid + 256 * k;
+  for (int k = 0; k < 2048 / NTH; ++k) {
+    const int idx = tid + NTH * k;
     f.hv[k] = 0.0;
     if (!sep_left && idx < 3 * NP * NP) {
       const int n = fbase + idx / (NP * NP);
@@ -53,13 +58,14 @@ static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain&
   }
 }
 // qw / lo / hi: the per-state weight and bound tables (K.q_w, K.lo, K.hi, or a copy of them in LDS)
+template <int NTH = 256>
 static __device__ __forceinline__ double build_finish(double* Dm, double* bv, const NodeFetch& f, const FteConst& K, int t,
                                                       int tid, const double* qw, const double* lo, const double* hi,
                                                       long long* dbg = nullptr) {
   const bool sep_left = K.pin_left && t == 0;
   const int fbase = 3 * (t - K.pin_left);
   // (2) structure that needs no memory: zeros, identity padding, intra-node third-difference couplings
-  for (int e = tid; e < BS * LD; e += 256) Dm[e] = 0.0;
+  for (int e = tid; e < BS * LD; e += NTH) Dm[e] = 0.0;
   if (dbg && tid == 0) dbg[24] = (long long)wall_clock64();
   __syncthreads();
   if (dbg && tid == 0) dbg[25] = (long long)wall_clock64();
@@ -80,8 +86,8 @@ static __device__ __forceinline__ double build_finish(double* Dm, double* bv, co
   if (dbg && tid == 0) dbg[26] = (long long)wall_clock64();
   // (3) drop the H blocks in (their targets are disjoint from the entries written in (2))
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = tid + 256 * k;
+  for (int k = 0; k < 2048 / NTH; ++k) {
+    const int idx = tid + NTH * k;
     if (!sep_left && idx < 3 * NP * NP) {
       const int ii = idx / (NP * NP), rem = idx % (NP * NP), p = rem / NP, pc = rem % NP;
       if (fbase + ii < K.n_frames) Dm[(ii * NP + p) * LD + ii * NP + pc] = f.hv[k];
@@ -117,11 +123,17 @@ static __device__ double build_node(double* Dm, double* bv, const BcrChain& ch, 
 }
 
 // max over the workgroup -> gn_part[node]
+template <int NTH = 256>
 static __device__ void publish_gmax(double gmax, double* red, double* gn_part, int node, int tid) {
   for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
   if ((tid & 63) == 0) red[tid >> 6] = gmax;
   __syncthreads();
-  if (tid == 0) gn_part[node] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (tid == 0) {
+    double v = red[0];
+#pragma unroll
+    for (int w = 1; w < NTH / 64; ++w) v = fmax(v, red[w]);
+    gn_part[node] = v;
+  }
 }
 
 // Level-0 couplings are the constant third-difference blocks E (<= 3 non-zeros per column, all on the
@@ -130,12 +142,13 @@ static __device__ void publish_gmax(double gmax, double* red, double* gn_part, i
 //   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
 // coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
 // right: columns in node i+1).  450 doubles, filled once per workgroup.
+template <int NTH = 256>
 static __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid,
                                           const double* qw = nullptr) {
   if (!qw) qw = K.q_w;
   const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
   const int64_t f_i = K.n_offset + (int64_t)loc_i;
-  for (int e = tid; e < 2 * 9 * NP; e += 256) {
+  for (int e = tid; e < 2 * 9 * NP; e += NTH) {
     const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
     double v = 0.0;
     if (ii <= jj) {

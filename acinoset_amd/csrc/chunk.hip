@@ -98,7 +98,7 @@ __device__ __forceinline__ void tile_store(double* M, int ib, int jb, const d4& 
 // column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1 = the next node's b~), and row 79
 // of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases, no extra barriers.
 // LDS: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 159.9 KB, one workgroup per CU.
-constexpr int SW_VEC = 18 * NP + BS + 8 + 8 + 3 * NP;   // cL cR | bv | red | sync | kq klo khi
+constexpr int SW_VEC = 18 * NP + BS + 8 + 8 + 3 * NP + 64;   // cL cR | bv | red | sync | kq klo khi | debug stamps
 static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
 
 // The value of x, made opaque to the optimiser: address arithmetic derived from it cannot be hoisted out of the node loop
@@ -112,100 +112,6 @@ template <class T>
 __device__ __forceinline__ T* opaque_ptr(T* p) {
   asm volatile("" : "+s"(p));
   return p;
-}
-
-// NB tile products C(q) (-)= A(q) B(q)^T style updates of chol80's trailing phase, batched: every LDS operand of the
-// batch is requested before the first matrix-core instruction and the NB accumulator chains interleave, so one wave alone
-// keeps its matrix core busy (tile by tile, each product would wait ~200 cycles for its operands and ~70 per dependent
-// MFMA).  code = 16 ti + tj; ti <= kb marks a tile of U (first written when ti == kb).
-template <int NB>
-__device__ __forceinline__ void trail_batch(double* Lm, int kb, const uint8_t* codes, int li, int lk) {
-  d4 a[NB];
-  double av[NB][4], bw[NB][4];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) {
-    const int ti = codes[q] >> 4, tj = codes[q] & 15;
-    const double* A = Lm + (ti * 16) * LD + kb * 16;
-    const double* B = Lm + (tj * 16) * LD + kb * 16;
-    const double* Cc = Lm + (ti * 16) * LD + tj * 16;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      av[q][s] = A[li * LD + 4 * s + lk];
-      bw[q][s] = B[li * LD + 4 * s + lk];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) a[q][rr] = ti != kb ? Cc[(lk + 4 * rr) * LD + li] : 0.0;
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-#pragma unroll
-    for (int q = 0; q < NB; ++q) a[q] = mfma(-av[q][s], bw[q][s], a[q]);
-  }
-#pragma unroll
-  for (int q = 0; q < NB; ++q) {
-    const int ti = codes[q] >> 4, tj = codes[q] & 15;
-    double* Cc = Lm + (ti * 16) * LD + tj * 16;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
-  }
-}
-
-// Blocked Cholesky of the 80x80 matrix in LDS by ONE wave (same result layout as chol80: U = L^-T in the upper tiles).
-__device__ __forceinline__ void chol80_one_wave(double* Lm, int lane, int* err) {
-  const int li = lane & 15, lk = lane >> 4;
-  chol16_inv(Lm, lane, err);
-#pragma unroll 1
-  for (int kb = 0; kb < NT; ++kb) {
-    {  // panel: tile(t, kb) <- tile(t, kb) U_kk for the four t != kb, as one batch
-      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
-      double bq[4], av[4][4];
-      d4 acc[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = q + (q >= kb ? 1 : 0);
-        const double* A = Lm + (t * 16) * LD + kb * 16;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
-        acc[q] = d4{0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = q + (q >= kb ? 1 : 0);
-        double* A = Lm + (t * 16) * LD + kb * 16;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
-      }
-    }
-    if (kb == NT - 1) break;
-    {                                         // next diagonal tile, then its 16-pivot chain
-      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
-      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
-      d4 a;
-      double av[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
-      chol16_inv_acc(Cc, a, lane, err);
-    }
-    // the other trailing tiles (U tiles included), four at a time: 13 = 4+4+4+1, 11 = 4+4+3, 8 = 4+4, 4
-    const uint8_t* codes = c_trail[kb];
-    const int ntask = c_trail_n[kb];
-    int q0 = 0;
-#pragma unroll 1
-    for (; q0 + 4 <= ntask; q0 += 4) trail_batch<4>(Lm, kb, codes + q0, li, lk);
-    if (ntask - q0 == 3) trail_batch<3>(Lm, kb, codes + q0, li, lk);
-    else if (ntask - q0 == 1) trail_batch<1>(Lm, kb, codes + q0, li, lk);
-  }
 }
 
 // Barrier among n waves of the workgroup that share the LDS counter cnt (the other waves are busy elsewhere and must not
@@ -240,7 +146,7 @@ struct TrailList {
       }
   }
 };
-template <int KB>
+template <int KB, int PART = 0, int NPARTS = 1>
 __device__ __forceinline__ void trail_step(double* Lm, int li, int lk) {
   double P[NT][4];
 #pragma unroll
@@ -250,11 +156,12 @@ __device__ __forceinline__ void trail_step(double* Lm, int li, int lk) {
   // the products of the step as a compile-time list (ti, tj): lower part first - rows KB+2 .. 4, row KB+2 feeds the next
   // look-ahead (the look-ahead tile (KB+1, KB+1) itself is the chain wave's) -, then the tiles of U (ti <= KB < tj, first
   // written at ti == KB); processed four at a time with their accumulator chains interleaved
+  // (PART of NPARTS: products PART, PART + NPARTS, ... of the list - two helper waves take alternate products)
   constexpr TrailList<KB> TL{};
-  constexpr int NTOT = TL.n;
+  constexpr int NTOT = (TL.n - PART + NPARTS - 1) / NPARTS;
   auto tile_of = [&](int q, int& ti, int& tj) {
-    ti = TL.ti[q];
-    tj = TL.tj[q];
+    ti = TL.ti[PART + NPARTS * q];
+    tj = TL.tj[PART + NPARTS * q];
   };
 #pragma unroll
   for (int q0 = 0; q0 < NTOT; q0 += 4) {
@@ -311,7 +218,7 @@ __device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int*
 #pragma unroll
       for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
       if (role == 0) {
-        double* A = Lm + (c_panel[kb][0] * 16) * LD + kb * 16;
+        double* A = Lm + (panel_tile(kb, 0) * 16) * LD + kb * 16;
         double av[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
@@ -325,7 +232,7 @@ __device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int*
         d4 acc[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const double* A = Lm + (c_panel[kb][q + 1] * 16) * LD + kb * 16;
+          const double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
 #pragma unroll
           for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
           acc[q] = d4{0, 0, 0, 0};
@@ -337,7 +244,7 @@ __device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int*
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          double* A = Lm + (c_panel[kb][q + 1] * 16) * LD + kb * 16;
+          double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
         }
@@ -438,6 +345,40 @@ __device__ __forceinline__ void strips_u_w_acc(const double* U, const double* Y,
 #pragma unroll
         for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
     }
+  }
+}
+
+// One 16-column strip (tile column jb) of a triangular 80 x 80 product, five accumulator tiles, operands of k-step
+// s + 2 requested before the matrix-core work of k-step s (the compiler does not pipeline the loop by itself: it waits for
+// a step's operands, issues the step's products and only then requests the next operands).
+//   UT = true :  W(:, jb) = U^T F(:, jb),  W(ib, jb) = sum_{kb <= ib} U(kb, ib)^T F(kb, jb)   (in place in Y by the caller)
+//   UT = false:  T(:, jb) = U W(:, jb),    T(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb)
+template <bool UT>
+__device__ __forceinline__ void strip_product(const double* U, const double* Y, int jb, d4 (&acc)[NT], int li, int lk) {
+  constexpr int NSTEP = 4 * NT;
+  double a[3][NT], b[3];
+  const double* yb = Y + lk * LD + jb * 16 + li;
+  const double* ub = UT ? U + lk * LD + li : U + li * LD + lk;
+  auto fetch = [&](int buf, int step) {
+    const int kb = step >> 2;
+    b[buf] = yb[(4 * step) * LD];
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib)
+      if (UT ? ib >= kb : ib <= kb) a[buf][ib] = UT ? ub[(4 * step) * LD + ib * 16] : ub[(ib * 16) * LD + 4 * step];
+  };
+#pragma unroll
+  for (int ib = 0; ib < NT; ++ib) acc[ib] = d4{0, 0, 0, 0};
+  fetch(0, 0);
+  fetch(1, 1);
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    if (step + 2 < NSTEP) fetch((step + 2) % 3, step + 2);
+    __builtin_amdgcn_sched_barrier(0);                 // (keeps the requests ahead of the products in the instruction stream)
+    const int kb = step >> 2;
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib)
+      if (UT ? ib >= kb : ib <= kb) acc[ib] = mfma(a[step % 3][ib], b[step % 3], acc[ib]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -776,6 +717,462 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     Xc = Xn;
     Xn = tmp;
   }
+#undef SW_STAMP
+}
+
+// ================================================================================================================
+// The sweep kernel, eight waves.  The node loop has two dependency chains that only meet once per node:
+//   D chain     : U_k -> G_k = U_k U_k^T -> D~_k+1 = D_k+1 - E^T G_k E -> Cholesky -> U_k+1            (Xc -> Xn)
+//   spike chain : F_k -> W = U_k^T F_k -> D_L -= W^T W,  T_k = U_k W -> HBM,  F_k+1 = -E^T T_k          (Xc, Y)
+// Per node: a SERIAL part on all eight waves (G_k, its store, the two stencil passes, the next node built), then a
+// PARALLEL part in which waves 0..2 factor the next node (wave 0: the five 16-pivot chains with the look-ahead tile;
+// waves 1, 2: panel and trailing tiles, alternate products) while waves 3..7 run the WHOLE spike chain of node k, each
+// on its own 16-column strip of the spike (strip = wave - 3; only W^T W reads across strips: two 5-wave LDS-counter
+// barriers per node).  Two waves share every SIMD, so the matrix-core work of the spike fills the issue slots the
+// pivot chains leave empty.  Same arithmetic, tile by tile, as the four-wave form it replaces.
+constexpr int SW8_T = 512;
+// role of wave w in the parallel part: 0 = pivot chains, 1 / 2 = factor helpers, 3 + sw = spike strip sw.  Waves w and w + 4
+// share a SIMD and its matrix pipe; the matrix-core work is dealt so that the four pipes carry about the same load:
+//   SIMD 0: pivot chains (~70 matrix instructions, at raised priority) + strip 0 (180)
+//   SIMD 1, 2: one factor helper each (~100) + strips 1, 2 (180 each)     SIMD 3: strips 3 and 4 (360)
+__device__ __forceinline__ int role8(int wave) { return (0x75436210u >> (4 * wave)) & 15; }   // {0, 1, 2, 6, 3, 4, 5, 7}
+// G = U U^T: the 15 lower tiles dealt by matrix-core work (tile (ib, jb) costs 4 (5 - ib) instructions): wave w takes the
+// tiles in the nibbles of entry w, 15 = none:  {0} {1,10} {2,11} {3,6} {4,7} {5,8} {9,12,13} {14}
+__device__ __forceinline__ int gram8_tile(int wave, int q) {
+  const unsigned long long tb0 = 0x0F630FB20FA10FF0ull;   // waves 0..3, 16 bits each, nibble q = q-th tile
+  const unsigned long long tbl = 0x0FFE0DC90F850F74ull;   // waves 4..7
+  const unsigned v = (unsigned)((wave < 4 ? tb0 : tbl) >> (16 * (wave & 3))) & 0xFFFFu;
+  const int t = (v >> (4 * q)) & 15;
+  return t == 15 ? -1 : t;
+}
+
+// chol80 by THREE waves: role 0 = pivot chains + look-ahead (never waits for a helper inside a step), roles 1, 2 = the
+// other panel tiles (2 + 1) and the trailing products (alternate entries of the step's list).
+// sync[0]: barrier of the three, sync[2]: barrier of the two helpers, sync[3]: one-way flag "role 0's panel tile posted".
+__device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int* err, int* sync, int& t3, int& t2, int& posted,
+                                            long long* dbg = nullptr) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (role == 0) {
+    __builtin_amdgcn_s_setprio(3);                     // the chain's VALU wins the issue arbitration against its SIMD mate
+    chol16_inv(Lm, lane, err);
+  }
+  sub_barrier(sync, t3, 3, lane);
+#pragma unroll 1
+  for (int kb = 0; kb < NT; ++kb) {
+    {  // panel: tile(t, kb) <- tile(t, kb) U_kk
+      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+      double bq[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
+      if (role != 1) {
+        double* A = Lm + (panel_tile(kb, role == 0 ? 0 : 3) * 16) * LD + kb * 16;
+        double av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bq[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+      } else {
+        double av[2][4];
+        d4 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
+          acc[q] = d4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
+        }
+      }
+    }
+    if (kb == NT - 1) {
+      if (role == 0) __builtin_amdgcn_s_setprio(0);
+      sub_barrier(sync, t3, 3, lane);
+      break;
+    }
+    ++posted;
+    if (role == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (dbg && lane == 0) dbg[40 + 2 * kb] = (long long)wall_clock64();
+      // next diagonal tile, then its 16-pivot chain
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      chol16_inv_acc(Cc, a, lane, err);
+      if (dbg && lane == 0) dbg[41 + 2 * kb] = (long long)wall_clock64();
+    } else {
+      sub_barrier(sync + 2, t2, 2, lane);              // the helpers' three panel tiles
+      while (__hip_atomic_load(sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < posted) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (role == 1) {
+        if (kb == 0) trail_step<0, 0, 2>(Lm, li, lk);
+        else if (kb == 1) trail_step<1, 0, 2>(Lm, li, lk);
+        else if (kb == 2) trail_step<2, 0, 2>(Lm, li, lk);
+        else trail_step<3, 0, 2>(Lm, li, lk);
+      } else {
+        if (kb == 0) trail_step<0, 1, 2>(Lm, li, lk);
+        else if (kb == 1) trail_step<1, 1, 2>(Lm, li, lk);
+        else if (kb == 2) trail_step<2, 1, 2>(Lm, li, lk);
+        else trail_step<3, 1, 2>(Lm, li, lk);
+      }
+      if (dbg && lane == 0) dbg[48 + 4 * (role - 1) + kb] = (long long)wall_clock64();
+    }
+    sub_barrier(sync, t3, 3, lane);
+  }
+}
+
+// The NQ tiles (ib[q], jb[q]) of the left separator's update D_L -= W^T W that one spike wave owns: accumulators
+// loaded from / stored to the workgroup's block in global memory (L2-resident between nodes).
+template <int NQ>
+__device__ __forceinline__ void syrk_load_n(d4 (&acc)[NQ], const double* __restrict__ Ag, bool load, const int (&ib)[NQ],
+                                            const int (&jb)[NQ], int li, int lk) {
+  // (loads unconditional, THEN the select: a conditional load compiles to a branch per element with a full wait in front)
+  const double* base = Ag + lk * BS + li;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = base[(ib[q] * 16 + 4 * rr) * BS + jb[q] * 16];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = load ? acc[q][rr] : 0.0;
+}
+template <int NQ>
+__device__ __forceinline__ void syrk_run_n(d4 (&acc)[NQ], const double* W, double* __restrict__ Ag, const int (&ib)[NQ],
+                                           const int (&jb)[NQ], int li, int lk) {
+  const double* p = W + lk * LD + li;
+  double a0[NQ], b0[NQ], a1[NQ], b1[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    a0[q] = p[ib[q] * 16];
+    b0[q] = p[jb[q] * 16];
+  }
+#pragma unroll
+  for (int s = 0; s < BS / 4; s += 2) {      // operands of step s + 1 requested before the matrix-core work of step s
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      a1[q] = p[(4 * (s + 1)) * LD + ib[q] * 16];
+      b1[q] = p[(4 * (s + 1)) * LD + jb[q] * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = mfma(-a0[q], b0[q], acc[q]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < BS / 4) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        a0[q] = p[(4 * (s + 2)) * LD + ib[q] * 16];
+        b0[q] = p[(4 * (s + 2)) * LD + jb[q] * 16];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = mfma(-a1[q], b1[q], acc[q]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double* base = Ag + lk * BS + li;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) base[(ib[q] * 16 + 4 * rr) * BS + jb[q] * 16] = acc[q][rr];
+}
+
+__global__ void __launch_bounds__(SW8_T)
+k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+               int m, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
+  double* Xn = Xc + MAT;                               // G_k -> stencil workspace -> D~_k+1 -> U_k+1
+  double* Y = Xn + MAT;                                // spike: F_k -> W -> T_k -> F_k+1; column 79 = right-hand side
+  double* cL = Y + MAT;                                // coupling tables of the current node
+  double* cR = cL + 9 * NP;
+  double* bv = cR + 9 * NP;                            // [80] right-hand side of the node built last
+  double* red = bv + BS;                               // [8]
+  int* sync = reinterpret_cast<int*>(red + 8);         // [0] factor trio | [1] spike waves | [2] helper pair | [3] flag
+  double* kq = red + 16;                               // [25] each: copies of K.q_w, K.lo, K.hi
+  double* klo = kq + NP;
+  double* khi = klo + NP;
+  long long* lst = reinterpret_cast<long long*>(khi + NP);   // [64] debug stamps, copied out at the end of the stamped node
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const FteConst& K = *cst;
+  const int c = blockIdx.x;
+  const int first = c * m;
+  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
+  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const size_t MB = (size_t)BS * BS;
+  const int role = __builtin_amdgcn_readfirstlane(role8(wave));
+  const int n_spike = hasL ? 5 : 1;          // first run: only the right-hand side column (strip 4) is alive
+  int t3 = 0, t2 = 0, tflag = 0, t5 = 0;     // rounds of the wave-subset barriers
+  // (debug stamps: workgroup dbg[29] writes wall-clock ticks of its phases at node dbg[30]; selectors read ONCE)
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[29]) ? ch.dbg : nullptr;
+  const int dbg_k = dbgp ? (int)ch.dbg[30] : -1;
+  // (stamps go to LDS: a global store in front of a release fence would itself delay the wave that is being timed)
+#define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
+  if (tid < 4) sync[tid] = 0;
+  if (tid < 64) lst[tid] = 0;
+  if (tid < NP) {
+    kq[tid] = K.q_w[tid];
+    klo[tid] = K.lo[tid];
+    khi[tid] = K.hi[tid];
+  }
+  __syncthreads();
+
+  {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
+    NodeFetch f;
+    build_fetch<SW8_T>(f, ch, K, first, tid);
+    fill_coupling_coef<SW8_T>(cL, cR, K, first, tid, kq);
+    for (int e = tid; e < MAT; e += SW8_T) Y[e] = 0.0;
+    const double gmax = build_finish<SW8_T>(Xc, bv, f, K, first, tid, kq, klo, khi);
+    publish_gmax<SW8_T>(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
+    if (hasL)
+      for (int e = tid; e < 9 * NP; e += SW8_T) {
+        const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
+        if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
+      }
+    if (tid < BS) Y[tid * LD + (BS - 1)] = bv[tid];
+    __syncthreads();
+    if (role < 3) chol80_trio(Xc, role, lane, numeric_err, sync, t3, t2, tflag);
+    __syncthreads();
+  }
+
+#pragma unroll 1
+  for (int k = 0; k < n_int; ++k) {
+    const int node = first + k, next = node + 1;
+    const bool last = k + 1 == n_int;
+    const bool has_next = !last || hasR;
+    // ================= serial part (all eight waves): G_k, then the next node =================
+    // (thread index made opaque per iteration: the index arithmetic of the build / stencil phases is recomputed instead of
+    //  being hoisted out of the node loop and spilled - a scratch reload behind the 51 KB store of G waits for that store)
+    const int tid_ = opaque(tid);
+    const int sp_ = tid_ % NP, sc0 = tid_ / NP;
+    const bool s_act = tid_ < 20 * NP;
+    NodeFetch f;
+    if (has_next) build_fetch<SW8_T>(f, ch, K, next, tid_);
+    if (wave == 0) SW_STAMP(0);
+    if (k > 0) fill_coupling_coef<SW8_T>(cL, cR, K, node, tid_, kq);
+    {
+      const int gi = opaque(lane & 15), gk = opaque(lane >> 4);
+      d4 g[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = gram8_tile(wave, q);
+        if (t >= 0) g[q] = tile_u_ut(Xc, tri_i(t), tri_j(t), gi, gk);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = gram8_tile(wave, q);
+        if (t >= 0) {
+          const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            Xn[(ib * 16 + gk + 4 * rr) * LD + jb * 16 + gi] = g[q][rr];
+            if (ib != jb) Xn[(jb * 16 + gi) * LD + ib * 16 + gk + 4 * rr] = g[q][rr];
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // G in Xn, tables of this node visible
+    if (wave == 0) SW_STAMP(1);
+    if (has_next) {
+      // the next node's H / g / x were requested at the top of the iteration and have arrived; pin them down HERE: behind
+      // the 51 KB store of G the wait for them would be a wait for the stores as well (one counter for loads and stores)
+#pragma unroll
+      for (int q = 0; q < 2048 / SW8_T; ++q) asm volatile("" : "+v"(f.hv[q]));
+      asm volatile("" : "+v"(f.xv), "+v"(f.gv), "+v"(f.lam));
+    }
+    {
+      double2* d2 = reinterpret_cast<double2*>(ch.D + node * MB);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int idx = tid_ + SW8_T * q;
+        if (idx < BS * BS / 2) {
+          const int e = 2 * idx, r = e / BS, cc = e % BS;
+          d2[idx] = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
+        }
+      }
+    }
+    if (has_next) {
+      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+      if (s_act) {
+        c00 = cR[(0 * 3 + 0) * NP + sp_];  c01 = cR[(0 * 3 + 1) * NP + sp_];  c02 = cR[(0 * 3 + 2) * NP + sp_];
+        c11 = cR[(1 * 3 + 1) * NP + sp_];  c12 = cR[(1 * 3 + 2) * NP + sp_];  c22 = cR[(2 * 3 + 2) * NP + sp_];
+      }
+      __syncthreads();                                 // the store above has read Xn
+      if (s_act) {                                     // pass 1: Xn <- G E, in place (rows sc0 + 20 j, state sp_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* rowp = Xn + (sc0 + 20 * j) * LD + sp_;
+          const double g0 = rowp[0], g1 = rowp[NP], g2 = rowp[2 * NP];
+          rowp[0] = g0 * c00 + g1 * c01 + g2 * c02;
+          rowp[NP] = g1 * c11 + g2 * c12;
+          rowp[2 * NP] = g2 * c22;
+        }
+      }
+      __syncthreads();
+      double dv[4][3];
+      if (wave == 0) SW_STAMP(2);
+      if (s_act) {                                     // pass 2: dv = -E^T (G E) (columns sc0 + 20 j, state sp_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double* colp = Xn + sp_ * LD + sc0 + 20 * j;
+          const double t0 = colp[0], t1 = colp[NP * LD], t2_ = colp[2 * NP * LD];
+          dv[j][0] = -(c00 * t0 + c01 * t1 + c02 * t2_);
+          dv[j][1] = -(c11 * t1 + c12 * t2_);
+          dv[j][2] = -(c22 * t2_);
+        }
+      }
+      __syncthreads();                                 // pass-2 reads done: Xn may be rebuilt
+      if (wave == 0) SW_STAMP(3);
+      const double gmax = build_finish<SW8_T>(Xn, bv, f, K, next, tid_, kq, klo, khi);
+      publish_gmax<SW8_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
+      if (s_act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* colp = Xn + sp_ * LD + sc0 + 20 * j;
+          colp[0] += dv[j][0];
+          colp[NP * LD] += dv[j][1];
+          colp[2 * NP * LD] += dv[j][2];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) SW_STAMP(4);
+    // ================= parallel part =================
+    if (role < 3) {
+      // blocked Cholesky of the next node
+      if (!last)
+        chol80_trio(Xn, role, opaque(lane), numeric_err, sync, t3, t2, tflag, (dbgp && k == dbg_k) ? lst : nullptr);
+      SW_STAMP(8 + wave);
+    } else if (hasL || role == 7) {
+      // the spike chain of node k on strip sw (columns 16 sw .. 16 sw + 15)
+      // (wave and lane indices made opaque per node: see tid_ above)
+      const int sw = __builtin_amdgcn_readfirstlane(opaque(role)) - 3;
+      const int ln = opaque(lane);
+      const int li = ln & 15, lk = ln >> 4;
+      // D_L -= W^T W: three of the 15 lower tiles per wave (tile t = sw + 5 q)
+      d4 accL[3] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+      int sib[3], sjb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        sib[q] = tri_i(sw + 5 * q);
+        sjb[q] = tri_j(sw + 5 * q);
+      }
+      double* Ag = sp.AL + (size_t)(hasL ? opaque(c - 1) : 0) * MB;   // (global address space kept: no pointer through asm)
+      // the left separator's update so far (HBM / L2, owned by this workgroup): requested now, needed after W
+      if (hasL) syrk_load_n<3>(accL, Ag, k > 0, sib, sjb, li, lk);
+      {
+        d4 wacc[NT];
+        strip_product<true>(Xc, Y, sw, wacc, li, lk);  // W strip, then in place over F (own strip: every read precedes)
+#pragma unroll
+        for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, sw, wacc[ib], li, lk);
+      }
+      SW_STAMP(16 + 4 * sw);
+      sub_barrier(sync + 1, t5, n_spike, ln);          // every strip of W is in Y
+      SW_STAMP(17 + 4 * sw);
+      if (hasL) syrk_run_n<3>(accL, Y, Ag, sib, sjb, li, lk);
+      SW_STAMP(18 + 4 * sw);
+      d4 town[NT];
+      strip_product<false>(Xc, Y, sw, town, li, lk);   // T strip = U W strip (reads its own strip of W only)
+      sub_barrier(sync + 1, t5, n_spike, ln);          // nobody reads W any more
+#pragma unroll
+      for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, sw, town[ib], li, lk);
+      SW_STAMP(19 + 4 * sw);
+      // ---- T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then F_k+1 = -E^T T_k in place,
+      //      column 79 += the next node's right-hand side.  Own strip only: no barrier (LDS operations of a wave are ordered)
+      const int c_lo = 16 * sw;
+      if (hasL) {
+        double* Tg = ch.Wl + node * MB;
+        double v0[16], v1[4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v0[j] = Y[ln * LD + c_lo + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v1[j] = Y[(64 + li) * LD + c_lo + 4 * lk + j];   // rows 64..79: 4 x 4 columns
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Tg[(size_t)(c_lo + j) * BS + ln] = v0[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Tg[(size_t)(c_lo + 4 * lk + j) * BS + 64 + li] = v1[j];
+      }
+      if (sw == 4) {
+        ch.b[(size_t)node * BS + ln] = Y[ln * LD + (BS - 1)];
+        if (ln < 16) ch.b[(size_t)node * BS + 64 + ln] = Y[(64 + ln) * LD + (BS - 1)];
+      }
+      if (has_next) {
+        // lane = (state p, column group): the six stencil coefficients of p are read once, rows p, 25 + p, 50 + p of the
+        // lane's columns are rewritten in place
+        const int p = ln % NP, cg = ln / NP;        // cg 0, 1 (lanes 50..63 idle)
+        if (cg < 2) {
+          const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
+          const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
+          const double b0 = bv[p], b1 = bv[NP + p], b2 = bv[2 * NP + p];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int cc = c_lo + cg + 2 * q;
+            const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
+            double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
+            if (cc == BS - 1) {
+              o0 += b0;
+              o1 += b1;
+              o2 += b2;
+            }
+            Y[p * LD + cc] = o0;
+            Y[(NP + p) * LD + cc] = o1;
+            Y[(2 * NP + p) * LD + cc] = o2;
+          }
+        }
+        if (ln < 16)
+          for (int r = 3 * NP; r < BS; ++r) Y[r * LD + c_lo + ln] = 0.0;     // padding rows couple to nothing
+      }
+      SW_STAMP(8 + wave);
+    }
+    __syncthreads();                                   // next node factored, F_k+1 complete
+    if (wave == 0) SW_STAMP(7);
+    if (dbgp && k == dbg_k) {
+      __syncthreads();
+      if (tid < 64 && lst[tid]) dbgp[tid] = lst[tid];
+    }
+    if (last && hasR) {                                // the node built last is the right separator
+      {
+        double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)c * MB);
+        for (int idx = tid; idx < BS * BS / 2; idx += SW8_T) {
+          const int e = 2 * idx, r = e / BS, cc = e % BS;
+          d2[idx] = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
+        }
+      }
+      if (tid < BS) sp.b[(size_t)c * BS + tid] = Y[tid * LD + (BS - 1)];
+      if (hasL) {
+        double* Cg = sp.Cpl + (size_t)(c - 1) * MB;    // block(R, L): rows R, columns L
+        for (int e = tid; e < BS * BS; e += SW8_T) {
+          const int r = e / BS, cc = e % BS;
+          Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
+        }
+      }
+    }
+    double* tmp = Xc;
+    Xc = Xn;
+    Xn = tmp;
+  }
+#undef SW_STAMP
 }
 
 // Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as
@@ -861,8 +1258,18 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   }
 }
 
+static bool sweep_eight_waves() {
+  static const bool v = [] {
+    const char* e = std::getenv("ACINO_SWEEP_WAVES");
+    return !(e && std::atoi(e) == 4);
+  }();
+  return v;
+}
+
 int chunk_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep8),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
   return ACINO_OK;
 }
@@ -872,8 +1279,12 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
                  Profiler* prof) {
   {
     ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
-                       pl.n_chunks);
+    if (sweep_eight_waves())
+      hipLaunchKernelGGL(k_chunk_sweep8, dim3(pl.n_chunks), dim3(SW8_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status,
+                         pl.m, pl.n_chunks);
+    else
+      hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                         pl.n_chunks);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;

@@ -182,15 +182,24 @@ __device__ __forceinline__ void chol16_inv(double* T, int lane, int* err) {
 // LOOK-AHEAD: in the trailing phase wave 0 takes only the next diagonal tile, keeps the result in registers (the
 // MFMA C layout is the factorisation's layout) and goes straight into its 16-pivot chain, while waves 1..3 do all
 // other trailing tiles (<= 5 each) - the inverse costs no time on the critical path.
-// task tables for waves 1..3: [kb][n] = 16*ti + tj ; ti <= kb marks a tile of U (overwrite when ti == kb)
-static __constant__ uint8_t c_trail_n[4] = {13, 11, 8, 4};
-static __constant__ uint8_t c_trail[4][13] = {
-    {0x21, 0x22, 0x31, 0x32, 0x33, 0x41, 0x42, 0x43, 0x44, 0x01, 0x02, 0x03, 0x04},
-    {0x32, 0x33, 0x42, 0x43, 0x44, 0x02, 0x03, 0x04, 0x12, 0x13, 0x14, 0, 0},
-    {0x43, 0x44, 0x03, 0x04, 0x13, 0x14, 0x23, 0x24, 0, 0, 0, 0, 0},
-    {0x04, 0x14, 0x24, 0x34, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
-// panel: row tile taken by wave w at block column kb (wave 0 always takes the tile the look-ahead needs next)
-static __constant__ uint8_t c_panel[5][4] = {{1, 2, 3, 4}, {2, 0, 3, 4}, {3, 0, 1, 4}, {4, 0, 1, 2}, {0, 1, 2, 3}};
+// Task tables as ARITHMETIC on packed literals: a __constant__ byte table costs a global_load + s_waitcnt vmcnt(0) at every
+// lookup (gfx950 has no sub-dword scalar loads) - on the pivot chain's critical path that was ~0.5 us per block column.
+// trailing tasks of waves 1..3 at block column kb: code = 16*ti + tj ; ti <= kb marks a tile of U (overwrite when ti == kb)
+//   kb 0: 21 22 31 32 33 41 42 43 44 01 02 03 04 | kb 1: 32 33 42 43 44 02 03 04 12 13 14 | kb 2: 43 44 03 04 13 14 23 24
+//   kb 3: 04 14 24 34
+__device__ __forceinline__ int trail_n(int kb) { return (0x04080B0Du >> (8 * kb)) & 0xFF; }
+__device__ __forceinline__ int trail_code(int kb, int t) {
+  const unsigned long long lo = kb == 0 ? 0x4342413332312221ull
+                                : (kb == 1 ? 0x0403024443423332ull : (kb == 2 ? 0x2423141304034443ull : 0x34241404ull));
+  const unsigned long long hi = kb == 0 ? 0x0403020144ull : (kb == 1 ? 0x141312ull : 0ull);
+  return (int)(((t < 8 ? lo : hi) >> (8 * (t & 7))) & 0xFF);
+}
+// panel: row tile q of block column kb, {1,2,3,4}, {2,0,3,4}, {3,0,1,4}, {4,0,1,2}, {0,1,2,3}: entry 0 is always the tile
+// the look-ahead needs next
+__device__ __forceinline__ int panel_tile(int kb, int q) {
+  const unsigned v = kb < 4 ? (unsigned)(0x2104410343024321ull >> (16 * kb)) & 0xFFFFu : 0x3210u;
+  return (v >> (4 * q)) & 15;
+}
 
 __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -199,7 +208,7 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
   for (int kb = 0; kb < NT; ++kb) {
     const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
     {  // panel: tile(t,kb) <- tile(t,kb) * U_kk   (L(ib,kb) = A(ib,kb) L_kk^-T below, U(j,kb) above the diagonal)
-      double* A = Lm + (c_panel[kb][wave] * 16) * LD + kb * 16;
+      double* A = Lm + (panel_tile(kb, wave) * 16) * LD + kb * 16;
       double av[4], bv[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -229,9 +238,9 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
       chol16_inv_acc(Cc, a, lane, err);
       if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
     } else {
-      const int ntask = c_trail_n[kb];
+      const int ntask = trail_n(kb);
       for (int t = wave - 1; t < ntask; t += 3) {
-        const int code = c_trail[kb][t], ti = code >> 4, tj = code & 15;
+        const int code = trail_code(kb, t), ti = code >> 4, tj = code & 15;
         double* Cc = Lm + (ti * 16) * LD + tj * 16;
         const double* A = Lm + (ti * 16) * LD + kb * 16;
         const double* B = Lm + (tj * 16) * LD + kb * 16;

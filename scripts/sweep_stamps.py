@@ -35,6 +35,18 @@ for role in (0, 1):
     for kb in range(5):
         names[b + 2 + 3 * kb] = f"chol r{role}: panel {kb}"; names[b + 3 + 3 * kb] = f"chol r{role}: barrier p{kb}"
         if kb < 4: names[b + 4 + 3 * kb] = f"chol r{role}: " + ("chain" if role == 0 else "trailing") + f" {kb}"
+import os
+if os.environ.get("ACINO_SWEEP_WAVES") != "4":          # the eight-wave kernel's stamp slots
+    names = {0: "iter start", 1: "G in LDS", 2: "G stored + pass 1", 3: "pass 2", 4: "node built (parallel part starts)",
+             7: "end of node (barrier)"}
+    for w in range(8):
+        names[8 + w] = f"wave {w}: parallel role done"
+    for sw in range(5):
+        names[16 + 4 * sw] = f"spike {sw}: W strip"; names[17 + 4 * sw] = f"spike {sw}: barrier 1"
+        names[18 + 4 * sw] = f"spike {sw}: syrk"; names[19 + 4 * sw] = f"spike {sw}: T stored"
+    for kb in range(4):
+        names[40 + 2 * kb] = f"chain: panel {kb} posted"; names[41 + 2 * kb] = f"chain: pivots {kb + 1} done"
+        names[48 + kb] = f"helper 1: trailing {kb}"; names[52 + kb] = f"helper 2: trailing {kb}"
 for i in sorted(names, key=lambda i: d[i]):
     if d[i]:
         print(f"{(d[i] - t0) / 100.0:8.2f} us  {names[i]}")
