@@ -965,12 +965,54 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     // (thread index made opaque per iteration: the index arithmetic of the build / stencil phases is recomputed instead of
     //  being hoisted out of the node loop and spilled - a scratch reload behind the 51 KB store of G waits for that store)
     const int tid_ = opaque(tid);
-    const int sp_ = tid_ % NP, sc0 = tid_ / NP;
-    const bool s_act = tid_ < 20 * NP;
-    NodeFetch f;
-    if (has_next) build_fetch<SW8_T>(f, ch, K, next, tid_);
+    // The next node is built by PAIRS OF STATES: thread e (and e + 512 < 625) owns the 3 x 3 frame block of the state pair
+    // (p, p') = (e / 25, e % 25) - the nine entries [(j, p)][(j', p')] of the node.  Everything that lands in the block is the
+    // thread's own: the Gauss-Newton entries H_j[p][p'] (requested here, a whole node ahead of their use), the Schur update
+    // -(E^T G_k E) of the block (nine entries of G_k in, nine out: E couples only equal states), and for p = p' the damping,
+    // the bound pinning, the intra-node third-difference couplings and the right-hand side.  No zero fill, no in-place pass.
+    const int fb_next = 3 * next;                      // (chunked contexts have no pinned separator: node t holds frames 3t ..)
+    double hq[2][3] = {{0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, cvq[3] = {0, 0, 0}, lamq = 0.0;
+    bool liveq[3] = {false, false, false}, ownq[3] = {false, false, false};
+    const int e1 = tid_ + SW8_T;
+    const bool own1 = e1 < NP * NP;
+    const int pd0 = tid_ / NP, pc0 = tid_ % NP, pd1 = own1 ? e1 / NP : 0, pc1 = own1 ? e1 % NP : 0;
+    const bool diag0 = pd0 == pc0, diag1 = own1 && pd1 == pc1;
+    const int pdg = diag1 ? pd1 : pd0;                 // (a thread owns at most one diagonal pair)
+    if (has_next) {
+      const int cur = ch.st->cur;
+      const double* Hg = cur ? ch.H1 : ch.H0;
+      lamq = ch.st->lam;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (fb_next + j < K.n_frames) {
+          hq[0][j] = Hg[(size_t)(fb_next + j) * NP * NP + tid_];
+          if (own1) hq[1][j] = Hg[(size_t)(fb_next + j) * NP * NP + e1];
+        }
+      if (diag0 || diag1) {
+        const double* xg = cur ? ch.x1 : ch.x0;
+        const double* gg = cur ? ch.g1 : ch.g0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (fb_next + j < K.n_frames) {
+            xq[j] = xg[(size_t)(fb_next + j + HALO) * NP + pdg];
+            gq[j] = gg[(size_t)(fb_next + j) * NP + pdg];
+          }
+        // intra-node third-difference couplings of state pdg, frame pairs (0,1), (0,2), (1,2) (needed when the node is written:
+        // worked out here, beside the loads in flight, so that the write phase reads no constants through the scalar cache)
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          const int j = pr == 2 ? 1 : 0, jp = pr == 0 ? 1 : 2;
+          if (fb_next + jp < K.n_frames)
+            cvq[pr] = 2.0 * kq[pdg] * band_coef_clip(K.n_offset + fb_next + j, jp - j, K.n_global, K.clip_len);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        liveq[j] = fb_next + j < K.n_frames;
+        ownq[j] = fb_next + j >= K.own_lo && fb_next + j < K.own_hi;
+      }
+    }
     if (wave == 0) SW_STAMP(0);
-    if (k > 0) fill_coupling_coef<SW8_T>(cL, cR, K, node, tid_, kq);
     {
       const int gi = opaque(lane & 15), gk = opaque(lane >> 4);
       d4 g[3];
@@ -979,6 +1021,7 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         const int t = gram8_tile(wave, q);
         if (t >= 0) g[q] = tile_u_ut(Xc, tri_i(t), tri_j(t), gi, gk);
       }
+      if (k > 0) fill_coupling_coef<SW8_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int t = gram8_tile(wave, q);
@@ -994,13 +1037,12 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     }
     __syncthreads();                                   // G in Xn, tables of this node visible
     if (wave == 0) SW_STAMP(1);
-    if (has_next) {
-      // the next node's H / g / x were requested at the top of the iteration and have arrived; pin them down HERE: behind
-      // the 51 KB store of G the wait for them would be a wait for the stores as well (one counter for loads and stores)
+    // the next node's H / g / x were requested at the top of the iteration and have arrived; pin them down HERE: behind
+    // the 51 KB store of G the wait for them would be a wait for the stores as well (one counter for loads and stores).
+    // (Unconditionally: with a path around the pin the compiler's wait-count analysis still sees the loads pending below.)
 #pragma unroll
-      for (int q = 0; q < 2048 / SW8_T; ++q) asm volatile("" : "+v"(f.hv[q]));
-      asm volatile("" : "+v"(f.xv), "+v"(f.gv), "+v"(f.lam));
-    }
+    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(hq[0][j]), "+v"(hq[1][j]), "+v"(xq[j]), "+v"(gq[j]));
+    asm volatile("" : "+v"(lamq));
     {
       double2* d2 = reinterpret_cast<double2*>(ch.D + node * MB);
 #pragma unroll
@@ -1013,48 +1055,83 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       }
     }
     if (has_next) {
-      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-      if (s_act) {
-        c00 = cR[(0 * 3 + 0) * NP + sp_];  c01 = cR[(0 * 3 + 1) * NP + sp_];  c02 = cR[(0 * 3 + 2) * NP + sp_];
-        c11 = cR[(1 * 3 + 1) * NP + sp_];  c12 = cR[(1 * 3 + 2) * NP + sp_];  c22 = cR[(2 * 3 + 2) * NP + sp_];
-      }
-      __syncthreads();                                 // the store above has read Xn
-      if (s_act) {                                     // pass 1: Xn <- G E, in place (rows sc0 + 20 j, state sp_)
+      // S = E^T G_k E on the thread's blocks: (G E)[(jj, p)][(i', p')] = sum_{jj' >= i'} G[(jj, p)][(jj', p')] c_{i' jj'}(p'),
+      // S[(i, p)][(i', p')] = sum_{jj >= i} c_{i jj}(p) (G E)[(jj, p)][(i', p')]      (c = cR: the right coupling of node k)
+      double S[2][3][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double* rowp = Xn + (sc0 + 20 * j) * LD + sp_;
-          const double g0 = rowp[0], g1 = rowp[NP], g2 = rowp[2 * NP];
-          rowp[0] = g0 * c00 + g1 * c01 + g2 * c02;
-          rowp[NP] = g1 * c11 + g2 * c12;
-          rowp[2 * NP] = g2 * c22;
+      for (int sl = 0; sl < 2; ++sl) {
+        const int pr = sl ? pd1 : pd0, pc = sl ? pc1 : pc0;
+        if (sl == 0 || own1) {
+          const double a00 = cR[0 * NP + pr], a01 = cR[1 * NP + pr], a02 = cR[2 * NP + pr];
+          const double a11 = cR[4 * NP + pr], a12 = cR[5 * NP + pr], a22 = cR[8 * NP + pr];
+          const double b00 = cR[0 * NP + pc], b01 = cR[1 * NP + pc], b02 = cR[2 * NP + pc];
+          const double b11 = cR[4 * NP + pc], b12 = cR[5 * NP + pc], b22 = cR[8 * NP + pc];
+          double m[3][3];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) {
+            const double* gp = Xn + (jj * NP + pr) * LD + pc;
+            const double g0 = gp[0], g1 = gp[NP], g2 = gp[2 * NP];
+            m[jj][0] = g0 * b00 + g1 * b01 + g2 * b02;
+            m[jj][1] = g1 * b11 + g2 * b12;
+            m[jj][2] = g2 * b22;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 3; ++ii) {
+            S[sl][0][ii] = a00 * m[0][ii] + a01 * m[1][ii] + a02 * m[2][ii];
+            S[sl][1][ii] = a11 * m[1][ii] + a12 * m[2][ii];
+            S[sl][2][ii] = a22 * m[2][ii];
+          }
         }
       }
-      __syncthreads();
-      double dv[4][3];
+      __syncthreads();                                 // every read of G done (the store above included): Xn is rebuilt
       if (wave == 0) SW_STAMP(2);
-      if (s_act) {                                     // pass 2: dv = -E^T (G E) (columns sc0 + 20 j, state sp_)
+      double gmax = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double* colp = Xn + sp_ * LD + sc0 + 20 * j;
-          const double t0 = colp[0], t1 = colp[NP * LD], t2_ = colp[2 * NP * LD];
-          dv[j][0] = -(c00 * t0 + c01 * t1 + c02 * t2_);
-          dv[j][1] = -(c11 * t1 + c12 * t2_);
-          dv[j][2] = -(c22 * t2_);
+      for (int sl = 0; sl < 2; ++sl) {
+        const int pr = sl ? pd1 : pd0, pc = sl ? pc1 : pc0;
+        const bool dg = sl ? diag1 : diag0;
+        if (sl == 0 || own1) {
+          double v[3][3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) v[j][jp] = (j == jp ? hq[sl][j] : 0.0);
+          if (dg) {
+            // diagonal pair: Marquardt damping, bound pinning, right-hand side, projected-gradient norm of rows (j, p) and the
+            // intra-node third-difference couplings (frame pairs (0,1), (0,2), (1,2) of state p)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              double d = 1.0, bb = 0.0;
+              if (liveq[j]) {
+                d = hq[sl][j];
+                const double gtol = GRAD_ZERO_REL * d;
+                const bool fixed = (xq[j] <= klo[pr] && gq[j] > gtol) || (xq[j] >= khi[pr] && gq[j] < -gtol);
+                d = d + lamq * fmax(d, DIAG_FLOOR);
+                if (fixed) d *= FIX_SCALE;
+                bb = fixed ? 0.0 : -gq[j];
+                if (ownq[j]) gmax = fmax(gmax, fabs(bb));   // (window sharding: owned frames only)
+              }
+              v[j][j] = d;
+              bv[j * NP + pr] = bb;
+            }
+            v[0][1] = v[1][0] = cvq[0];
+            v[0][2] = v[2][0] = cvq[1];
+            v[1][2] = v[2][1] = cvq[2];
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) Xn[(j * NP + pr) * LD + jp * NP + pc] = v[j][jp] - S[sl][j][jp];
         }
       }
-      __syncthreads();                                 // pass-2 reads done: Xn may be rebuilt
+      // padding rows / columns 75 .. 79: identity
+      for (int e = tid_; e < BS * BS - 9 * NP * NP; e += SW8_T) {
+        const int r = e < 5 * BS ? 3 * NP + e / BS : (e - 5 * BS) / 5, cc = e < 5 * BS ? e % BS : 3 * NP + (e - 5 * BS) % 5;
+        Xn[r * LD + cc] = r == cc ? 1.0 : 0.0;
+      }
+      if (tid_ < BS - 3 * NP) bv[3 * NP + tid_] = 0.0;
       if (wave == 0) SW_STAMP(3);
-      const double gmax = build_finish<SW8_T>(Xn, bv, f, K, next, tid_, kq, klo, khi);
       publish_gmax<SW8_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
-      if (s_act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double* colp = Xn + sp_ * LD + sc0 + 20 * j;
-          colp[0] += dv[j][0];
-          colp[NP * LD] += dv[j][1];
-          colp[2 * NP * LD] += dv[j][2];
-        }
-      }
     }
     __syncthreads();
     if (wave == 0) SW_STAMP(4);
