@@ -43,33 +43,7 @@ void ChunkPlan::build(int nodes, int chunk_nodes) {
   n_sep = n_chunks - 1;
 }
 
-// ---- tile products on LDS matrices (leading dimension LD), one 16x16 output tile per call, all operands read first ----
-// (U^T F)(ib, jb) = sum_{kb <= ib} U(kb, ib)^T F(kb, jb): U upper triangular in X (strictly-lower tiles are workspace)
-__device__ __forceinline__ d4 tile_ut_f(const double* X, const double* Y, int ib, int jb, int li, int lk) {
-  const double* pa = X + lk * LD + ib * 16 + li;
-  const double* pb = Y + lk * LD + jb * 16 + li;
-  const d4 z = {0, 0, 0, 0};
-  switch (ib) {
-    case 0: return mma_seq<4, false>(z, pa, 4 * LD, pb, 4 * LD);
-    case 1: return mma_seq<8, false>(z, pa, 4 * LD, pb, 4 * LD);
-    case 2: return mma_seq<12, false>(z, pa, 4 * LD, pb, 4 * LD);
-    case 3: return mma_seq<16, false>(z, pa, 4 * LD, pb, 4 * LD);
-    default: return mma_seq<20, false>(z, pa, 4 * LD, pb, 4 * LD);
-  }
-}
-// (U W)(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb)
-__device__ __forceinline__ d4 tile_u_w(const double* X, const double* Y, int ib, int jb, int li, int lk) {
-  const double* pa = X + (ib * 16 + li) * LD + ib * 16 + lk;
-  const double* pb = Y + (ib * 16 + lk) * LD + jb * 16 + li;
-  const d4 z = {0, 0, 0, 0};
-  switch (ib) {
-    case 0: return mma_seq<20, false>(z, pa, 4, pb, 4 * LD);
-    case 1: return mma_seq<16, false>(z, pa, 4, pb, 4 * LD);
-    case 2: return mma_seq<12, false>(z, pa, 4, pb, 4 * LD);
-    case 3: return mma_seq<8, false>(z, pa, 4, pb, 4 * LD);
-    default: return mma_seq<4, false>(z, pa, 4, pb, 4 * LD);
-  }
-}
+// ---- tile helpers on LDS matrices (leading dimension LD): one 16x16 output tile per call, all operands read first ----
 // (U U^T)(ib, jb), jb <= ib:  sum_{k >= 16 ib} U[ib16 + i][k] U[jb16 + j][k]
 __device__ __forceinline__ d4 tile_u_ut(const double* X, int ib, int jb, int li, int lk) {
   const double* pa = X + (ib * 16 + li) * LD + ib * 16 + lk;
@@ -88,16 +62,17 @@ __device__ __forceinline__ void tile_store(double* M, int ib, int jb, const d4& 
   for (int rr = 0; rr < 4; ++rr) M[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = a[rr];
 }
 
-// ================================================================================================================
-// The sweep kernel.  Per node the work splits into a SERIAL part (all four waves) and a PARALLEL part:
-//   serial   : G_k = U_k U_k^T -> HBM;  D~_k+1 = D_k+1 - E^T G_k E  (the next node's H / g / x were requested before G)
-//   parallel : wave 0 factors D~_k+1 ALONE (one-wave blocked Cholesky: no workgroup barrier on the pivot chain),
-//              waves 1..3 do the spike algebra of node k meanwhile: W = U_k^T F_k, D_L -= W^T W, T_k = U_k W -> HBM,
-//              F_k+1 = -E^T T_k, each wave on its own 16-column strips (two 3-wave LDS barriers per node for W^T W).
-// The right-hand side rides along as COLUMN 79 of the spike (the left separator has 75 unknowns, columns 75..79 are free):
-// column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1 = the next node's b~), and row 79
-// of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases, no extra barriers.
-// LDS: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 159.9 KB, one workgroup per CU.
+// The 15 lower 16x16 tiles of an 80 x 80 row-major matrix as 1920 two-double items: item idx -> (row, even column).
+// Tile row ib holds 16 rows of 8 (ib + 1) items each; cumulative item counts 0, 128, 384, 768, 1280, 1920.
+constexpr int LOWER_ITEMS = 1920;
+__device__ __forceinline__ void lower_item(int idx, int& row, int& col) {
+  const int ib = (idx >= 128) + (idx >= 384) + (idx >= 768) + (idx >= 1280);
+  const int rem = idx - 64 * ib * (ib + 1), w = 8 * (ib + 1);      // 64 ib (ib + 1) = items in the tile rows above
+  row = 16 * ib + rem / w;
+  col = 2 * (rem % w);
+}
+
+// LDS of the sweep kernel: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 160.5 KB, one workgroup per CU.
 constexpr int SW_VEC = 18 * NP + BS + 8 + 8 + 3 * NP + 64;   // cL cR | bv | red | sync | kq klo khi | debug stamps
 static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
 
@@ -107,11 +82,6 @@ static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
 __device__ __forceinline__ int opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
-}
-template <class T>
-__device__ __forceinline__ T* opaque_ptr(T* p) {
-  asm volatile("" : "+s"(p));
-  return p;
 }
 
 // Barrier among n waves of the workgroup that share the LDS counter cnt (the other waves are busy elsewhere and must not
@@ -200,154 +170,6 @@ __device__ __forceinline__ void trail_step(double* Lm, int li, int lk) {
   }
 }
 
-// chol80 by a PAIR of waves: role 0 runs the five 16-pivot chains with the look-ahead update of the next diagonal tile
-// (exactly wave 0 of chol80), role 1 does every other panel and trailing tile, batched four at a time.
-__device__ __forceinline__ void chol80_pair(double* Lm, int role, int lane, int* err, int* cnt, int& target, int& posted,
-                                            long long* dbg = nullptr) {
-  const int li = lane & 15, lk = lane >> 4;
-#define CH_STAMP(i) do { if (dbg && lane == 0) dbg[i] = (long long)wall_clock64(); } while (0)
-  if (role == 0) chol16_inv(Lm, lane, err);
-  CH_STAMP(32 + 16 * role);
-  sub_barrier(cnt, target, 2, lane);
-  CH_STAMP(33 + 16 * role);
-#pragma unroll 1
-  for (int kb = 0; kb < NT; ++kb) {
-    {  // panel: tile(t, kb) <- tile(t, kb) U_kk: role 0 the tile its look-ahead needs next, role 1 the other three
-      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
-      double bq[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
-      if (role == 0) {
-        double* A = Lm + (panel_tile(kb, 0) * 16) * LD + kb * 16;
-        double av[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
-        d4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bq[s], acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
-      } else {
-        double av[3][4];
-        d4 acc[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
-          acc[q] = d4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
-        }
-      }
-    }
-    CH_STAMP(34 + 16 * role + 3 * kb);
-    if (kb == NT - 1) {
-      sub_barrier(cnt, target, 2, lane);
-      break;
-    }
-    // role 0 goes straight on with the look-ahead (it needs only its own panel tile); role 1's trailing products also
-    // read that tile: one-way flag cnt[3] (monotonic: `posted` panel tiles so far)
-    ++posted;
-    if (role == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_fetch_add(cnt + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      while (__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < posted) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    CH_STAMP(35 + 16 * role + 3 * kb);
-    if (role == 0) {                          // next diagonal tile, then its 16-pivot chain
-      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
-      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
-      d4 a;
-      double av[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
-      chol16_inv_acc(Cc, a, lane, err);
-    } else {                                  // the other trailing tiles (U tiles included): 13 | 11 | 8 | 4
-      if (kb == 0) trail_step<0>(Lm, li, lk);
-      else if (kb == 1) trail_step<1>(Lm, li, lk);
-      else if (kb == 2) trail_step<2>(Lm, li, lk);
-      else trail_step<3>(Lm, li, lk);
-    }
-    CH_STAMP(36 + 16 * role + 3 * kb);
-    sub_barrier(cnt, target, 2, lane);
-  }
-#undef CH_STAMP
-}
-
-// W(:, strips) = U^T F(:, strips), in place in Y, for NS 16-column strips of one wave: W(ib, jb) = sum_{kb <= ib}
-// U(kb, ib)^T F(kb, jb).  k loop outermost: the U operand of a k-step is shared by the NS strips, the F operand by the row
-// tiles ib >= kb, and the NS (5 - kb) accumulator chains of a step are independent.
-template <int NS>
-__device__ __forceinline__ void strips_ut_f(const double* U, double* Y, const int (&jbs)[NS], int li, int lk) {
-  d4 acc[NS][NT];
-#pragma unroll
-  for (int j = 0; j < NS; ++j)
-#pragma unroll
-    for (int ib = 0; ib < NT; ++ib) acc[j][ib] = d4{0, 0, 0, 0};
-#pragma unroll
-  for (int kb = 0; kb < NT; ++kb) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = 16 * kb + 4 * s + lk;
-      double b[NS], a[NT];
-#pragma unroll
-      for (int j = 0; j < NS; ++j) b[j] = Y[k * LD + jbs[j] * 16 + li];
-#pragma unroll
-      for (int ib = kb; ib < NT; ++ib) a[ib] = U[k * LD + ib * 16 + li];
-#pragma unroll
-      for (int ib = kb; ib < NT; ++ib)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NS; ++j)
-#pragma unroll
-    for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[j], acc[j][ib], li, lk);
-}
-// T(:, strips) = U W(:, strips): T(ib, jb) = sum_{kb >= ib} U(ib, kb) W(kb, jb); accumulators out (the caller stores them
-// once nobody reads W any more)
-template <int NS>
-__device__ __forceinline__ void strips_u_w_acc(const double* U, const double* Y, const int (&jbs)[NS], d4 (&acc)[NS][NT], int li,
-                                               int lk) {
-#pragma unroll
-  for (int j = 0; j < NS; ++j)
-#pragma unroll
-    for (int ib = 0; ib < NT; ++ib) acc[j][ib] = d4{0, 0, 0, 0};
-#pragma unroll
-  for (int kb = 0; kb < NT; ++kb) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = 16 * kb + 4 * s + lk;
-      double b[NS], a[NT];
-#pragma unroll
-      for (int j = 0; j < NS; ++j) b[j] = Y[k * LD + jbs[j] * 16 + li];
-#pragma unroll
-      for (int ib = 0; ib <= kb; ++ib) a[ib] = U[(ib * 16 + li) * LD + k];
-#pragma unroll
-      for (int ib = 0; ib <= kb; ++ib)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) acc[j][ib] = mfma(a[ib], b[j], acc[j][ib]);
-    }
-  }
-}
-
 // One 16-column strip (tile column jb) of a triangular 80 x 80 product, five accumulator tiles, operands of k-step
 // s + 2 requested before the matrix-core work of k-step s (the compiler does not pipeline the loop by itself: it waits for
 // a step's operands, issues the step's products and only then requests the next operands).
@@ -382,346 +204,8 @@ __device__ __forceinline__ void strip_product(const double* U, const double* Y, 
   }
 }
 
-template <int SET>
-struct SyrkSet {   // the 15 lower tiles over two waves.  SET 0: rows 4 and 3 (9 tiles) | SET 1: rows 2, 1, 0 (6 tiles)
-  static constexpr int nt = SET == 0 ? 9 : 6;
-  static constexpr int nv = SET == 0 ? 5 : 3;
-  static constexpr int ib(int q) { return SET == 0 ? (q < 5 ? 4 : 3) : (q < 3 ? 2 : (q < 5 ? 1 : 0)); }
-  static constexpr int jb(int q) { return SET == 0 ? (q < 5 ? q : q - 5) : (q < 3 ? q : (q < 5 ? q - 3 : 0)); }
-};
-template <int SET>
-__device__ __forceinline__ void syrk_load(d4 (&acc)[9], const double* __restrict__ Ag, bool load, int li, int lk) {
-  using T = SyrkSet<SET>;
-  const double* base = Ag + lk * BS + li;
-#pragma unroll
-  for (int q = 0; q < T::nt; ++q) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) acc[q][rr] = load ? base[(T::ib(q) * 16 + 4 * rr) * BS + T::jb(q) * 16] : 0.0;
-  }
-}
-template <int SET>
-__device__ __forceinline__ void syrk_run(d4 (&acc)[9], const double* W, double* __restrict__ Ag, int li, int lk) {
-  using T = SyrkSet<SET>;
-  const double* p = W + lk * LD + li;
-  double v0[T::nv], v1[T::nv];
-#pragma unroll
-  for (int cidx = 0; cidx < T::nv; ++cidx) v0[cidx] = p[cidx * 16];
-#pragma unroll
-  for (int s = 0; s < BS / 4; s += 2) {      // operands of step s + 1 requested before the matrix-core work of step s
-#pragma unroll
-    for (int cidx = 0; cidx < T::nv; ++cidx) v1[cidx] = p[(4 * (s + 1)) * LD + cidx * 16];
-#pragma unroll
-    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v0[T::ib(q)], v0[T::jb(q)], acc[q]);
-    if (s + 2 < BS / 4) {
-#pragma unroll
-      for (int cidx = 0; cidx < T::nv; ++cidx) v0[cidx] = p[(4 * (s + 2)) * LD + cidx * 16];
-    }
-#pragma unroll
-    for (int q = 0; q < T::nt; ++q) acc[q] = mfma(-v1[T::ib(q)], v1[T::jb(q)], acc[q]);
-  }
-  double* base = Ag + lk * BS + li;
-#pragma unroll
-  for (int q = 0; q < T::nt; ++q) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) base[(T::ib(q) * 16 + 4 * rr) * BS + T::jb(q) * 16] = acc[q][rr];
-  }
-}
-
-// G = U U^T: the 15 lower tiles dealt to the waves at compile time (tile t = WAVE + 4 q), so a wave's products are
-// straight-line code whose operand reads and matrix-core chains interleave.
-template <int WAVE>
-__device__ __forceinline__ void gram_tiles(const double* U, double* G, int li, int lk) {
-  constexpr int8_t TI[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
-  constexpr int8_t TJ[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
-  constexpr int nq = WAVE < 3 ? 4 : 3;
-  d4 g[nq];
-#pragma unroll
-  for (int q = 0; q < nq; ++q) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int ib = TI[WAVE + 4 * q], jb = TJ[WAVE + 4 * q];
-    g[q] = tile_u_ut(U, ib, jb, li, lk);
-  }
-#pragma unroll
-  for (int q = 0; q < nq; ++q) {
-    const int ib = TI[WAVE + 4 * q], jb = TJ[WAVE + 4 * q];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      G[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = g[q][rr];
-      if (ib != jb) G[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = g[q][rr];
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256)
-k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
-               int m, int n_chunks) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (status && *status != 0) return;
-  double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
-  double* Xn = Xc + MAT;                               // G_k -> stencil workspace -> D~_k+1 -> U_k+1
-  double* Y = Xn + MAT;                                // spike: F_k -> W -> T_k -> F_k+1; column 79 = right-hand side
-  double* cL = Y + MAT;                                // coupling tables of the current node
-  double* cR = cL + 9 * NP;
-  double* bv = cR + 9 * NP;                            // [80] right-hand side of the node built last
-  double* red = bv + BS;                               // [8]
-  int* sync = reinterpret_cast<int*>(red + 8);
-  double* kq = red + 16;                               // [25] each: copies of K.q_w, K.lo, K.hi
-  double* klo = kq + NP;
-  double* khi = klo + NP;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const FteConst& K = *cst;
-  const int c = blockIdx.x;
-  const int first = c * m;
-  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
-  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
-  const size_t MB = (size_t)BS * BS;
-  int t01 = 0, t23 = 0, tflag = 0;           // rounds of the three wave-subset barriers (sync[0], [1], [2])
-  // (debug stamps: workgroup dbg[29] writes wall-clock ticks of its phases at node dbg[30]; selectors read ONCE)
-  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[29]) ? ch.dbg : nullptr;
-  const int dbg_k = dbgp ? (int)ch.dbg[30] : -1;
-#define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) dbgp[i] = (long long)wall_clock64(); } while (0)
-  if (tid < 4) sync[tid] = 0;
-  if (tid < NP) {
-    kq[tid] = K.q_w[tid];
-    klo[tid] = K.lo[tid];
-    khi[tid] = K.hi[tid];
-  }
-  __syncthreads();
-
-  {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
-    NodeFetch f;
-    build_fetch(f, ch, K, first, tid);
-    fill_coupling_coef(cL, cR, K, first, tid, kq);
-    for (int e = tid; e < MAT; e += 256) Y[e] = 0.0;
-    const double gmax = build_finish(Xc, bv, f, K, first, tid, kq, klo, khi);
-    publish_gmax(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
-    if (hasL)
-      for (int e = tid; e < 9 * NP; e += 256) {
-        const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
-        if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
-      }
-    if (tid < BS) Y[tid * LD + (BS - 1)] = bv[tid];
-    __syncthreads();
-    if (wave < 2) chol80_pair(Xc, wave, lane, numeric_err, sync, t01, tflag);
-    __syncthreads();
-  }
-
-#pragma unroll 1
-  for (int k = 0; k < n_int; ++k) {
-    const int node = first + k, next = node + 1;
-    const bool last = k + 1 == n_int;
-    const bool has_next = !last || hasR;
-    // ================= serial part: G_k, then the next node =================
-    // (thread index made opaque per iteration: the index arithmetic of the build / stencil phases is recomputed instead of
-    //  being hoisted out of the node loop and spilled - a scratch reload behind the 51 KB store of G waits for that store)
-    const int tid_ = opaque(tid);
-    const int sp_ = tid_ % NP, sc0 = tid_ / NP;
-    const bool s_act = tid_ < 10 * NP;
-    NodeFetch f;
-    if (has_next) build_fetch(f, ch, K, next, tid_);
-    if (wave == 0) SW_STAMP(0);
-    if (k > 0) fill_coupling_coef(cL, cR, K, node, tid_, kq);
-    {
-      const int gi = opaque(li), gk = opaque(lk);
-      if (wave == 0) gram_tiles<0>(Xc, Xn, gi, gk);
-      else if (wave == 1) gram_tiles<1>(Xc, Xn, gi, gk);
-      else if (wave == 2) gram_tiles<2>(Xc, Xn, gi, gk);
-      else gram_tiles<3>(Xc, Xn, gi, gk);
-    }
-    __syncthreads();                                   // G in Xn, tables of this node visible
-    if (wave == 0) SW_STAMP(1);
-    if (has_next) {
-      // the next node's H / g / x were requested at the top of the iteration and have arrived; pin them down HERE: behind
-      // the 51 KB store of G the wait for them would be a wait for the stores as well (one counter for loads and stores)
-      // ("+v": the values leave the asm as NEW definitions, so no later use is tied to the loads' counter any more)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(f.hv[q]));
-      asm volatile("" : "+v"(f.xv), "+v"(f.gv), "+v"(f.lam));
-    }
-    store_mat(ch.D + node * MB, Xn, tid_);
-    if (has_next) {
-      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-      if (s_act) {
-        c00 = cR[(0 * 3 + 0) * NP + sp_];  c01 = cR[(0 * 3 + 1) * NP + sp_];  c02 = cR[(0 * 3 + 2) * NP + sp_];
-        c11 = cR[(1 * 3 + 1) * NP + sp_];  c12 = cR[(1 * 3 + 2) * NP + sp_];  c22 = cR[(2 * 3 + 2) * NP + sp_];
-      }
-      __syncthreads();                                 // the store above has read Xn
-      if (s_act) {                                     // pass 1: Xn <- G E, in place (rows sc0 + 10 j, state sp_)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          double* rowp = Xn + (sc0 + 10 * j) * LD + sp_;
-          const double g0 = rowp[0], g1 = rowp[NP], g2 = rowp[2 * NP];
-          rowp[0] = g0 * c00 + g1 * c01 + g2 * c02;
-          rowp[NP] = g1 * c11 + g2 * c12;
-          rowp[2 * NP] = g2 * c22;
-        }
-      }
-      __syncthreads();
-      double dv[8][3];
-      if (wave == 0) SW_STAMP(2);
-      if (s_act) {                                     // pass 2: dv = -E^T (G E) (columns sc0 + 10 j, state sp_)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const double* colp = Xn + sp_ * LD + sc0 + 10 * j;
-          const double t0 = colp[0], t1 = colp[NP * LD], t2 = colp[2 * NP * LD];
-          dv[j][0] = -(c00 * t0 + c01 * t1 + c02 * t2);
-          dv[j][1] = -(c11 * t1 + c12 * t2);
-          dv[j][2] = -(c22 * t2);
-        }
-      }
-      __syncthreads();                                 // pass-2 reads done: Xn may be rebuilt
-      if (wave == 0) SW_STAMP(3);
-      const double gmax = build_finish(Xn, bv, f, K, next, tid_, kq, klo, khi,
-                                       (dbgp && k == dbg_k) ? dbgp : nullptr);
-      if (wave == 0) SW_STAMP(13);
-      publish_gmax(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
-      if (wave == 0) SW_STAMP(14);
-      if (s_act) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          double* colp = Xn + sp_ * LD + sc0 + 10 * j;
-          colp[0] += dv[j][0];
-          colp[NP * LD] += dv[j][1];
-          colp[2 * NP * LD] += dv[j][2];
-        }
-      }
-    }
-    if (wave == 0) SW_STAMP(15);
-    __syncthreads();
-    if (wave == 0) SW_STAMP(4);
-    // ================= parallel part =================
-    // waves 0, 1: blocked Cholesky of the next node (pivot chains | panel and trailing tiles)
-    // waves 2, 3: W = U_k^T F_k on their 16-column strips, then D_L -= W^T W
-    if (wave < 2) {
-      if (!last)
-        chol80_pair(Xn, wave, opaque(lane), numeric_err, sync, t01, tflag,
-                    (dbgp && k == dbg_k) ? dbgp : nullptr);
-      if (wave == 0) SW_STAMP(5);
-    } else {
-      const int li = opaque(lane & 15), lk = opaque(lane >> 4);
-      if (hasL) {
-        // the left separator's update so far (HBM / L2, owned by this workgroup): requested now, needed after W
-        d4 accL[9];
-        double* Ag = opaque_ptr(sp.AL + (size_t)(c - 1) * MB);
-        if (wave == 2) {
-          syrk_load<1>(accL, Ag, k > 0, li, lk);
-          const int jbs[3] = {0, 1, 4};
-          strips_ut_f<3>(Xc, Y, jbs, li, lk);
-        } else {
-          syrk_load<0>(accL, Ag, k > 0, li, lk);
-          const int jbs[2] = {2, 3};
-          strips_ut_f<2>(Xc, Y, jbs, li, lk);
-        }
-        SW_STAMP(8 + 8 * (wave - 2));
-        sub_barrier(sync + 1, t23, 2, lane);           // every strip of W is in Y
-        SW_STAMP(9 + 8 * (wave - 2));
-        if (wave == 2) syrk_run<1>(accL, Y, Ag, li, lk);
-        else syrk_run<0>(accL, Y, Ag, li, lk);
-        SW_STAMP(10 + 8 * (wave - 2));
-      } else if (wave == 2) {                          // first run: only the right-hand side column is alive
-        const int jbs[1] = {4};
-        strips_ut_f<1>(Xc, Y, jbs, li, lk);
-      }
-    }
-    __syncthreads();                                   // next node factored; W complete and no longer needed by W^T W
-    if (wave == 0) SW_STAMP(6);
-    {
-      // ---- T = U_k W, all four waves: wave w takes strip w, strip 4 (11 columns + the right-hand side) is dealt by row
-      //      tile: (0,4) | (1,4) | (2,4), (4,4) | (3,4).  Results wait in registers until every read of W is done.
-      const int li = opaque(lane & 15), lk = opaque(lane >> 4);
-      d4 town[1][NT], tx0 = {0, 0, 0, 0}, tx1 = {0, 0, 0, 0};
-      const int jbs[1] = {hasL ? wave : 4};
-      const bool own = hasL || wave == 2;
-      if (own) strips_u_w_acc<1>(Xc, Y, jbs, town, li, lk);
-      if (hasL) {
-        if (wave == 0) tx0 = tile_u_w(Xc, Y, 0, 4, li, lk);
-        else if (wave == 1) tx0 = tile_u_w(Xc, Y, 1, 4, li, lk);
-        else if (wave == 2) {
-          tx0 = tile_u_w(Xc, Y, 2, 4, li, lk);
-          tx1 = tile_u_w(Xc, Y, 4, 4, li, lk);
-        } else tx0 = tile_u_w(Xc, Y, 3, 4, li, lk);
-      }
-      __syncthreads();
-      if (own) {
-#pragma unroll
-        for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, jbs[0], town[0][ib], li, lk);
-      }
-      if (hasL) {
-        tile_store(Y, wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? 2 : 3)), 4, tx0, li, lk);
-        if (wave == 2) tile_store(Y, 4, 4, tx1, li, lk);
-      }
-    }
-    __syncthreads();                                   // T_k complete in Y
-    if (wave == 0) SW_STAMP(7);
-    {
-      // ---- T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then F_k+1 = -E^T T_k in place,
-      //      column 79 += the next node's right-hand side.  20 columns per wave (first run: column 79 only).
-      const int c_lo = hasL ? 20 * wave : BS - 1, c_hi = hasL ? c_lo + 20 : (wave == 3 ? BS : BS - 1);
-      if (hasL) {
-        double* Tg = ch.Wl + node * MB;
-        // (all 25 LDS reads of the wave first, then the stores)
-        double v0[20], v1[5];
-#pragma unroll
-        for (int j = 0; j < 20; ++j) v0[j] = Y[lane * LD + c_lo + j];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) v1[j] = Y[(64 + (lane & 15)) * LD + c_lo + 5 * (lane >> 4) + j];   // rows 64..79: 4 x 5 columns
-#pragma unroll
-        for (int j = 0; j < 20; ++j) Tg[(size_t)(c_lo + j) * BS + lane] = v0[j];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) Tg[(size_t)(c_lo + 5 * (lane >> 4) + j) * BS + 64 + (lane & 15)] = v1[j];
-      }
-      if (wave == 3) {
-        ch.b[(size_t)node * BS + lane] = Y[lane * LD + (BS - 1)];
-        if (lane < 16) ch.b[(size_t)node * BS + 64 + lane] = Y[(64 + lane) * LD + (BS - 1)];
-      }
-      if (has_next) {
-        // lane = (state p, column group): the six stencil coefficients of p are read once, rows p, 25 + p, 50 + p of the
-        // lane's columns are rewritten in place
-        const int ncol = c_hi - c_lo, p = lane % NP, cg = lane / NP;        // cg 0, 1 (lanes 50..63 idle)
-        if (cg < 2 && ncol > 0) {
-          const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
-          const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
-          const double b0 = bv[p], b1 = bv[NP + p], b2 = bv[2 * NP + p];
-          for (int cc = c_lo + cg; cc < c_hi; cc += 2) {
-            const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
-            double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
-            if (cc == BS - 1) {
-              o0 += b0;
-              o1 += b1;
-              o2 += b2;
-            }
-            Y[p * LD + cc] = o0;
-            Y[(NP + p) * LD + cc] = o1;
-            Y[(2 * NP + p) * LD + cc] = o2;
-          }
-        }
-        if (lane < ncol)
-          for (int r = 3 * NP; r < BS; ++r) Y[r * LD + c_lo + lane] = 0.0;     // padding rows couple to nothing
-      }
-    }
-    __syncthreads();
-    if (wave == 0) SW_STAMP(27);
-    if (last && hasR) {                                // the node built last is the right separator
-      store_mat(sp.D + (size_t)c * MB, Xn, tid);
-      if (tid < BS) sp.b[(size_t)c * BS + tid] = Y[tid * LD + (BS - 1)];
-      if (hasL) {
-        double* Cg = sp.Cpl + (size_t)(c - 1) * MB;    // block(R, L): rows R, columns L
-        for (int e = tid; e < BS * BS; e += 256) {
-          const int r = e / BS, cc = e % BS;
-          Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
-        }
-      }
-    }
-    double* tmp = Xc;
-    Xc = Xn;
-    Xn = tmp;
-  }
-#undef SW_STAMP
-}
-
 // ================================================================================================================
-// The sweep kernel, eight waves.  The node loop has two dependency chains that only meet once per node:
+// The sweep kernel (eight waves).  Per node k of a run (D~_k, F_k, b~_k in LDS; see the head of the file) the loop has two dependency chains that only meet once per node:
 //   D chain     : U_k -> G_k = U_k U_k^T -> D~_k+1 = D_k+1 - E^T G_k E -> Cholesky -> U_k+1            (Xc -> Xn)
 //   spike chain : F_k -> W = U_k^T F_k -> D_L -= W^T W,  T_k = U_k W -> HBM,  F_k+1 = -E^T T_k          (Xc, Y)
 // Per node: a SERIAL part on all eight waves (G_k, its store, the two stencil passes, the next node built), then a
@@ -729,8 +213,10 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
 // waves 1, 2: panel and trailing tiles, alternate products) while waves 3..7 run the WHOLE spike chain of node k, each
 // on its own 16-column strip of the spike (strip = wave - 3; only W^T W reads across strips: two 5-wave LDS-counter
 // barriers per node).  Two waves share every SIMD, so the matrix-core work of the spike fills the issue slots the
-// pivot chains leave empty.  Same arithmetic, tile by tile, as the four-wave form it replaces.
-constexpr int SW8_T = 512;
+// pivot chains leave empty.  The right-hand side rides along as COLUMN 79 of the spike (the left separator has 75 unknowns,
+// columns 75..79 are free): column 79 of W is y = U^T b~, of T it is z = D~^-1 b~, of F_k+1 it is -E^T z (+ b_k+1), and row 79
+// of W^T W is y^T W = the left separator's right-hand-side update - no mat-vec phases.
+constexpr int SW_T = 512;
 // role of wave w in the parallel part: 0 = pivot chains, 1 / 2 = factor helpers, 3 + sw = spike strip sw.  Waves w and w + 4
 // share a SIMD and its matrix pipe; the matrix-core work is dealt so that the four pipes carry about the same load:
 //   SIMD 0: pivot chains (~70 matrix instructions, at raised priority) + strip 0 (180)
@@ -897,8 +383,8 @@ __device__ __forceinline__ void syrk_run_n(d4 (&acc)[NQ], const double* W, doubl
     for (int rr = 0; rr < 4; ++rr) base[(ib[q] * 16 + 4 * rr) * BS + jb[q] * 16] = acc[q][rr];
 }
 
-__global__ void __launch_bounds__(SW8_T)
-k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+__global__ void __launch_bounds__(SW_T)
+k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
                int m, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
@@ -940,13 +426,13 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
 
   {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
     NodeFetch f;
-    build_fetch<SW8_T>(f, ch, K, first, tid);
-    fill_coupling_coef<SW8_T>(cL, cR, K, first, tid, kq);
-    for (int e = tid; e < MAT; e += SW8_T) Y[e] = 0.0;
-    const double gmax = build_finish<SW8_T>(Xc, bv, f, K, first, tid, kq, klo, khi);
-    publish_gmax<SW8_T>(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
+    build_fetch<SW_T>(f, ch, K, first, tid);
+    fill_coupling_coef<SW_T>(cL, cR, K, first, tid, kq);
+    for (int e = tid; e < MAT; e += SW_T) Y[e] = 0.0;
+    const double gmax = build_finish<SW_T>(Xc, bv, f, K, first, tid, kq, klo, khi);
+    publish_gmax<SW_T>(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
     if (hasL)
-      for (int e = tid; e < 9 * NP; e += SW8_T) {
+      for (int e = tid; e < 9 * NP; e += SW_T) {
         const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
         if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
       }
@@ -973,7 +459,7 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     const int fb_next = 3 * next;                      // (chunked contexts have no pinned separator: node t holds frames 3t ..)
     double hq[2][3] = {{0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, cvq[3] = {0, 0, 0}, lamq = 0.0;
     bool liveq[3] = {false, false, false}, ownq[3] = {false, false, false};
-    const int e1 = tid_ + SW8_T;
+    const int e1 = tid_ + SW_T;
     const bool own1 = e1 < NP * NP;
     const int pd0 = tid_ / NP, pc0 = tid_ % NP, pd1 = own1 ? e1 / NP : 0, pc1 = own1 ? e1 % NP : 0;
     const bool diag0 = pd0 == pc0, diag1 = own1 && pd1 == pc1;
@@ -1021,7 +507,7 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         const int t = gram8_tile(wave, q);
         if (t >= 0) g[q] = tile_u_ut(Xc, tri_i(t), tri_j(t), gi, gk);
       }
-      if (k > 0) fill_coupling_coef<SW8_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
+      if (k > 0) fill_coupling_coef<SW_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int t = gram8_tile(wave, q);
@@ -1044,13 +530,15 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(hq[0][j]), "+v"(hq[1][j]), "+v"(xq[j]), "+v"(gq[j]));
     asm volatile("" : "+v"(lamq));
     {
-      double2* d2 = reinterpret_cast<double2*>(ch.D + node * MB);
+      // G_k -> HBM, lower tiles only (G is symmetric: the back-substitution mirrors them)
+      double* Gg = ch.D + node * MB;
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        const int idx = tid_ + SW8_T * q;
-        if (idx < BS * BS / 2) {
-          const int e = 2 * idx, r = e / BS, cc = e % BS;
-          d2[idx] = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
+      for (int q = 0; q < (LOWER_ITEMS + SW_T - 1) / SW_T; ++q) {
+        const int idx = tid_ + SW_T * q;
+        if (idx < LOWER_ITEMS) {
+          int r, cc;
+          lower_item(idx, r, cc);
+          *reinterpret_cast<double2*>(Gg + r * BS + cc) = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
         }
       }
     }
@@ -1125,13 +613,13 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
         }
       }
       // padding rows / columns 75 .. 79: identity
-      for (int e = tid_; e < BS * BS - 9 * NP * NP; e += SW8_T) {
+      for (int e = tid_; e < BS * BS - 9 * NP * NP; e += SW_T) {
         const int r = e < 5 * BS ? 3 * NP + e / BS : (e - 5 * BS) / 5, cc = e < 5 * BS ? e % BS : 3 * NP + (e - 5 * BS) % 5;
         Xn[r * LD + cc] = r == cc ? 1.0 : 0.0;
       }
       if (tid_ < BS - 3 * NP) bv[3 * NP + tid_] = 0.0;
       if (wave == 0) SW_STAMP(3);
-      publish_gmax<SW8_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
+      publish_gmax<SW_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
     }
     __syncthreads();
     if (wave == 0) SW_STAMP(4);
@@ -1175,21 +663,10 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
 #pragma unroll
       for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, sw, town[ib], li, lk);
       SW_STAMP(19 + 4 * sw);
-      // ---- T^T -> HBM (the back-substitution reads along its columns; column 79 is z_k), then F_k+1 = -E^T T_k in place,
-      //      column 79 += the next node's right-hand side.  Own strip only: no barrier (LDS operations of a wave are ordered)
+      // ---- z_k (column 79 of T) -> HBM, then F_k+1 = -E^T T_k in place, column 79 += the next node's right-hand side.
+      //      Own strip only: no barrier (LDS operations of a wave are ordered).  T_k itself is not stored: the
+      //      back-substitution regenerates T_k x_L from G_k.
       const int c_lo = 16 * sw;
-      if (hasL) {
-        double* Tg = ch.Wl + node * MB;
-        double v0[16], v1[4];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v0[j] = Y[ln * LD + c_lo + j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v1[j] = Y[(64 + li) * LD + c_lo + 4 * lk + j];   // rows 64..79: 4 x 4 columns
-#pragma unroll
-        for (int j = 0; j < 16; ++j) Tg[(size_t)(c_lo + j) * BS + ln] = v0[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Tg[(size_t)(c_lo + 4 * lk + j) * BS + 64 + li] = v1[j];
-      }
       if (sw == 4) {
         ch.b[(size_t)node * BS + ln] = Y[ln * LD + (BS - 1)];
         if (ln < 16) ch.b[(size_t)node * BS + 64 + ln] = Y[(64 + ln) * LD + (BS - 1)];
@@ -1231,7 +708,7 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
     if (last && hasR) {                                // the node built last is the right separator
       {
         double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)c * MB);
-        for (int idx = tid; idx < BS * BS / 2; idx += SW8_T) {
+        for (int idx = tid; idx < BS * BS / 2; idx += SW_T) {
           const int e = 2 * idx, r = e / BS, cc = e % BS;
           d2[idx] = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
         }
@@ -1239,7 +716,7 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
       if (tid < BS) sp.b[(size_t)c * BS + tid] = Y[tid * LD + (BS - 1)];
       if (hasL) {
         double* Cg = sp.Cpl + (size_t)(c - 1) * MB;    // block(R, L): rows R, columns L
-        for (int e = tid; e < BS * BS; e += SW8_T) {
+        for (int e = tid; e < BS * BS; e += SW_T) {
           const int r = e / BS, cc = e % BS;
           Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
         }
@@ -1254,7 +731,8 @@ k_chunk_sweep8(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
 
 // Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as
 // column 79 of the spike, so row 79 of AL holds -(sum W^T y) = the update of b, and rows / columns >= 75 of AL are not
-// part of the Schur update.
+// part of the Schur update.  (A launch of its own: folding it into the sweep - the later of a separator's two runs adds AL -
+// needs a device-scope release per workgroup, i.e. an L2 write-back on a multi-XCD part: measured +140 us on the sweep.)
 __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __restrict__ status) {
   if (status && *status != 0) return;
   const int q = blockIdx.x, tid = threadIdx.x;
@@ -1268,85 +746,145 @@ __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __re
   if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] += A[(size_t)(BS - 1) * BS + tid];
 }
 
-// One workgroup per run, right to left: x_k = z_k - G_k (E_r(k) x_k+1) - T_k x_L.  G_k is symmetric and T_k is stored
-// transposed, so thread (column r, third of the rows) reads consecutive addresses along a wave - no LDS staging; the next
-// node's operands are requested before the current node's sums are reduced.
-__global__ void __launch_bounds__(256)
+// Back-substitution, one workgroup per run.  x_k = z_k - G_k (E x_k+1) - T_k x_L with T_k = D~_k^-1 F_k; T_k is not
+// stored.  Its action on the left separator's solution obeys the recurrence of the spike itself,
+//     f_0 = F_0 x_L = E_l x_L,    t_k = T_k x_L = G_k f_k,    f_k+1 = F_k+1 x_L = -E^T t_k,
+// so the run is walked twice over the same 31 KB per node (the lower tiles of G_k, mirrored into a symmetric LDS copy):
+//   forward  k = 0 .. n-2 :  t_k = G_k f_k, f_k+1 = -E^T t_k            (f_k kept: 80 doubles per node, ch.Wl)
+//   backward k = n-1 .. 0 :  x_k = z_k - G_k (E x_k+1 + f_k)
+// i.e. <= 61 KB of HBM reads per node instead of the 102 KB of G_k and T_k^T - and no T_k^T store in the sweep (51 KB per node).
+// The next node's tiles are requested (registers) before the current node's products and staged into LDS afterwards.
+constexpr int BK_T = 256;
+constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 8 items per thread (the last round is half empty)
+__global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
                 int n_chunks) {
   if (status && *status != 0) return;
-  __shared__ double xn[BS], xl[BS], vv[BS], ysc[3 * BS], cL[9 * NP], cR[9 * NP];
+  __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[3 * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
   const int c = blockIdx.x, first = c * m;
   const bool hasL = c > 0, hasR = c + 1 < n_chunks;
   const int n_int = hasR ? m - 1 : ch.n_nodes - first;
   const size_t MB = (size_t)BS * BS;
-  const int col = tid % BS, part = tid / BS, c0 = 27 * part, nc = part < 2 ? 27 : 26;
+  const int row = tid % BS, part = tid / BS, c0 = 27 * part, nc = part < 2 ? 27 : 26;
+  double2 gq[BK_Q];
+  auto fetch = [&](int node) {                          // lower tiles of G_node -> registers
+    const double* G = ch.D + node * MB;
+#pragma unroll
+    for (int q = 0; q < BK_Q; ++q) {
+      const int idx = tid + BK_T * q;
+      if (idx < LOWER_ITEMS) {
+        int r, cc;
+        lower_item(idx, r, cc);
+        gq[q] = *reinterpret_cast<const double2*>(G + r * BS + cc);
+      }
+    }
+  };
+  auto stage = [&]() {                                  // registers -> symmetric matrix in LDS (strictly-lower tiles mirrored)
+#pragma unroll
+    for (int q = 0; q < BK_Q; ++q) {
+      const int idx = tid + BK_T * q;
+      if (idx < LOWER_ITEMS) {
+        int r, cc;
+        lower_item(idx, r, cc);
+        Gs[r * LD + cc] = gq[q].x;
+        Gs[r * LD + cc + 1] = gq[q].y;
+        if ((cc >> 4) < (r >> 4)) {
+          Gs[cc * LD + r] = gq[q].x;
+          Gs[(cc + 1) * LD + r] = gq[q].y;
+        }
+      }
+    }
+  };
+  auto product = [&]() {                                // ysc <- partial sums of Gs u (three per row)
+    if (tid < 3 * BS) {
+      double s0 = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 27; ++kk)
+        if (kk < nc) s0 += Gs[(c0 + kk) * LD + row] * u[c0 + kk];
+      ysc[tid] = s0;
+    }
+  };
   if (tid < BS) {
     xl[tid] = hasL ? sp.b[(size_t)(c - 1) * BS + tid] : 0.0;
     const double xr = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
     xn[tid] = xr;
     if (hasR) ch.b[(size_t)(first + n_int) * BS + tid] = xr;      // the separator's solution joins the chain's vector
   }
-  double g[27], t[27];
-  auto fetch = [&](int node) {
-    if (tid < 3 * BS) {
-      const double* G = ch.D + node * MB;
-      const double* Tt = ch.Wl + node * MB;
-#pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        g[k] = k < nc ? G[(size_t)(c0 + k) * BS + col] : 0.0;
-        t[k] = (hasL && k < nc) ? Tt[(size_t)(c0 + k) * BS + col] : 0.0;
-      }
-    }
-  };
-  fetch(first + n_int - 1);
-  for (int k = n_int - 1; k >= 0; --k) {
-    const int node = first + k;
-    fill_coupling_coef(cL, cR, *cst, node, tid);
-    const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
-    __syncthreads();                                   // tables, xn of the previous round
+  double* fst = ch.Wl + (size_t)first * BS;             // f_k of this run's nodes
+  if (hasL) {
+    // ---------------- forward: t_k = G_k f_k, f_k+1 = -E^T t_k ----------------
+    fetch(first);
+    fill_coupling_coef(cL, cR, *cst, first, tid);
+    __syncthreads();                                   // xl, tables
     if (tid < BS) {
       double v = 0.0;
       if (tid < 3 * NP) {
         const int a = tid / NP, p = tid % NP;
+        for (int jj = a; jj < 3; ++jj) v += cL[(a * 3 + jj) * NP + p] * xl[jj * NP + p];    // (E_l x_L)[(a, p)]
+      }
+      u[tid] = v;
+      fst[tid] = v;
+    }
+    stage();
+    for (int k = 0; k + 1 < n_int; ++k) {              // (f_n is not needed: the last node takes no forward product)
+      const int node = first + k;
+      __syncthreads();                                 // Gs, u
+      fetch(node + 1);
+      if (k > 0) fill_coupling_coef(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
+      product();
+      __syncthreads();                                 // ysc, cR; every read of Gs and u done
+      if (tid < BS) xn[tid] = (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];   // t_k (xn is free until the backward pass)
+      stage();
+      __syncthreads();
+      if (tid < BS) {
+        double v = 0.0;
+        if (tid < 3 * NP) {
+          const int a = tid / NP, p = tid % NP;
+          for (int bb = a; bb < 3; ++bb) v -= cR[(a * 3 + bb) * NP + p] * xn[bb * NP + p];   // -(E^T t_k)[(a, p)]
+        }
+        u[tid] = v;
+        fst[(size_t)(k + 1) * BS + tid] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < BS) xn[tid] = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
+  }
+  // ---------------- backward: x_k = z_k - G_k (E x_k+1 + f_k) ----------------
+  // (the last node's tiles are still in LDS after the forward pass; the first run has no forward pass)
+  if (!hasL) {
+    fetch(first + n_int - 1);
+    stage();
+  }
+  for (int k = n_int - 1; k >= 0; --k) {
+    const int node = first + k;
+    fill_coupling_coef(cL, cR, *cst, node, tid);
+    const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
+    const double fi = (hasL && tid < BS) ? fst[(size_t)k * BS + tid] : 0.0;
+    if (k > 0) fetch(node - 1);
+    __syncthreads();                                   // tables, xn of the previous round, Gs
+    if (tid < BS) {
+      double v = fi;
+      if (tid < 3 * NP) {
+        const int a = tid / NP, p = tid % NP;
         for (int ii = 0; ii <= a; ++ii) v += cR[(ii * 3 + a) * NP + p] * xn[ii * NP + p];   // (E_r x_k+1)[(a, p)]
       }
-      vv[tid] = v;
+      u[tid] = v;
     }
     __syncthreads();
-    if (tid < 3 * BS) {
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < 27; ++kk) {
-        const int cc = c0 + (kk < nc ? kk : 0);
-        s0 += g[kk] * vv[cc];
-        s1 += t[kk] * xl[cc];
-      }
-      ysc[tid] = s0 + s1;
-    }
-    if (k > 0) fetch(node - 1);
-    __syncthreads();
+    product();
+    __syncthreads();                                   // ysc; every read of Gs done
     if (tid < BS) {
       const double x = zi - ((ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid]);
       xn[tid] = x;
       ch.b[(size_t)node * BS + tid] = x;
     }
+    if (k > 0) stage();
   }
-}
-
-static bool sweep_eight_waves() {
-  static const bool v = [] {
-    const char* e = std::getenv("ACINO_SWEEP_WAVES");
-    return !(e && std::atoi(e) == 4);
-  }();
-  return v;
 }
 
 int chunk_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
-  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep8),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
   return ACINO_OK;
 }
@@ -1356,12 +894,8 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
                  Profiler* prof) {
   {
     ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
-    if (sweep_eight_waves())
-      hipLaunchKernelGGL(k_chunk_sweep8, dim3(pl.n_chunks), dim3(SW8_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status,
-                         pl.m, pl.n_chunks);
-    else
-      hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(256), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
-                         pl.n_chunks);
+    hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(SW_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                       pl.n_chunks);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;
@@ -1382,7 +916,7 @@ int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, co
   }
   {
     ProfSpan span(prof, PC_CHUNK_BACKSUB, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(256), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks);
+    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;

@@ -25,7 +25,6 @@ struct Buffers {
   int* numeric_err;
   int* sched;         // elim (3/entry), remain (4/entry), tail (4/entry), dropped-coupling pairs (2/entry), tail counter
   double* trunc_eps2; // [n_pairs + 1]
-  double* sep_bl;     // [n_sep][80] (chunked solver)
   double* refine_buf; // [3][n_isolated][80] (incomplete reduction with refinement sweeps)
 };
 
@@ -111,10 +110,10 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
   BcrChain chn;
   chn.n_nodes = (int)T;
-  chn.D = c.take<double>(T * BS * BS);                       // chunked: G_k of the interior nodes
+  chn.D = c.take<double>(T * BS * BS);                       // chunked: G_k of the interior nodes (lower tiles)
   chn.U = chunked ? nullptr : c.take<double>(T * BS * BS);
   chn.Cpl = chunked ? nullptr : c.take<double>(T * BS * BS);
-  chn.Wl = c.take<double>(T * BS * BS);                      // chunked: T_k^T of the interior nodes
+  chn.Wl = c.take<double>(chunked ? T * BS : T * BS * BS);   // chunked: f_k = F_k x_L of the interior nodes, [80] each
   chn.Wr = chunked ? nullptr : c.take<double>(T * BS * BS);
   chn.b = c.take<double>(T * BS);
   chn.d_elim = nullptr;
@@ -132,7 +131,6 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   chn.H0 = b.H[0]; chn.H1 = b.H[1];
   chn.gn_part = b.gn_part;
   BcrChain sc = chn;
-  b.sep_bl = nullptr;
   if (chunked) {
     const size_t S = lay.plan.n_sep > 0 ? lay.plan.n_sep : 1;
     sc.n_nodes = lay.plan.n_sep;
@@ -142,7 +140,6 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
     sc.Wl = c.take<double>(S * BS * BS);
     sc.Wr = c.take<double>(S * BS * BS);
     sc.b = c.take<double>(S * BS);
-    b.sep_bl = c.take<double>(S * BS);
     sc.implicit_couplings = 0;      // dense couplings, plain (non-fused) kernels
     sc.st = nullptr;
     sc.x0 = sc.x1 = sc.g0 = sc.g1 = sc.H0 = sc.H1 = nullptr;
@@ -1284,7 +1281,7 @@ int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
 }
 
 // Debug / test aid: copies an internal buffer to d_out (at most n doubles).  what: 0 chain.b (step per node), 1 sep.D,
-// 2 sep.b, 3 sep.Cpl, 4 sep.AL, 5 sep.bl, 6 chain.D (G of the interior nodes), 7 chain.Wl (T^T of the interior nodes).
+// 2 sep.b, 3 sep.Cpl, 4 sep.AL, 6 chain.D (G of the interior nodes, lower tiles), 7 chain.Wl (chunked: f_k, [80] per node).
 int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream) {
   ACINO_REQUIRE(ctx && d_out && n >= 0, "args");
   const size_t MB = (size_t)BS * BS;
@@ -1297,9 +1294,8 @@ int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n,
     case 2: src = ctx->sepchain.b; cnt = S * BS; break;
     case 3: src = ctx->sepchain.Cpl; cnt = S * MB; break;
     case 4: src = ctx->sepchain.Wr; cnt = S * MB; break;
-    case 5: src = ctx->b.sep_bl; cnt = S * BS; break;
     case 6: src = ctx->chain.D; cnt = T * MB; break;
-    case 7: src = ctx->chain.Wl; cnt = T * MB; break;
+    case 7: src = ctx->chain.Wl; cnt = ctx->plan.active() ? T * BS : T * MB; break;
     default: ACINO_REQUIRE(false, "what");
   }
   if ((size_t)n < cnt) cnt = (size_t)n;
