@@ -44,7 +44,9 @@ def test_argument_validation_happens_before_any_device_call(lib):
     assert lib.acino_selftest_mfma(null, null, 6, null, null) == -1
     p = fte.make_params(100, 6, 1 / 120)
     nbytes = lib.acino_fte_workspace_bytes(C.byref(p))
-    assert nbytes > 34 * 3 * 80 * 80 * 8                       # three 80x80 matrices per super-block
+    assert nbytes > 34 * 80 * 80 * 8                           # chunked solver: ONE 80x80 matrix per super-block (G_k) ...
+    p_bcr = fte.make_params(100, 6, 1 / 120, chunk_nodes=-1)
+    assert lib.acino_fte_workspace_bytes(C.byref(p_bcr)) > 34 * 3 * 80 * 80 * 8 > nbytes      # ... whole-chain reduction: five
     p_bad = fte.make_params(100, 6, 1 / 120, pin_left=True, n_global=200, n_offset=50)   # offset not a multiple of 3
     h = C.c_void_p()
     assert lib.acino_fte_create(C.byref(h), C.byref(p_bad), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), nbytes, null) == -1
