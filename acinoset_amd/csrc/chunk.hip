@@ -739,11 +739,33 @@ __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __re
   const size_t MB = (size_t)BS * BS;
   double* D = sp.D + q * MB;
   const double* A = sp.AL + q * MB;
-  for (int e = tid; e < BS * BS; e += 256) {
-    const int r = e / BS, cc = e % BS;
-    if ((cc >> 4) <= (r >> 4) && r < 3 * NP && cc < 3 * NP) D[e] += A[e];
+  // every operand of the thread in flight before the first add (the launch is two HBM round trips, not one per element)
+  constexpr int NQ = (LOWER_ITEMS + 255) / 256;
+  double2 dv[NQ], av[NQ];
+  const double bq = tid < 3 * NP ? sp.b[(size_t)q * BS + tid] : 0.0, aq = tid < 3 * NP ? A[(size_t)(BS - 1) * BS + tid] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < LOWER_ITEMS) {
+      int r, cc;
+      lower_item(idx, r, cc);
+      dv[k] = *reinterpret_cast<const double2*>(D + r * BS + cc);
+      av[k] = *reinterpret_cast<const double2*>(A + r * BS + cc);
+    }
   }
-  if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] += A[(size_t)(BS - 1) * BS + tid];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < LOWER_ITEMS) {
+      int r, cc;
+      lower_item(idx, r, cc);
+      if (r < 3 * NP) {                                // rows / columns 75 .. 79 of AL are not part of the Schur update
+        const double ax = cc < 3 * NP ? av[k].x : 0.0, ay = cc + 1 < 3 * NP ? av[k].y : 0.0;
+        *reinterpret_cast<double2*>(D + r * BS + cc) = make_double2(dv[k].x + ax, dv[k].y + ay);
+      }
+    }
+  }
+  if (tid < 3 * NP) sp.b[(size_t)q * BS + tid] = bq + aq;
 }
 
 // Back-substitution, one workgroup per run.  x_k = z_k - G_k (E x_k+1) - T_k x_L with T_k = D~_k^-1 F_k; T_k is not
