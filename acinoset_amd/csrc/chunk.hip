@@ -241,6 +241,8 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
   if (role == 0) {
     __builtin_amdgcn_s_setprio(3);                     // the chain's VALU wins the issue arbitration against its SIMD mate
     chol16_inv(Lm, lane, err);
+  } else {
+    __builtin_amdgcn_s_setprio(2);                     // a helper's short bursts go ahead of its SIMD mate's strip products
   }
   sub_barrier(sync, t3, 3, lane);
 #pragma unroll 1
@@ -284,7 +286,7 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
       }
     }
     if (kb == NT - 1) {
-      if (role == 0) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
       sub_barrier(sync, t3, 3, lane);
       break;
     }
