@@ -479,7 +479,35 @@ def main():
                     what=("overlapping windows (halo %d frames): 2 all-gathers / step, step exact to the decay over the halo" % args.halo)
                     if kind == "windows" else "separator system: 1 all-reduce on the separator rows + 2 all-gathers / step, exact step")
 
+    def time_replicas():
+        """Weak scaling over sequences (config 5's placement): every rank runs the SINGLE-GPU solver on its own copy of the
+        whole sequence, no collective in the data path; same barrier / synchronise bracket, max over ranks."""
+        cx = fte.FTEContext(torch.as_tensor(det), *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
+        sd = torch.cuda.Stream()
+        sd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sd):
+            if not args.no_graph:
+                cx.enable_graph(True)
+            cx.set_x(x0_full[:, fte.ACTIVE])
+            for _ in range(args.warmup):
+                cx.step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                cx.step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0_
+        tm = torch.tensor([dt_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt_ = float(tm.item())
+        cx.close()
+        return dict(ms_per_step=1e3 * dt_ / args.steps, value=world * args.frames * args.steps / dt_, unit="frames/s", scaling="weak",
+                    what=f"{world} independent {args.frames}-frame sequences, one per GPU, single-GPU solver, no data-path collective")
+
     other = time_other_driver("windows") if (world > 1 and args.shard == "both") else None
+    replicas = time_replicas() if (world > 1 and args.shard == "both") else None
     common = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,                           # never stops: every step is full work
                   shared_gpu="ACINO_FORCE_DEVICE" in os.environ)                             # (ranks sharing one GPU: functional runs only)
     solver_kw = {}
@@ -637,7 +665,8 @@ def main():
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},
         }
         if world > 1:
-            out["drivers"] = {"headline": "windows" if windows else "separators", "windows": other if not windows else None}
+            out["drivers"] = {"headline": "windows" if windows else "separators", "windows": other if not windows else None,
+                              "replicas": replicas}
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
                                   "payload_bytes": ({"all_gather_edge_slabs": world * 2 * (args.halo + 3) * 25 * 8, "all_gather_scalars": world * 8 * 8}
