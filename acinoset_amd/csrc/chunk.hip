@@ -778,19 +778,20 @@ __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __re
 //   backward k = n-1 .. 0 :  x_k = z_k - G_k (E x_k+1 + f_k)
 // i.e. <= 61 KB of HBM reads per node instead of the 102 KB of G_k and T_k^T - and no T_k^T store in the sweep (51 KB per node).
 // The next node's tiles are requested (registers) before the current node's products and staged into LDS afterwards.
-constexpr int BK_T = 256;
-constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 8 items per thread (the last round is half empty)
+constexpr int BK_T = 512;
+constexpr int BK_P = BK_T / BS, BK_W = (BS + BK_P - 1) / BK_P;      // 6 partial sums per row, <= 14 columns each
+constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 4 items per thread (the last round is mostly empty)
 __global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
                 int n_chunks) {
   if (status && *status != 0) return;
-  __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[3 * BS], cL[9 * NP], cR[9 * NP];
+  __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
   const int c = blockIdx.x, first = c * m;
   const bool hasL = c > 0, hasR = c + 1 < n_chunks;
   const int n_int = hasR ? m - 1 : ch.n_nodes - first;
   const size_t MB = (size_t)BS * BS;
-  const int row = tid % BS, part = tid / BS, c0 = 27 * part, nc = part < 2 ? 27 : 26;
+  const int row = tid % BS, part = tid / BS, c0 = BK_W * part, nc = min(BK_W, BS - c0);
   double2 gq[BK_Q];
   auto fetch = [&](int node) {                          // lower tiles of G_node -> registers
     const double* G = ch.D + node * MB;
@@ -820,14 +821,20 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       }
     }
   };
-  auto product = [&]() {                                // ysc <- partial sums of Gs u (three per row)
-    if (tid < 3 * BS) {
+  auto product = [&]() {                                // ysc <- partial sums of Gs u (BK_P per row)
+    if (tid < BK_P * BS) {
       double s0 = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < 27; ++kk)
+      for (int kk = 0; kk < BK_W; ++kk)
         if (kk < nc) s0 += Gs[(c0 + kk) * LD + row] * u[c0 + kk];
       ysc[tid] = s0;
     }
+  };
+  auto row_sum = [&](int r) {                           // fixed order
+    double v = ysc[r];
+#pragma unroll
+    for (int q = 1; q < BK_P; ++q) v += ysc[q * BS + r];
+    return v;
   };
   if (tid < BS) {
     xl[tid] = hasL ? sp.b[(size_t)(c - 1) * BS + tid] : 0.0;
@@ -839,7 +846,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   if (hasL) {
     // ---------------- forward: t_k = G_k f_k, f_k+1 = -E^T t_k ----------------
     fetch(first);
-    fill_coupling_coef(cL, cR, *cst, first, tid);
+    fill_coupling_coef<BK_T>(cL, cR, *cst, first, tid);
     __syncthreads();                                   // xl, tables
     if (tid < BS) {
       double v = 0.0;
@@ -855,10 +862,10 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       const int node = first + k;
       __syncthreads();                                 // Gs, u
       fetch(node + 1);
-      if (k > 0) fill_coupling_coef(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
+      if (k > 0) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
       product();
       __syncthreads();                                 // ysc, cR; every read of Gs and u done
-      if (tid < BS) xn[tid] = (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];   // t_k (xn is free until the backward pass)
+      if (tid < BS) xn[tid] = row_sum(tid);              // t_k (xn is free until the backward pass)
       stage();
       __syncthreads();
       if (tid < BS) {
@@ -882,7 +889,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   }
   for (int k = n_int - 1; k >= 0; --k) {
     const int node = first + k;
-    fill_coupling_coef(cL, cR, *cst, node, tid);
+    fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);
     const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
     const double fi = (hasL && tid < BS) ? fst[(size_t)k * BS + tid] : 0.0;
     if (k > 0) fetch(node - 1);
@@ -899,7 +906,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
     product();
     __syncthreads();                                   // ysc; every read of Gs done
     if (tid < BS) {
-      const double x = zi - ((ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid]);
+      const double x = zi - row_sum(tid);
       xn[tid] = x;
       ch.b[(size_t)node * BS + tid] = x;
     }
