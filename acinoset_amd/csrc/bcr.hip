@@ -569,33 +569,42 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
 // x_i = U (y_i - W_l x_l - W_r x_r),  U = L^-T.  All three matrices are requested at once (into registers: ONE HBM round
 // trip instead of three) and take their turn in the single LDS buffer; the mat-vecs use 240 threads (three partial
 // sums per row).
-__global__ void __launch_bounds__(256)
+// NTH = 256, or 512 for the short launches of a separator chain (latency-bound mat-vecs: more waves shorten each)
+template <int NTH>
+__global__ void __launch_bounds__(NTH)
 k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Mb = reinterpret_cast<double*>(smem_raw);
   double* xv = Mb + MAT;       // [2][80] x_l, x_r
   double* tv = xv + 2 * BS;    // [80]
-  double* ysc = tv + BS;       // [3][80]
+  double* ysc = tv + BS;       // [NPART][80]
+  constexpr int NPART = NTH / BS, WID = (BS + NPART - 1) / NPART, NV = (BS * BS / 2 + NTH - 1) / NTH;
   const int tid = threadIdx.x;
   const int i = elim[3 * blockIdx.x], l = elim[3 * blockIdx.x + 1], r = elim[3 * blockIdx.x + 2];
   const size_t MB = (size_t)BS * BS;
-  double2 vl[13], vr[13], vu[13];
-  if (l >= 0) fetch_mat(vl, ch.Wl + i * MB, tid);
-  if (r >= 0) fetch_mat(vr, ch.Wr + i * MB, tid);
-  fetch_mat(vu, ch.U + i * MB, tid);
+  double2 vl[NV], vr[NV], vu[NV];
+  if (l >= 0) fetch_mat<NTH>(vl, ch.Wl + i * MB, tid);
+  if (r >= 0) fetch_mat<NTH>(vr, ch.Wr + i * MB, tid);
+  fetch_mat<NTH>(vu, ch.U + i * MB, tid);
   double t = (tid < BS) ? ch.b[(size_t)i * BS + tid] : 0.0;
   if (tid < BS) {
     xv[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
     xv[BS + tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
   }
-  const int row = tid % BS, part = tid / BS, c0 = 27 * part, c1 = part < 2 ? c0 + 27 : BS;
+  const int row = tid % BS, part = tid / BS, c0 = WID * part, c1 = min(c0 + WID, BS);
+  auto row_sum = [&](int r) {     // fixed order
+    double v = ysc[r];
+#pragma unroll
+    for (int q = 1; q < NPART; ++q) v += ysc[q * BS + r];
+    return v;
+  };
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     if ((side == 0 ? l : r) < 0) continue;
-    stage_mat(Mb, side == 0 ? vl : vr, tid);
+    stage_mat<NTH>(Mb, side == 0 ? vl : vr, tid);
     __syncthreads();
-    if (tid < 3 * BS) {                     // row `row` of W, columns [c0, c1) (stride-81 rows: conflict free)
+    if (tid < NPART * BS) {                     // row `row` of W, columns [c0, c1) (stride-81 rows: conflict free)
       const double* x = xv + side * BS;
       double s0 = 0.0, s1 = 0.0;
       int c = c0;
@@ -607,18 +616,18 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
       ysc[tid] = s0 + s1;
     }
     __syncthreads();
-    if (tid < BS) t -= (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];
+    if (tid < BS) t -= row_sum(tid);
   }
-  stage_mat(Mb, vu, tid);
+  stage_mat<NTH>(Mb, vu, tid);
   if (tid < BS) tv[tid] = t;
   __syncthreads();
-  if (tid < 3 * BS) {                       // x = U t (U upper triangular): columns >= row only
+  if (tid < NPART * BS) {                       // x = U t (U upper triangular): columns >= row only
     double s0 = 0.0;
     for (int c = max(c0, row); c < c1; ++c) s0 += Mb[row * LD + c] * tv[c];
     ysc[tid] = s0;
   }
   __syncthreads();
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = (ysc[tid] + ysc[BS + tid]) + ysc[2 * BS + tid];
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = row_sum(tid);
 }
 
 // The deepest levels of the back-substitution as ONE launch.  Per node the three matrices do not depend on anything
@@ -964,7 +973,9 @@ k_bcr_trunc_check(BcrChain ch, const int* __restrict__ status) {
 // block(j, l) = Cpl[l] (rows j, columns l); block(j, r) = Cpl[j]^T.  Entry p of the isolated level is node iso[3 p].
 // src / dst: iterates indexed by p (src == nullptr: the truncated solve's x0 is read from ch.b and saved to x0);
 // to_chain: the new iterate also goes to ch.b (only legal when src != nullptr: nobody reads ch.b then).
-__global__ void __launch_bounds__(256)
+// (512 threads: the launch is <= ~60 workgroups of three dependent mat-vecs - more waves per workgroup shorten each)
+constexpr int RF_T = 512, RF_P = RF_T / BS, RF_W = (BS + RF_P - 1) / RF_P, RF_V = (BS * BS / 2 + RF_T - 1) / RF_T;
+__global__ void __launch_bounds__(RF_T)
 k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* __restrict__ src, double* __restrict__ dst,
              double* __restrict__ x0, int to_chain, double* __restrict__ norms, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -975,7 +986,7 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
   double* xl = Mu + MAT;          // [80] each
   double* xr = xl + BS;
   double* tv = xr + BS;
-  double* part = tv + BS;         // [3][80]
+  double* part = tv + BS;         // [RF_P][80]
   const int tid = threadIdx.x, p = blockIdx.x;
   const int j = iso[3 * p], l = p > 0 ? iso[3 * (p - 1)] : -1, r = p + 1 < n_iso ? iso[3 * (p + 1)] : -1;
   const size_t MB = (size_t)BS * BS;
@@ -983,10 +994,10 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
     const double2* s0 = reinterpret_cast<const double2*>(ch.Cpl + (l >= 0 ? (size_t)l : 0) * MB);
     const double2* s1 = reinterpret_cast<const double2*>(ch.Cpl + (size_t)j * MB);
     const double2* s2 = reinterpret_cast<const double2*>(ch.U + (size_t)j * MB);
-    double2 v0[13], v1[13], v2[13];
+    double2 v0[RF_V], v1[RF_V], v2[RF_V];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const int idx = tid + 256 * k;
+    for (int k = 0; k < RF_V; ++k) {
+      const int idx = tid + RF_T * k;
       if (idx < BS * BS / 2) {
         v0[k] = l >= 0 ? s0[idx] : make_double2(0.0, 0.0);
         v1[k] = r >= 0 ? s1[idx] : make_double2(0.0, 0.0);
@@ -994,8 +1005,8 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
       }
     }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const int idx = tid + 256 * k;
+    for (int k = 0; k < RF_V; ++k) {
+      const int idx = tid + RF_T * k;
       if (idx < BS * BS / 2) {
         const int e = 2 * idx, rr = e / BS, c = e % BS;
         Ml[rr * LD + c] = v0[k].x;  Ml[rr * LD + c + 1] = v0[k].y;
@@ -1018,11 +1029,17 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
     }
   }
   __syncthreads();
-  const int row = tid % BS, pr = tid / BS, k0 = 27 * pr, k1 = min(k0 + 27, BS);
-  if (tid < 3 * BS) {             // t = block(j, l) x_l + block(j, r) x_r  (fixed trip count: the LDS reads pipeline)
+  const int row = tid % BS, pr = tid / BS, k0 = RF_W * pr, k1 = min(k0 + RF_W, BS);
+  auto row_sum = [&](int r) {     // the RF_P partial sums of row r, fixed order
+    double v = part[r];
+#pragma unroll
+    for (int q = 1; q < RF_P; ++q) v += part[q * BS + r];
+    return v;
+  };
+  if (tid < RF_P * BS) {             // t = block(j, l) x_l + block(j, r) x_r  (fixed trip count: the LDS reads pipeline)
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) {
+    for (int q = 0; q < RF_W; ++q) {
       const int k = k0 + (k0 + q < k1 ? q : 0);
       const double w = k0 + q < k1 ? 1.0 : 0.0;
       s0 += w * Ml[row * LD + k] * xl[k];
@@ -1031,13 +1048,13 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
     part[tid] = s0 + s1;
   }
   __syncthreads();
-  if (tid < BS) tv[tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];
+  if (tid < BS) tv[tid] = row_sum(tid);
   __syncthreads();
-  if (tid < 3 * BS) {             // w = U^T t  (U upper triangular: rows <= column)
+  if (tid < RF_P * BS) {             // w = U^T t  (U upper triangular: rows <= column)
     double s = 0.0;
     const int c1 = min(k1, row + 1);
 #pragma unroll
-    for (int q = 0; q < 27; ++q) {
+    for (int q = 0; q < RF_W; ++q) {
       const bool on = k0 + q < c1;
       const int k = k0 + (on ? q : 0);
       s += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
@@ -1045,12 +1062,12 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
     part[tid] = s;
   }
   __syncthreads();
-  if (tid < BS) xl[tid] = (part[tid] + part[BS + tid]) + part[2 * BS + tid];      // (xl reused: w)
+  if (tid < BS) xl[tid] = row_sum(tid);      // (xl reused: w)
   __syncthreads();
-  if (tid < 3 * BS) {             // d = U w
+  if (tid < RF_P * BS) {             // d = U w
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) {
+    for (int q = 0; q < RF_W; ++q) {
       const bool on = k0 + q >= row && k0 + q < k1;
       const int k = on ? k0 + q : row;
       s += (on ? 1.0 : 0.0) * Mu[row * LD + k] * xl[k];
@@ -1060,7 +1077,7 @@ k_bcr_refine(BcrChain ch, const int* __restrict__ iso, int n_iso, const double* 
   __syncthreads();
   double dabs = 0.0, xabs = 0.0;
   if (tid < BS) {
-    const double x = xj0 - ((part[tid] + part[BS + tid]) + part[2 * BS + tid]);
+    const double x = xj0 - row_sum(tid);
     dst[(size_t)p * BS + tid] = x;
     if (to_chain) ch.b[(size_t)j * BS + tid] = x;
     // size of this sweep's update of the node (against its own previous value) and of the solution
@@ -1197,8 +1214,8 @@ static constexpr size_t kElimLds = (MAT + BS + 8 + 18 * NP + 3 * BS) * sizeof(do
 static constexpr size_t kElimDeepLds = (MAT + BS + 3 * BS) * sizeof(double);
 static constexpr size_t kUpdateLds = (MAT + BS + 8) * sizeof(double);
 static constexpr size_t kUpdateDeepLds = (2 * MAT + 2 * BS + 3 * BS) * sizeof(double);
-static constexpr size_t kBacksubLds = (MAT + 6 * BS) * sizeof(double);
-static constexpr size_t kBacksubTailLds = (3 * MAT + 6 * BS) * sizeof(double);
+static constexpr size_t kBacksubLds = (MAT + 9 * BS) * sizeof(double);
+static constexpr size_t kBacksubTailLds = (3 * MAT + 9 * BS) * sizeof(double);
 static constexpr size_t kUpdate0Lds = (MAT + BS + 8 + 36 * NP) * sizeof(double);
 static constexpr size_t kTruncCheckLds = (3 * MAT + 8) * sizeof(double);
 
@@ -1213,7 +1230,9 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateDeepLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub_tail),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
-  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub),
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub<512>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_backsub<256>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_update0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdate0Lds));
@@ -1327,7 +1346,7 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     const int* iso = ch.d_elim + 3 * lv.elim_off;
     {
       ProfSpan sp(prof, PC_BACKSUB, s, lv.n_elim);
-      hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch, iso, d_status);
+      hipLaunchKernelGGL(k_bcr_backsub<512>, dim3(lv.n_elim), dim3(512), kBacksubLds, s, ch, iso, d_status);
     }
     ACINO_LAUNCH_CHECK();
     double* x0 = ch.refine_buf;
@@ -1339,7 +1358,7 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
       // trunc_eps2 layout with refinement, n = isolated nodes: [0, n) |update| and [n, 2n) |x| of the last sweep,
       // [2n, 3n) |update| and [3n, 4n) |x| of the sweep before it
       double* norms = last ? ch.trunc_eps2 : (sw + 2 == sch.refine ? ch.trunc_eps2 + 2 * (size_t)lv.n_elim : (double*)nullptr);
-      hipLaunchKernelGGL(k_bcr_refine, dim3(lv.n_elim), dim3(256), kBacksubTailLds, s, ch, iso, lv.n_elim,
+      hipLaunchKernelGGL(k_bcr_refine, dim3(lv.n_elim), dim3(RF_T), kBacksubTailLds, s, ch, iso, lv.n_elim,
                          sw == 0 ? (const double*)nullptr : it[(sw - 1) & 1], it[sw & 1], x0, (last && sw > 0) ? 1 : 0, norms,
                          d_status);
       ACINO_LAUNCH_CHECK();
@@ -1368,8 +1387,12 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
         hipLaunchKernelGGL(k_bcr_backsub0, dim3(lv.n_elim), dim3(256), 0, s, ch,
                            ch.d_elim + 3 * lv.elim_off, d_c, d_status);
       else
-        hipLaunchKernelGGL(k_bcr_backsub, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
-                           ch.d_elim + 3 * lv.elim_off, d_status);
+        if (lv.n_elim <= 256)
+          hipLaunchKernelGGL(k_bcr_backsub<512>, dim3(lv.n_elim), dim3(512), kBacksubLds, s, ch,
+                             ch.d_elim + 3 * lv.elim_off, d_status);
+        else
+          hipLaunchKernelGGL(k_bcr_backsub<256>, dim3(lv.n_elim), dim3(256), kBacksubLds, s, ch,
+                             ch.d_elim + 3 * lv.elim_off, d_status);
     }
     ACINO_LAUNCH_CHECK();
   }

@@ -298,18 +298,20 @@ __device__ __forceinline__ void load_mat_t(double* dst, const double* __restrict
 }
 // The two halves of load_mat, for kernels that want several matrices in flight but only ONE LDS buffer: request a
 // matrix into registers now (13 x 16 B per thread), stage it into LDS when its turn comes.
-__device__ __forceinline__ void fetch_mat(double2 (&v)[13], const double* __restrict__ src, int tid) {
+template <int NTH = 256>
+__device__ __forceinline__ void fetch_mat(double2 (&v)[(BS * BS / 2 + NTH - 1) / NTH], const double* __restrict__ src, int tid) {
   const double2* s2 = reinterpret_cast<const double2*>(src);
 #pragma unroll
-  for (int k = 0; k < 13; ++k) {
-    const int idx = tid + 256 * k;
+  for (int k = 0; k < (BS * BS / 2 + NTH - 1) / NTH; ++k) {
+    const int idx = tid + NTH * k;
     if (idx < BS * BS / 2) v[k] = s2[idx];
   }
 }
-__device__ __forceinline__ void stage_mat(double* dst, const double2 (&v)[13], int tid) {
+template <int NTH = 256>
+__device__ __forceinline__ void stage_mat(double* dst, const double2 (&v)[(BS * BS / 2 + NTH - 1) / NTH], int tid) {
 #pragma unroll
-  for (int k = 0; k < 13; ++k) {
-    const int idx = tid + 256 * k;
+  for (int k = 0; k < (BS * BS / 2 + NTH - 1) / NTH; ++k) {
+    const int idx = tid + NTH * k;
     if (idx < BS * BS / 2) {
       const int e = 2 * idx, r = e / BS, c = e % BS;
       dst[r * LD + c] = v[k].x;
