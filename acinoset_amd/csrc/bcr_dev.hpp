@@ -165,4 +165,15 @@ static __device__ void fill_coupling_coef(double* coefL, double* coefR, const Ft
   }
 }
 
+// True when the coupling tables of every node first .. last are those of an interior node of one long sequence - no clip
+// structure, every frame slot alive, every third-difference row involved at least three frames away from either end of the
+// sequence (band_coef's interior branch) - i.e. identical: a kernel walking a run of nodes fills them once.  (Conservative
+// by a node on either side.)
+static __device__ __forceinline__ bool coupling_tables_uniform(const FteConst& K, int first, int last) {
+  if (K.clip_len > 0) return false;
+  const int64_t lo = K.n_offset + 3 * (int64_t)(first - K.pin_left) - 3;   // first frame a left table of `first` refers to
+  const int64_t hi = K.n_offset + 3 * (int64_t)(last - K.pin_left) + 5;    // last frame a right table of `last` refers to
+  return lo >= 3 && hi + 3 <= K.n_global - 4 && 3 * (last - K.pin_left) + 5 < K.n_frames;
+}
+
 }  // namespace acino

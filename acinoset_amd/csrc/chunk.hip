@@ -410,6 +410,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   const int n_int = hasR ? m - 1 : ch.n_nodes - first;
   const size_t MB = (size_t)BS * BS;
   const int role = __builtin_amdgcn_readfirstlane(role8(wave));
+  const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
   const int n_spike = hasL ? 5 : 1;          // first run: only the right-hand side column (strip 4) is alive
   int t3 = 0, t2 = 0, tflag = 0, t5 = 0;     // rounds of the wave-subset barriers
   // (debug stamps: workgroup dbg[29] writes wall-clock ticks of its phases at node dbg[30]; selectors read ONCE)
@@ -509,7 +510,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
         const int t = gram8_tile(wave, q);
         if (t >= 0) g[q] = tile_u_ut(Xc, tri_i(t), tri_j(t), gi, gk);
       }
-      if (k > 0) fill_coupling_coef<SW_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
+      if (k > 0 && !uni_tables) fill_coupling_coef<SW_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int t = gram8_tile(wave, q);
@@ -792,6 +793,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   const int n_int = hasR ? m - 1 : ch.n_nodes - first;
   const size_t MB = (size_t)BS * BS;
   const int row = tid % BS, part = tid / BS, c0 = BK_W * part, nc = min(BK_W, BS - c0);
+  const bool uni_tables = coupling_tables_uniform(*cst, first, first + n_int - 1);   // (one fill serves every node of the run)
   double2 gq[BK_Q];
   auto fetch = [&](int node) {                          // lower tiles of G_node -> registers
     const double* G = ch.D + node * MB;
@@ -862,7 +864,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       const int node = first + k;
       __syncthreads();                                 // Gs, u
       fetch(node + 1);
-      if (k > 0) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
+      if (k > 0 && !uni_tables) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
       product();
       __syncthreads();                                 // ysc, cR; every read of Gs and u done
       if (tid < BS) xn[tid] = row_sum(tid);              // t_k (xn is free until the backward pass)
@@ -889,7 +891,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   }
   for (int k = n_int - 1; k >= 0; --k) {
     const int node = first + k;
-    fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);
+    if (!uni_tables || !hasL) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);   // (uniform: filled by the forward pass)
     const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
     const double fi = (hasL && tid < BS) ? fst[(size_t)k * BS + tid] : 0.0;
     if (k > 0) fetch(node - 1);
