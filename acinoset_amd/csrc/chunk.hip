@@ -784,7 +784,7 @@ constexpr int BK_P = BK_T / BS, BK_W = (BS + BK_P - 1) / BK_P;      // 6 partial
 constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 4 items per thread (the last round is mostly empty)
 __global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
-                int n_chunks) {
+                int n_chunks, TrialOut trial) {
   if (status && *status != 0) return;
   __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
@@ -794,6 +794,41 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   const size_t MB = (size_t)BS * BS;
   const int row = tid % BS, part = tid / BS, c0 = BK_W * part, nc = min(BK_W, BS - c0);
   const bool uni_tables = coupling_tables_uniform(*cst, first, first + n_int - 1);   // (one fill serves every node of the run)
+  // ---- the trial iterate of the run's frames (fte_api.hip k_trial, same arithmetic): thread r < 75 owns row r of every node
+  const int t_cur = ch.st->cur, t_nf = cst->n_frames, t_own_lo = cst->own_lo, t_own_hi = cst->own_hi;
+  const double t_lam = ch.st->lam;
+  const double* t_x = t_cur ? ch.x1 : ch.x0;
+  double* t_xt = const_cast<double*>(t_cur ? ch.x0 : ch.x1);   // (the other iterate buffer: the chain view holds both read-only)
+  const double* t_g = t_cur ? ch.g1 : ch.g0;
+  const double* t_hd = t_cur ? trial.hd1 : trial.hd0;
+  const bool t_thr = tid < 3 * NP;
+  const int t_p = tid % NP, t_a = tid / NP;
+  const double t_lo = t_thr ? cst->lo[t_p] : 0.0, t_hi = t_thr ? cst->hi[t_p] : 0.0;
+  double t_pred = 0.0, t_step = 0.0;
+  double t_xv = 0.0, t_gv = 0.0, t_d0 = 0.0;            // operands of the node being solved (requested a node ahead)
+  double s_xv = 0.0, s_gv = 0.0, s_d0 = 0.0, s_dx = 0.0;  // ... and of the run's right separator
+  auto trial_fetch = [&](int node) {
+    const int n = 3 * node + t_a;
+    if (t_thr && n < t_nf) {
+      t_xv = t_x[(size_t)(n + HALO) * NP + t_p];
+      t_gv = t_g[(size_t)n * NP + t_p];
+      t_d0 = t_hd[(size_t)n * NP + t_p];
+    }
+  };
+  auto trial_row = [&](int node, double delta) {        // (a bound-active variable takes a step of exactly 0: see k_trial)
+    const int n = 3 * node + t_a;
+    if (t_thr && n < t_nf) {
+      const double gtol = GRAD_ZERO_REL * t_d0;
+      const bool fixed = (t_xv <= t_lo && t_gv > gtol) || (t_xv >= t_hi && t_gv < -gtol);
+      const double d = fixed ? 0.0 : delta, pg = fixed ? 0.0 : t_gv;
+      const double xnew = fmin(fmax(t_xv + d, t_lo), t_hi);
+      t_xt[(size_t)(n + HALO) * NP + t_p] = xnew;
+      if (n >= t_own_lo && n < t_own_hi) {              // (window sharding: only owned frames enter the global sums)
+        t_pred += 0.5 * d * (t_lam * fmax(t_d0, DIAG_FLOOR) * d - pg);
+        t_step = fmax(t_step, fabs(xnew - t_xv));
+      }
+    }
+  };
   double2 gq[BK_Q];
   auto fetch = [&](int node) {                          // lower tiles of G_node -> registers
     const double* G = ch.D + node * MB;
@@ -843,6 +878,13 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
     const double xr = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
     xn[tid] = xr;
     if (hasR) ch.b[(size_t)(first + n_int) * BS + tid] = xr;      // the separator's solution joins the chain's vector
+    if (hasR) {                                         // (the separator's trial row: operands requested here, used at the end)
+      trial_fetch(first + n_int);
+      s_xv = t_xv;
+      s_gv = t_gv;
+      s_d0 = t_d0;
+      s_dx = xr;
+    }
   }
   double* fst = ch.Wl + (size_t)first * BS;             // f_k of this run's nodes
   if (hasL) {
@@ -894,6 +936,8 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
     if (!uni_tables || !hasL) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);   // (uniform: filled by the forward pass)
     const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
     const double fi = (hasL && tid < BS) ? fst[(size_t)k * BS + tid] : 0.0;
+    double xtr = 0.0;
+    trial_fetch(node);
     if (k > 0) fetch(node - 1);
     __syncthreads();                                   // tables, xn of the previous round, Gs
     if (tid < BS) {
@@ -911,8 +955,31 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       const double x = zi - row_sum(tid);
       xn[tid] = x;
       ch.b[(size_t)node * BS + tid] = x;
+      xtr = x;
     }
     if (k > 0) stage();
+    trial_row(node, xtr);                              // (after the staging: nothing on the node chain waits for it)
+  }
+  if (hasR) {
+    t_xv = s_xv;
+    t_gv = s_gv;
+    t_d0 = s_d0;
+    trial_row(first + n_int, s_dx);
+  }
+  // the run's share of the predicted reduction (sum) and of the step length (max): waves 0 and 1 hold the 75 rows
+  for (int off = 32; off > 0; off >>= 1) {
+    t_pred += __shfl_down(t_pred, off, 64);
+    t_step = fmax(t_step, __shfl_down(t_step, off, 64));
+  }
+  __syncthreads();                                     // (ysc is free)
+  if ((tid & 63) == 0 && tid < 128) {
+    ysc[2 * (tid >> 6)] = t_pred;
+    ysc[2 * (tid >> 6) + 1] = t_step;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    trial.pred_part[c] = ysc[0] + ysc[2];
+    trial.step_part[c] = fmax(ysc[1], ysc[3]);
   }
 }
 
@@ -942,14 +1009,14 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
 
 int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
                   const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
-                  Profiler* prof) {
+                  Profiler* prof, const TrialOut& trial) {
   if (pl.n_sep > 0) {
     int rc = bcr_backsub(sepch, sepsch, d_c, d_status, s, prof, d_numeric_err);
     if (rc) return rc;
   }
   {
     ProfSpan span(prof, PC_CHUNK_BACKSUB, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks);
+    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks, trial);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;

@@ -23,6 +23,15 @@ struct SepView {
   double* b;    // [80]
 };
 
+// The trial iterate folded into the back-substitution (what k_trial does for the other solvers): the run that solves a node
+// also forms x_t = clip(x + delta) of its three frames and the run's share of the predicted reduction / step length.
+struct TrialOut {
+  const double* hd0;   // diag of the Gauss-Newton blocks, [N][25], buffer 0 / 1 (as the iterate)
+  const double* hd1;
+  double* pred_part;   // [n_chunks] per-run partial sums -> k_totals
+  double* step_part;
+};
+
 int chunk_set_func_attributes();
 // forward: sweep of every run + separator assembly + reduction of the separator chain
 int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
@@ -31,6 +40,6 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
 // backward: separator chain back-substitution, then every run from its right end to its left end; x -> ch.b
 int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,
                   const BcrSchedule& sepsch, const FteConst* d_c, int* d_numeric_err, const int* d_status, hipStream_t s,
-                  Profiler* prof);
+                  Profiler* prof, const TrialOut& trial);
 
 }  // namespace acino

@@ -42,6 +42,7 @@ struct acino_fte_ctx {
   int n_trunc = 0;               // dropped couplings of an incomplete reduction (of whichever chain `sched` reduces)
   const double* d_det;
   int n_blk_asm, n_blk_trial;
+  int n_pred;         // entries of pred_part / step_part: blocks of k_trial, or runs of the chunked back-substitution (which folds it in)
   size_t ws_bytes;
   acino::Profiler prof;
   bool graph_on = false;            // replay the LM step as a hipGraph (single-shard contexts, non-null stream)
@@ -98,8 +99,9 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   for (int k = 0; k < 2; ++k) b.H[k] = c.take<double>(N * NP * NP);
   for (int k = 0; k < 2; ++k) b.hd[k] = c.take<double>(N * NP);
   b.cost_part = c.take<double>(n_assemble_blocks((int)N) + 1);
-  b.pred_part = c.take<double>((N * NP + 255) / 256 + 1);
-  b.step_part = c.take<double>((N * NP + 255) / 256 + 1);
+  const size_t n_pred = std::max((N * NP + 255) / 256, (size_t)std::max(lay.plan.n_chunks, 0)) + 1;
+  b.pred_part = c.take<double>(n_pred);
+  b.step_part = c.take<double>(n_pred);
   b.gn_part = c.take<double>(T + 1);
   b.totals = c.take<double>(8);
   b.nbehind = c.take<int>(4);
@@ -624,7 +626,7 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
   {
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1024), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
-                       b.step_part, ctx->n_blk_trial, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
+                       b.step_part, ctx->n_pred, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
                        with_step ? 1 : 0, b.cst, b.numeric_err, fused_control, b.trunc_eps2, ctx->n_trunc);
   }
   ACINO_LAUNCH_CHECK();
@@ -725,6 +727,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, ctx->sepchain.Wr, ctx->sepchain.b};
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
+  ctx->n_pred = ctx->plan.active() ? ctx->plan.n_chunks : ctx->n_blk_trial;
   rc = bcr_set_func_attributes();
   if (!rc) rc = chunk_set_func_attributes();
   if (rc) {
@@ -1012,12 +1015,14 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
   }
   if (ctx->plan.active())
     return chunk_backsub(ctx->chain, ctx->plan, ctx->sep, ctx->sepchain, ctx->sched, ctx->b.cst, ctx->b.numeric_err,
-                         &ctx->b.state->status, s, &ctx->prof);
+                         &ctx->b.state->status, s, &ctx->prof,
+                         TrialOut{ctx->b.hd[0], ctx->b.hd[1], ctx->b.pred_part, ctx->b.step_part});
   return bcr_backsub(ctx->chain, ctx->sched, ctx->b.cst, &ctx->b.state->status, s, &ctx->prof, ctx->b.numeric_err);
 }
 
 int acino_fte_trial(acino_fte_ctx* ctx, void* stream) {
   ACINO_REQUIRE(ctx, "null");
+  if (ctx->plan.active()) return ACINO_OK;      // chunked solver: the back-substitution has formed the trial iterate already
   const Buffers& b = ctx->b;
   {
     ProfSpan sp(&ctx->prof, PC_TRIAL, (hipStream_t)stream, ctx->h.n_frames);
