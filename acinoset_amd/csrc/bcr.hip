@@ -1289,7 +1289,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
       //  the wide eliminations are only mildly bandwidth-sensitive, so triangle-only transfers could save ~8 us at best.)
       // (64: measured again in round 2 - the strip form for levels of up to 128 / 256 / 512 nodes moves time from k_bcr_elim
       //  to k_bcr_elim_deep one for one: 0.889 / 0.902 / 0.968 ms per step against 0.893)
-      const bool deep = explicit_c && lv.n_elim <= 64;
+      // (128 since round 3: the separator chain of the chunked solver starts with ~119 eliminated nodes on an otherwise idle
+      //  chip - two strip workgroups per node: 28.7 -> 25.4 us for that level)
+      const bool deep = explicit_c && lv.n_elim <= 128;
       // (measured dead end, round 2: the wide levels >= 1 in the strip form of k_bcr_elim_deep with T = 1, compiled for
       //  THREE workgroups per CU - 168 VGPRs, 12 B/lane of scratch -: k_bcr_elim 0.288 -> 0.341 ms per step.  The
       //  level is not occupancy-bound; the third workgroup only adds contention for the one LDS pipe.)
