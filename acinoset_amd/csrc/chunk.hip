@@ -615,12 +615,9 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
             for (int jp = 0; jp < 3; ++jp) Xn[(j * NP + pr) * LD + jp * NP + pc] = v[j][jp] - S[sl][j][jp];
         }
       }
-      // padding rows / columns 75 .. 79: identity
-      for (int e = tid_; e < BS * BS - 9 * NP * NP; e += SW_T) {
-        const int r = e < 5 * BS ? 3 * NP + e / BS : (e - 5 * BS) / 5, cc = e < 5 * BS ? e % BS : 3 * NP + (e - 5 * BS) % 5;
-        Xn[r * LD + cc] = r == cc ? 1.0 : 0.0;
-      }
-      if (tid_ < BS - 3 * NP) bv[3 * NP + tid_] = 0.0;
+      // (padding rows / columns 75 .. 79 need no write: the identity block of D~_k gives an identity block of G_k = D~_k^-1,
+      //  exactly - every product behind it has an exact 0 or 1 factor -, and G_k is what Xn holds there; bv[75 .. 79] = 0
+      //  since the first node was built)
       if (wave == 0) SW_STAMP(3);
       publish_gmax<SW_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
     }
