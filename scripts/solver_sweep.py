@@ -38,5 +38,5 @@ for (m, K, r) in cfgs:
     plan = fte.solver_plan(c.params)
     c.close()
     ks = {k: round(1e3 * v["ms"] / 5, 1) for k, v in prof.items() if v["launches"]}
-    print(f"m={m} K={K} r={r} plan={plan}: {1e3 * dt / 20:.1f} us/step  cost23={st['cost']:.10f} acc={st['accepted']} "
+    print(f"m={m} K={K} r={r} plan={plan}: {1e6 * dt / 20:.1f} us/step  cost23={st['cost']:.10f} acc={st['accepted']} "
           f"status={st['status_name']} eps={st['trunc_eps']:.2e}\n    us/step by kernel: {ks}", flush=True)

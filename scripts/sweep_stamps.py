@@ -25,28 +25,16 @@ d = dbg.cpu().numpy()
 check(lib().acino_fte_debug_stamps(c._h, None))
 c.close()
 t0 = d[0]
-names = {0: "iter start", 1: "G in LDS", 2: "G stored + pass 1", 3: "pass 2", 4: "node built (parallel part starts)", 5: "wave0: chol80 done",
-         8: "w2: W strips", 9: "w2: barrier 1", 10: "w2: syrk", 11: "w2: barrier 2", 24: "build: zero fill issued", 25: "build: barrier 1", 26: "build: couplings", 28: "build: H dropped", 31: "build: barrier 2", 13: "build_finish returned", 14: "gmax published", 15: "dv added", 6: "chol + W^T W done (barrier)", 7: "T complete (barrier)",
-         16: "w3: W strips", 17: "w3: barrier 1", 18: "w3: syrk", 19: "w3: barrier 2", 20: "w1: at tail barrier", 21: "w1: tail barrier passed",
-         22: "w1: tail done", 27: "end of node"}
-for role in (0, 1):
-    b = 32 + 16 * role
-    names[b] = f"chol r{role}: first tile"; names[b + 1] = f"chol r{role}: barrier"
-    for kb in range(5):
-        names[b + 2 + 3 * kb] = f"chol r{role}: panel {kb}"; names[b + 3 + 3 * kb] = f"chol r{role}: barrier p{kb}"
-        if kb < 4: names[b + 4 + 3 * kb] = f"chol r{role}: " + ("chain" if role == 0 else "trailing") + f" {kb}"
-import os
-if os.environ.get("ACINO_SWEEP_WAVES") != "4":          # the eight-wave kernel's stamp slots
-    names = {0: "iter start", 1: "G in LDS", 2: "G stored + pass 1", 3: "pass 2", 4: "node built (parallel part starts)",
-             7: "end of node (barrier)"}
-    for w in range(8):
-        names[8 + w] = f"wave {w}: parallel role done"
-    for sw in range(5):
-        names[16 + 4 * sw] = f"spike {sw}: W strip"; names[17 + 4 * sw] = f"spike {sw}: barrier 1"
-        names[18 + 4 * sw] = f"spike {sw}: syrk"; names[19 + 4 * sw] = f"spike {sw}: T stored"
-    for kb in range(4):
-        names[40 + 2 * kb] = f"chain: panel {kb} posted"; names[41 + 2 * kb] = f"chain: pivots {kb + 1} done"
-        names[48 + kb] = f"helper 1: trailing {kb}"; names[52 + kb] = f"helper 2: trailing {kb}"
+names = {0: "iter start", 1: "G in LDS", 2: "G stored, E^T G E in registers (barrier)", 3: "next node written", 4: "gradient norm published: parallel part starts",
+         7: "end of node (barrier)"}
+for w in range(8):
+    names[8 + w] = f"wave {w}: parallel role done"
+for sw in range(5):
+    names[16 + 4 * sw] = f"spike {sw}: W strip"; names[17 + 4 * sw] = f"spike {sw}: barrier 1"
+    names[18 + 4 * sw] = f"spike {sw}: syrk"; names[19 + 4 * sw] = f"spike {sw}: T stored"
+for kb in range(4):
+    names[40 + 2 * kb] = f"chain: panel {kb} posted"; names[41 + 2 * kb] = f"chain: pivots {kb + 1} done"
+    names[48 + kb] = f"helper 1: trailing {kb}"; names[52 + kb] = f"helper 2: trailing {kb}"
 for i in sorted(names, key=lambda i: d[i]):
     if d[i]:
         print(f"{(d[i] - t0) / 100.0:8.2f} us  {names[i]}")
