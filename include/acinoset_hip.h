@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ACINO_ABI_VERSION 2   /* 2: acino_fte_params grew (chunk_nodes, refine_sweeps), 17 profiler classes, status 5-7 / numeric_err bit mask, d_dbg[32] */
+#define ACINO_ABI_VERSION 2   /* 2: acino_fte_params grew (chunk_nodes, refine_sweeps), 17 profiler classes, status 5-7 / numeric_err bit mask, d_dbg[64] */
 
 typedef enum acino_status {
   ACINO_OK = 0,
