@@ -158,3 +158,18 @@ def test_build_id_matches_sources_and_cpu_baseline_worker(tmp_path):
     import bench
     probe = bench.probe_reference_cpu_path()
     assert set(probe["probe"]) == {"cv2", "pyomo", "ipopt"} and ("unavailable" in probe["note"]) == (not probe["available"])
+
+
+def test_bench_baseline_bookkeeping():
+    """bench.py's CPU-baseline hygiene (host only): the fingerprint names the oracle sources / sample / host it was measured
+    with and is stable; the reference-path probe reports what is missing here and would time the repo's own Pyomo
+    formulation where Pyomo + IPOPT exist."""
+    import bench
+    sample = np.arange(4 * 6 * 20 * 3, dtype=np.float64).reshape(4, 6, 20, 3)
+    f1, f2 = bench._baseline_fingerprint(sample), bench._baseline_fingerprint(sample.copy())
+    assert f1 == f2 and len(f1["oracle_sources_sha256"]) == 16 and f1["nproc"] == os.cpu_count()
+    assert bench._baseline_fingerprint(sample + 1.0)["sample_sha256"] != f1["sample_sha256"]
+    probe = bench.probe_reference_cpu_path()
+    assert set(probe["probe"]) == {"cv2", "pyomo", "ipopt"}
+    if not (probe["probe"]["pyomo"] and probe["probe"]["ipopt"]):
+        assert probe["available"] is False and "oracle/pyomo_model.py" in probe["note"]
