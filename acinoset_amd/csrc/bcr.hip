@@ -97,8 +97,8 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   const bool fused = ch.st != nullptr && level == 0;
   const bool impl_l = ch.implicit_couplings && l >= 0 && l == i - 1, impl_r = ch.implicit_couplings && r >= 0 && r == i + 1;
   if (!fused && (impl_l || impl_r)) fill_coupling_coef(coefL, coefR, *cst, i, tid);   // visible after the barriers below
-// (debug stamps: workgroup dbg[29] of the launch at level dbg[30] writes wall-clock ticks of its phases)
-#define ACINO_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[29] && (long long)level == ch.dbg[30]) ch.dbg[k] = (long long)wall_clock64(); } while (0)
+// (debug stamps: workgroup dbg[64] of the launch at level dbg[65] writes wall-clock ticks of its phases into dbg[0..63])
+#define ACINO_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[64] && (long long)level == ch.dbg[65]) ch.dbg[k] = (long long)wall_clock64(); } while (0)
   ACINO_STAMP(0);
   if (fused) {
     double gmax = build_node(Lm, yv, ch, *cst, i, tid);
@@ -109,7 +109,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   }
   __syncthreads();
   ACINO_STAMP(1);
-  chol80(Lm, tid, numeric_err, (ch.dbg && (long long)blockIdx.x == ch.dbg[29] && (long long)level == ch.dbg[30]) ? ch.dbg : nullptr);
+  chol80(Lm, tid, numeric_err, (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && (long long)level == ch.dbg[65]) ? ch.dbg : nullptr);
   ACINO_STAMP(2);
   if (fused) ACINO_STAMP(3);
   if (fused) {

@@ -413,9 +413,10 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
   const int n_spike = hasL ? 5 : 1;          // first run: only the right-hand side column (strip 4) is alive
   int t3 = 0, t2 = 0, tflag = 0, t5 = 0;     // rounds of the wave-subset barriers
-  // (debug stamps: workgroup dbg[29] writes wall-clock ticks of its phases at node dbg[30]; selectors read ONCE)
-  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[29]) ? ch.dbg : nullptr;
-  const int dbg_k = dbgp ? (int)ch.dbg[30] : -1;
+  // (debug stamps: workgroup dbg[64] writes wall-clock ticks of its phases at node dbg[65] into dbg[0..63]; the selectors
+  //  sit OUTSIDE the stamp range and are read ONCE)
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64]) ? ch.dbg : nullptr;
+  const int dbg_k = dbgp ? (int)ch.dbg[65] : -1;
   // (stamps go to LDS: a global store in front of a release fence would itself delay the wave that is being timed)
 #define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
   if (tid < 4) sync[tid] = 0;

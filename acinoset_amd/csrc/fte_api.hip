@@ -314,7 +314,8 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
       // two updates (one sweep only: rho = 1/2 assumed), and a rho above 1/2 refuses the step.
       double bound;
       if (n_ref > 0) {
-        const double rho = n_ref >= 2 ? (r_d0 > 0.0 ? r_d1 / r_d0 : 0.0) : 0.5;
+        // (an update after a sweep that changed nothing - r_d0 == 0 < r_d1 - is no contraction: rho = 1 refuses the step)
+        const double rho = n_ref >= 2 ? (r_d0 > 0.0 ? r_d1 / r_d0 : (r_d1 > 0.0 ? 1.0 : 0.0)) : 0.5;
         bound = (rho <= 0.5 && r_x > 0.0) ? rho / (1.0 - rho) * r_d1 / r_x : (r_d1 == 0.0 ? 0.0 : 1.0);
         S.trunc_eps = bound;
       } else {
@@ -1277,8 +1278,9 @@ int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_p
   return ACINO_OK;
 }
 
-// Debug: phase timestamps (100 MHz wall clock) of workgroup d_dbg[29] of the k_bcr_elim launch at level d_dbg[30] go to
-// d_dbg[0..28] (a caller buffer of 32 entries).
+// Debug: phase timestamps (100 MHz wall clock) go to d_dbg[0..63] of a caller buffer of ACINO_DEBUG_STAMP_ENTRIES (72)
+// entries; the selectors are d_dbg[64] = workgroup index and d_dbg[65] = reduction level (k_bcr_elim) / node of the run
+// (k_chunk_sweep).
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
   ACINO_REQUIRE(ctx, "null");
   ctx->chain.dbg = d_dbg;
@@ -1287,6 +1289,7 @@ int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
 
 // Debug / test aid: copies an internal buffer to d_out (at most n doubles).  what: 0 chain.b (step per node), 1 sep.D,
 // 2 sep.b, 3 sep.Cpl, 4 sep.AL, 6 chain.D (G of the interior nodes, lower tiles), 7 chain.Wl (chunked: f_k, [80] per node).
+// (5 is not assigned.)
 int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream) {
   ACINO_REQUIRE(ctx && d_out && n >= 0, "args");
   const size_t MB = (size_t)BS * BS;

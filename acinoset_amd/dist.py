@@ -160,7 +160,13 @@ def combine_partials(gathered):
     total[2] = gathered[:, 2].max()
     total[3] = gathered[:, 3].max()
     total[4] = gathered[:, 4].sum()
-    total[5] = gathered[:, 5].max()      # numeric flags (pivot / sync timeout / truncation): any rank's failure is everyone's
+    # numeric flags (bit 0 pivot, 1 sync timeout, 2 truncation) are a bit MASK: OR over the ranks, exactly as the device
+    # controller combines them (k_control_gathered) - a max would let rank A (bit 0) and rank B (bit 2) derive different
+    # statuses from the same totals and part ways in the next collective
+    flags = 0
+    for v in gathered[:, 5].tolist():
+        flags |= int(v) if v > 0 else 0
+    total[5] = float(flags)
     return total
 
 
@@ -336,13 +342,9 @@ class HipWindowBackend:
         n = self.ctx.N
         x = torch.empty((n, N_ACTIVE), dtype=torch.float64, device=self.device)
         self._c(lib().acino_fte_copy_frames, 0, 0, 0, n, ptr(x), stream_ptr())
-        levels = int(self.ctx.params.bcr_levels) + 1
-        if int(self.ctx.params.bcr_levels) == 0 or levels >= fte.solver_plan(self.ctx.params)["levels"]:
-            levels = 0
+        levels = self.ctx._next_levels()
         self.ctx.close()
-        self.ctx._kw = dict(self.ctx._kw, bcr_levels=levels)
-        self.ctx._kw.pop("trunc_distance", None)
-        self.ctx._create()
+        self.ctx._rebuild_with_levels(levels)      # (refinement sweeps, tolerance and precision travel with the rebuild)
         return x
 
     def _c(self, fn, *args):

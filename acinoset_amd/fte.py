@@ -120,7 +120,7 @@ class FTEContext:
         self.cams = torch.as_tensor(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr), device=dev)
         if self.cams.shape[0] != self.C:
             raise ValueError("camera count mismatch between det and the rig")
-        self._kw = dict(kw)
+        self._kw = self._resolve_defaults(dict(kw))
         self._graph = False
         self._create()
 
@@ -133,14 +133,20 @@ class FTEContext:
     REFINE_SWEEPS = 3
     TRUNC_TOL = 1e-12
 
-    def _create(self):
-        kw = dict(self._kw)
+    @classmethod
+    def _resolve_defaults(cls, kw):
+        """The linear-solver defaults, resolved ONCE and kept in the keyword set every rebuild of the context starts from
+        (an escalation only replaces ``bcr_levels``: refinement sweeps, tolerance and precision travel with it)."""
         pinned = bool(kw.get("pin_left")) or bool(kw.get("pin_right"))
         if "bcr_levels" not in kw and not pinned:
             kw["bcr_levels"] = "auto"
-            kw.setdefault("trunc_distance", self.TRUNC_DISTANCE)
-            kw.setdefault("refine_sweeps", self.REFINE_SWEEPS)
-            kw.setdefault("trunc_tol", self.TRUNC_TOL)
+            kw.setdefault("trunc_distance", cls.TRUNC_DISTANCE)
+            kw.setdefault("refine_sweeps", cls.REFINE_SWEEPS)
+            kw.setdefault("trunc_tol", cls.TRUNC_TOL)
+        return kw
+
+    def _create(self):
+        kw = dict(self._kw)
         auto = kw.get("bcr_levels") == "auto"
         if auto:
             kw["bcr_levels"] = 0
@@ -167,15 +173,24 @@ class FTEContext:
         applied): the same problem with one more reduction level (the complete reduction once the chain is exhausted),
         restarted from the current iterate."""
         x = self.result()[0]
-        levels = int(self.params.bcr_levels) + 1
-        if levels >= solver_plan(self.params)["levels"]:
-            levels = 0
+        levels = self._next_levels()
         self.close()
-        self._kw = dict(self._kw, bcr_levels=levels)
-        self._kw.pop("trunc_distance", None)
-        self._create()
+        self._rebuild_with_levels(levels)
         check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
         return levels
+
+    def _next_levels(self):
+        levels = int(self.params.bcr_levels) + 1
+        if int(self.params.bcr_levels) == 0 or levels >= solver_plan(self.params)["levels"]:
+            levels = 0
+        return levels
+
+    def _rebuild_with_levels(self, levels):
+        """Same problem, same refinement settings / tolerance / precision, another number of reduction levels."""
+        self._kw = dict(self._kw, bcr_levels=levels, refine_sweeps=int(self.params.refine_sweeps) or
+                        int(self._kw.get("refine_sweeps", 0)), trunc_tol=float(self.params.trunc_tol))
+        self._kw.pop("trunc_distance", None)
+        self._create()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -201,6 +216,7 @@ class FTEContext:
         its damping (after a lambda overflow: lam0) and goes back to "running" - used to polish a mixed-precision solve
         with fp64 iterations."""
         check(lib().acino_fte_set_precision(self._h, PRECISIONS[precision]))
+        self._kw["precision"] = precision            # (a later rebuild - escalation - keeps the switched arithmetic)
         check(lib().acino_fte_reevaluate(self._h, stream_ptr()))
 
     def enable_graph(self, on=True):
@@ -216,16 +232,17 @@ class FTEContext:
         check(lib().acino_fte_step(self._h, stream_ptr()))
 
     def solve(self, max_iter):
-        """Up to max_iter LM iterations.  A step the truncated linear solve could not verify (status 7) is never applied:
-        the context is rebuilt with one more reduction level and the solve continues from the current iterate."""
+        """Up to max_iter LM iterations IN TOTAL.  A step the truncated linear solve could not verify (status 7) is never
+        applied: the context is rebuilt with one more reduction level and the solve continues from the current iterate
+        (the rebuilt controller starts from lam0 again); a refusal that uses up the last iteration is returned as status 7."""
         st = FteState()
         done = 0
         while True:
-            check(lib().acino_fte_solve(self._h, max(int(max_iter) - done, 1), C.byref(st), stream_ptr()))
+            check(lib().acino_fte_solve(self._h, max(int(max_iter) - done, 0), C.byref(st), stream_ptr()))
             info = st.as_dict()
             info["iter"] += done
-            if info["status"] != 7:
-                info["bcr_levels"] = int(self.params.bcr_levels)
+            info["bcr_levels"] = int(self.params.bcr_levels)
+            if info["status"] != 7 or info["iter"] >= int(max_iter):
                 return info
             done = info["iter"]
             self._escalate()

@@ -176,8 +176,12 @@ typedef struct acino_fte_params {
                             * reduction over the whole chain (the round-1/2 solver).  With chunking, bcr_levels counts
                             * reduction levels of the SEPARATOR chain. */
   int32_t refine_sweeps;   /* incomplete reduction (bcr_levels > 0): block-Jacobi sweeps that re-introduce the dropped
-                            * couplings after the truncated solve (0 = none).  r sweeps leave a relative energy-norm error
-                            * <= (2 eps)^(r+1) / (1 - 2 eps); that bound - not eps itself - is what trunc_tol is compared with. */
+                            * couplings after the truncated solve (0 = none).  In theory r sweeps leave a relative
+                            * energy-norm error <= (2 eps)^(r+1) / (1 - 2 eps).  What the device CHECKS against trunc_tol with
+                            * r > 0 is an a-posteriori estimate from the sweeps themselves (eps is not measured then):
+                            * rho / (1 - rho) * max|last update| / max|x| with rho = ratio of the max-norms of the last two
+                            * updates (r = 1: rho = 1/2 assumed); rho > 1/2, or an update after a sweep that changed nothing,
+                            * refuses the step (status 7).  The estimate is written to acino_fte_state::trunc_eps. */
 } acino_fte_params;
 #define ACINO_PREC_F64 0
 #define ACINO_PREC_BF16_ROWS 1
@@ -197,7 +201,8 @@ typedef struct acino_fte_state {
   int32_t n_behind;        /* weighted detections with z_cam < 1e-6 (kept, as the reference)  */
   int32_t last_accept;
   int32_t pad0, pad1;
-  double trunc_eps;        /* incomplete reduction: measured size of the dropped couplings in the last iteration (0: complete) */
+  double trunc_eps;        /* incomplete reduction: what was compared with trunc_tol in the last iteration - the measured
+                            * size of the dropped couplings, or (refine_sweeps > 0) the sweeps' error estimate (0: complete) */
 } acino_fte_state;
 
 typedef struct acino_fte_ctx acino_fte_ctx;   /* opaque host handle */
@@ -257,12 +262,15 @@ int acino_fte_get_grad_hess(acino_fte_ctx* ctx, double* d_g, double* d_h, void* 
 #define ACINO_PROF_CLASSES 17
 int acino_fte_profile_begin(acino_fte_ctx* ctx);
 /* Test aid: copies an internal buffer of the linear solver to d_out (at most n doubles).  what: 0 = the solution vector
- * per 3-frame node [n_nodes][80] (after acino_fte_backsub_local), 1..5 = separator-side buffers of the chunked solver
- * (D, b, coupling blocks, left-run contributions), 6 / 7 = G_k and T_k^T of the interior nodes. */
+ * per 3-frame node [n_nodes][80] (after acino_fte_backsub_local); separator-side buffers of the chunked solver: 1 = D,
+ * 2 = b, 3 = coupling blocks, 4 = left-run contributions AL (5 is not assigned: ACINO_ERR_INVALID_ARG); 6 = G_k of the
+ * interior nodes (lower 16 x 16 tiles), 7 = f_k = F_k x_L, [80] per interior node (T_k is not stored). */
 int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n, void* stream);
-/* Debug aid: phase timestamps (wall_clock64 ticks) of ONE workgroup of the elimination kernel -> d_dbg[0..28] of a
- * caller buffer of 64 entries (the chunk sweep stamps up to [63]); the caller sets d_dbg[29] = workgroup index and d_dbg[30] = reduction level to stamp
- * (read by every launch while enabled).  NULL disables. */
+/* Debug aid: phase timestamps (wall_clock64 ticks) of ONE workgroup of the elimination kernel / the chunk sweep ->
+ * d_dbg[0..63] of a caller buffer of ACINO_DEBUG_STAMP_ENTRIES (72) int64 entries; the caller sets d_dbg[64] = workgroup
+ * index and d_dbg[65] = reduction level (k_bcr_elim) or node of the run (k_chunk_sweep) to stamp (read by every launch
+ * while enabled).  NULL disables. */
+#define ACINO_DEBUG_STAMP_ENTRIES 72
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg);
 int acino_fte_profile_end(acino_fte_ctx* ctx, double* ms_by_class, int* launches_by_class, int64_t* units_by_class,
                           void* stream);

@@ -9,14 +9,14 @@ from acinoset_amd._lib import lib, ptr, check
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 seq = synth.make_sequence(n, "loop"); det = seq["det"]
 x0 = fte.triangulation_init(det, seq["K"], seq["D"], seq["R"], seq["t"], 0.5)
-ctx = fte.FTEContext(det, seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0)
+ctx = fte.FTEContext(det, seq["K"], seq["D"], seq["R"], seq["t"], seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, chunk_nodes=-1)   # (k_bcr_elim levels: the whole-chain solver)
 ctx.set_x(x0[:, fte.ACTIVE])
-dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(72, dtype=torch.int64, device="cuda")
 check(lib().acino_fte_debug_stamps(ctx._h, ptr(dbg)))
 names = ["load / build", "chol80", "wave 0: two W_l strips (coalesced B operand)", "wave 0: one W_r strip (transposed B operand) [level 0: z and G]", "store"]
 for level in (0, 1, 2, 3):
     for wg in (0, 100, 700):
-        dbg.zero_(); dbg[29] = wg; dbg[30] = level
+        dbg.zero_(); dbg[64] = wg; dbg[65] = level
         for _ in range(2): ctx.step()
         torch.cuda.synchronize()
         d = dbg.cpu().numpy()

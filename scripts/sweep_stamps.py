@@ -15,9 +15,9 @@ c = fte.FTEContext(det, *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lam
 c.set_x(x0)
 for _ in range(3):
     c.step()
-dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
-dbg[29] = wg
-dbg[30] = kk
+dbg = torch.zeros(72, dtype=torch.int64, device="cuda")
+dbg[64] = wg
+dbg[65] = kk
 check(lib().acino_fte_debug_stamps(c._h, ptr(dbg)))
 c.step()
 torch.cuda.synchronize()

@@ -175,3 +175,16 @@ def test_windowed_driver_matches_single_process_oracle(tmp_path, world, halo):
     pos = fk.cheetah_fk(prob.full_state(x))
     pos_o = fk.cheetah_fk(prob.full_state(xo))
     assert np.abs(pos - pos_o).max() < 1e-3                                                # north-star tolerance, metres
+
+
+def test_combine_partials_ors_the_numeric_flag_mask():
+    """Slot 5 of the per-rank sums is a bit mask (bit 0 pivot, 1 sync timeout, 2 truncation).  The host combination must be
+    the device's (k_control_gathered ORs): with a max, rank A (bit 0) and rank B (bit 2) would see 4, derive statuses 5 and
+    7, and part ways in the next collective (round-3 advisor finding)."""
+    sys.path.insert(0, ROOT)
+    from acinoset_amd import dist as adist
+    g = torch.zeros(3, 8, dtype=torch.float64)
+    g[:, 0] = torch.tensor([1.0, 2.0, 3.0])
+    g[0, 5], g[1, 5], g[2, 5] = 1.0, 4.0, 0.0
+    tot = adist.combine_partials(g)
+    assert tot[5].item() == 5.0 and tot[0].item() == 6.0
