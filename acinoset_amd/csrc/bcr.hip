@@ -218,7 +218,7 @@ __device__ __forceinline__ void deep_row_tile(const double* Lm, const double (&b
 }
 __global__ void __launch_bounds__(256, 2)
 k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, const int* __restrict__ status, int T,
-                int extra, int nx, int per, int total) {
+                int extra, int nx, int per, int total, const double* __restrict__ AL) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Lm = reinterpret_cast<double*>(smem_raw);
@@ -236,9 +236,42 @@ k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, con
   const size_t MB = (size_t)BS * BS;
   double bv[20];
   if (g < T) deep_strip_operands(ch, i, l, r, g, bv, li, lk);       // first strip: in flight during the factorisation
+  // level 0 of the chunked solver's separator chain: D_i and b_i still lack the contribution AL of the run on the node's
+  // right (lower tiles, rows / columns < 75; row 79 = its update of b) - added here instead of by a launch of its own
+  constexpr int NQA = (LOWER_ITEMS + 255) / 256;
+  double2 av[NQA];
+  double ab = 0.0;
+  if (AL) {
+    const double* A = AL + i * MB;
+#pragma unroll
+    for (int k = 0; k < NQA; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < LOWER_ITEMS) {
+        int rr, cc;
+        lower_item(idx, rr, cc);
+        av[k] = *reinterpret_cast<const double2*>(A + rr * BS + cc);
+      }
+    }
+    if (tid < 3 * NP) ab = A[(size_t)(BS - 1) * BS + tid];
+  }
   load_mat(Lm, ch.D + i * MB, tid);
-  if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid];
+  if (tid < BS) yv[tid] = ch.b[(size_t)i * BS + tid] + ab;
   __syncthreads();
+  if (AL) {
+#pragma unroll
+    for (int k = 0; k < NQA; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < LOWER_ITEMS) {
+        int rr, cc;
+        lower_item(idx, rr, cc);
+        if (rr < 3 * NP) {
+          if (cc < 3 * NP) Lm[rr * LD + cc] += av[k].x;
+          if (cc + 1 < 3 * NP) Lm[rr * LD + cc + 1] += av[k].y;
+        }
+      }
+    }
+    __syncthreads();
+  }
   chol80(Lm, tid, g == g_store ? numeric_err : nullptr);
   for (int sidx = g; sidx < 10 && g < T; sidx += T) {
     if (sidx != g) deep_strip_operands(ch, i, l, r, sidx, bv, li, lk);
@@ -471,7 +504,7 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
 // LDS buffers, the D_j tile is requested with them and only added at the end.  grid = n_remain * 2 * S.
 __global__ void __launch_bounds__(256)
 k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __restrict__ status, int S, int nx, int per,
-                  int total) {
+                  int total, const double* __restrict__ AL) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Wb = reinterpret_cast<double*>(smem_raw);
@@ -488,7 +521,7 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   const size_t MB = (size_t)BS * BS;
   if (role == 2) {   // b_j -= W_r(im)^T y(im) + W_l(ip)^T y(ip), straight from HBM: thread (column, third of the rows),
                      // lanes along a row of W (coalesced); keeps this mat-vec off the tile workgroups' critical path
-    if (im < 0 && ip < 0) return;
+    if (im < 0 && ip < 0 && !AL) return;
     if (tid < BS) {
       yv[tid] = im >= 0 ? ch.b[(size_t)im * BS + tid] : 0.0;
       yv2[tid] = ip >= 0 ? ch.b[(size_t)ip * BS + tid] : 0.0;
@@ -513,11 +546,14 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
       ysc[tid] = s0 + s1;
     }
     __syncthreads();
-    if (tid < BS) ch.b[(size_t)j * BS + tid] -= ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    // (AL: row 79 of the right run's contribution is its update of b_j - see k_bcr_elim_deep)
+    if (tid < BS)
+      ch.b[(size_t)j * BS + tid] = ch.b[(size_t)j * BS + tid] - (ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid]) +
+                                   ((AL && tid < 3 * NP) ? AL[j * MB + (size_t)(BS - 1) * BS + tid] : 0.0);
     return;
   }
   if (role == 0) {
-    if (im < 0 && ip < 0) return;
+    if (im < 0 && ip < 0 && !AL) return;
     double* Dj = ch.D + j * MB;
     d4 dt[4];
 #pragma unroll
@@ -526,8 +562,24 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
       if (t < 15) {
         const int ib = tri_i(t), jb = tri_j(t);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dt[q][rr] = Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li];
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r_ = ib * 16 + lk + 4 * rr, c_ = jb * 16 + li;
+          dt[q][rr] = Dj[r_ * BS + c_];
+          if (AL && r_ < 3 * NP && c_ < 3 * NP) dt[q][rr] += AL[j * MB + (size_t)r_ * BS + c_];
+        }
       }
+    }
+    if (im < 0 && ip < 0) {          // (no eliminated neighbour: only the run's contribution is added)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = sub + S * (wave + 4 * q);
+        if (t < 15) {
+          const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Dj[(ib * 16 + lk + 4 * rr) * BS + jb * 16 + li] = dt[q][rr];
+        }
+      }
+      return;
     }
     const bool both = im >= 0 && ip >= 0;
     if (both) load_mat2(Wb, ch.Wr + im * MB, Wb2, ch.Wl + ip * MB, tid);
@@ -1108,6 +1160,249 @@ __global__ void k_bcr_refine_copy(BcrChain ch, const int* __restrict__ iso, cons
   if (threadIdx.x < BS) ch.b[(size_t)iso[3 * blockIdx.x] * BS + threadIdx.x] = src[(size_t)blockIdx.x * BS + threadIdx.x];
 }
 
+// ---- the whole back-substitution of a truncated + refined reduction as ONE launch -------------------------------------
+// (separator chain of the chunked solver: <= ~240 nodes, every kernel of it a latency chain.)  What were 2 + r + K launches
+// - truncated solve of the isolated nodes, r block-Jacobi sweeps, K back-substitution levels, each re-reading its three
+// 51 KB matrices - is one workgroup per node that loads its matrices ONCE into LDS and then only trades 80-double vectors
+// with its neighbours through memory:
+//   isolated node p (blocks 0 .. n_iso-1):  x0 = U y;  sweep s = 1..r:  x(s) = x0 - U U^T (C_l x_l(s-1) + C_r x_r(s-1));
+//     version s of the node's iterate goes to xbuf[s & 1][p] and is announced by ver[p] = s + 1 (release, agent scope); a
+//     neighbour writes version s only after it has read this node's version s - 1, so two buffers suffice.
+//   node i of level k < K (blocks after them, deepest level first):  x_i = U (y_i - W_l x_l - W_r x_r) once done[l], done[r].
+// Isolated workgroups wait for EACH OTHER, so all n_iso of them must be resident together: one per CU (156 KB of LDS), the
+// lowest block indices of the launch - the host only uses this kernel for n_iso <= 128 on a GPU that is not shared
+// (acino_fte_params::shared_gpu = 0); every other workgroup waits for lower block indices only.  Waits are bounded polls
+// (as in k_bcr_backsub_tail): a timeout flags the step (numeric_err bit 1 -> status 6) and lets the launch drain.
+// The flags are zeroed by the consumer that follows (k_chunk_backsub), i.e. before the next launch of this kernel.
+constexpr int ST_T = 512, ST_P = ST_T / BS, ST_W = (BS + ST_P - 1) / ST_P, ST_V = (BS * BS / 2 + ST_T - 1) / ST_T;
+struct SepTailArgs {
+  const int* iso;        // [n_iso][3] entries of the isolated level (node, -1, -1)
+  int n_iso, refine;
+  int n_lv;              // regular levels below the isolated one
+  int lv_off[12];        // elim-entry offset of level K-1, K-2, ... 0
+  int lv_cnt[12];
+  int* ver;              // [n_iso]
+  int* done;             // [n_nodes]
+  double* xbuf;          // [2][n_iso][80]
+  double* norms;         // [4][n_iso]: |update|, |x| of the last sweep; the same of the sweep before it
+};
+__device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_err) {
+  long long polls = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++polls > (1ll << 22)) {
+      if (numeric_err) atomicOr(numeric_err, 2);
+      break;
+    }
+  }
+}
+__global__ void __launch_bounds__(ST_T)
+k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __restrict__ numeric_err) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* Ml = reinterpret_cast<double*>(smem_raw);
+  double* Mr = Ml + MAT;
+  double* Mu = Mr + MAT;
+  double* xl = Mu + MAT;          // [80] each
+  double* xr = xl + BS;
+  double* tv = xr + BS;
+  double* part = tv + BS;         // [ST_P][80]
+  const int tid = threadIdx.x;
+  const size_t MB = (size_t)BS * BS;
+  const int row = tid % BS, pr = tid / BS, k0 = ST_W * pr, k1 = min(k0 + ST_W, BS);
+  auto row_sum = [&](int r) {     // the ST_P partial sums of row r, fixed order
+    double v = part[r];
+#pragma unroll
+    for (int q = 1; q < ST_P; ++q) v += part[q * BS + r];
+    return v;
+  };
+  auto load3 = [&](const double* m0, const double* m1, const double* m2) {   // all three matrices in flight before the first LDS write
+    const double2* s0 = reinterpret_cast<const double2*>(m0);
+    const double2* s1 = reinterpret_cast<const double2*>(m1);
+    const double2* s2 = reinterpret_cast<const double2*>(m2);
+    double2 v0[ST_V], v1[ST_V], v2[ST_V];
+#pragma unroll
+    for (int k = 0; k < ST_V; ++k) {
+      const int idx = tid + ST_T * k;
+      if (idx < BS * BS / 2) {
+        v0[k] = m0 ? s0[idx] : make_double2(0.0, 0.0);
+        v1[k] = m1 ? s1[idx] : make_double2(0.0, 0.0);
+        v2[k] = s2[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ST_V; ++k) {
+      const int idx = tid + ST_T * k;
+      if (idx < BS * BS / 2) {
+        const int e = 2 * idx, rr = e / BS, c = e % BS;
+        Ml[rr * LD + c] = v0[k].x;  Ml[rr * LD + c + 1] = v0[k].y;
+        Mr[rr * LD + c] = v1[k].x;  Mr[rr * LD + c + 1] = v1[k].y;
+        Mu[rr * LD + c] = v2[k].x;  Mu[rr * LD + c + 1] = v2[k].y;
+      }
+    }
+  };
+  // x = U t (U upper triangular, t in tv) -> value of row tid for tid < 80 (two barriers inside)
+  auto upper_matvec = [&]() {
+    if (tid < ST_P * BS) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < ST_W; ++q) {
+        const bool on = k0 + q >= row && k0 + q < k1;
+        const int k = on ? k0 + q : row;
+        s += (on ? 1.0 : 0.0) * Mu[row * LD + k] * tv[k];
+      }
+      part[tid] = s;
+    }
+    __syncthreads();
+    const double v = tid < BS ? row_sum(tid) : 0.0;
+    __syncthreads();
+    return v;
+  };
+  if ((int)blockIdx.x < a.n_iso) {
+    // ---------------- isolated node: truncated solve + refinement sweeps ----------------
+    const int p = blockIdx.x, n_iso = a.n_iso;
+    const int j = a.iso[3 * p], l = p > 0 ? a.iso[3 * (p - 1)] : -1, r = p + 1 < n_iso ? a.iso[3 * (p + 1)] : -1;
+    load3(l >= 0 ? ch.Cpl + (size_t)l * MB : nullptr, r >= 0 ? ch.Cpl + (size_t)j * MB : nullptr, ch.U + (size_t)j * MB);
+    if (tid < BS) tv[tid] = ch.b[(size_t)j * BS + tid];         // y_j = U^T b_j (written by the reduction)
+    __syncthreads();
+    const double x0 = upper_matvec();                            // truncated solve
+    double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0;
+    double* xb0 = a.xbuf;
+    double* xb1 = a.xbuf + (size_t)n_iso * BS;
+    if (a.refine > 0) {
+      if (tid < BS) xb0[(size_t)p * BS + tid] = x0;
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.ver + p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int s = 1; s <= a.refine; ++s) {
+      const double* src = (s - 1) & 1 ? xb1 : xb0;
+      double* dst = s & 1 ? xb1 : xb0;
+      if (tid == 0) {
+        if (l >= 0) st_wait(a.ver + p - 1, s, numeric_err);
+        if (r >= 0) st_wait(a.ver + p + 1, s, numeric_err);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      if (tid < BS) {
+        xl[tid] = l >= 0 ? __builtin_nontemporal_load(src + (size_t)(p - 1) * BS + tid) : 0.0;
+        xr[tid] = r >= 0 ? __builtin_nontemporal_load(src + (size_t)(p + 1) * BS + tid) : 0.0;
+      }
+      __syncthreads();
+      if (tid < ST_P * BS) {         // t = block(j, l) x_l + block(j, r) x_r ;  block(j, r) = Cpl[j]^T
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < ST_W; ++q) {
+          const int k = k0 + (k0 + q < k1 ? q : 0);
+          const double w = k0 + q < k1 ? 1.0 : 0.0;
+          s0 += w * Ml[row * LD + k] * xl[k];
+          s1 += w * Mr[k * LD + row] * xr[k];
+        }
+        part[tid] = s0 + s1;
+      }
+      __syncthreads();
+      if (tid < BS) tv[tid] = row_sum(tid);
+      __syncthreads();
+      if (tid < ST_P * BS) {         // w = U^T t  (rows <= column)
+        double sm = 0.0;
+        const int c1 = min(k1, row + 1);
+#pragma unroll
+        for (int q = 0; q < ST_W; ++q) {
+          const bool on = k0 + q < c1;
+          const int k = k0 + (on ? q : 0);
+          sm += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+        }
+        part[tid] = sm;
+      }
+      __syncthreads();
+      const double w = tid < BS ? row_sum(tid) : 0.0;
+      __syncthreads();
+      if (tid < BS) tv[tid] = w;
+      __syncthreads();
+      const double d = upper_matvec();                           // d = U w
+      if (tid < BS) {
+        const double x = x0 - d;
+        dabs_prev = dabs;
+        xabs_prev = xabs;
+        dabs = fabs(x - xcur);
+        xabs = fabs(x);
+        xcur = x;
+        if (s < a.refine) dst[(size_t)p * BS + tid] = x;
+      }
+      if (s < a.refine) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.ver + p, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (tid < BS) ch.b[(size_t)j * BS + tid] = xcur;
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.done + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.norms && a.refine > 0) {            // (waves 0 and 1 hold the 80 rows)
+      for (int off = 32; off > 0; off >>= 1) {
+        dabs = fmax(dabs, __shfl_down(dabs, off, 64));
+        xabs = fmax(xabs, __shfl_down(xabs, off, 64));
+        dabs_prev = fmax(dabs_prev, __shfl_down(dabs_prev, off, 64));
+        xabs_prev = fmax(xabs_prev, __shfl_down(xabs_prev, off, 64));
+      }
+      if ((tid & 63) == 0 && tid < 128) {
+        double* q4 = part + 4 * (tid >> 6);
+        q4[0] = dabs;
+        q4[1] = xabs;
+        q4[2] = dabs_prev;
+        q4[3] = xabs_prev;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        a.norms[p] = fmax(part[0], part[4]);
+        a.norms[n_iso + p] = fmax(part[1], part[5]);
+        if (a.refine >= 2) {
+          a.norms[2 * n_iso + p] = fmax(part[2], part[6]);
+          a.norms[3 * n_iso + p] = fmax(part[3], part[7]);
+        }
+      }
+    }
+    return;
+  }
+  // ---------------- node of a regular level ----------------
+  int q = (int)blockIdx.x - a.n_iso, lvl = 0;
+  while (lvl < a.n_lv && q >= a.lv_cnt[lvl]) q -= a.lv_cnt[lvl++];
+  if (lvl >= a.n_lv) return;
+  const int* en = ch.d_elim + 3 * (a.lv_off[lvl] + q);
+  const int i = en[0], l = en[1], r = en[2];
+  load3(l >= 0 ? ch.Wl + (size_t)i * MB : nullptr, r >= 0 ? ch.Wr + (size_t)i * MB : nullptr, ch.U + (size_t)i * MB);
+  const double yi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;
+  if (tid == 0) {
+    if (l >= 0) st_wait(a.done + l, 1, numeric_err);
+    if (r >= 0) st_wait(a.done + r, 1, numeric_err);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (tid < BS) {
+    xl[tid] = l >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)l * BS + tid) : 0.0;
+    xr[tid] = r >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)r * BS + tid) : 0.0;
+  }
+  __syncthreads();
+  if (tid < ST_P * BS) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int qq = 0; qq < ST_W; ++qq) {
+      const int k = k0 + (k0 + qq < k1 ? qq : 0);
+      const double w = k0 + qq < k1 ? 1.0 : 0.0;
+      s0 += w * Ml[row * LD + k] * xl[k];
+      s1 += w * Mr[row * LD + k] * xr[k];
+    }
+    part[tid] = s0 + s1;
+  }
+  __syncthreads();
+  const double t = tid < BS ? yi - row_sum(tid) : 0.0;
+  __syncthreads();
+  if (tid < BS) tv[tid] = t;
+  __syncthreads();
+  const double x = upper_matvec();
+  if (tid < BS) ch.b[(size_t)i * BS + tid] = x;
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(a.done + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- host side ------------------------------------------------------------------------------
 void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, int refine_sweeps) {
   refine = 0;
@@ -1240,6 +1535,8 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTruncCheckLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bcr_refine),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep_tail),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
   return ACINO_OK;
 }
 
@@ -1272,11 +1569,19 @@ static bool dbg_check(const char* what, int level, const BcrChain& ch, const int
   return e != 0 || nan_d || nan_b;
 }
 
+bool bcr_level0_adds_al(const BcrSchedule& sch) {
+  if (sch.levels.empty() || getenv("ACINO_SEP_COMBINE")) return false;
+  const BcrLevel& lv = sch.levels[0];
+  // (every node of the chain must pass through exactly one of the two narrow-level kernels at level 0)
+  return !lv.isolated && lv.n_elim <= 128 && lv.n_remain <= 128;
+}
+
 int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof) {
   static const bool dbg = getenv("ACINO_DEBUG_SYNC") != nullptr;
   bool dbg_hit = false;
   int level = 0;
+  const bool add_al = ch.AL0 != nullptr && bcr_level0_adds_al(sch);
   for (const BcrLevel& lv : sch.levels) {
     {
       const bool fused0 = level == 0 && ch.st != nullptr;
@@ -1302,7 +1607,8 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
         const int extra = (!lv.isolated && lv.n_elim * (T + 1) <= 256) ? 1 : 0;
         const int total = lv.n_elim * (T + extra), nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
         hipLaunchKernelGGL(k_bcr_elim_deep, dim3(8 * per), dim3(256), kElimDeepLds, s, ch,
-                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, extra, nx, per, total);
+                           ch.d_elim + 3 * lv.elim_off, d_numeric_err, d_status, T, extra, nx, per, total,
+                           (level == 0 && add_al) ? ch.AL0 : (const double*)nullptr);
       } else
         hipLaunchKernelGGL(k_bcr_elim, dim3(lv.n_elim), dim3(256), kElimLds, s, ch, ch.d_elim + 3 * lv.elim_off,
                            d_c, d_numeric_err, d_status, level);
@@ -1320,7 +1626,8 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
           const int S = lv.n_remain <= 32 ? 4 : (lv.n_remain <= 64 ? 2 : 1);
           const int total = (2 * S + 1) * lv.n_remain, nx = std::min(8, (total + 31) / 32), per = (total + nx - 1) / nx;
           hipLaunchKernelGGL(k_bcr_update_deep, dim3(8 * per), dim3(256), kUpdateDeepLds, s, ch,
-                             ch.d_remain + 4 * lv.remain_off, d_status, S, nx, per, total);
+                             ch.d_remain + 4 * lv.remain_off, d_status, S, nx, per, total,
+                             (level == 0 && add_al) ? ch.AL0 : (const double*)nullptr);
         } else
           hipLaunchKernelGGL(k_bcr_update, dim3(3 * lv.n_remain), dim3(256), kUpdateLds, s, ch,
                              ch.d_remain + 4 * lv.remain_off, d_c, d_status, level);
@@ -1342,6 +1649,32 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof, int* d_numeric_err) {
   int top = (int)sch.levels.size() - 1;
+  if (sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf && ch.st_flags && top <= 12 &&
+      sch.levels[top].n_elim <= 128) {
+    // one launch for the truncated solve, the sweeps and every level above them (k_sep_tail)
+    const BcrLevel& iso = sch.levels[top];
+    SepTailArgs a;
+    a.iso = ch.d_elim + 3 * iso.elim_off;
+    a.n_iso = iso.n_elim;
+    a.refine = sch.refine;
+    a.n_lv = top;
+    int blocks = iso.n_elim;
+    for (int k = top - 1, q = 0; k >= 0; --k, ++q) {
+      a.lv_off[q] = sch.levels[k].elim_off;
+      a.lv_cnt[q] = sch.levels[k].n_elim;
+      blocks += sch.levels[k].n_elim;
+    }
+    a.ver = ch.st_flags;
+    a.done = ch.st_flags + iso.n_elim;
+    a.xbuf = ch.refine_buf + (size_t)iso.n_elim * BS;
+    a.norms = ch.trunc_eps2;
+    {
+      ProfSpan sp(prof, PC_REFINE, s, blocks);
+      hipLaunchKernelGGL(k_sep_tail, dim3(blocks), dim3(ST_T), kBacksubTailLds, s, ch, a, d_status, d_numeric_err);
+    }
+    ACINO_LAUNCH_CHECK();
+    return ACINO_OK;
+  }
   if (sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf) {
     // truncated solve of the isolated nodes, then the block-Jacobi sweeps over their dropped couplings
     const BcrLevel& lv = sch.levels[top];

@@ -51,6 +51,9 @@ struct BcrChain {
   int n_pairs = 0;
   double* trunc_eps2 = nullptr;   // ... and [n_pairs] squared Frobenius norms of L_b^-1 C L_a^-T, written every reduction
   double* refine_buf = nullptr;   // [3][n_isolated][80] x0 and the two iterates of the refinement sweeps
+  const double* AL0 = nullptr;    // separator chain of the chunked solver: [n][80][80] left-run contributions (lower tiles; row 79:
+                                  // the update of b), added to D / b by the LEVEL-0 kernels of the reduction when set
+  int* st_flags = nullptr;        // k_sep_tail: [n_isolated] iterate versions, then [n_nodes] done flags (null: per-level kernels)
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
   long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
   // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build
@@ -66,5 +69,8 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof = nullptr, int* d_numeric_err = nullptr);
 int bcr_set_func_attributes();
+// true when level 0 of the schedule runs the narrow-level kernels, which can add the chunk sweep's left-run contributions
+// (BcrChain::AL0) themselves - no k_sep_combine launch
+bool bcr_level0_adds_al(const BcrSchedule& sch);
 
 }  // namespace acino

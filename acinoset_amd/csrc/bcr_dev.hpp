@@ -13,6 +13,16 @@ __device__ __forceinline__ int tri_j(int t) {
   return t - (i * (i + 1)) / 2;
 }
 
+// The 15 lower 16x16 tiles of an 80 x 80 row-major matrix as 1920 two-double items: item idx -> (row, even column).
+// Tile row ib holds 16 rows of 8 (ib + 1) items each; cumulative item counts 0, 128, 384, 768, 1280, 1920.
+constexpr int LOWER_ITEMS = 1920;
+__device__ __forceinline__ void lower_item(int idx, int& row, int& col) {
+  const int ib = (idx >= 128) + (idx >= 384) + (idx >= 768) + (idx >= 1280);
+  const int rem = idx - 64 * ib * (ib + 1), w = 8 * (ib + 1);      // 64 ib (ib + 1) = items in the tile rows above
+  row = 16 * ib + rem / w;
+  col = 2 * (rem % w);
+}
+
 // Damped Gauss-Newton block of chain node t, built in LDS (leading dimension LD) straight from the
 // assembly's H/g (no set-up pass through HBM): D = H_gn + lam*diag(H_gn), bound-active variables
 // pinned by a 2^70 diagonal boost, identity on padding / non-existent frames; bv = -g (0 where pinned).

@@ -62,16 +62,6 @@ __device__ __forceinline__ void tile_store(double* M, int ib, int jb, const d4& 
   for (int rr = 0; rr < 4; ++rr) M[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = a[rr];
 }
 
-// The 15 lower 16x16 tiles of an 80 x 80 row-major matrix as 1920 two-double items: item idx -> (row, even column).
-// Tile row ib holds 16 rows of 8 (ib + 1) items each; cumulative item counts 0, 128, 384, 768, 1280, 1920.
-constexpr int LOWER_ITEMS = 1920;
-__device__ __forceinline__ void lower_item(int idx, int& row, int& col) {
-  const int ib = (idx >= 128) + (idx >= 384) + (idx >= 768) + (idx >= 1280);
-  const int rem = idx - 64 * ib * (ib + 1), w = 8 * (ib + 1);      // 64 ib (ib + 1) = items in the tile rows above
-  row = 16 * ib + rem / w;
-  col = 2 * (rem % w);
-}
-
 // LDS of the sweep kernel: three 80 x 81 matrices (U_k | D~_k+1 -> U_k+1 | spike) + tables = 160.5 KB, one workgroup per CU.
 constexpr int SW_VEC = 18 * NP + BS + 8 + 8 + 3 * NP + 64;   // cL cR | bv | red | sync | kq klo khi | debug stamps
 static constexpr size_t kSweepLds = (3 * MAT + SW_VEC) * sizeof(double);
@@ -646,6 +636,9 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
       }
       double* Ag = sp.AL + (size_t)(hasL ? opaque(c - 1) : 0) * MB;   // (global address space kept: no pointer through asm)
       // the left separator's update so far (HBM / L2, owned by this workgroup): requested now, needed after W
+      // (kept in memory between nodes, not in registers: measured in round 4 - the register form runs the sweep in 303.0 us
+      //  against 303.7 us, the load is hidden behind the W strip - and memory does not depend on how the register allocator
+      //  treats values that live across the lane-masked regions of the serial part; NOTES_perf.md)
       if (hasL) syrk_load_n<3>(accL, Ag, k > 0, sib, sjb, li, lk);
       {
         d4 wacc[NT];
@@ -871,6 +864,8 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
     for (int q = 1; q < BK_P; ++q) v += ysc[q * BS + r];
     return v;
   };
+  if (c == 0 && sp.flags)                               // (k_sep_tail's hand-off flags: clean for the next iteration)
+    for (int e = tid; e < sp.n_flags; e += BK_T) sp.flags[e] = 0;
   if (tid < BS) {
     xl[tid] = hasL ? sp.b[(size_t)(c - 1) * BS + tid] : 0.0;
     const double xr = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
@@ -997,12 +992,16 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;
-  {
+  BcrChain sc = sepch;
+  sc.AL0 = nullptr;
+  if (bcr_level0_adds_al(sepsch)) {
+    sc.AL0 = sp.AL;                  // level 0 of the reduction adds the runs' contributions itself
+  } else {
     ProfSpan span(prof, PC_SEP_COMBINE, s, pl.n_sep);
     hipLaunchKernelGGL(k_sep_combine, dim3(pl.n_sep), dim3(256), 0, s, sp, d_status);
   }
   ACINO_LAUNCH_CHECK();
-  return bcr_reduce(sepch, sepsch, d_c, d_numeric_err, d_status, s, prof);
+  return bcr_reduce(sc, sepsch, d_c, d_numeric_err, d_status, s, prof);
 }
 
 int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, const BcrChain& sepch,

@@ -19,8 +19,11 @@ struct ChunkPlan {
 struct SepView {
   double* D;    // [80][80] built node - (right end of the run on its left)          -> + AL by k_sep_combine
   double* Cpl;  // [80][80] block(separator q + 1, separator q)
-  double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles; row 79: its update of b (aliases the chain's Wr)
+  double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles; row 79: its update of b.  An array of its
+                // own: level 0 of the separator reduction reads it while sibling workgroups already write W_l / W_r
   double* b;    // [80]
+  int* flags = nullptr;   // the hand-off flags of k_sep_tail, zeroed again by k_chunk_backsub (n_flags ints; may be null)
+  int n_flags = 0;
 };
 
 // The trial iterate folded into the back-substitution (what k_trial does for the other solvers): the run that solves a node

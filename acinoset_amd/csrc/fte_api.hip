@@ -26,6 +26,8 @@ struct Buffers {
   int* sched;         // elim (3/entry), remain (4/entry), tail (4/entry), dropped-coupling pairs (2/entry), tail counter
   double* trunc_eps2; // [n_pairs + 1]
   double* refine_buf; // [3][n_isolated][80] (incomplete reduction with refinement sweeps)
+  int* st_flags;      // [n_isolated + n_sep] hand-off flags of k_sep_tail (chunked solver with refinement)
+  int n_st_flags;
 };
 
 }  // namespace acino
@@ -110,6 +112,12 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.trunc_eps2 = c.take<double>(4 * (n_pairs + 1) + 1);   // (refinement: four [n_isolated] arrays of sweep norms)
   b.refine_buf = nullptr;
   if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
+  b.st_flags = nullptr;
+  b.n_st_flags = 0;
+  if (lay.sched.refine > 0 && chunked) {
+    b.n_st_flags = lay.sched.levels.back().n_elim + lay.plan.n_sep;
+    b.st_flags = c.take<int>((size_t)b.n_st_flags);
+  }
   BcrChain chn;
   chn.n_nodes = (int)T;
   chn.D = c.take<double>(T * BS * BS);                       // chunked: G_k of the interior nodes (lower tiles)
@@ -142,6 +150,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
     sc.Wl = c.take<double>(S * BS * BS);
     sc.Wr = c.take<double>(S * BS * BS);
     sc.b = c.take<double>(S * BS);
+    sc.AL0 = c.take<double>(S * BS * BS);   // (the sweep's left-run contributions; handed to the reduction by chunk_reduce)
     sc.implicit_couplings = 0;      // dense couplings, plain (non-fused) kernels
     sc.st = nullptr;
     sc.x0 = sc.x1 = sc.g0 = sc.g1 = sc.H0 = sc.H1 = nullptr;
@@ -702,6 +711,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size(),
                        ctx->sched.pairs.data(), sizeof(int) * ctx->sched.pairs.size(), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
+  if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     set_error("context upload failed: %s", hipGetErrorString(e));
@@ -723,9 +733,15 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     }
     ctx->n_trunc = rc.n_pairs;
     rc.refine_buf = ctx->b.refine_buf;
+    // one persistent launch for the separator chain's back-substitution: its isolated workgroups wait for each other, so it
+    // is kept off GPUs that other spin-waiting kernels may share (shared_gpu: batched clips, several ranks on one device)
+    rc.st_flags = (ctx->plan.active() && !p->shared_gpu && !getenv("ACINO_NO_SEP_TAIL")) ? ctx->b.st_flags : nullptr;
   }
-  if (ctx->plan.active())
-    ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, ctx->sepchain.Wr, ctx->sepchain.b};
+  if (ctx->plan.active()) {
+    ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, const_cast<double*>(ctx->sepchain.AL0), ctx->sepchain.b};
+    ctx->sep.flags = ctx->sepchain.st_flags;
+    ctx->sep.n_flags = ctx->sepchain.st_flags ? ctx->b.n_st_flags : 0;
+  }
   ctx->n_blk_asm = n_assemble_blocks(p->n_frames);
   ctx->n_blk_trial = (int)(((size_t)p->n_frames * NP + 255) / 256);
   ctx->n_pred = ctx->plan.active() ? ctx->plan.n_chunks : ctx->n_blk_trial;
@@ -1301,7 +1317,7 @@ int acino_fte_debug_read(acino_fte_ctx* ctx, int what, double* d_out, int64_t n,
     case 1: src = ctx->sepchain.D; cnt = S * MB; break;
     case 2: src = ctx->sepchain.b; cnt = S * BS; break;
     case 3: src = ctx->sepchain.Cpl; cnt = S * MB; break;
-    case 4: src = ctx->sepchain.Wr; cnt = S * MB; break;
+    case 4: src = ctx->sepchain.AL0; cnt = S * MB; break;
     case 6: src = ctx->chain.D; cnt = T * MB; break;
     case 7: src = ctx->chain.Wl; cnt = ctx->plan.active() ? T * BS : T * MB; break;
     default: ACINO_REQUIRE(false, "what");

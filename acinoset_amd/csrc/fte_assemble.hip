@@ -19,15 +19,21 @@
 
 namespace acino {
 
+// 6 408 B per frame: 8 frames = 51 KB per workgroup, so THREE workgroups share a CU (12 waves: the projection phase is a
+// chain of fp64 transcendentals per thread and lives on latency hiding).  Two arrays share storage with one that is dead
+// by the time they are written: the twists (phase C) take the place of sin / cos (phases A-B), the subtree sums (phase D)
+// are written over the first NGRP rows of the per-marker blocks, column by column by the thread that has just read it.
 struct FrameLds {
   static constexpr bool kHasOm = true;
-  double sc[22][2];       // sin, cos of active angle (index a-3)
+  union {
+    double sc[22][2];     // phases A-B: sin, cos of active angle (index a-3)
+    double xi[22][6];     // phase C on: twist (pivot x omega, omega)
+  };
   double pos[21][3];      // markers 0..19, head = 20
   double om[22][3];       // rotation axis of active angle in the inertial frame
-  double xi[22][6];       // twist (pivot x omega, omega)
-  double lam[NL][27];     // per-marker 6x6 symmetric (21) + wrench (6)
-  double sub[NGRP][27];   // subtree sums
+  double lam[NL][27];     // per-marker 6x6 symmetric (21) + wrench (6); after phase D rows 0..NGRP-1 = subtree sums
 };
+static_assert(NGRP <= NL, "subtree sums are stored over the per-marker blocks");
 
 // index of (i,j), i<=j, in the packed upper triangle of a 6x6
 __device__ __forceinline__ int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
@@ -331,7 +337,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       double s2 = Lm[4][q] + Lm[8][q] + Lm[11][q] + s3 + s6 + s8;
       double s1 = Lm[3][q] + s2;
       double s0 = Lm[0][q] + Lm[1][q] + Lm[2][q] + s1;
-      double(*S)[27] = F[f].sub;
+      double(*S)[27] = F[f].lam;      // in place: column q of this frame is this thread's alone, all 20 reads are done
       S[0][q] = s0; S[1][q] = s1; S[2][q] = s2; S[3][q] = s3; S[4][q] = s4; S[5][q] = s5; S[6][q] = s6;
       S[7][q] = s7; S[8][q] = s8; S[9][q] = s9; S[10][q] = s10; S[11][q] = s11; S[12][q] = s12; S[13][q] = s13;
     }
@@ -358,7 +364,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       }
       const double b0 = band_coef_clip(ng, 0, K.n_global, K.clip_len);
       const int g = c_state_grp[bq];
-      const double* S = F[f].sub[g < 0 ? 0 : g];
+      const double* S = F[f].lam[g < 0 ? 0 : g];   // (subtree sums, written over the per-marker blocks by phase D)
       double xb[6];
       if (bq < 3) {
 #pragma unroll

