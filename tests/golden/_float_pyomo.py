@@ -69,9 +69,15 @@ class VarData(_Num):
 
     def _v(self):
         self.reads += 1
+        if READ_LOG is not None:
+            READ_LOG.append(self)
         return 0.0 if self.value is None else self.value      # Pyomo builds symbolically; an unset Var reads as 0 here
 
     __hash__ = object.__hash__
+
+
+READ_LOG = None          # set to a list to record every VarData that is read (ConstraintList uses it)
+Any = object()           # the `within=Any` domain marker of src/build.py's Params
 
 
 def sin(a): return F(math.sin(_val(a)))
@@ -89,7 +95,7 @@ class _Component:
 
 
 class Param(_Component):
-    def __init__(self, *sets, initialize=None, mutable=False):
+    def __init__(self, *sets, initialize=None, mutable=False, within=None):
         self.sets, self.init, self.data = sets, initialize, {}
 
     def construct(self, model):
@@ -124,6 +130,20 @@ class Constraint(_Component):
     def evaluate(self, model):
         self.data = {idx: self.rule(model, *idx) for idx in itertools.product(*self.sets)}
         return self.data
+
+
+class ConstraintList(_Component):
+    """src/build.py:270-273 adds already-evaluated inequalities one by one: each entry keeps the inequality and the
+    variables that were read while its expression was formed (with READ_LOG enabled)."""
+    def __init__(self):
+        self.entries = []
+
+    def add(self, expr=None):
+        global READ_LOG
+        touched = tuple(READ_LOG) if READ_LOG is not None else ()
+        if READ_LOG is not None:
+            del READ_LOG[:]
+        self.entries.append((expr, touched))
 
 
 class Objective(_Component):

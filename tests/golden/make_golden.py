@@ -21,6 +21,7 @@ Outputs (all DATA: inputs + expected outputs):
   kat34_build_runs.npz     stored IPOPT runs x,dx,ddx,positions + skeletons (KAT-3/4)
   dummy_scene.json    the 6-camera rig (configs/dummy_scene.json is a data file)
   dlc_tables.json     synthetic wide DLC tables -> utils.create_dlc_points_2d_file long table (read_hdf patched)
+  skel_fte_model.npz  build.py's skeleton-driven FTE model text on floats, on the shipped human skeleton / scene / DLC tables
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -324,11 +325,15 @@ def _feasible_objective(ctx, X):
     """obj (:486-500) at the iterate X [N,45] with every equality of :359-399 satisfied through the reference's own
     residuals (each is affine with unit slope in the variable it defines).  Returns (obj, worst equality residual)."""
     m, P, N, L, C, fp = (ctx[k] for k in ("m", "P", "N", "L", "C", "fp"))
+    Ts = getattr(m, ctx.get("ts_attr", "Ts"))
 
     def set_from_residual(comp, idx, var):
         v0 = 0.0 if var.value is None else var.value
         var.value = v0
-        r0 = comp.rule(m, *idx).r
+        first = comp.rule(m, *idx)
+        if first is fp.Constraint.Skip:                # (build.py skips the measurement rows of the marker "neck")
+            return
+        r0 = first.r
         var.value = v0 + 1.0
         slope = comp.rule(m, *idx).r - r0              # +-1 or +-Ts: the constraint is affine in `var`
         var.value = v0 - r0 / slope
@@ -343,9 +348,9 @@ def _feasible_objective(ctx, X):
         for n in range(2, N + 1):
             set_from_residual(m.integrate_p, (n, p), m.dx[n, p])
         # free variables dx_1, ddx_1 chosen so that slack_2 = slack_3 = 0 (the optimum of the free variables)
-        ddx3 = (m.dx[3, p].value - m.dx[2, p].value) / m.Ts
+        ddx3 = (m.dx[3, p].value - m.dx[2, p].value) / Ts
         m.ddx[1, p].value = m.ddx[2, p].value = ddx3
-        m.dx[1, p].value = m.dx[2, p].value - m.Ts * ddx3
+        m.dx[1, p].value = m.dx[2, p].value - Ts * ddx3
         for n in range(3, N + 1):
             set_from_residual(m.integrate_v, (n, p), m.ddx[n, p])
         for n in range(2, N + 1):
@@ -393,6 +398,158 @@ def gen_fte_model():
     np.savez_compressed(os.path.join(OUT, "fte_model.npz"), **out)
     print("fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
           "boxes", int(np.isfinite(lo_b).sum()), names[:3])
+
+
+def _build_lines(lo, hi):
+    """Lines lo..hi (1-based, inclusive) of the reference's src/build.py, dedented."""
+    src = open(os.path.join(REF, "src", "build.py")).read().splitlines()
+    return textwrap.dedent("\n".join(src[lo - 1:hi]))
+
+
+def _skel_model_setup(n_frames=8, start_frame=60):
+    """The reference's OWN skeleton-driven FTE model text (build_model, src/build.py:28-304) on floats, on the SHIPPED
+    inputs: skeletons/new_human.pickle (the one its __main__ loads, :491), data/4_cam_scene_static_sba.json (2 cameras),
+    the two DeepLabCut tables data/*.h5 (read with oracle/skel_fte.read_dlc_h5: pytables is absent).
+
+    Slice-exec of build.py :32-95 (sympy poses from the skeleton dictionary, pose_to_3d / pos_funcs), :100-102, :113-129
+    (DataFrame accessors), :131 (h), :134-142 (P, L, C, proj_funcs, R), :151-165 (forehead line estimate), :168-302 (sets,
+    weights, parameters, variables, initialisation, every constraint, the ConstraintList of angle limits :263-266, the objective)
+    against tests/golden/_float_pyomo.py.  NOT executed: :97-99 / :104-109 (file loading: the arrays are supplied), :132-133
+    (start_frame = 60 kept, N = 100 replaced by n_frames to keep the fixture small - the text is O(N^2)), :144-147 (the
+    triangulation, which needs cv2: the 3-D table comes from the reference's get_pairwise_3d_points_from_df with the
+    repo's oracle as the injected triangulate_func)."""
+    import glob
+    import pandas as pd
+    import sympy as sp
+    from scipy import stats
+    sys.path.insert(0, OUT)
+    import _float_pyomo as fp
+    sys.path.insert(0, os.path.join(REF, "src"))
+    import build as ref_build  # noqa: E402
+    from calib import calib as ref_calib  # noqa: E402
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import camera as ocam, skel_fte as osf
+
+    skel = pickle.load(open(os.path.join(REF, "skeletons", "new_human.pickle"), "rb"))
+    scene = json.load(open(os.path.join(REF, "data", "4_cam_scene_static_sba.json")))
+    K_arr = np.array([c["k"] for c in scene["cameras"]], dtype=np.float64)
+    D_arr = np.array([c["d"] for c in scene["cameras"]], dtype=np.float64)
+    R_arr = np.array([c["r"] for c in scene["cameras"]], dtype=np.float64)
+    t_arr = np.array([c["t"] for c in scene["cameras"]], dtype=np.float64)
+    # body-part order of the shipped tables (SURVEY section 8c; the column index itself needs pytables)
+    parts = ["ankle1", "knee1", "hip1", "hip2", "knee2", "ankle2", "wrist1", "elbow1", "shoulder1", "shoulder2", "elbow2",
+             "wrist2", "chin", "forehead"]
+    paths = sorted(glob.glob(os.path.join(REF, "data", "*.h5")))
+    tabs = [osf.read_dlc_h5(f)[1] for f in paths]
+    assert len(tabs) == len(K_arr) == 2 and all(t.shape[1] == len(parts) for t in tabs)
+    f0, f1 = 0, start_frame + n_frames + 40            # rows of the long table (the line estimate regresses over all of them)
+    rows = [dict(frame=n, camera=c, marker=parts[k], x=tabs[c][n, k, 0], y=tabs[c][n, k, 1], likelihood=tabs[c][n, k, 2])
+            for c in range(len(tabs)) for n in range(f0, f1) for k in range(len(parts))]
+    points_2d_df = pd.DataFrame(rows, columns=["frame", "camera", "marker", "x", "y", "likelihood"])
+
+    def tri(a, b, k1, d1, r1, t1, k2, d2, r2, t2):
+        return ocam.triangulate_points_fisheye(np.asarray(a, float).reshape(-1, 2), np.asarray(b, float).reshape(-1, 2),
+                                               k1, np.asarray(d1).reshape(4), r1, np.asarray(t1).reshape(3),
+                                               k2, np.asarray(d2).reshape(4), r2, np.asarray(t2).reshape(3))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        points_3d_df = ref_calib.get_pairwise_3d_points_from_df(points_2d_df[points_2d_df["likelihood"] > 0.4], K_arr,
+                                                                D_arr.reshape((-1, 4)), R_arr, t_arr, tri)
+    ns = dict(sp=sp, np=np, sin=fp.sin, cos=fp.cos, stats=stats, skel_dict=skel, points_2d_df=points_2d_df,
+              points_3d_df=points_3d_df, K_arr=K_arr, D_arr=D_arr, R_arr=R_arr, t_arr=t_arr,
+              rot_x=ref_build.rot_x, rot_y=ref_build.rot_y, rot_z=ref_build.rot_z,
+              pt3d_to_x2d=ref_build.pt3d_to_x2d, pt3d_to_y2d=ref_build.pt3d_to_y2d,
+              ConcreteModel=fp.ConcreteModel, RangeSet=fp.RangeSet, Param=fp.Param, Var=fp.Var, Constraint=fp.Constraint,
+              ConstraintList=fp.ConstraintList, Objective=fp.Objective, Any=fp.Any, print=lambda *a, **k: None)
+    import io, contextlib
+
+    def run(lo, hi):
+        exec(compile(_build_lines(lo, hi), f"build.py[{lo}:{hi}]", "exec"), ns)
+    with contextlib.redirect_stdout(io.StringIO()):
+        run(32, 95)
+        run(100, 102)
+        run(113, 129)
+        run(131, 131)
+        ns["start_frame"], ns["N"] = start_frame, n_frames
+        run(134, 142)
+        run(151, 165)
+        run(168, 262)
+        fp.READ_LOG = []
+        run(263, 266)
+        fp.READ_LOG = None
+        run(267, 302)
+    m, P, N, L, C = ns["m"], ns["P"], ns["N"], ns["L"], ns["C"]
+    names = osf.pose_names(skel)
+    assert P == 48 and L == len(names) == 15 and C == 2 and N == n_frames
+    # the angle limits: every ConstraintList entry is |x[n, i]| <= c on ONE variable
+    where = {id(v): k for k, v in m.x.data.items()}
+    lo_b, hi_b = np.full((N, P), -np.inf), np.full((N, P), np.inf)
+    for ineq, touched in m.angs.entries:
+        assert len(touched) == 1 and isinstance(ineq, fp.Ineq)
+        n, i = where[id(touched[0])]
+        v = touched[0].value
+        assert abs(ineq.lhs - abs(0.0 if v is None else v)) < 1e-15
+        lo_b[n - 1, i - 1], hi_b[n - 1, i - 1] = -ineq.rhs, ineq.rhs
+    meas = np.full((N, C, L, 2), np.nan)
+    for n in range(1, N + 1):
+        for c in range(1, C + 1):
+            for l in range(1, L + 1):
+                for d in (1, 2):
+                    v = m.meas[n, c, l, d]
+                    if v is not fp.Constraint.Skip:
+                        meas[n - 1, c - 1, l - 1, d - 1] = float(v)
+    out = dict(skeleton_json=np.array(json.dumps(skel)), parts=np.array(parts), pose_names=np.array(names),
+               K=K_arr, D=D_arr.reshape(-1, 4), R=R_arr, t=t_arr, h=float(ns["h"]), R_meas=float(ns["R"]),
+               start_frame=start_frame, n_frames=N,
+               det=np.stack([t[f0:f1] for t in tabs], 1),                       # [frames, C, 14, 3] rows of the shipped tables
+               forehead_table=points_3d_df[points_3d_df["marker"] == "forehead"][["frame", "x", "y", "z"]].values.astype(float),
+               model_err_weight=np.array([m.model_err_weight[p] for p in range(1, P + 1)], dtype=np.float64),
+               meas_err_weight=np.array([[[float(fp._val(m.meas_err_weight[n, c, l])) for l in range(1, L + 1)]
+                                          for c in range(1, C + 1)] for n in range(1, N + 1)]),
+               meas=meas, bounds_lo=lo_b, bounds_hi=hi_b,
+               init_x=np.array([[m.x[n, p].value for p in range(1, P + 1)] for n in range(1, N + 1)]),
+               init_poses=np.array([[[m.poses[n, l, d].value for d in (1, 2, 3)] for l in range(1, L + 1)]
+                                    for n in range(1, N + 1)]))
+    return dict(m=m, P=P, N=N, L=L, C=C, fp=fp, out=out, skel=skel, ts_attr="h")
+
+
+def gen_skel_fte():
+    """skel_fte_model.npz: constants, weight tables, the box table, the initialisation and - at iterates around the
+    initial point - the OBJECTIVE of the reference's skeleton-driven model with every equality satisfied, plus its
+    central-difference gradient in the 36 states the poses depend on at one of them."""
+    ctx = _skel_model_setup()
+    m, P, N, out = ctx["m"], ctx["P"], ctx["N"], ctx["out"]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import skel_fte as osf
+    act = osf.active_states(ctx["skel"])
+    rng = np.random.default_rng(77)
+    X0 = out["init_x"].copy()
+    cases_x, cases_obj, worst = [], [], []
+    for case in range(4):
+        X = X0.copy()
+        X[:, act] += rng.normal(0, (0.0, 1e-3, 2e-2, 0.2)[case], (N, len(act)))
+        if case == 3:
+            inact = np.setdiff1d(np.arange(P), act)
+            X[:, inact] = rng.normal(0, 0.3, (N, len(inact))) * np.linspace(0, 1, N)[:, None] ** 3   # moves no pose: only the model term sees it
+        obj, w = _feasible_objective(ctx, X)
+        cases_x.append(X)
+        cases_obj.append(obj)
+        worst.append(w)
+    Xg = cases_x[2]
+    g = np.zeros((N, len(act)))
+    hstep = 1e-6
+    for n in range(N):
+        for k, p in enumerate(act):
+            Xp, Xm = Xg.copy(), Xg.copy()
+            Xp[n, p] += hstep
+            Xm[n, p] -= hstep
+            g[n, k] = (_feasible_objective(ctx, Xp)[0] - _feasible_objective(ctx, Xm)[0]) / (2 * hstep)
+    out.update(case_x=np.array(cases_x), case_obj=np.array(cases_obj), case_max_eq_residual=np.array(worst),
+               grad_case=2, grad_fd=g, grad_fd_step=hstep, active=act)
+    np.savez_compressed(os.path.join(OUT, "skel_fte_model.npz"), **out)
+    print("skel_fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
+          "bounded entries", int(np.isfinite(out["bounds_lo"]).sum()), "weights > 0:", int((out["meas_err_weight"] > 0).sum()))
+
 
 
 def gen_fte_stationary():
@@ -655,8 +812,9 @@ def gen_dummy_scene():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not present: golden fixtures can only be regenerated in the build container"
     install_stubs()
-    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "fte_stationary", "fte_lbfgs", "ekf"]
+    parts = sys.argv[1:] or ["helpers", "fk", "index", "kat1", "kat34", "scene", "dlc", "fte_model", "fte_stationary", "fte_lbfgs", "ekf",
+                             "skel_fte"]
     for name, fn in (("helpers", gen_ref_helpers), ("fk", gen_cheetah_fk), ("index", gen_index_path),
-                     ("fte_model", gen_fte_model), ("fte_stationary", gen_fte_stationary), ("fte_lbfgs", gen_fte_lbfgs), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
+                     ("fte_model", gen_fte_model), ("skel_fte", gen_skel_fte), ("fte_stationary", gen_fte_stationary), ("fte_lbfgs", gen_fte_lbfgs), ("ekf", gen_ekf), ("kat1", gen_kat1), ("kat34", gen_kat34), ("scene", gen_dummy_scene), ("dlc", gen_dlc_tables)):
         if name in parts:
             fn()
