@@ -12,10 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
 BUILD_ID_SOURCE = "camera_kernels.hip"      # defines acino_build_id()
-SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "chunk.hip", "fte_api.hip", "sba.hip", "ekf.hip"]
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "chunk.hip", "fte_api.hip", "sba.hip", "ekf.hip", "skel_fte.hip"]
 HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "bcr_dev.hpp", "chunk.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
-ABI_VERSION = 2          # ACINO_ABI_VERSION of include/acinoset_hip.h
+ABI_VERSION = 3          # ACINO_ABI_VERSION of include/acinoset_hip.h
 N_ACTIVE = 25
 N_STATES = 45
 N_MARKERS = 20
@@ -61,6 +61,24 @@ class EkfParams(C.Structure):
 class SkelOp(C.Structure):
     _fields_ = [("child", C.c_int32), ("parent", C.c_int32), ("angle", C.c_int32), ("flags", C.c_int32),
                 ("off", C.c_double * 3)]
+
+
+class SkelFteParams(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_cams", C.c_int32), ("n_pose", C.c_int32), ("n_ops", C.c_int32),
+                ("n_angles", C.c_int32), ("n_active", C.c_int32), ("max_iter", C.c_int32), ("pad0", C.c_int32),
+                ("h", C.c_double), ("model_weight", C.c_double), ("l1_eps", C.c_double), ("lam0", C.c_double),
+                ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double), ("lam_max", C.c_double)]
+
+
+class SkelFteInfo(C.Structure):
+    _fields_ = [("cost_initial", C.c_double), ("cost_final", C.c_double), ("gnorm_inf", C.c_double), ("lam", C.c_double),
+                ("iterations", C.c_int32), ("accepted", C.c_int32), ("status", C.c_int32), ("pad0", C.c_int32)]
+
+    def as_dict(self):
+        names = {0: "max_iter", 1: "ftol", 2: "xtol", 3: "gtol", 4: "lambda_overflow", 5: "numeric"}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if not f.startswith("pad")}
+        d["status_name"] = names.get(self.status, "?")
+        return d
 
 
 class SbaParams(C.Structure):
@@ -155,6 +173,11 @@ SIGNATURES = {
     "acino_ekf_workspace_bytes": (_Z, [_L, _I]),
     "acino_ekf_run": (_I, [C.POINTER(EkfParams), _P, _P, _P, _P, _Z, _P, _P, _P, _P]),
     "acino_skeleton_fk": (_I, [_P, _L, _I, _I, C.POINTER(SkelOp), _I, _P, _P]),
+    "acino_sizeof_skel_fte_params": (_Z, []),
+    "acino_sizeof_skel_fte_info": (_Z, []),
+    "acino_skel_fte_workspace_bytes": (_Z, [C.POINTER(SkelFteParams)]),
+    "acino_skel_fte_solve": (_I, [C.POINTER(SkelFteParams), C.POINTER(SkelOp), C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P,
+                                  _P, _Z, C.POINTER(SkelFteInfo), _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
     "acino_debug_poison_lds": (_I, [_I, _I, _P]),
 }
@@ -278,6 +301,9 @@ def lib():
         raise RuntimeError("libacinoset_hip.so struct layout differs from the Python binding (stale build?)")
     if handle.acino_sizeof_sba_params() != C.sizeof(SbaParams) or handle.acino_sizeof_sba_info() != C.sizeof(SbaInfo):
         raise RuntimeError("libacinoset_hip.so SBA struct layout differs from the Python binding (stale build?)")
+    if (handle.acino_sizeof_skel_fte_params() != C.sizeof(SkelFteParams) or
+            handle.acino_sizeof_skel_fte_info() != C.sizeof(SkelFteInfo)):
+        raise RuntimeError("libacinoset_hip.so skeleton-FTE struct layout differs from the Python binding (stale build?)")
     if handle.acino_sizeof_ekf_params() != C.sizeof(EkfParams):
         raise RuntimeError("libacinoset_hip.so EKF struct layout differs from the Python binding (stale build?)")
     _lib = handle

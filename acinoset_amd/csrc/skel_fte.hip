@@ -1,0 +1,828 @@
+// Full Trajectory Estimation for a GENERIC skeleton (gfx950, fp64): the reference's skeleton-driven model
+// build_model / solve_optimisation of src/build.py:28-335 - pickled skeleton -> sympy poses -> Pyomo NLP -> IPOPT - in the
+// reduced form of oracle/skel_fte.py:
+//     min_x  sum |w_ncl (pi_c(pose_l(x_n))_d - z_ncld)|  +  sum_{n >= 3, p} (w_model / h^4) (third difference of x_p)^2
+//     s.t.   lo[n, p] <= x[n, p] <= hi[n, p]
+// (L1 measurement loss build.py:299, constant model weight 0.002 :186-191, limits :263-266), solved by the projected
+// Levenberg-Marquardt of the cheetah path with IRLS curvature w^2 / max(|e|, l1_eps).  The cheetah kernels are specialised to
+// 25 states and 80-wide three-frame nodes; a skeleton file gives 3 + 3 L states per frame (48 for the shipped human, 36 of
+// them move a pose), so this path has its own, size-generic kernels:
+//   k_skel_assemble  one workgroup per frame: link program (pose[child] = pose[parent] + M(parent's own angles) off, with
+//                    dM/dangle off beside it), fisheye projection + 2x3 Jacobian per (pose, camera), the residual
+//                    Jacobian rows A[r][p] in LDS, H_n = A^T W A, g_n, cost
+//   k_skel_build     the damped block-banded system: P x P blocks (P padded to a multiple of 16), three sub-diagonals of
+//                    diagonal smoothness couplings, bound-active variables deleted (unit row / column)
+//   k_skel_solve     ONE workgroup: banded block Cholesky frame by frame - the 4P x P panel of a frame in LDS, diagonal
+//                    16 x 16 tiles by the register-resident pivot chain of dense80.hpp, panel / trailing / window updates
+//                    as fp64 MFMA tile products - with the forward substitution folded in, then the backward substitution
+//   k_skel_trial, k_skel_reduce   trial iterate, predicted reduction, the sums the controller needs
+// The controller itself runs on the host (four doubles read back per iteration): these are sequences of 10^2 .. 10^3 frames,
+// the path is latency-bound by construction and not the benchmark path.
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#include "dense80.hpp"
+
+namespace acino {
+
+constexpr int SK_MAXP = 64;        // active states per frame
+constexpr int SK_MAXROWS = 256;    // residual rows per frame = 2 * poses * cameras
+
+struct SkelDev {                   // device-resident description of one problem
+  int32_t n_frames, n_cams, n_pose, n_ops, n_act, PT, n_rows, pad;
+  double q;                        // model weight / h^4
+  double l1_eps, lam_floor;
+  acino_skel_op op[ACINO_SKEL_MAX_OPS];
+  int8_t amap[ACINO_SKEL_MAX_OPS][4];              // per op: active index of the parent's phi, theta, psi (-1: none)
+  unsigned long long pmask[ACINO_SKEL_MAX_OPS + 1];  // per pose slot: the ops on its path from the root
+  Cam cams[ACINO_MAX_CAMS];
+};
+
+// ---- assembly ---------------------------------------------------------------------------------------------------
+template <bool JAC>
+__global__ void __launch_bounds__(256)
+k_skel_assemble(const SkelDev* __restrict__ dev, const double* __restrict__ x, const double* __restrict__ meas,
+                const double* __restrict__ wgt, double* __restrict__ H, double* __restrict__ g, double* __restrict__ hd,
+                double* __restrict__ cost_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const SkelDev& D = *dev;
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int P = D.n_act, C = D.n_cams, NPOSE = D.n_pose, NOPS = D.n_ops, R = D.n_rows, lda = P | 1;
+  double* xs = reinterpret_cast<double*>(smem_raw);          // [64] active states of this frame
+  double* opv = xs + SK_MAXP;                                 // [n_ops][4][3]: M off, dM/dphi off, dM/dtheta off, dM/dpsi off
+  double* pos = opv + ACINO_SKEL_MAX_OPS * 12;                // [n_pose][3]
+  double* jrow = pos + (ACINO_SKEL_MAX_OPS + 1) * 3;          // [R][3] projection Jacobian row
+  double* gsr = jrow + SK_MAXROWS * 3;                        // [R] d cost / d residual
+  double* hwr = gsr + SK_MAXROWS;                             // [R] IRLS curvature weight
+  double* red = hwr + SK_MAXROWS;                             // [8]
+  double* A = red + 8;                                        // [R][lda]
+  if (tid < P) xs[tid] = x[(size_t)n * P + tid];
+  __syncthreads();
+  // ---- link operators: R_loc = Rz(psi) Rx(phi) Ry(theta) of the parent's own angles (reference sign convention)
+  if (tid < NOPS) {
+    const acino_skel_op& o = D.op[tid];
+    const int f = o.flags;
+    double sp = 0, cp = 1, st = 0, ct = 1, sz = 0, cz = 1;
+    if (f & 1) sincos(D.amap[tid][0] >= 0 ? xs[D.amap[tid][0]] : 0.0, &sp, &cp);
+    if (f & 2) sincos(D.amap[tid][1] >= 0 ? xs[D.amap[tid][1]] : 0.0, &st, &ct);
+    if (f & 4) sincos(D.amap[tid][2] >= 0 ? xs[D.amap[tid][2]] : 0.0, &sz, &cz);
+    const double Ry[3][3] = {{ct, 0, -st}, {0, 1, 0}, {st, 0, ct}}, dRy[3][3] = {{-st, 0, -ct}, {0, 0, 0}, {ct, 0, -st}};
+    const double Rx[3][3] = {{1, 0, 0}, {0, cp, sp}, {0, -sp, cp}}, dRx[3][3] = {{0, 0, 0}, {0, -sp, cp}, {0, -cp, -sp}};
+    const double Rz[3][3] = {{cz, sz, 0}, {-sz, cz, 0}, {0, 0, 1}}, dRz[3][3] = {{-sz, cz, 0}, {-cz, -sz, 0}, {0, 0, 0}};
+    auto mul = [](const double (&a)[3][3], const double (&b)[3][3], double (&c)[3][3]) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+    };
+    double RxRy[3][3], M[4][3][3], T1[3][3], T2[3][3];
+    mul(Rx, Ry, RxRy);
+    mul(Rz, RxRy, M[0]);                 // R_loc
+    mul(dRx, Ry, T1);
+    mul(Rz, T1, M[1]);                   // d / d phi
+    mul(Rx, dRy, T1);
+    mul(Rz, T1, M[2]);                   // d / d theta
+    mul(dRz, RxRy, M[3]);                // d / d psi
+    (void)T2;
+    const bool untr = (f & 8) != 0;      // bit 3: R_loc itself, else its transpose
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const bool on = m == 0 || ((f >> (m - 1)) & 1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double v = 0.0;
+        if (on) {
+          v = untr ? M[m][i][0] * o.off[0] + M[m][i][1] * o.off[1] + M[m][i][2] * o.off[2]
+                   : M[m][0][i] * o.off[0] + M[m][1][i] * o.off[1] + M[m][2][i] * o.off[2];
+        }
+        opv[(tid * 4 + m) * 3 + i] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 3) {                         // poses, coordinate by coordinate, in program order
+    for (int s = 0; s < NPOSE; ++s) pos[s * 3 + tid] = xs[tid];
+    for (int k = 0; k < NOPS; ++k) pos[D.op[k].child * 3 + tid] = pos[D.op[k].parent * 3 + tid] + opv[(k * 4) * 3 + tid];
+  }
+  __syncthreads();
+  double my_cost = 0.0;
+  // ---- projection of every (pose, camera): residuals, L1 cost, Jacobian rows (pt3d_to_2d, build.py:457-481)
+  if (tid < NPOSE * C) {
+    const int l = tid / C, c = tid % C;
+    const Cam& cam = D.cams[c];
+    const double px = pos[l * 3], py = pos[l * 3 + 1], pz = pos[l * 3 + 2];
+    const double* mz = meas + (((size_t)n * C + c) * NPOSE + l) * 2;
+    const double um = mz[0], vm = mz[1];
+    double w = wgt[((size_t)n * C + c) * NPOSE + l];
+    if (!(m_finite(um) && m_finite(vm))) w = 0.0;
+    const double xc = cam.R[0] * px + cam.R[1] * py + cam.R[2] * pz + cam.t[0];
+    const double yc = cam.R[3] * px + cam.R[4] * py + cam.R[5] * pz + cam.t[1];
+    const double zc = cam.R[6] * px + cam.R[7] * py + cam.R[8] * pz + cam.t[2];
+    if (fabs(zc) < 1e-9) w = 0.0;        // (the singular plane itself; no other cut, as the reference)
+    const int r0 = 2 * tid;
+    double ju[3] = {0, 0, 0}, jv[3] = {0, 0, 0}, gu = 0, gv = 0, hu = 0, hv = 0;
+    if (w != 0.0) {
+      const double iz = 1.0 / zc;
+      const double a = xc * iz, b = yc * iz;
+      const double r2 = a * a + b * b + 1e-12;
+      const double r = sqrt(r2), ir = 1.0 / r;
+      const double th = atan(r), th2 = th * th;
+      const double poly = 1 + th2 * (cam.k1 + th2 * (cam.k2 + th2 * (cam.k3 + th2 * cam.k4)));
+      const double thD = th * poly, m = thD * ir;
+      const double eu = w * (cam.fx * a * m + cam.cx - um), ev = w * (cam.fy * b * m + cam.cy - vm);
+      my_cost = fabs(eu) + fabs(ev);
+      if (JAC) {
+        const double dthD = 1 + th2 * (3 * cam.k1 + th2 * (5 * cam.k2 + th2 * (7 * cam.k3 + th2 * 9 * cam.k4)));
+        const double dm_dr = (dthD / (1 + r2) * r - thD) * (ir * ir);
+        const double dm_da = dm_dr * a * ir, dm_db = dm_dr * b * ir;
+        const double du_da = cam.fx * (m + a * dm_da), du_db = cam.fx * a * dm_db;
+        const double dv_da = cam.fy * b * dm_da, dv_db = cam.fy * (m + b * dm_db);
+        const double uc0 = du_da * iz, uc1 = du_db * iz, uc2 = -(du_da * a + du_db * b) * iz;
+        const double vc0 = dv_da * iz, vc1 = dv_db * iz, vc2 = -(dv_da * a + dv_db * b) * iz;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          ju[j] = uc0 * cam.R[j] + uc1 * cam.R[3 + j] + uc2 * cam.R[6 + j];
+          jv[j] = vc0 * cam.R[j] + vc1 * cam.R[3 + j] + vc2 * cam.R[6 + j];
+        }
+        gu = w * (eu > 0 ? 1.0 : (eu < 0 ? -1.0 : 0.0));
+        gv = w * (ev > 0 ? 1.0 : (ev < 0 ? -1.0 : 0.0));
+        hu = w * w / fmax(fabs(eu), D.l1_eps);
+        hv = w * w / fmax(fabs(ev), D.l1_eps);
+      }
+    }
+    if (JAC) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        jrow[r0 * 3 + j] = ju[j];
+        jrow[(r0 + 1) * 3 + j] = jv[j];
+      }
+      gsr[r0] = gu;
+      gsr[r0 + 1] = gv;
+      hwr[r0] = hu;
+      hwr[r0 + 1] = hv;
+    }
+  }
+  if (JAC) {
+    for (int e = tid; e < R * lda; e += 256) A[e] = 0.0;
+    __syncthreads();
+    // residual Jacobian: root columns, then one entry per (row, op on the pose's path, enabled angle of the op's parent)
+    for (int e = tid; e < R * 3; e += 256) A[(e / 3) * lda + e % 3] = jrow[e];
+    for (int e = tid; e < R * NOPS; e += 256) {
+      const int r = e / NOPS, k = e % NOPS, l = r / (2 * C);
+      if ((D.pmask[l] >> k) & 1ull) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const int p = D.amap[k][ax];
+          if (p >= 0) {
+            const double* dv = opv + (k * 4 + 1 + ax) * 3;
+            A[r * lda + p] = jrow[r * 3] * dv[0] + jrow[r * 3 + 1] * dv[1] + jrow[r * 3 + 2] * dv[2];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // H_n = A^T W A (upper pairs, mirrored), g_n = A^T gs (+ the smoothness terms, as the cheetah assembly)
+    const double b0 = band_coef(n, 0, D.n_frames);
+    for (int e = tid; e < P * P; e += 256) {
+      const int p = e / P, pc = e % P;
+      if (pc < p) continue;
+      double s = 0.0;
+      for (int r = 0; r < R; ++r) s += hwr[r] * A[r * lda + p] * A[r * lda + pc];
+      if (p == pc) {
+        s += 2.0 * D.q * b0;
+        hd[(size_t)n * P + p] = s;
+      }
+      H[((size_t)n * P + p) * P + pc] = s;
+      H[((size_t)n * P + pc) * P + p] = s;
+    }
+  }
+  if (tid < P) {
+    const double* xc = x + (size_t)n * P + tid;
+    if (n >= 3) {
+      const double d3 = xc[0] - 3.0 * xc[-P] + 3.0 * xc[-2 * P] - xc[-3 * P];
+      my_cost += D.q * d3 * d3;
+    }
+    if (JAC) {
+      double gs = 0.0;
+#pragma unroll
+      for (int k = -3; k <= 3; ++k) {
+        const int nn = n + k;
+        if (nn < 0 || nn >= D.n_frames) continue;
+        const double bc = k >= 0 ? band_coef(n, k, D.n_frames) : band_coef(nn, -k, D.n_frames);
+        gs += bc * xc[k * P];
+      }
+      double gm = 0.0;
+      for (int r = 0; r < R; ++r) gm += gsr[r] * A[r * lda + tid];
+      g[(size_t)n * P + tid] = gm + 2.0 * D.q * gs;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) my_cost += __shfl_down(my_cost, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = my_cost;
+  __syncthreads();
+  if (tid == 0) cost_part[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- the damped system ----------------------------------------------------------------------------------------------
+// band[n][j] (j = 0..3): block (n + j, n), [PT][PT] row-major; rhs[n][PT]; gn_part[n] = max |projected gradient|.
+__device__ __forceinline__ bool skel_fixed(double xv, double gv, double d0, double lo, double hi) {
+  const double gtol = GRAD_ZERO_REL * d0;
+  return (xv <= lo && gv > gtol) || (xv >= hi && gv < -gtol);
+}
+__global__ void __launch_bounds__(256)
+k_skel_build(const SkelDev* __restrict__ dev, const double* __restrict__ x, const double* __restrict__ g,
+             const double* __restrict__ H, const double* __restrict__ hd, const double* __restrict__ lo,
+             const double* __restrict__ hi, double lam, double* __restrict__ band, double* __restrict__ rhs,
+             double* __restrict__ gn_part) {
+  const SkelDev& D = *dev;
+  const int tid = threadIdx.x, n = blockIdx.x, P = D.n_act, PT = D.PT, N = D.n_frames;
+  __shared__ unsigned char fx[4][SK_MAXP];
+  __shared__ double red[4];
+  for (int e = tid; e < 4 * P; e += 256) {
+    const int j = e / P, p = e % P, nn = n + j;
+    bool f = false;
+    if (nn < N) {
+      const size_t q = (size_t)nn * P + p;
+      f = skel_fixed(x[q], g[q], hd[q], lo[q], hi[q]);
+    }
+    fx[j][p] = f ? 1 : 0;
+  }
+  __syncthreads();
+  double* B = band + (size_t)n * 4 * PT * PT;
+  for (int e = tid; e < PT * PT; e += 256) {
+    const int p = e / PT, pc = e % PT;
+    double v = 0.0;
+    if (p < P && pc < P) {
+      if (fx[0][p] || fx[0][pc]) v = p == pc ? 1.0 : 0.0;
+      else {
+        v = H[((size_t)n * P + p) * P + pc];
+        if (p == pc) v += lam * fmax(hd[(size_t)n * P + p], D.lam_floor);
+      }
+    } else if (p == pc) v = 1.0;
+    B[e] = v;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      double c = 0.0;
+      if (p == pc && p < P && n + j < N && !fx[0][p] && !fx[j][p]) c = 2.0 * D.q * band_coef(n, j, N);
+      B[(size_t)j * PT * PT + e] = c;
+    }
+  }
+  double gmax = 0.0;
+  if (tid < PT) {
+    double b = 0.0;
+    if (tid < P && !fx[0][tid]) b = -g[(size_t)n * P + tid];
+    rhs[(size_t)n * PT + tid] = b;
+    gmax = fabs(b);
+  }
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = gmax;
+  __syncthreads();
+  if (tid == 0) gn_part[n] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ---- banded block Cholesky + substitutions, one workgroup ----------------------------------------------------------------
+// Frame n: panel = [A_nn; A_n+1,n; A_n+2,n; A_n+3,n] (4 PT x PT) in LDS, leading dimension PT + 1.
+//   for kb:  diagonal tile -> U_kk = L_kk^-T (register pivot chain, dense80.hpp)
+//            tile(t, kb) <- tile(t, kb) U_kk for every row tile below;   tile(rt, ct) -= tile(rt, kb) tile(ct, kb)^T
+//   forward: y_n = L_nn^-1 r_n,  r_n+j -= L_n+j,n y_n
+//   window : A_n+i,n+j -= L_n+i,n L_n+j,n^T  (1 <= j <= i <= 3; read-modify-write of the band in memory)
+// then right to left:  x_n = L_nn^-T (y_n - sum_j L_n+j,n^T x_n+j).  Diagonal tiles keep U_kk, all other tiles L.
+template <int PT>
+__global__ void __launch_bounds__(256)
+k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const double* __restrict__ rhs,
+             double* __restrict__ yv, double* __restrict__ delta, int* __restrict__ numeric_err) {
+  constexpr int LDP = PT + 1, NTP = PT / 16, RT = 4 * NTP;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Pn = reinterpret_cast<double*>(smem_raw);       // [4 PT][LDP]
+  double* ring = Pn + 4 * PT * LDP;                        // [4][PT] right-hand sides / solutions of frames n .. n + 3
+  double* tv = ring + 4 * PT;                              // [PT]
+  const int N = dev->n_frames;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  auto load_panel = [&](int n) {
+    for (int e = tid; e < 4 * PT * PT; e += 256) {
+      const int j = e / (PT * PT), rem = e % (PT * PT);
+      Pn[(j * PT + rem / PT) * LDP + rem % PT] = (n + j < N) ? band[((size_t)n * 4 + j) * PT * PT + rem] : 0.0;
+    }
+  };
+  for (int e = tid; e < 3 * PT; e += 256) ring[e] = (e / PT < N) ? rhs[e] : 0.0;      // frames 0, 1, 2
+  __syncthreads();
+  for (int n = 0; n < N; ++n) {
+    load_panel(n);
+    if (tid < PT) ring[((n + 3) & 3) * PT + tid] = (n + 3 < N) ? rhs[(size_t)(n + 3) * PT + tid] : 0.0;
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NTP; ++kb) {
+      double* Tkk = Pn + (kb * 16) * LDP + kb * 16;
+      if (wave == 0) {
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Tkk[(lk + 4 * r) * LDP + li];
+        chol16_inv_acc<LDP>(Tkk, acc, lane, numeric_err);
+      }
+      __syncthreads();
+      for (int t = kb + 1 + wave; t < RT; t += 4) {          // panel: tile(t, kb) <- tile(t, kb) U_kk
+        double* At = Pn + (t * 16) * LDP + kb * 16;
+        double av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          av[s] = At[li * LDP + 4 * s + lk];
+          bv[s] = Tkk[(4 * s + lk) * LDP + li];
+        }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) At[(lk + 4 * rr) * LDP + li] = acc[rr];
+      }
+      __syncthreads();
+      int q = 0;                                             // trailing tiles inside the panel
+      for (int ct = kb + 1; ct < NTP; ++ct)
+        for (int rt = ct; rt < RT; ++rt, ++q) {
+          if ((q & 3) != wave) continue;
+          double* Cc = Pn + (rt * 16) * LDP + ct * 16;
+          const double* Ar = Pn + (rt * 16) * LDP + kb * 16;
+          const double* Ac = Pn + (ct * 16) * LDP + kb * 16;
+          d4 a;
+          double av[4], bv[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LDP + li];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            av[s] = Ar[li * LDP + 4 * s + lk];
+            bv[s] = Ac[li * LDP + 4 * s + lk];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LDP + li] = a[rr];
+        }
+      __syncthreads();
+    }
+    // ---- forward substitution with the block just factored
+    double* rn = ring + (n & 3) * PT;
+    for (int kb = 0; kb < NTP; ++kb) {
+      if (tid >= 16 * kb && tid < 16 * kb + 16) {
+        double u = rn[tid];
+        for (int c = 0; c < 16 * kb; ++c) u -= Pn[tid * LDP + c] * rn[c];
+        tv[tid] = u;
+      }
+      __syncthreads();
+      if (tid >= 16 * kb && tid < 16 * kb + 16) {             // y = U_kk^T u  (U upper triangular)
+        double y = 0.0;
+        for (int r = 16 * kb; r <= tid; ++r) y += Pn[r * LDP + tid] * tv[r];
+        rn[tid] = y;
+      }
+      __syncthreads();
+    }
+    if (tid < PT) yv[(size_t)n * PT + tid] = rn[tid];
+    if (tid < 3 * PT) {
+      const int j = 1 + tid / PT, i = tid % PT;
+      if (n + j < N) {
+        double s = 0.0;
+        for (int c = 0; c < PT; ++c) s += Pn[(j * PT + i) * LDP + c] * rn[c];
+        ring[((n + j) & 3) * PT + i] -= s;
+      }
+    }
+    // ---- window update in memory: block (n + i, n + j) -= L_i L_j^T, stored at band[n + j][i - j]
+    {
+      int q = 0;
+      for (int i = 1; i < 4; ++i)
+        for (int j = 1; j <= i; ++j) {
+          if (n + i >= N) continue;
+          double* Cg = band + ((size_t)(n + j) * 4 + (i - j)) * PT * PT;
+          for (int rt = 0; rt < NTP; ++rt)
+            for (int ct = 0; ct < NTP; ++ct, ++q) {
+              if ((q & 3) != wave) continue;
+              const double* Ar = Pn + (i * PT + rt * 16) * LDP;
+              const double* Ac = Pn + (j * PT + ct * 16) * LDP;
+              d4 a;
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) a[rr] = Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li];
+              for (int s = 0; s < PT / 4; ++s) a = mfma(-Ar[li * LDP + 4 * s + lk], Ac[li * LDP + 4 * s + lk], a);
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li] = a[rr];
+            }
+        }
+    }
+    // ---- the factored panel replaces the frame's blocks (read again by the backward pass)
+    for (int e = tid; e < 4 * PT * PT; e += 256) {
+      const int j = e / (PT * PT), rem = e % (PT * PT);
+      if (n + j < N || j == 0) band[((size_t)n * 4 + j) * PT * PT + rem] = Pn[(j * PT + rem / PT) * LDP + rem % PT];
+    }
+    __syncthreads();
+  }
+  // ---------------- backward ----------------
+  for (int e = tid; e < 4 * PT; e += 256) ring[e] = 0.0;
+  __syncthreads();
+  for (int n = N - 1; n >= 0; --n) {
+    load_panel(n);
+    __syncthreads();
+    if (tid < PT) {
+      double t = yv[(size_t)n * PT + tid];
+      for (int j = 1; j < 4; ++j) {
+        if (n + j >= N) break;
+        const double* xj = ring + ((n + j) & 3) * PT;
+        for (int r = 0; r < PT; ++r) t -= Pn[(j * PT + r) * LDP + tid] * xj[r];
+      }
+      tv[tid] = t;
+    }
+    __syncthreads();
+    double* xn = ring + (n & 3) * PT;
+    for (int kb = NTP - 1; kb >= 0; --kb) {
+      if (tid >= 16 * kb && tid < 16 * kb + 16) {
+        double s = tv[tid];
+        for (int r = 16 * (kb + 1); r < PT; ++r) s -= Pn[r * LDP + tid] * xn[r];
+        tv[tid] = s;
+      }
+      __syncthreads();
+      if (tid >= 16 * kb && tid < 16 * kb + 16) {             // x = U_kk s
+        double xx = 0.0;
+        for (int c = tid; c < 16 * kb + 16; ++c) xx += Pn[tid * LDP + c] * tv[c];
+        xn[tid] = xx;
+      }
+      __syncthreads();
+    }
+    if (tid < PT) delta[(size_t)n * PT + tid] = xn[tid];
+    __syncthreads();
+  }
+}
+
+// ---- trial iterate and the controller's sums -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_skel_trial(const SkelDev* __restrict__ dev, const double* __restrict__ x, double* __restrict__ xt,
+             const double* __restrict__ g, const double* __restrict__ hd, const double* __restrict__ lo,
+             const double* __restrict__ hi, const double* __restrict__ delta, double lam, double* __restrict__ pred_part,
+             double* __restrict__ step_part) {
+  const SkelDev& D = *dev;
+  const int tid = threadIdx.x;
+  const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+  double pred = 0.0, step = 0.0;
+  if (e < (int64_t)D.n_frames * D.n_act) {
+    const int n = (int)(e / D.n_act), p = (int)(e % D.n_act);
+    const double xv = x[e], gv = g[e], d0 = hd[e];
+    const bool fixed = skel_fixed(xv, gv, d0, lo[e], hi[e]);
+    const double d = fixed ? 0.0 : delta[(size_t)n * D.PT + p], pg = fixed ? 0.0 : gv;
+    const double xn = fmin(fmax(xv + d, lo[e]), hi[e]);
+    xt[e] = xn;
+    pred = 0.5 * d * (lam * fmax(d0, D.lam_floor) * d - pg);
+    step = fabs(xn - xv);
+  }
+  __shared__ double rp[4], rs[4];
+  for (int off = 32; off > 0; off >>= 1) {
+    pred += __shfl_down(pred, off, 64);
+    step = fmax(step, __shfl_down(step, off, 64));
+  }
+  if ((tid & 63) == 0) {
+    rp[tid >> 6] = pred;
+    rs[tid >> 6] = step;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    pred_part[blockIdx.x] = (rp[0] + rp[1]) + (rp[2] + rp[3]);
+    step_part[blockIdx.x] = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+  }
+}
+
+// totals = {cost, pred, step_inf, gnorm_inf}; fixed order
+__global__ void __launch_bounds__(1024)
+k_skel_reduce(const double* __restrict__ cost_part, int n_cost, const double* __restrict__ pred_part,
+              const double* __restrict__ step_part, int n_trial, const double* __restrict__ gn_part, int n_gn,
+              double* __restrict__ totals) {
+  __shared__ double sh[16][4];
+  double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
+  for (int i = threadIdx.x; i < n_cost; i += 1024) c += cost_part[i];
+  for (int i = threadIdx.x; i < n_trial; i += 1024) {
+    p += pred_part[i];
+    s = fmax(s, step_part[i]);
+  }
+  for (int i = threadIdx.x; i < n_gn; i += 1024) g = fmax(g, gn_part[i]);
+  for (int off = 32; off > 0; off >>= 1) {
+    c += __shfl_down(c, off, 64);
+    p += __shfl_down(p, off, 64);
+    s = fmax(s, __shfl_down(s, off, 64));
+    g = fmax(g, __shfl_down(g, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    double* w = sh[threadIdx.x >> 6];
+    w[0] = c;
+    w[1] = p;
+    w[2] = s;
+    w[3] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c = p = s = g = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      c += sh[w][0];
+      p += sh[w][1];
+      s = fmax(s, sh[w][2]);
+      g = fmax(g, sh[w][3]);
+    }
+    totals[0] = c;
+    totals[1] = p;
+    totals[2] = s;
+    totals[3] = g;
+  }
+}
+
+__global__ void k_skel_clip(const SkelDev* __restrict__ dev, const double* __restrict__ src, const double* __restrict__ lo,
+                            const double* __restrict__ hi, double* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < (int64_t)dev->n_frames * dev->n_act) dst[e] = fmin(fmax(src[e], lo[e]), hi[e]);
+}
+
+// poses of active-state rows: pos[N][n_pose][3]
+__global__ void __launch_bounds__(256)
+k_skel_poses(const SkelDev* __restrict__ dev, const double* __restrict__ x, double* __restrict__ pos) {
+  const SkelDev& D = *dev;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= D.n_frames) return;
+  const double* xs = x + n * D.n_act;
+  double* out = pos + n * D.n_pose * 3;
+  for (int s = 0; s < D.n_pose; ++s)
+    for (int j = 0; j < 3; ++j) out[s * 3 + j] = xs[j];
+  for (int k = 0; k < D.n_ops; ++k) {
+    const acino_skel_op& o = D.op[k];
+    double Rm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (o.flags & 2) {
+      double s, c;
+      sincos(D.amap[k][1] >= 0 ? xs[D.amap[k][1]] : 0.0, &s, &c);
+      Rm[0][0] = c; Rm[0][2] = -s; Rm[2][0] = s; Rm[2][2] = c;
+    }
+    if (o.flags & 1) {
+      double s, c;
+      sincos(D.amap[k][0] >= 0 ? xs[D.amap[k][0]] : 0.0, &s, &c);
+      for (int j = 0; j < 3; ++j) {
+        const double r1 = Rm[1][j], r2 = Rm[2][j];
+        Rm[1][j] = c * r1 + s * r2;
+        Rm[2][j] = -s * r1 + c * r2;
+      }
+    }
+    if (o.flags & 4) {
+      double s, c;
+      sincos(D.amap[k][2] >= 0 ? xs[D.amap[k][2]] : 0.0, &s, &c);
+      for (int j = 0; j < 3; ++j) {
+        const double r0 = Rm[0][j], r1 = Rm[1][j];
+        Rm[0][j] = c * r0 + s * r1;
+        Rm[1][j] = -s * r0 + c * r1;
+      }
+    }
+    for (int i = 0; i < 3; ++i) {
+      const double d = (o.flags & 8) ? Rm[i][0] * o.off[0] + Rm[i][1] * o.off[1] + Rm[i][2] * o.off[2]
+                                     : Rm[0][i] * o.off[0] + Rm[1][i] * o.off[1] + Rm[2][i] * o.off[2];
+      out[o.child * 3 + i] = out[o.parent * 3 + i] + d;
+    }
+  }
+}
+
+struct SkelLayout {
+  size_t dev, x[2], g[2], H[2], hd[2], cost[2], band, rhs, yv, delta, pred, step, gn, totals, err, total;
+};
+static size_t sk_align(size_t v) { return (v + 255) / 256 * 256; }
+static SkelLayout skel_layout(int N, int P, int PT) {
+  SkelLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = sk_align(off + bytes);
+    return o;
+  };
+  L.dev = take(sizeof(SkelDev));
+  for (int k = 0; k < 2; ++k) L.x[k] = take(sizeof(double) * (size_t)N * P);
+  for (int k = 0; k < 2; ++k) L.g[k] = take(sizeof(double) * (size_t)N * P);
+  for (int k = 0; k < 2; ++k) L.H[k] = take(sizeof(double) * (size_t)N * P * P);
+  for (int k = 0; k < 2; ++k) L.hd[k] = take(sizeof(double) * (size_t)N * P);
+  for (int k = 0; k < 2; ++k) L.cost[k] = take(sizeof(double) * (size_t)N);
+  L.band = take(sizeof(double) * (size_t)N * 4 * PT * PT);
+  L.rhs = take(sizeof(double) * (size_t)(N + 4) * PT);
+  L.yv = take(sizeof(double) * (size_t)N * PT);
+  L.delta = take(sizeof(double) * (size_t)N * PT);
+  const size_t nt = ((size_t)N * P + 255) / 256 + 1;
+  L.pred = take(sizeof(double) * nt);
+  L.step = take(sizeof(double) * nt);
+  L.gn = take(sizeof(double) * (size_t)N);
+  L.totals = take(sizeof(double) * 8);
+  L.err = take(sizeof(int) * 4);
+  L.total = off;
+  return L;
+}
+
+static int skel_validate(const acino_skel_fte_params* p) {
+  ACINO_REQUIRE(p != nullptr, "params");
+  ACINO_REQUIRE(p->n_frames >= 1, "n_frames >= 1");
+  ACINO_REQUIRE(p->n_cams >= 1 && p->n_cams <= ACINO_MAX_CAMS, "n_cams in 1..16");
+  ACINO_REQUIRE(p->n_pose >= 1 && p->n_pose <= ACINO_SKEL_MAX_OPS + 1, "n_pose");
+  ACINO_REQUIRE(p->n_ops >= 0 && p->n_ops <= ACINO_SKEL_MAX_OPS, "n_ops <= ACINO_SKEL_MAX_OPS");
+  ACINO_REQUIRE(p->n_angles >= 1, "n_angles");
+  ACINO_REQUIRE(p->n_active >= 3 && p->n_active <= SK_MAXP, "n_active in 3..64 (x, y, z and the angles that move a pose)");
+  ACINO_REQUIRE(2 * p->n_pose * p->n_cams <= SK_MAXROWS, "2 * n_pose * n_cams <= 256 residual rows per frame");
+  ACINO_REQUIRE(p->n_pose * p->n_cams <= 256, "n_pose * n_cams <= 256");
+  ACINO_REQUIRE(p->h > 0 && p->model_weight >= 0 && p->l1_eps > 0, "h > 0, model_weight >= 0, l1_eps > 0");
+  ACINO_REQUIRE(p->lam0 > 0 && p->max_iter >= 0, "lam0 > 0, max_iter >= 0");
+  return ACINO_OK;
+}
+
+}  // namespace acino
+
+using namespace acino;
+
+extern "C" {
+
+size_t acino_sizeof_skel_fte_params(void) { return sizeof(acino_skel_fte_params); }
+size_t acino_sizeof_skel_fte_info(void) { return sizeof(acino_skel_fte_info); }
+
+size_t acino_skel_fte_workspace_bytes(const acino_skel_fte_params* p) {
+  if (!p || p->n_frames < 1 || p->n_active < 3 || p->n_active > SK_MAXP) return 0;
+  const int PT = (p->n_active + 15) / 16 * 16;
+  return skel_layout(p->n_frames, p->n_active, PT).total + 256;
+}
+
+int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_ops, const int32_t* h_active,
+                         const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
+                         const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
+                         acino_skel_fte_info* info, void* stream) {
+  int rc = skel_validate(p);
+  if (rc) return rc;
+  ACINO_REQUIRE(h_ops && h_active && d_meas && d_w && d_cams24 && d_lo && d_hi && d_x && d_workspace, "null buffer");
+  ACINO_REQUIRE(((uintptr_t)d_workspace & 255) == 0, "workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = p->n_frames, P = p->n_active, PT = (P + 15) / 16 * 16, L = p->n_angles;
+  const SkelLayout lay = skel_layout(N, P, PT);
+  ACINO_REQUIRE(workspace_bytes >= lay.total, "workspace too small (acino_skel_fte_workspace_bytes)");
+  // ---- the program: active index of every op's parent angles, the ops on every pose's path
+  std::vector<SkelDev> hv(1);
+  SkelDev& h = hv[0];
+  memset(&h, 0, sizeof(h));
+  h.n_frames = N;
+  h.n_cams = p->n_cams;
+  h.n_pose = p->n_pose;
+  h.n_ops = p->n_ops;
+  h.n_act = P;
+  h.PT = PT;
+  h.n_rows = 2 * p->n_pose * p->n_cams;
+  h.q = p->model_weight / (p->h * p->h * p->h * p->h);
+  h.l1_eps = p->l1_eps;
+  h.lam_floor = DIAG_FLOOR;
+  ACINO_REQUIRE(h_active[0] == 0 && h_active[1] == 1 && h_active[2] == 2, "the first three active states are x, y, z");
+  std::vector<int> where(3 + 3 * L, -1);
+  for (int a = 0; a < P; ++a) {
+    ACINO_REQUIRE(h_active[a] >= 0 && h_active[a] < 3 + 3 * L && (a == 0 || h_active[a] > h_active[a - 1]),
+                  "active state indices must be increasing and inside [0, 3 + 3 L)");
+    where[h_active[a]] = a;
+  }
+  std::vector<unsigned long long> path(p->n_pose, 0ull);
+  for (int k = 0; k < p->n_ops; ++k) {
+    const acino_skel_op& o = h_ops[k];
+    ACINO_REQUIRE(o.child >= 0 && o.child < p->n_pose && o.parent >= 0 && o.parent < p->n_pose, "op slot out of range");
+    ACINO_REQUIRE(o.angle >= 0 && o.angle < L, "op angle index out of range");
+    h.op[k] = o;
+    for (int ax = 0; ax < 3; ++ax) {
+      const int st = 3 + ax * L + o.angle;
+      const int a = ((o.flags >> ax) & 1) ? where[st] : -1;
+      ACINO_REQUIRE(!((o.flags >> ax) & 1) || a >= 0, "an enabled angle of a parent part is missing from the active states");
+      h.amap[k][ax] = (int8_t)a;
+    }
+    h.amap[k][3] = -1;
+    path[o.child] = path[o.parent] | (1ull << k);          // (a slot defined twice keeps its last definition, as the poses)
+  }
+  for (int l = 0; l < p->n_pose; ++l) h.pmask[l] = path[l];
+  char* base = (char*)d_workspace;
+  auto D = [&](size_t off) { return reinterpret_cast<double*>(base + off); };
+  SkelDev* d_dev = reinterpret_cast<SkelDev*>(base + lay.dev);
+  int* d_err = reinterpret_cast<int*>(base + lay.err);
+  ACINO_HIP_CHECK(hipMemcpyAsync(d_dev, &h, sizeof(SkelDev), hipMemcpyHostToDevice, s));
+  ACINO_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(d_dev) + offsetof(SkelDev, cams), d_cams24,
+                                 sizeof(double) * ACINO_CAM_STRIDE * p->n_cams, hipMemcpyDeviceToDevice, s));
+  ACINO_HIP_CHECK(hipMemsetAsync(d_err, 0, 4 * sizeof(int), s));
+  ACINO_HIP_CHECK(hipStreamSynchronize(s));                // (h lives on this frame)
+  const size_t lds_asm = sizeof(double) * (SK_MAXP + ACINO_SKEL_MAX_OPS * 12 + (ACINO_SKEL_MAX_OPS + 1) * 3 + SK_MAXROWS * 5 + 8 +
+                                           (size_t)h.n_rows * (P | 1));
+  const size_t lds_solve = sizeof(double) * ((size_t)4 * PT * (PT + 1) + 5 * PT);
+  {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
+      const int big = 160 * 1024;
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_assemble<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_assemble<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<48>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    }
+  }
+  ACINO_REQUIRE(lds_asm <= 160 * 1024, "residual rows x active states do not fit the assembly's LDS");
+  const int n_trial = (int)(((size_t)N * P + 255) / 256);
+  auto assemble = [&](int buf, bool jac) -> int {
+    if (jac)
+      hipLaunchKernelGGL(k_skel_assemble<true>, dim3(N), dim3(256), lds_asm, s, d_dev, D(lay.x[buf]), d_meas, d_w,
+                         D(lay.H[buf]), D(lay.g[buf]), D(lay.hd[buf]), D(lay.cost[buf]));
+    else
+      hipLaunchKernelGGL(k_skel_assemble<false>, dim3(N), dim3(256), lds_asm, s, d_dev, D(lay.x[buf]), d_meas, d_w,
+                         D(lay.H[buf]), D(lay.g[buf]), D(lay.hd[buf]), D(lay.cost[buf]));
+    ACINO_LAUNCH_CHECK();
+    return ACINO_OK;
+  };
+  double tot[8];
+  int herr[4] = {0, 0, 0, 0};
+  auto read_totals = [&](int cost_buf, bool with_step) -> int {
+    hipLaunchKernelGGL(k_skel_reduce, dim3(1), dim3(1024), 0, s, D(lay.cost[cost_buf]), N, D(lay.pred), D(lay.step),
+                       with_step ? n_trial : 0, D(lay.gn), with_step ? N : 0, D(lay.totals));
+    ACINO_LAUNCH_CHECK();
+    ACINO_HIP_CHECK(hipMemcpyAsync(tot, D(lay.totals), sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipMemcpyAsync(herr, d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    return ACINO_OK;
+  };
+  hipLaunchKernelGGL(k_skel_clip, dim3(n_trial), dim3(256), 0, s, d_dev, d_x, d_lo, d_hi, D(lay.x[0]));
+  ACINO_LAUNCH_CHECK();
+  int cur = 0;
+  if ((rc = assemble(0, true))) return rc;
+  if ((rc = read_totals(0, false))) return rc;
+  // ---- the controller (lm_control_local of fte_api.hip / oracle.fte.lm_solve, on the host)
+  double F = tot[0], lam = p->lam0, nu = 2.0, gnorm = 0.0;
+  const double cost0 = F, lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
+  int status = 0, it = 0, accepted = 0;
+  for (it = 1; it <= p->max_iter; ++it) {
+    hipLaunchKernelGGL(k_skel_build, dim3(N), dim3(256), 0, s, d_dev, D(lay.x[cur]), D(lay.g[cur]), D(lay.H[cur]),
+                       D(lay.hd[cur]), d_lo, d_hi, lam, D(lay.band), D(lay.rhs), D(lay.gn));
+    ACINO_LAUNCH_CHECK();
+    switch (PT) {
+      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+    }
+    ACINO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_skel_trial, dim3(n_trial), dim3(256), 0, s, d_dev, D(lay.x[cur]), D(lay.x[cur ^ 1]), D(lay.g[cur]),
+                       D(lay.hd[cur]), d_lo, d_hi, D(lay.delta), lam, D(lay.pred), D(lay.step));
+    ACINO_LAUNCH_CHECK();
+    if ((rc = assemble(cur ^ 1, true))) return rc;
+    if ((rc = read_totals(cur ^ 1, true))) return rc;
+    const double Ft = tot[0], pred = tot[1], step = tot[2];
+    gnorm = tot[3];
+    if (herr[0]) {
+      status = 5;
+      break;
+    }
+    if (gnorm <= p->gtol) {
+      status = 3;
+      break;
+    }
+    const double gain = pred > 0.0 ? (F - Ft) / pred : -1.0;
+    if (Ft < F) {
+      const double dF = F - Ft;
+      cur ^= 1;
+      F = Ft;
+      ++accepted;
+      const double t = 2.0 * gain - 1.0;
+      lam = lam * std::max(1.0 / 3.0, 1.0 - t * t * t);
+      nu = 2.0;
+      if (dF <= p->ftol * fabs(Ft)) {
+        status = 1;
+        break;
+      }
+      if (step <= p->xtol) {
+        status = 2;
+        break;
+      }
+    } else {
+      lam *= nu;
+      nu *= 2.0;
+      if (lam > lam_max) {
+        status = 4;
+        break;
+      }
+    }
+  }
+  if (it > p->max_iter) it = p->max_iter;
+  ACINO_HIP_CHECK(hipMemcpyAsync(d_x, D(lay.x[cur]), sizeof(double) * (size_t)N * P, hipMemcpyDeviceToDevice, s));
+  if (d_pos) {
+    hipLaunchKernelGGL(k_skel_poses, dim3((N + 255) / 256), dim3(256), 0, s, d_dev, D(lay.x[cur]), d_pos);
+    ACINO_LAUNCH_CHECK();
+  }
+  ACINO_HIP_CHECK(hipStreamSynchronize(s));
+  if (info) {
+    info->cost_initial = cost0;
+    info->cost_final = F;
+    info->gnorm_inf = gnorm;
+    info->lam = lam;
+    info->iterations = it;
+    info->accepted = accepted;
+    info->status = status;
+    info->pad0 = 0;
+  }
+  if (status == 5) {
+    set_error("non-positive pivot in the banded factorisation (system not positive definite)");
+    return ACINO_ERR_NUMERIC;
+  }
+  return ACINO_OK;
+}
+
+}  // extern "C"

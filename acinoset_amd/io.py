@@ -64,15 +64,67 @@ def dlc_wide_to_long(wide_dfs):
     return long_df[["frame", "camera", "marker", "x", "y", "likelihood"]]
 
 
-def create_dlc_points_2d_file(dlc_df_fpaths):
-    """utils.create_dlc_points_2d_file: reads the per-camera DLC .h5 tables (pandas + pytables, as the reference)."""
-    import pandas as pd
+def read_dlc_table(path):
+    """One DeepLabCut table -> (bodyparts, values[N, K, 3] = x, y, likelihood per body part, frame index[N]).
+
+    With pytables installed this is ``pandas.read_hdf`` (what the reference calls, utils.py:108).  Without it the two
+    things needed are taken from the file directly, which works for the uncompressed fixed-format tables DeepLabCut writes
+    (the shipped data/*.h5): the column MultiIndex is stored as pickle text (``V<name>`` tokens, body parts in column order,
+    each followed by x / y / likelihood), the table itself as contiguous records of one int64 row index and 3 K float64."""
+    import re
     try:
-        dfs = [pd.read_hdf(p) for p in dlc_df_fpaths]
-    except ImportError as exc:          # pragma: no cover - depends on the host environment
-        raise ImportError("reading DLC .h5 files needs pandas with pytables, exactly as the reference does; "
-                          "pass already-loaded tables to dlc_wide_to_long() instead") from exc
-    return dlc_wide_to_long(dfs)
+        import pandas as pd
+        df = pd.read_hdf(path)
+        d = df.droplevel(0, axis=1) if getattr(df.columns, "nlevels", 1) == 3 else df
+        parts = list(dict.fromkeys(d.columns.get_level_values(0)))
+        vals = np.stack([np.stack([d[(q, c)].to_numpy(dtype=np.float64) for c in ("x", "y", "likelihood")], 1) for q in parts], 1)
+        return parts, vals, np.asarray(d.index, dtype=np.int64)
+    except ImportError:
+        pass
+    with open(path, "rb") as f:
+        raw = f.read()
+    toks = [t.decode() for t in re.findall(rb"V([A-Za-z0-9_\-]+)\n", raw[:1 << 16])]
+    parts = []
+    if "x" in toks and toks.index("x") >= 1:        # ... scorer, <first body part>, x, y, likelihood, <next body part>, ... names
+        for name in toks[toks.index("x") - 1:]:
+            if name == "names":
+                break
+            if name not in ("x", "y", "likelihood") and name not in parts:
+                parts.append(name)
+    if not parts:
+        raise ValueError(f"{path}: no DeepLabCut column index found (is this a pandas fixed-format table?)")
+    rec = 8 + 24 * len(parts)
+    dt = np.dtype([("i", "<i8"), ("v", "<f8", (3 * len(parts),))])
+    for off in range(0, min(len(raw) - 3 * rec, 1 << 16), 8):
+        head = np.frombuffer(raw, dtype="<i8", count=1, offset=off)[0]
+        if head != 0:
+            continue
+        n = (len(raw) - off) // rec
+        idx = np.frombuffer(raw, dtype=dt, count=min(n, 64), offset=off)["i"]
+        if len(idx) >= 3 and np.array_equal(idx, np.arange(len(idx))):
+            tab = np.frombuffer(raw, dtype=dt, count=n, offset=off)
+            good = int(np.argmax(tab["i"] != np.arange(n))) if (tab["i"] != np.arange(n)).any() else n
+            tab = tab[:good]
+            return parts, tab["v"].reshape(good, len(parts), 3).copy(), tab["i"].copy()
+    raise ValueError(f"{path}: no uncompressed table of {len(parts)} body parts found")
+
+
+def create_dlc_points_2d_file(dlc_df_fpaths):
+    """utils.create_dlc_points_2d_file (utils.py:105-120): the per-camera DLC tables as ONE long table
+    [frame, camera, marker, x, y, likelihood], camera = position of the file in the list."""
+    import pandas as pd
+    out = []
+    for cam, path in enumerate(dlc_df_fpaths):
+        parts, vals, frames = read_dlc_table(path)
+        order = sorted(range(len(parts)), key=lambda k: parts[k])      # (rows ordered by frame, marker - as the reference's unstack)
+        n, m = len(frames), len(parts)
+        block = {"frame": np.repeat(frames, m), "camera": np.full(n * m, cam, dtype=object),
+                 "marker": np.tile(np.array([parts[k] for k in order], dtype=object), n)}
+        for ci, coord in enumerate(("x", "y", "likelihood")):
+            block[coord] = vals[:, order, ci].reshape(-1)
+        out.append(pd.DataFrame(block))
+    long_df = pd.concat(out, ignore_index=True)
+    return long_df[["frame", "camera", "marker", "x", "y", "likelihood"]]
 
 
 def dense_detections(points_2d_df, n_cameras, markers, start_frame=None, end_frame=None):

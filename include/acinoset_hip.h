@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define ACINO_ABI_VERSION 2   /* 2: acino_fte_params grew (chunk_nodes, refine_sweeps), 17 profiler classes, status 5-7 / numeric_err bit mask, d_dbg[64] */
+#define ACINO_ABI_VERSION 3   /* 2: acino_fte_params grew (chunk_nodes, refine_sweeps), 17 profiler classes, status 5-7 / numeric_err bit mask;
+                               * 3: acino_skel_fte_* (generic-skeleton FTE), debug-stamp buffer of 72 entries with the selectors at [64], [65] */
 
 typedef enum acino_status {
   ACINO_OK = 0,
@@ -379,6 +380,40 @@ typedef struct acino_skel_op {
 /* d_q[N][3 + 3 L] -> d_pos[N][n_pose][3]; h_ops is a HOST array. */
 int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_pose, const acino_skel_op* h_ops,
                       int n_ops, double* d_pos, void* stream);
+
+/* ---- generic-skeleton Full Trajectory Estimation (src/build.py:28-335: build_model + solve_optimisation) -------------
+ * The skeleton-driven NLP of the reference in reduced form (oracle/skel_fte.py):
+ *   min  sum |w_ncl (pi_c(pose_l(x_n))_d - z_ncld)|  +  sum_{n>=3,p} (model_weight / h^4) (x_n - 3 x_n-1 + 3 x_n-2 - x_n-3)_p^2
+ *   s.t. lo[n][p] <= x[n][p] <= hi[n][p]
+ * over the n_active states that move a pose (x, y, z and the enabled angles of parent parts; h_active[n_active] holds
+ * their indices in the full state [x y z | phi | theta | psi], increasing, starting 0, 1, 2 - every other state stays at
+ * its initial 0 as in the reference).  h_ops is the link program of acino_skeleton_fk.  d_meas[N][C][n_pose][2] and
+ * d_w[N][C][n_pose] are indexed by POSE SLOT: the caller pairs slots with detections (the reference pairs by position in
+ * the skeleton's marker list, build.py:113-128,288-292) and sets w = 1/R where likelihood > threshold, else 0.
+ * d_x[N][n_active]: initial iterate in, solution out.  d_pos[N][n_pose][3] (may be NULL): poses of the solution.
+ * Solved by the projected Levenberg-Marquardt of the cheetah path (L1 loss: IRLS curvature w^2 / max(|e|, l1_eps), cost
+ * and gradient those of |e|); the controller runs on the host.  Limits: n_active <= 64, 2 n_pose C <= 256. */
+typedef struct acino_skel_fte_params {
+  int32_t n_frames, n_cams, n_pose, n_ops, n_angles, n_active;
+  int32_t max_iter, pad0;
+  double h;                   /* time step (build.py:131: 1/120)                           */
+  double model_weight;        /* build.py:186-191: 0.002 for every state                    */
+  double l1_eps;              /* floor of |e| in the IRLS weight (scaled residual units)     */
+  double lam0, ftol, xtol, gtol, lam_max;
+} acino_skel_fte_params;
+typedef struct acino_skel_fte_info {
+  double cost_initial, cost_final, gnorm_inf, lam;
+  int32_t iterations, accepted;
+  int32_t status;             /* 0 max_iter, 1 ftol, 2 xtol, 3 gtol, 4 lambda overflow, 5 numeric failure */
+  int32_t pad0;
+} acino_skel_fte_info;
+size_t acino_sizeof_skel_fte_params(void);
+size_t acino_sizeof_skel_fte_info(void);
+size_t acino_skel_fte_workspace_bytes(const acino_skel_fte_params* p);
+int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_ops, const int32_t* h_active,
+                         const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
+                         const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
+                         acino_skel_fte_info* info, void* stream);
 
 /* ---- extended Kalman filter + RTS smoother (src/all_optimizations.py:569-865) ---------
  * One call filters and smooths n_seq independent sequences of n_frames frames (same rig).  States are the reference's

@@ -547,6 +547,11 @@ def gen_skel_fte():
     out.update(case_x=np.array(cases_x), case_obj=np.array(cases_obj), case_max_eq_residual=np.array(worst),
                grad_case=2, grad_fd=g, grad_fd_step=hstep, active=act)
     np.savez_compressed(os.path.join(OUT, "skel_fte_model.npz"), **out)
+    # a longer slice of the SHIPPED detections (data rows only) for the real-data workload of the GPU tests / bench.py
+    import glob
+    tabs = [osf.read_dlc_h5(f)[1] for f in sorted(glob.glob(os.path.join(REF, "data", "*.h5")))]
+    np.savez_compressed(os.path.join(OUT, "human_dlc_slice.npz"), det=np.stack([t[:460] for t in tabs], 1).astype(np.float32),
+                        parts=out["parts"], note=np.array("rows 0..459 of data/Ex1Cam{3,4}...h5 (x, y, likelihood), float32 as stored by DeepLabCut"))
     print("skel_fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
           "bounded entries", int(np.isfinite(out["bounds_lo"]).sum()), "weights > 0:", int((out["meas_err_weight"] > 0).sum()))
 

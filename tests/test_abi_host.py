@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= declared
-    assert lib.acino_abi_version() == _lib.ABI_VERSION == 2     # (2: acino_fte_params grew, 17 profiler classes - include/acinoset_hip.h)
+    assert lib.acino_abi_version() == _lib.ABI_VERSION == 3     # (3: acino_skel_fte_* - include/acinoset_hip.h)
     assert lib.acino_sizeof_fte_params() == C.sizeof(_lib.FteParams)
     assert lib.acino_sizeof_fte_state() == C.sizeof(_lib.FteState)
 
