@@ -288,8 +288,9 @@ k_skel_build(const SkelDev* __restrict__ dev, const double* __restrict__ x, cons
 //   forward: y_n = L_nn^-1 r_n,  r_n+j -= L_n+j,n y_n
 //   window : A_n+i,n+j -= L_n+i,n L_n+j,n^T  (1 <= j <= i <= 3; read-modify-write of the band in memory)
 // then right to left:  x_n = L_nn^-T (y_n - sum_j L_n+j,n^T x_n+j).  Diagonal tiles keep U_kk, all other tiles L.
+constexpr int SK_ST = 512, SK_SW = SK_ST / 64;      // threads / waves of the solve kernel
 template <int PT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SK_ST)
 k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const double* __restrict__ rhs,
              double* __restrict__ yv, double* __restrict__ delta, int* __restrict__ numeric_err) {
   constexpr int LDP = PT + 1, NTP = PT / 16, RT = 4 * NTP;
@@ -300,12 +301,12 @@ k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const d
   const int N = dev->n_frames;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   auto load_panel = [&](int n) {
-    for (int e = tid; e < 4 * PT * PT; e += 256) {
+    for (int e = tid; e < 4 * PT * PT; e += SK_ST) {
       const int j = e / (PT * PT), rem = e % (PT * PT);
       Pn[(j * PT + rem / PT) * LDP + rem % PT] = (n + j < N) ? band[((size_t)n * 4 + j) * PT * PT + rem] : 0.0;
     }
   };
-  for (int e = tid; e < 3 * PT; e += 256) ring[e] = (e / PT < N) ? rhs[e] : 0.0;      // frames 0, 1, 2
+  for (int e = tid; e < 3 * PT; e += SK_ST) ring[e] = (e / PT < N) ? rhs[e] : 0.0;      // frames 0, 1, 2
   __syncthreads();
   for (int n = 0; n < N; ++n) {
     load_panel(n);
@@ -321,7 +322,7 @@ k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const d
         chol16_inv_acc<LDP>(Tkk, acc, lane, numeric_err);
       }
       __syncthreads();
-      for (int t = kb + 1 + wave; t < RT; t += 4) {          // panel: tile(t, kb) <- tile(t, kb) U_kk
+      for (int t = kb + 1 + wave; t < RT; t += SK_SW) {          // panel: tile(t, kb) <- tile(t, kb) U_kk
         double* At = Pn + (t * 16) * LDP + kb * 16;
         double av[4], bv[4];
 #pragma unroll
@@ -339,7 +340,7 @@ k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const d
       int q = 0;                                             // trailing tiles inside the panel
       for (int ct = kb + 1; ct < NTP; ++ct)
         for (int rt = ct; rt < RT; ++rt, ++q) {
-          if ((q & 3) != wave) continue;
+          if (q % SK_SW != wave) continue;
           double* Cc = Pn + (rt * 16) * LDP + ct * 16;
           const double* Ar = Pn + (rt * 16) * LDP + kb * 16;
           const double* Ac = Pn + (ct * 16) * LDP + kb * 16;
@@ -384,36 +385,55 @@ k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const d
         ring[((n + j) & 3) * PT + i] -= s;
       }
     }
-    // ---- window update in memory: block (n + i, n + j) -= L_i L_j^T, stored at band[n + j][i - j]
+    // ---- window update in memory: block (n + i, n + j) -= L_i L_j^T, stored at band[n + j][i - j].  Every wave requests ALL
+    //      its tiles first (one round trip to memory instead of one per tile), then multiplies, then stores.
     {
-      int q = 0;
-      for (int i = 1; i < 4; ++i)
-        for (int j = 1; j <= i; ++j) {
-          if (n + i >= N) continue;
-          double* Cg = band + ((size_t)(n + j) * 4 + (i - j)) * PT * PT;
-          for (int rt = 0; rt < NTP; ++rt)
-            for (int ct = 0; ct < NTP; ++ct, ++q) {
-              if ((q & 3) != wave) continue;
-              const double* Ar = Pn + (i * PT + rt * 16) * LDP;
-              const double* Ac = Pn + (j * PT + ct * 16) * LDP;
-              d4 a;
+      constexpr int WT = 6 * NTP * NTP, PER = (WT + SK_SW - 1) / SK_SW;
+      d4 acc[PER];
+      auto tile_of = [&](int t, int& i, int& j, int& rt, int& ct) {
+        const int blk = t / (NTP * NTP), rem = t % (NTP * NTP);
+        i = blk < 1 ? 1 : (blk < 3 ? 2 : 3);
+        j = blk < 1 ? 1 : (blk < 3 ? blk : blk - 2);
+        rt = rem / NTP;
+        ct = rem % NTP;
+      };
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) a[rr] = Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li];
-              for (int s = 0; s < PT / 4; ++s) a = mfma(-Ar[li * LDP + 4 * s + lk], Ac[li * LDP + 4 * s + lk], a);
+      for (int q = 0; q < PER; ++q) {
+        const int t = wave + SK_SW * q;
+        int i = 1, j = 1, rt = 0, ct = 0;
+        tile_of(t < WT ? t : 0, i, j, rt, ct);
+        if (t < WT && n + i < N) {
+          const double* Cg = band + ((size_t)(n + j) * 4 + (i - j)) * PT * PT;
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li] = a[rr];
-            }
+          for (int rr = 0; rr < 4; ++rr) acc[q][rr] = Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li];
         }
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int t = wave + SK_SW * q;
+        int i = 1, j = 1, rt = 0, ct = 0;
+        tile_of(t < WT ? t : 0, i, j, rt, ct);
+        if (t < WT && n + i < N) {
+          const double* Ar = Pn + (i * PT + rt * 16) * LDP;
+          const double* Ac = Pn + (j * PT + ct * 16) * LDP;
+          d4 a = acc[q];
+#pragma unroll
+          for (int s4 = 0; s4 < PT / 4; ++s4) a = mfma(-Ar[li * LDP + 4 * s4 + lk], Ac[li * LDP + 4 * s4 + lk], a);
+          double* Cg = band + ((size_t)(n + j) * 4 + (i - j)) * PT * PT;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Cg[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li] = a[rr];
+        }
+      }
     }
     // ---- the factored panel replaces the frame's blocks (read again by the backward pass)
-    for (int e = tid; e < 4 * PT * PT; e += 256) {
+    for (int e = tid; e < 4 * PT * PT; e += SK_ST) {
       const int j = e / (PT * PT), rem = e % (PT * PT);
       if (n + j < N || j == 0) band[((size_t)n * 4 + j) * PT * PT + rem] = Pn[(j * PT + rem / PT) * LDP + rem % PT];
     }
     __syncthreads();
   }
   // ---------------- backward ----------------
-  for (int e = tid; e < 4 * PT; e += 256) ring[e] = 0.0;
+  for (int e = tid; e < 4 * PT; e += SK_ST) ring[e] = 0.0;
   __syncthreads();
   for (int n = N - 1; n >= 0; --n) {
     load_panel(n);
@@ -754,10 +774,10 @@ int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_
                        D(lay.hd[cur]), d_lo, d_hi, lam, D(lay.band), D(lay.rhs), D(lay.gn));
     ACINO_LAUNCH_CHECK();
     switch (PT) {
-      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(1), dim3(256), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
     }
     ACINO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_skel_trial, dim3(n_trial), dim3(256), 0, s, d_dev, D(lay.x[cur]), D(lay.x[cur ^ 1]), D(lay.g[cur]),
