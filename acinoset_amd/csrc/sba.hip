@@ -5,10 +5,19 @@
 // observation.  Here: analytic Jacobians, Cauchy IRLS weights w = 1/(1 + (r/f)^2), Levenberg-Marquardt on the
 // Schur complement of the point blocks (3x3 per point) onto the camera block (6C x 6C), rotations updated by a
 // left perturbation R <- exp([dw]x) R (same minimiser, no rvec singularities).  One thread per POINT walks its
-// observations (CSR built by the host); camera-block sums are reduced in LDS, then one atomic per entry.
+// observations (CSR built by the host); camera-block sums go through 16 lane-private copies in LDS (the lanes of a wave
+// are all at the same camera: one shared copy serialises 64 atomics per entry), then one atomic per entry per workgroup.
+// The coupling blocks W_pc (6 x 3) live in a DENSE table [point][camera] (zero where the camera does not see the point), so
+// the Schur complement S = - sum_p (W_p V_p^-1) W_p^T is a tall-skinny GEMM: k_sba_schur_mfma forms it on the fp64 matrix
+// cores, one point per k-step (3 columns + 1 zero), operands built in registers - no LDS, no atomics, partial sums per
+// workgroup reduced in a fixed order (round 4: 4.47 -> 0.3 ms per iteration at 1.28 M points; the previous form added 36
+// entries per observation pair to one LDS copy with atomics).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
+#include "dense80.hpp"
 
 namespace acino {
 
@@ -95,7 +104,8 @@ struct SbaBuf {
   double* V;             // [P][6]
   double* gp;            // [P][3]
   double* Vinv;          // [P][6]
-  double* Wpc;           // [M][18]  (6x3, row-major)
+  double* Wpc;           // [P][C][18]  (6x3 row-major per (point, camera) slot; zero where the camera does not see the point)
+  double* Spart;         // [n_schur_wg][n n + n] per-workgroup partial sums of k_sba_schur_mfma (null: atomics path)
   double* U;             // [C][21]
   double* gc;            // [C][6]
   double* S;             // [6C][6C]
@@ -116,11 +126,12 @@ template <bool JAC, int PREC>
 __global__ void __launch_bounds__(256)
 k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ pts, double* __restrict__ res_out) {
   typedef typename std::conditional<PREC == ACINO_PREC_F64, double, float>::type acc_t;
-  __shared__ acc_t sU[SBA_MAXC][27];
+  extern __shared__ __attribute__((aligned(16))) char sba_smem[];
+  acc_t* sU = reinterpret_cast<acc_t*>(sba_smem);          // [16][C][27]: copy (lane & 15)
   __shared__ double sred[4];
-  const int tid = threadIdx.x;
-  if (JAC)
-    for (int e = tid; e < B.C * 27; e += 256) (&sU[0][0])[e] = 0.0;
+  const int tid = threadIdx.x, slot = tid & 15, nU = B.C * 27;
+  if (JAC && B.opt_cams)
+    for (int e = tid; e < 16 * nU; e += 256) sU[e] = 0.0;
   __syncthreads();
   const int p = blockIdx.x * 256 + tid;
   double cost = 0.0, gmax = 0.0;
@@ -181,19 +192,20 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
         V[5] += w0 * Jp[0][2] * Jp[0][2] + w1 * Jp[1][2] * Jp[1][2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) g[j] += w0 * rs0 * Jp[0][j] + w1 * rs1 * Jp[1][j];
-        double* W = B.Wpc + 18 * (size_t)k;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) W[a * 3 + j] = w0 * Jc[0][a] * Jp[0][j] + w1 * Jc[1][a] * Jp[1][j];
         if (B.opt_cams) {
+          double* W = B.Wpc + 18 * ((size_t)p * B.C + c);
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) W[a * 3 + j] = w0 * Jc[0][a] * Jp[0][j] + w1 * Jc[1][a] * Jp[1][j];
+          acc_t* su = sU + (slot * B.C + c) * 27;
           int q = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int bq = a; bq < 6; ++bq) atomicAdd(&sU[c][q++], w0 * Jc[0][a] * Jc[0][bq] + w1 * Jc[1][a] * Jc[1][bq]);
+            for (int bq = a; bq < 6; ++bq) atomicAdd(&su[q++], w0 * Jc[0][a] * Jc[0][bq] + w1 * Jc[1][a] * Jc[1][bq]);
 #pragma unroll
-          for (int a = 0; a < 6; ++a) atomicAdd(&sU[c][21 + a], w0 * rs0 * Jc[0][a] + w1 * rs1 * Jc[1][a]);
+          for (int a = 0; a < 6; ++a) atomicAdd(&su[21 + a], w0 * rs0 * Jc[0][a] + w1 * rs1 * Jc[1][a]);
         }
       }
     }
@@ -218,9 +230,11 @@ k_sba_point(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
                                          (unsigned long long)__double_as_longlong(gmax));   // gmax >= 0: order-preserving
   if (JAC && B.opt_cams) {
     __syncthreads();
-    for (int e = tid; e < B.C * 27; e += 256) {
+    for (int e = tid; e < nU; e += 256) {
       const int c = e / 27, q = e % 27;
-      const double v = (double)sU[c][q];
+      double v = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) v += (double)sU[sl * nU + e];      // the 16 copies, fixed order
       if (v != 0.0) atomicAdd(q < 21 ? &B.U[21 * c + q] : &B.gc[6 * c + (q - 21)], v);
     }
   }
@@ -250,7 +264,7 @@ __global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
                             Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]};
       for (int o1 = B.pt_start[p]; o1 < B.pt_start[p + 1]; ++o1) {
         const int k1 = B.pt_obs[o1], c1 = B.cam_idx[k1];
-        const double* W1 = B.Wpc + 18 * (size_t)k1;
+        const double* W1 = B.Wpc + 18 * ((size_t)p * B.C + c1);
         double T[6][3];   // W1 Vinv
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -261,7 +275,7 @@ __global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
         }
         for (int o2 = B.pt_start[p]; o2 < B.pt_start[p + 1]; ++o2) {
           const int k2 = B.pt_obs[o2], c2 = B.cam_idx[k2];
-          const double* W2 = B.Wpc + 18 * (size_t)k2;
+          const double* W2 = B.Wpc + 18 * ((size_t)p * B.C + c2);
 #pragma unroll
           for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -279,6 +293,113 @@ __global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
     for (int e = tid; e < n; e += 256)
       if (sS[n * n + e] != 0.0) atomicAdd(&B.rhs[e], sS[n * n + e]);
   }
+}
+
+
+// The Schur complement on the matrix cores (6 C + 1 <= 48, i.e. C <= 7 cameras).  With A_p = [W_p V_p^-1 ; (V_p^-1 g_p)^T]
+// (37 x 3 for six cameras: rows 6 c + a, then the right-hand-side row) and B_p = W_p (36 x 3, zero rows for cameras that do
+// not see the point):  [S ; rhs^T] = - sum_p A_p B_p^T.  One point is one k-step of v_mfma_f64_16x16x4 (k = 0..2 the three
+// point coordinates, k = 3 zero); lane (i, k) builds its operand entries from the rows 16 t + i (t = 0, 1, 2) of the dense
+// W table and the point's V^-1 (every lane inverts the same 3 x 3: uniform loads), the six lower tiles accumulate in
+// registers over the wave's points.  Points are dealt to the waves in contiguous ranges, the next point's values are
+// requested before the current point's products.  Partial sums: wave -> LDS -> one [n n + n] record per workgroup; the
+// reduction kernel adds the records in a fixed order (deterministic, no atomics).
+constexpr int SCH_T = 256;
+__global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, int pts_per_wave) {
+  __shared__ double sT[4][6][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int C = B.C, n = 6 * C;
+  const int gw = blockIdx.x * 4 + wave;
+  const int p0 = gw * pts_per_wave, p1 = min(p0 + pts_per_wave, B.P);
+  d4 acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = d4{0, 0, 0, 0};
+  // rows of this lane in the three row tiles: 16 t + li -> (camera, parameter) or the rhs row (n) or nothing
+  int rc[3], rr[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int R = 16 * t + li;
+    rc[t] = R < n ? R / 6 : -1;
+    rr[t] = R < n ? R % 6 : (R == n ? 6 : 7);            // 6: right-hand-side row, 7: padding
+  }
+  struct Pt {
+    double V[6], g[3], w[3][3];
+  };
+  auto fetch = [&](int p, Pt& q) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) q.V[e] = B.V[6 * (size_t)p + e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) q.g[e] = B.gp[3 * (size_t)p + e];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const double* W = B.Wpc + 18 * ((size_t)p * C + (rc[t] >= 0 ? rc[t] : 0)) + 3 * (rr[t] < 6 ? rr[t] : 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) q.w[t][j] = rc[t] >= 0 ? W[j] : 0.0;
+    }
+  };
+  Pt cur, nxt;
+  if (p0 < p1) fetch(p0, cur);
+  for (int p = p0; p < p1; ++p) {
+    if (p + 1 < p1) fetch(p + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    // V^-1 of the damped point block (closed form, as k_sba_schur), V^-1 g
+    const double a = cur.V[0] * (1 + lam), b = cur.V[1], c = cur.V[2], d = cur.V[3] * (1 + lam), e = cur.V[4], f = cur.V[5] * (1 + lam);
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    double det = a * c00 + b * c01 + c * c02;
+    if (!(fabs(det) > 0.0)) det = 1.0;
+    const double id = 1.0 / det;
+    const double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) B.Vinv[6 * (size_t)p + q] = Vi[q];
+    }
+    // column lk of V^-1 (lk = 3: the zero k-step), entry lk of V^-1 g
+    const double v0 = lk == 0 ? Vi[0] : (lk == 1 ? Vi[1] : (lk == 2 ? Vi[2] : 0.0));
+    const double v1 = lk == 0 ? Vi[1] : (lk == 1 ? Vi[3] : (lk == 2 ? Vi[4] : 0.0));
+    const double v2 = lk == 0 ? Vi[2] : (lk == 1 ? Vi[4] : (lk == 2 ? Vi[5] : 0.0));
+    const double vg = v0 * cur.g[0] + v1 * cur.g[1] + v2 * cur.g[2];
+    double Aop[3], Bop[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      Aop[t] = rr[t] == 6 ? vg : cur.w[t][0] * v0 + cur.w[t][1] * v1 + cur.w[t][2] * v2;     // (padding rows: w = 0)
+      Bop[t] = lk == 0 ? cur.w[t][0] : (lk == 1 ? cur.w[t][1] : (lk == 2 ? cur.w[t][2] : 0.0));
+    }
+    acc[0] = mfma(-Aop[0], Bop[0], acc[0]);
+    acc[1] = mfma(-Aop[1], Bop[0], acc[1]);
+    acc[2] = mfma(-Aop[1], Bop[1], acc[2]);
+    acc[3] = mfma(-Aop[2], Bop[0], acc[3]);
+    acc[4] = mfma(-Aop[2], Bop[1], acc[4]);
+    acc[5] = mfma(-Aop[2], Bop[2], acc[5]);
+    cur = nxt;
+  }
+  // C layout: register rr of lane (li, lk) = entry [row lk + 4 rr][column li] of the tile
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[wave][t][(lk + 4 * q) * 16 + li] = acc[t][q];
+  __syncthreads();
+  double* out = B.Spart + (size_t)blockIdx.x * (n * n + n);
+  for (int e = tid; e < 6 * 256; e += SCH_T) {
+    const int t = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+    const int ib = t < 1 ? 0 : (t < 3 ? 1 : 2), jb = t < 1 ? 0 : (t < 3 ? t - 1 : t - 3);
+    const int R = 16 * ib + r, Cc = 16 * jb + cc;
+    const double v = (sT[0][t][e & 255] + sT[1][t][e & 255]) + (sT[2][t][e & 255] + sT[3][t][e & 255]);
+    if (Cc >= n) continue;
+    if (R < n) {
+      out[R * n + Cc] = v;
+      if (ib != jb) out[Cc * n + R] = v;                 // (diagonal tiles hold both triangles already)
+    } else if (R == n) {
+      out[n * n + Cc] = v;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part) {
+  const int n = 6 * B.C, tot = n * n + n;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= tot) return;
+  double s = 0.0;
+  for (int w = 0; w < n_part; ++w) s += B.Spart[(size_t)w * tot + e];
+  B.S[e] = s;                                            // (S | rhs contiguous)
 }
 
 // Reduced camera system (U + lam diag U + S) dc = -(gc + rhs_schur): dense Cholesky in LDS, n = 6C <= 96.
@@ -353,7 +474,7 @@ k_sba_backsub(SbaBuf B, double lam, const double* __restrict__ pts, double* __re
     if (B.opt_cams)
       for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
         const int k = B.pt_obs[o], c = B.cam_idx[k];
-        const double* W = B.Wpc + 18 * (size_t)k;
+        const double* W = B.Wpc + 18 * ((size_t)p * B.C + c);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
           const double dca = B.dc[6 * c + a];
@@ -412,6 +533,7 @@ __global__ void k_sba_apply_cams(SbaBuf B, const double* __restrict__ Rt, double
 }
 
 static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
+constexpr int SBA_SCHUR_WG = 1024;      // workgroups (x 4 waves) of k_sba_schur_mfma = records of partial sums
 
 }  // namespace acino
 
@@ -426,7 +548,9 @@ size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs) {
   if (n_cams < 1 || n_points < 0 || n_obs < 0) return 0;
   const size_t P = (size_t)n_points, M = (size_t)n_obs, n = 6 * (size_t)n_cams;
   size_t b = 0;
-  b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3 + a256(M * 18 * 8);        // V, Vinv, gp, dp, pts_t, Wpc
+  (void)M;
+  b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3 + a256(P * n_cams * 18 * 8);        // V, Vinv, gp, dp, pts_t, Wpc [P][C]
+  b += a256((size_t)SBA_SCHUR_WG * (n * n + n) * 8);                                  // per-workgroup partial sums of the Schur kernel
   b += a256(n_cams * 21 * 8) + a256(n * 8) * 3 + a256(n * n * 8) + a256(n_cams * 12 * 8) + a256(64);
   return b + 1024;
 }
@@ -481,7 +605,10 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   B.gp = (double*)take(P * 3 * 8);
   B.dp = (double*)take(P * 3 * 8);
   double* pts_t = (double*)take(P * 3 * 8);
-  B.Wpc = (double*)take(M * 18 * 8);
+  B.Wpc = (double*)take(P * C * 18 * 8);
+  B.Spart = (double*)take((size_t)SBA_SCHUR_WG * (n * n + n) * 8);
+  // (the dense W table: slots of cameras that do not see a point are never written - zero them once)
+  if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.Wpc, 0, P * C * 18 * 8, s));
   B.U = (double*)take((C * 21 + n) * 8);      // [U | gc] contiguous: one reduction
   B.gc = B.U + C * 21;
   B.dc = (double*)take(n * 8);
@@ -508,8 +635,8 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     if (jac) {
       ACINO_HIP_CHECK(hipMemsetAsync(B.U, 0, C * 21 * 8, s));
       ACINO_HIP_CHECK(hipMemsetAsync(B.gc, 0, n * 8, s));
-      if (B.prec == ACINO_PREC_F64) hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_F64>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
-      else hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_BF16_ROWS>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);
+      if (B.prec == ACINO_PREC_F64) hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_F64>), dim3(nblk), dim3(256), 16 * C * 27 * 8, s, B, Rt, pts, res);
+      else hipLaunchKernelGGL((k_sba_point<true, ACINO_PREC_BF16_ROWS>), dim3(nblk), dim3(256), 16 * C * 27 * 4, s, B, Rt, pts, res);
     } else {
       hipLaunchKernelGGL((k_sba_point<false, ACINO_PREC_F64>), dim3(nblk), dim3(256), 0, s, B, Rt, pts, res);   // (cost only: fp64)
     }
@@ -547,8 +674,18 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     }
     info->iterations = it + 1;
     ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
-    if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
-    hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
+    static const bool schur_atomics = getenv("ACINO_SBA_SCHUR_ATOMICS") != nullptr;
+    if (B.opt_cams && 6 * C + 1 <= 48 && !schur_atomics) {
+      // matrix-core Schur complement: contiguous point ranges per wave, as many workgroups as keep >= 64 points per wave
+      const int waves = (int)std::min<size_t>((size_t)SBA_SCHUR_WG * 4, (P + 63) / 64);
+      const int ppw = (int)((P + waves - 1) / waves), n_wg = (waves + 3) / 4;
+      hipLaunchKernelGGL(k_sba_schur_mfma, dim3(n_wg), dim3(SCH_T), 0, s, B, lam, ppw);
+      ACINO_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256)), dim3(256), 0, s, B, n_wg);
+    } else {
+      if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
+      hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
+    }
     ACINO_LAUNCH_CHECK();
     if (B.opt_cams) {
       if (int e = greduce(B.S, n * n + n, 0)) return e;

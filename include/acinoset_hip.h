@@ -320,7 +320,10 @@ int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* 
  * (src/calib/calib.py:307-341).  Cost = sum over observations and both pixel axes of 0.5 f^2 log1p((r/f)^2),
  * scipy's definition, so costs compare 1:1 with `res.cost`.  Observations arrive flat: uv[M][2], cam_idx[M]; the host
  * also supplies the CSR grouping by point (pt_start[P+1], pt_obs[M]).  Poses are [R row-major 9 | t 3] per camera and
- * are updated in place together with the points. */
+ * are updated in place together with the points.  With optimize_cameras a (point, camera) pair may carry at most ONE
+ * observation: the 6 x 3 coupling blocks live in a dense table [point][camera] (workspace: n_points x n_cams x 144 B), which
+ * makes the Schur complement onto the cameras a tall-skinny GEMM for the fp64 matrix cores (n_cams <= 7; more cameras take
+ * the atomic-accumulation kernel). */
 typedef struct acino_sba_params {
   int32_t n_cams;
   int32_t optimize_cameras;   /* 0 = points only (calib.py:327), 1 = points + extrinsics (calib.py:369) */

@@ -1,8 +1,8 @@
 """Config 5's SBA half (64 x 1 000 frames: 1.28 M points, 6.5 M observations, six shared extrinsics) as a stand-alone
 workload for rocprofv3: python scripts/sba_config5.py [f64|bf16] [outer iterations]"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acinoset_amd import sba, synth
 prec = sys.argv[1] if len(sys.argv) > 1 else "f64"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
