@@ -403,6 +403,10 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
   const int n_spike = hasL ? 5 : 1;          // first run: only the right-hand side column (strip 4) is alive
   int t3 = 0, t2 = 0, tflag = 0, t5 = 0;     // rounds of the wave-subset barriers
+  // max |projected gradient| over the rows this thread builds, over the whole run: ONE entry of gn_part per run, published
+  // at the end (it was one per node: a shuffle tree and a barrier in every node's serial part, 14 x as many entries for
+  // k_totals to walk)
+  double gmax_run = 0.0;
   // (debug stamps: workgroup dbg[64] writes wall-clock ticks of its phases at node dbg[65] into dbg[0..63]; the selectors
   //  sit OUTSIDE the stamp range and are read ONCE)
   long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64]) ? ch.dbg : nullptr;
@@ -423,8 +427,8 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     build_fetch<SW_T>(f, ch, K, first, tid);
     fill_coupling_coef<SW_T>(cL, cR, K, first, tid, kq);
     for (int e = tid; e < MAT; e += SW_T) Y[e] = 0.0;
-    const double gmax = build_finish<SW_T>(Xc, bv, f, K, first, tid, kq, klo, khi);
-    publish_gmax<SW_T>(gmax, red, ch.gn_part, first, tid);   // (barrier inside: node, bv, tables, zeros complete)
+    gmax_run = build_finish<SW_T>(Xc, bv, f, K, first, tid, kq, klo, khi);
+    __syncthreads();                                   // node, bv, tables, zeros complete
     if (hasL)
       for (int e = tid; e < 9 * NP; e += SW_T) {
         const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
@@ -567,7 +571,6 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
       }
       __syncthreads();                                 // every read of G done (the store above included): Xn is rebuilt
       if (wave == 0) SW_STAMP(2);
-      double gmax = 0.0;
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const int pr = sl ? pd1 : pd0, pc = sl ? pc1 : pc0;
@@ -591,7 +594,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
                 d = d + lamq * fmax(d, DIAG_FLOOR);
                 if (fixed) d *= FIX_SCALE;
                 bb = fixed ? 0.0 : -gq[j];
-                if (ownq[j]) gmax = fmax(gmax, fabs(bb));   // (window sharding: owned frames only)
+                if (ownq[j]) gmax_run = fmax(gmax_run, fabs(bb));   // (window sharding: owned frames only)
               }
               v[j][j] = d;
               bv[j * NP + pr] = bb;
@@ -610,7 +613,6 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
       //  exactly - every product behind it has an exact 0 or 1 factor -, and G_k is what Xn holds there; bv[75 .. 79] = 0
       //  since the first node was built)
       if (wave == 0) SW_STAMP(3);
-      publish_gmax<SW_T>(gmax, red, ch.gn_part, next, tid_);  // (barrier inside)
     }
     __syncthreads();
     if (wave == 0) SW_STAMP(4);
@@ -721,6 +723,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     Xn = tmp;
   }
 #undef SW_STAMP
+  publish_gmax<SW_T>(gmax_run, red, ch.gn_part, c, tid);
 }
 
 // Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as

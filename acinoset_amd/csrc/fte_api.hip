@@ -636,7 +636,8 @@ static int eval_iterate(acino_fte_ctx* ctx, int which, bool need_jac, bool with_
   {
     ProfSpan sp(&ctx->prof, PC_TOTALS, s);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1024), 0, s, b.state, b.cost_part, ctx->n_blk_asm, b.pred_part,
-                       b.step_part, ctx->n_pred, b.gn_part, ctx->chain.n_nodes, b.nbehind, b.totals,
+                       b.step_part, ctx->n_pred, b.gn_part, ctx->plan.active() ? ctx->plan.n_chunks : ctx->chain.n_nodes,   // (chunked: one entry per run)
+                       b.nbehind, b.totals,
                        with_step ? 1 : 0, b.cst, b.numeric_err, fused_control, b.trunc_eps2, ctx->n_trunc);
   }
   ACINO_LAUNCH_CHECK();
@@ -1222,7 +1223,9 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
   for (int it = 0; it < max_iter; ++it) {
     int rc = acino_fte_step(ctx, stream);
     if (rc) return rc;
-    if ((it & 7) == 7) {   // the device stops by itself; peek now and then to stop launching no-ops
+    // the device stops by itself; the host peeks now and then to stop launching no-ops - not before a stop is plausible
+    // (a synchronisation drains the launch queue: ~50 us of idle GPU each; a no-op step costs about as much)
+    if (it >= 11 && ((it - 11) & 3) == 0) {
       rc = acino_fte_get_state(ctx, &st, stream);
       if (rc) return rc;
       if (st.status != 0) break;

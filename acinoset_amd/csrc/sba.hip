@@ -304,86 +304,106 @@ __global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
 // registers over the wave's points.  Points are dealt to the waves in contiguous ranges, the next point's values are
 // requested before the current point's products.  Partial sums: wave -> LDS -> one [n n + n] record per workgroup; the
 // reduction kernel adds the records in a fixed order (deterministic, no atomics).
-constexpr int SCH_T = 256;
+constexpr int SBA_SCHUR_WG = 1024;      // workgroups (x 4 waves) of k_sba_schur_mfma = records of partial sums
+constexpr int SCH_T = 256, SCH_B = 16;     // threads; points per batch of one wave
 __global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, int pts_per_wave) {
-  __shared__ double sT[4][6][256];
+  // Each wave streams its points through its own LDS slab in batches of SCH_B: the batch's V (6), g (3) and W (18 C) values
+  // are contiguous in memory - copied with all 64 lanes, the NEXT batch's copy in flight (registers) while this batch's
+  // points go through the matrix cores.  (One point at a time from memory was latency-bound: 1.03 ms for 1.28 M points.)
+  extern __shared__ __attribute__((aligned(16))) char sch_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int C = B.C, n = 6 * C;
+  const int C = B.C, n = 6 * C, wrec = 18 * C, rec = 9 + wrec;            // doubles per point in the slab: V | g | W
+  constexpr int MAXQ = (SCH_B * (9 + 18 * 7) + 63) / 64;                    // registers per lane for one batch (C <= 7)
+  double* slab = reinterpret_cast<double*>(sch_smem) + (size_t)wave * SCH_B * rec;
   const int gw = blockIdx.x * 4 + wave;
   const int p0 = gw * pts_per_wave, p1 = min(p0 + pts_per_wave, B.P);
   d4 acc[6];
 #pragma unroll
   for (int t = 0; t < 6; ++t) acc[t] = d4{0, 0, 0, 0};
-  // rows of this lane in the three row tiles: 16 t + li -> (camera, parameter) or the rhs row (n) or nothing
-  int rc[3], rr[3];
+  int woff[3], rrow[3];                                                    // rows 16 t + li of [W V^-1 ; (V^-1 g)^T]
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int R = 16 * t + li;
-    rc[t] = R < n ? R / 6 : -1;
-    rr[t] = R < n ? R % 6 : (R == n ? 6 : 7);            // 6: right-hand-side row, 7: padding
+    woff[t] = R < n ? 3 * R : -1;                                          // (camera R / 6, parameter R % 6: offset 18 c + 3 r = 3 R)
+    rrow[t] = R < n ? 0 : (R == n ? 1 : 2);                                // 0 coupling row, 1 right-hand-side row, 2 padding
   }
-  struct Pt {
-    double V[6], g[3], w[3][3];
-  };
-  auto fetch = [&](int p, Pt& q) {
+  double stage[MAXQ];
+  // the batch starting at point pb: nb points; element e of the batch = V | g | W of the points, each array contiguous
+  auto fetch = [&](int pb, int nb) {
+    const int nV = 6 * nb, nG = 3 * nb, nW = wrec * nb;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) q.V[e] = B.V[6 * (size_t)p + e];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) q.g[e] = B.gp[3 * (size_t)p + e];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const double* W = B.Wpc + 18 * ((size_t)p * C + (rc[t] >= 0 ? rc[t] : 0)) + 3 * (rr[t] < 6 ? rr[t] : 0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) q.w[t][j] = rc[t] >= 0 ? W[j] : 0.0;
+    for (int q = 0; q < MAXQ; ++q) {
+      const int e = lane + 64 * q;
+      double v = 0.0;
+      if (e < nV) v = B.V[6 * (size_t)pb + e];
+      else if (e < nV + nG) v = B.gp[3 * (size_t)pb + (e - nV)];
+      else if (e < nV + nG + nW) v = B.Wpc[(size_t)wrec * pb + (e - nV - nG)];
+      stage[q] = v;
     }
   };
-  Pt cur, nxt;
-  if (p0 < p1) fetch(p0, cur);
-  for (int p = p0; p < p1; ++p) {
-    if (p + 1 < p1) fetch(p + 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    // V^-1 of the damped point block (closed form, as k_sba_schur), V^-1 g
-    const double a = cur.V[0] * (1 + lam), b = cur.V[1], c = cur.V[2], d = cur.V[3] * (1 + lam), e = cur.V[4], f = cur.V[5] * (1 + lam);
-    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    double det = a * c00 + b * c01 + c * c02;
-    if (!(fabs(det) > 0.0)) det = 1.0;
-    const double id = 1.0 / det;
-    const double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
-    if (lane == 0) {
+  auto stash = [&](int nb) {                                               // registers -> slab, point-major records
+    const int nV = 6 * nb, nG = 3 * nb, nW = wrec * nb;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) B.Vinv[6 * (size_t)p + q] = Vi[q];
+    for (int q = 0; q < MAXQ; ++q) {
+      const int e = lane + 64 * q;
+      if (e < nV) slab[(e / 6) * rec + e % 6] = stage[q];
+      else if (e < nV + nG) slab[((e - nV) / 3) * rec + 6 + (e - nV) % 3] = stage[q];
+      else if (e < nV + nG + nW) slab[((e - nV - nG) / wrec) * rec + 9 + (e - nV - nG) % wrec] = stage[q];
     }
-    // column lk of V^-1 (lk = 3: the zero k-step), entry lk of V^-1 g
-    const double v0 = lk == 0 ? Vi[0] : (lk == 1 ? Vi[1] : (lk == 2 ? Vi[2] : 0.0));
-    const double v1 = lk == 0 ? Vi[1] : (lk == 1 ? Vi[3] : (lk == 2 ? Vi[4] : 0.0));
-    const double v2 = lk == 0 ? Vi[2] : (lk == 1 ? Vi[4] : (lk == 2 ? Vi[5] : 0.0));
-    const double vg = v0 * cur.g[0] + v1 * cur.g[1] + v2 * cur.g[2];
-    double Aop[3], Bop[3];
+  };
+  int pb = p0;
+  if (pb < p1) fetch(pb, min(SCH_B, p1 - pb));
+  while (pb < p1) {
+    const int nb = min(SCH_B, p1 - pb);
+    stash(nb);                                                             // (a wave's LDS operations are ordered: no barrier)
+    if (pb + nb < p1) fetch(pb + nb, min(SCH_B, p1 - pb - nb));
+    for (int q = 0; q < nb; ++q) {
+      const double* r = slab + q * rec;
+      // V^-1 of the damped point block (closed form, as k_sba_schur), V^-1 g
+      const double a = r[0] * (1 + lam), b = r[1], c = r[2], d = r[3] * (1 + lam), e = r[4], f = r[5] * (1 + lam);
+      const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+      double det = a * c00 + b * c01 + c * c02;
+      if (!(fabs(det) > 0.0)) det = 1.0;
+      const double id = 1.0 / det;
+      const double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
+      if (lane < 6) B.Vinv[6 * (size_t)(pb + q) + lane] = lane == 0 ? Vi[0] : (lane == 1 ? Vi[1] : (lane == 2 ? Vi[2] : (lane == 3 ? Vi[3] : (lane == 4 ? Vi[4] : Vi[5]))));
+      // column lk of V^-1 (lk = 3: the zero k-step), entry lk of V^-1 g
+      const double v0 = lk == 0 ? Vi[0] : (lk == 1 ? Vi[1] : (lk == 2 ? Vi[2] : 0.0));
+      const double v1 = lk == 0 ? Vi[1] : (lk == 1 ? Vi[3] : (lk == 2 ? Vi[4] : 0.0));
+      const double v2 = lk == 0 ? Vi[2] : (lk == 1 ? Vi[4] : (lk == 2 ? Vi[5] : 0.0));
+      const double vg = v0 * r[6] + v1 * r[7] + v2 * r[8];
+      double Aop[3], Bop[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      Aop[t] = rr[t] == 6 ? vg : cur.w[t][0] * v0 + cur.w[t][1] * v1 + cur.w[t][2] * v2;     // (padding rows: w = 0)
-      Bop[t] = lk == 0 ? cur.w[t][0] : (lk == 1 ? cur.w[t][1] : (lk == 2 ? cur.w[t][2] : 0.0));
+      for (int t = 0; t < 3; ++t) {
+        const double* w = r + 9 + (woff[t] >= 0 ? woff[t] : 0);
+        const double w0 = woff[t] >= 0 ? w[0] : 0.0, w1 = woff[t] >= 0 ? w[1] : 0.0, w2 = woff[t] >= 0 ? w[2] : 0.0;
+        Aop[t] = rrow[t] == 1 ? vg : w0 * v0 + w1 * v1 + w2 * v2;
+        Bop[t] = lk == 0 ? w0 : (lk == 1 ? w1 : (lk == 2 ? w2 : 0.0));
+      }
+      acc[0] = mfma(-Aop[0], Bop[0], acc[0]);
+      acc[1] = mfma(-Aop[1], Bop[0], acc[1]);
+      acc[2] = mfma(-Aop[1], Bop[1], acc[2]);
+      acc[3] = mfma(-Aop[2], Bop[0], acc[3]);
+      acc[4] = mfma(-Aop[2], Bop[1], acc[4]);
+      acc[5] = mfma(-Aop[2], Bop[2], acc[5]);
     }
-    acc[0] = mfma(-Aop[0], Bop[0], acc[0]);
-    acc[1] = mfma(-Aop[1], Bop[0], acc[1]);
-    acc[2] = mfma(-Aop[1], Bop[1], acc[2]);
-    acc[3] = mfma(-Aop[2], Bop[0], acc[3]);
-    acc[4] = mfma(-Aop[2], Bop[1], acc[4]);
-    acc[5] = mfma(-Aop[2], Bop[2], acc[5]);
-    cur = nxt;
+    pb += nb;
   }
-  // C layout: register rr of lane (li, lk) = entry [row lk + 4 rr][column li] of the tile
+  // wave -> LDS -> one record per workgroup.  C layout: register q of lane (li, lk) = entry [row lk + 4 q][column li] of a tile
+  __syncthreads();                                                         // (the slabs are free)
+  double* sT = reinterpret_cast<double*>(sch_smem);                        // [4][6][256]
 #pragma unroll
   for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sT[wave][t][(lk + 4 * q) * 16 + li] = acc[t][q];
+    for (int q = 0; q < 4; ++q) sT[(wave * 6 + t) * 256 + (lk + 4 * q) * 16 + li] = acc[t][q];
   __syncthreads();
   double* out = B.Spart + (size_t)blockIdx.x * (n * n + n);
   for (int e = tid; e < 6 * 256; e += SCH_T) {
     const int t = e >> 8, r = (e >> 4) & 15, cc = e & 15;
     const int ib = t < 1 ? 0 : (t < 3 ? 1 : 2), jb = t < 1 ? 0 : (t < 3 ? t - 1 : t - 3);
     const int R = 16 * ib + r, Cc = 16 * jb + cc;
-    const double v = (sT[0][t][e & 255] + sT[1][t][e & 255]) + (sT[2][t][e & 255] + sT[3][t][e & 255]);
+    const double v = (sT[(0 * 6 + t) * 256 + (e & 255)] + sT[(1 * 6 + t) * 256 + (e & 255)]) +
+                     (sT[(2 * 6 + t) * 256 + (e & 255)] + sT[(3 * 6 + t) * 256 + (e & 255)]);
     if (Cc >= n) continue;
     if (R < n) {
       out[R * n + Cc] = v;
@@ -393,13 +413,21 @@ __global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, 
     }
   }
 }
-__global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part) {
+// the records, added in a fixed order in two stages (n_part <= 1024 records of n n + n doubles): stage 0 sums every 32nd record
+// into 32 intermediate records (behind the partial records in Spart), stage 1 sums those into [S | rhs]
+__global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part, int stage) {
   const int n = 6 * B.C, tot = n * n + n;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
   if (e >= tot) return;
+  double* mid = B.Spart + (size_t)SBA_SCHUR_WG * tot;
   double s = 0.0;
-  for (int w = 0; w < n_part; ++w) s += B.Spart[(size_t)w * tot + e];
-  B.S[e] = s;                                            // (S | rhs contiguous)
+  if (stage == 0) {
+    for (int w = g; w < n_part; w += 32) s += B.Spart[(size_t)w * tot + e];
+    mid[(size_t)g * tot + e] = s;
+  } else {
+    for (int w = 0; w < 32; ++w) s += mid[(size_t)w * tot + e];
+    B.S[e] = s;                                          // (S | rhs contiguous)
+  }
 }
 
 // Reduced camera system (U + lam diag U + S) dc = -(gc + rhs_schur): dense Cholesky in LDS, n = 6C <= 96.
@@ -533,7 +561,6 @@ __global__ void k_sba_apply_cams(SbaBuf B, const double* __restrict__ Rt, double
 }
 
 static size_t a256(size_t v) { return (v + 255) / 256 * 256; }
-constexpr int SBA_SCHUR_WG = 1024;      // workgroups (x 4 waves) of k_sba_schur_mfma = records of partial sums
 
 }  // namespace acino
 
@@ -550,7 +577,7 @@ size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs) {
   size_t b = 0;
   (void)M;
   b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3 + a256(P * n_cams * 18 * 8);        // V, Vinv, gp, dp, pts_t, Wpc [P][C]
-  b += a256((size_t)SBA_SCHUR_WG * (n * n + n) * 8);                                  // per-workgroup partial sums of the Schur kernel
+  b += a256((size_t)(SBA_SCHUR_WG + 32) * (n * n + n) * 8);                           // partial sums of the Schur kernel (+ 32 intermediate records)
   b += a256(n_cams * 21 * 8) + a256(n * 8) * 3 + a256(n * n * 8) + a256(n_cams * 12 * 8) + a256(64);
   return b + 1024;
 }
@@ -606,7 +633,7 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   B.dp = (double*)take(P * 3 * 8);
   double* pts_t = (double*)take(P * 3 * 8);
   B.Wpc = (double*)take(P * C * 18 * 8);
-  B.Spart = (double*)take((size_t)SBA_SCHUR_WG * (n * n + n) * 8);
+  B.Spart = (double*)take((size_t)(SBA_SCHUR_WG + 32) * (n * n + n) * 8);
   // (the dense W table: slots of cameras that do not see a point are never written - zero them once)
   if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.Wpc, 0, P * C * 18 * 8, s));
   B.U = (double*)take((C * 21 + n) * 8);      // [U | gc] contiguous: one reduction
@@ -679,9 +706,12 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
       // matrix-core Schur complement: contiguous point ranges per wave, as many workgroups as keep >= 64 points per wave
       const int waves = (int)std::min<size_t>((size_t)SBA_SCHUR_WG * 4, (P + 63) / 64);
       const int ppw = (int)((P + waves - 1) / waves), n_wg = (waves + 3) / 4;
-      hipLaunchKernelGGL(k_sba_schur_mfma, dim3(n_wg), dim3(SCH_T), 0, s, B, lam, ppw);
+      const size_t lds_m = std::max((size_t)4 * SCH_B * (9 + 18 * C), (size_t)4 * 6 * 256) * 8;
+      hipLaunchKernelGGL(k_sba_schur_mfma, dim3(n_wg), dim3(SCH_T), lds_m, s, B, lam, ppw);
       ACINO_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256)), dim3(256), 0, s, B, n_wg);
+      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256), 32), dim3(256), 0, s, B, n_wg, 0);
+      ACINO_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256), 1), dim3(256), 0, s, B, n_wg, 1);
     } else {
       if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
       hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);

@@ -359,14 +359,48 @@ def triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh):
     return x0
 
 
+# Contexts kept alive between solves (fte_solve(..., reuse_context=True)): a second sequence of the same shape on the same rig
+# finds its workspace, its uploaded constants and its captured hipGraph in place - what is left outside the LM loop is the
+# copy of the detections, the initial evaluation and the outputs.  One context per key; clear_context_cache() frees them.
+_CTX_CACHE = {}
+
+
+def clear_context_cache():
+    for ctx in _CTX_CACHE.values():
+        ctx.close()
+    _CTX_CACHE.clear()
+
+
+def _context_for(det, k_arr, d_arr, r_arr, t_arr, Ts, reuse, kw):
+    if not reuse:
+        return FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, **kw), False
+    import hashlib
+    cams = np.ascontiguousarray(calib.fisheye_records(k_arr, d_arr, r_arr, t_arr))
+    key = (tuple(det.shape), str(det.device), float(Ts), hashlib.sha256(cams.tobytes()).hexdigest(),
+           tuple(sorted((k, repr(v)) for k, v in kw.items())))
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None or not ctx._h.value:
+        for old in list(_CTX_CACHE.values()):            # (one workspace at a time: a 10 000-frame context holds ~1 GB)
+            old.close()
+        _CTX_CACHE.clear()
+        ctx = FTEContext(det.clone(), k_arr, d_arr, r_arr, t_arr, Ts, **kw)
+        ctx.enable_graph(True)
+        _CTX_CACHE[key] = ctx
+    else:
+        ctx.det.copy_(det)                                # (the library reads the detections through this tensor's pointer)
+    return ctx, True
+
+
 def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thresh=0.5, start_frame=0,
-              max_iter=100, init="nose_line", return_numpy=True, **kw):
+              max_iter=100, init="nose_line", return_numpy=True, reuse_context=False, **kw):
     """The FTE solve call.
 
     meas[N,C,20,2] pixel detections, likelihood[N,C,20], cameras as in the scene file (k_arr[C,3,3],
     d_arr[C,4(,1)], r_arr[C,3,3], t_arr[C,3(,1)]), Ts = 1/fps.  x0[N,45] optional initial state
     (default: the reference's nose-line initialisation).  Returns (results, info) where results has the
-    reference's fte.pickle layout and info the solver status (iterations, final cost, |g|_inf, ...)."""
+    reference's fte.pickle layout and info the solver status (iterations, final cost, |g|_inf, ...).
+    ``reuse_context``: keep the context (workspace, constants, captured graph) for the next call with the same shapes, rig
+    and options (see _CTX_CACHE above)."""
     meas_t = meas if isinstance(meas, torch.Tensor) else torch.as_tensor(np.asarray(meas, dtype=np.float64))
     lik_t = likelihood if isinstance(likelihood, torch.Tensor) else torch.as_tensor(np.asarray(likelihood, dtype=np.float64))
     det = torch.cat([meas_t.to(torch.float64), lik_t.to(torch.float64).unsqueeze(-1).to(meas_t.device)], dim=-1)
@@ -383,14 +417,17 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     inactive = np.setdiff1d(np.arange(N_STATES), ACTIVE)
     if np.any(x0[:, inactive] != 0):
         raise ValueError("states with Q == 0 must start (and stay) at 0 (all_optimizations.py:543)")
-    ctx = FTEContext(det, k_arr, d_arr, r_arr, t_arr, Ts, dlc_thresh=dlc_thresh, **kw)
+    _lib.require_gpu()
+    det = det.to(torch.device("cuda", torch.cuda.current_device()))
+    ctx, cached = _context_for(det, k_arr, d_arr, r_arr, t_arr, Ts, reuse_context, dict(kw, dlc_thresh=dlc_thresh))
     kw.pop("trunc_distance", None)
     try:
         ctx.set_x(x0[:, ACTIVE])
         info = ctx.solve(max_iter)
         x, pos, dx, ddx = ctx.result()
     finally:
-        ctx.close()
+        if not cached:
+            ctx.close()
     if info["status"] == 5:
         raise RuntimeError("FTE: block factorisation hit a non-positive pivot")
     conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)
