@@ -313,7 +313,6 @@ __global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, 
   extern __shared__ __attribute__((aligned(16))) char sch_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int C = B.C, n = 6 * C, wrec = 18 * C, rec = 9 + wrec;            // doubles per point in the slab: V | g | W
-  constexpr int MAXQ = (SCH_B * (9 + 18 * 7) + 63) / 64;                    // registers per lane for one batch (C <= 7)
   double* slab = reinterpret_cast<double*>(sch_smem) + (size_t)wave * SCH_B * rec;
   const int gw = blockIdx.x * 4 + wave;
   const int p0 = gw * pts_per_wave, p1 = min(p0 + pts_per_wave, B.P);
@@ -327,29 +326,39 @@ __global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, 
     woff[t] = R < n ? 3 * R : -1;                                          // (camera R / 6, parameter R % 6: offset 18 c + 3 r = 3 R)
     rrow[t] = R < n ? 0 : (R == n ? 1 : 2);                                // 0 coupling row, 1 right-hand-side row, 2 padding
   }
-  double stage[MAXQ];
-  // the batch starting at point pb: nb points; element e of the batch = V | g | W of the points, each array contiguous
+  // one batch in registers: V (6 nb <= 96 values: 2 per lane), g (3 nb <= 48: 1), W (18 C values per point: 2 per lane and
+  // point for C <= 7).  Every copy is a run of consecutive addresses; no division by a run-time value anywhere (the first
+  // form spent ~200 instructions per point on e / wrec, e % wrec).
+  double sv[2], sg, sw[SCH_B][2];
   auto fetch = [&](int pb, int nb) {
-    const int nV = 6 * nb, nG = 3 * nb, nW = wrec * nb;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
+    for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
-      double v = 0.0;
-      if (e < nV) v = B.V[6 * (size_t)pb + e];
-      else if (e < nV + nG) v = B.gp[3 * (size_t)pb + (e - nV)];
-      else if (e < nV + nG + nW) v = B.Wpc[(size_t)wrec * pb + (e - nV - nG)];
-      stage[q] = v;
+      sv[q] = e < 6 * nb ? B.V[6 * (size_t)pb + e] : 0.0;
     }
+    sg = lane < 3 * nb ? B.gp[3 * (size_t)pb + lane] : 0.0;
+#pragma unroll
+    for (int pt = 0; pt < SCH_B; ++pt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q;
+        sw[pt][q] = (pt < nb && e < wrec) ? B.Wpc[(size_t)wrec * (pb + pt) + e] : 0.0;
+      }
   };
   auto stash = [&](int nb) {                                               // registers -> slab, point-major records
-    const int nV = 6 * nb, nG = 3 * nb, nW = wrec * nb;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
+    for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
-      if (e < nV) slab[(e / 6) * rec + e % 6] = stage[q];
-      else if (e < nV + nG) slab[((e - nV) / 3) * rec + 6 + (e - nV) % 3] = stage[q];
-      else if (e < nV + nG + nW) slab[((e - nV - nG) / wrec) * rec + 9 + (e - nV - nG) % wrec] = stage[q];
+      if (e < 6 * nb) slab[(e / 6) * rec + e % 6] = sv[q];
     }
+    if (lane < 3 * nb) slab[(lane / 3) * rec + 6 + lane % 3] = sg;
+#pragma unroll
+    for (int pt = 0; pt < SCH_B; ++pt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q;
+        if (pt < nb && e < wrec) slab[pt * rec + 9 + e] = sw[pt][q];
+      }
   };
   int pb = p0;
   if (pb < p1) fetch(pb, min(SCH_B, p1 - pb));

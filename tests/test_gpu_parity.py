@@ -1078,6 +1078,32 @@ def test_escalation_from_the_default_configuration_keeps_the_refinement_settings
     assert info["iter"] <= 2
 
 
+def test_device_side_initial_guess_and_context_reuse(mods):
+    """fte_solve(init="triangulation") forms its start on the device (triangulation_init_active) - the same guess as the numpy
+    triangulation_init, gaps included - and reuse_context keeps workspace + graph between solves: a second sequence of the same
+    shape solved through the kept context gives bit for bit what a fresh context gives."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(600, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    det = torch.as_tensor(seq["det"], device="cuda").clone()
+    det[100:140, :, 0:4, 2] = 0.0                      # 40 frames without any head marker: interpolated
+    det[:7, :, 0:4, 2] = 0.0                           # ... and a gap at the start: held flat
+    want = fte.triangulation_init(det, *rig, 0.5)[:, fte.ACTIVE]
+    got = fte.triangulation_init_active(det, *rig, 0.5).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-11
+    seq2 = synth.make_sequence(600, "loop", seed=7)
+    outs = []
+    for reuse in (False, True, True):
+        r1, i1 = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], init="triangulation", max_iter=60, reuse_context=reuse)
+        d2 = torch.as_tensor(seq2["det"], device="cuda")
+        r2, i2 = fte.fte_solve(d2[..., :2], d2[..., 2], *rig, seq["Ts"], init="triangulation", max_iter=60, reuse_context=reuse)
+        outs.append((r1["x"], i1["cost"], i1["iter"], r2["x"], i2["cost"], i2["iter"]))
+    fte.clear_context_cache()
+    for o in outs[1:]:
+        assert o[1] == outs[0][1] and o[2] == outs[0][2] and o[4] == outs[0][4] and o[5] == outs[0][5]
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[3], outs[0][3])
+
+
 def test_concurrent_contexts_do_not_interfere(mods):
     """Regression (round 2): the T + 1 workgroups that share one node of a narrow elimination level all read D_i; the one
     that stores the factor used to overwrite D_i in place, so a sibling dispatched late - which only happens when
