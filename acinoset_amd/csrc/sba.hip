@@ -330,20 +330,17 @@ __global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, 
   // point for C <= 7).  Every copy is a run of consecutive addresses; no division by a run-time value anywhere (the first
   // form spent ~200 instructions per point on e / wrec, e % wrec).
   double sv[2], sg, sw[SCH_B][2];
+  // (every load UNCONDITIONAL on a clamped, valid address: a conditional load compiles to a branch and a full wait per
+  //  element - 35 serialised round trips per batch; what is out of range is simply not stashed)
   auto fetch = [&](int pb, int nb) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane + 64 * q;
-      sv[q] = e < 6 * nb ? B.V[6 * (size_t)pb + e] : 0.0;
-    }
-    sg = lane < 3 * nb ? B.gp[3 * (size_t)pb + lane] : 0.0;
+    for (int q = 0; q < 2; ++q) sv[q] = B.V[6 * (size_t)pb + min(lane + 64 * q, 6 * nb - 1)];
+    sg = B.gp[3 * (size_t)pb + min(lane, 3 * nb - 1)];
 #pragma unroll
     for (int pt = 0; pt < SCH_B; ++pt)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int e = lane + 64 * q;
-        sw[pt][q] = (pt < nb && e < wrec) ? B.Wpc[(size_t)wrec * (pb + pt) + e] : 0.0;
-      }
+      for (int q = 0; q < 2; ++q)
+        sw[pt][q] = B.Wpc[(size_t)wrec * (pb + min(pt, nb - 1)) + min(lane + 64 * q, wrec - 1)];
   };
   auto stash = [&](int nb) {                                               // registers -> slab, point-major records
 #pragma unroll
