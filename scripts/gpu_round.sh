@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 1200 python -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q -rs -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
 export TMPDIR=/tmp
 cd /tmp
@@ -17,9 +17,19 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64
 cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 # the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
-mkdir -p $R/profiles/round3 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round3/ 2>/dev/null
+mkdir -p $R/profiles/round4 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round4/ 2>/dev/null
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
+# the widened rows and the secondary configs: kernel stats of a bench run WITH the secondary metrics (config 2's fused kernel,
+# the config-5 clip chain, k_sba_*, k_skel_*), the SBA / EKF reports, the wait-state counters of every FTE kernel
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_all -o all -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $OUT/rocprof_all.err
+cd $R
+find $OUT/rocprof_all -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats_with_secondary_configs.csv
+rm -rf $OUT/rocprof_all
+timeout 600 python scripts/extras_report.py $OUT/summary > $OUT/extras.log 2>&1
+timeout 900 bash scripts/pmc_waits.sh > /dev/null 2>&1; cp $R/gpurun_out/waits/waits.txt $OUT/summary/pmc_wait_states.txt 2>/dev/null
+timeout 600 python scripts/shard_model.py > $OUT/summary/shard_model.txt 2>&1
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
 # keep the merge-back small: the raw counter dumps are not needed once summarised
