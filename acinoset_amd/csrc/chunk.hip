@@ -25,9 +25,12 @@
 
 namespace acino {
 
-void ChunkPlan::build(int nodes, int chunk_nodes) {
-  n_nodes = nodes;
+void ChunkPlan::build(int nodes_total, int chunk_nodes, bool pin_l, bool pin_r) {
+  n_nodes = nodes_total;
   m = n_chunks = n_sep = 0;
+  node0 = pin_l ? 1 : 0;
+  pin_right = pin_r ? 1 : 0;
+  const int nodes = nodes_total - node0;             // the swept part of the chain (a right pin is its last node)
   if (chunk_nodes < 0 || nodes < 1) return;
   int mm = chunk_nodes;
   if (mm == 0) {
@@ -40,7 +43,10 @@ void ChunkPlan::build(int nodes, int chunk_nodes) {
   mm = std::max(2, mm);
   m = mm;
   n_chunks = (nodes + mm - 1) / mm;
-  n_sep = n_chunks - 1;
+  // a right pin must not be a run of its own (a run builds its right separator from at least one interior node): the last
+  // run then takes m + 1 nodes
+  if (pin_r && n_chunks > 1 && nodes - (n_chunks - 1) * mm == 1) --n_chunks;
+  n_sep = n_chunks - 1 + node0 + pin_right;
 }
 
 // ---- tile helpers on LDS matrices (leading dimension LD): one 16x16 output tile per call, all operands read first ----
@@ -377,7 +383,7 @@ __device__ __forceinline__ void syrk_run_n(d4 (&acc)[NQ], const double* W, doubl
 
 __global__ void __launch_bounds__(SW_T)
 k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
-               int m, int n_chunks) {
+               int m, int n_chunks, int node0, int pin_right) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
   double* Xc = reinterpret_cast<double*>(smem_raw);   // D~_k -> U_k
@@ -395,9 +401,11 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const FteConst& K = *cst;
   const int c = blockIdx.x;
-  const int first = c * m;
-  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
-  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const int first = node0 + c * m;
+  const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
+  const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;       // (the last run: whatever is left, m + 1 at most)
+  const int n_int = hasR ? len - 1 : len;
+  const int sL = c - 1 + node0, sR = c + node0;                    // separator-chain indices of the run's two ends
   const size_t MB = (size_t)BS * BS;
   const int role = __builtin_amdgcn_readfirstlane(role8(wave));
   const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
@@ -415,6 +423,10 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
 #define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
   if (tid < 4) sync[tid] = 0;
   if (tid < 64) lst[tid] = 0;
+  if (c == 0 && node0) {                               // the left pin owns no frames here: its block starts from zero, the
+    for (int e = tid; e < BS * BS; e += SW_T) sp.D[e] = 0.0;       // run's spike contribution AL is added by the reduction
+    if (tid < BS) sp.b[tid] = 0.0;
+  }
   if (tid < NP) {
     kq[tid] = K.q_w[tid];
     klo[tid] = K.lo[tid];
@@ -454,7 +466,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     // thread's own: the Gauss-Newton entries H_j[p][p'] (requested here, a whole node ahead of their use), the Schur update
     // -(E^T G_k E) of the block (nine entries of G_k in, nine out: E couples only equal states), and for p = p' the damping,
     // the bound pinning, the intra-node third-difference couplings and the right-hand side.  No zero fill, no in-place pass.
-    const int fb_next = 3 * next;                      // (chunked contexts have no pinned separator: node t holds frames 3t ..)
+    const int fb_next = 3 * (next - node0);            // (node t holds the local frames 3 (t - pin_left) ..)
     double hq[2][3] = {{0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, cvq[3] = {0, 0, 0}, lamq = 0.0;
     bool liveq[3] = {false, false, false}, ownq[3] = {false, false, false};
     const int e1 = tid_ + SW_T;
@@ -636,7 +648,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
         sib[q] = tri_i(sw + 5 * q);
         sjb[q] = tri_j(sw + 5 * q);
       }
-      double* Ag = sp.AL + (size_t)(hasL ? opaque(c - 1) : 0) * MB;   // (global address space kept: no pointer through asm)
+      double* Ag = sp.AL + (size_t)(hasL ? opaque(sL) : 0) * MB;   // (global address space kept: no pointer through asm)
       // the left separator's update so far (HBM / L2, owned by this workgroup): requested now, needed after W
       // (kept in memory between nodes, not in registers: measured in round 4 - the register form runs the sweep in 303.0 us
       //  against 303.7 us, the load is hidden behind the W strip - and memory does not depend on how the register allocator
@@ -703,15 +715,15 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     }
     if (last && hasR) {                                // the node built last is the right separator
       {
-        double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)c * MB);
+        double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)sR * MB);
         for (int idx = tid; idx < BS * BS / 2; idx += SW_T) {
           const int e = 2 * idx, r = e / BS, cc = e % BS;
           d2[idx] = make_double2(Xn[r * LD + cc], Xn[r * LD + cc + 1]);
         }
       }
-      if (tid < BS) sp.b[(size_t)c * BS + tid] = Y[tid * LD + (BS - 1)];
+      if (tid < BS) sp.b[(size_t)sR * BS + tid] = Y[tid * LD + (BS - 1)];
       if (hasL) {
-        double* Cg = sp.Cpl + (size_t)(c - 1) * MB;    // block(R, L): rows R, columns L
+        double* Cg = sp.Cpl + (size_t)sL * MB;         // block(R, L): rows R, columns L
         for (int e = tid; e < BS * BS; e += SW_T) {
           const int r = e / BS, cc = e % BS;
           Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
@@ -778,13 +790,15 @@ constexpr int BK_P = BK_T / BS, BK_W = (BS + BK_P - 1) / BK_P;      // 6 partial
 constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 4 items per thread (the last round is mostly empty)
 __global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
-                int n_chunks, TrialOut trial) {
+                int n_chunks, int node0, int pin_right, TrialOut trial) {
   if (status && *status != 0) return;
   __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
-  const int c = blockIdx.x, first = c * m;
-  const bool hasL = c > 0, hasR = c + 1 < n_chunks;
-  const int n_int = hasR ? m - 1 : ch.n_nodes - first;
+  const int c = blockIdx.x, first = node0 + c * m;
+  const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
+  const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;
+  const int n_int = hasR ? len - 1 : len;
+  const int sL = c - 1 + node0, sR = c + node0;
   const size_t MB = (size_t)BS * BS;
   const int row = tid % BS, part = tid / BS, c0 = BK_W * part, nc = min(BK_W, BS - c0);
   const bool uni_tables = coupling_tables_uniform(*cst, first, first + n_int - 1);   // (one fill serves every node of the run)
@@ -802,7 +816,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   double t_xv = 0.0, t_gv = 0.0, t_d0 = 0.0;            // operands of the node being solved (requested a node ahead)
   double s_xv = 0.0, s_gv = 0.0, s_d0 = 0.0, s_dx = 0.0;  // ... and of the run's right separator
   auto trial_fetch = [&](int node) {
-    const int n = 3 * node + t_a;
+    const int n = 3 * (node - node0) + t_a;
     if (t_thr && n < t_nf) {
       t_xv = t_x[(size_t)(n + HALO) * NP + t_p];
       t_gv = t_g[(size_t)n * NP + t_p];
@@ -810,7 +824,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
     }
   };
   auto trial_row = [&](int node, double delta) {        // (a bound-active variable takes a step of exactly 0: see k_trial)
-    const int n = 3 * node + t_a;
+    const int n = 3 * (node - node0) + t_a;
     if (t_thr && n < t_nf) {
       const double gtol = GRAD_ZERO_REL * t_d0;
       const bool fixed = (t_xv <= t_lo && t_gv > gtol) || (t_xv >= t_hi && t_gv < -gtol);
@@ -870,8 +884,8 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   if (c == 0 && sp.flags)                               // (k_sep_tail's hand-off flags: clean for the next iteration)
     for (int e = tid; e < sp.n_flags; e += BK_T) sp.flags[e] = 0;
   if (tid < BS) {
-    xl[tid] = hasL ? sp.b[(size_t)(c - 1) * BS + tid] : 0.0;
-    const double xr = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
+    xl[tid] = hasL ? sp.b[(size_t)sL * BS + tid] : 0.0;
+    const double xr = hasR ? sp.b[(size_t)sR * BS + tid] : 0.0;
     xn[tid] = xr;
     if (hasR) ch.b[(size_t)(first + n_int) * BS + tid] = xr;      // the separator's solution joins the chain's vector
     if (hasR) {                                         // (the separator's trial row: operands requested here, used at the end)
@@ -919,7 +933,7 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       }
     }
     __syncthreads();
-    if (tid < BS) xn[tid] = hasR ? sp.b[(size_t)c * BS + tid] : 0.0;
+    if (tid < BS) xn[tid] = hasR ? sp.b[(size_t)sR * BS + tid] : 0.0;
   }
   // ---------------- backward: x_k = z_k - G_k (E x_k+1 + f_k) ----------------
   // (the last node's tiles are still in LDS after the forward pass; the first run has no forward pass)
@@ -991,7 +1005,7 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
   {
     ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
     hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(SW_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
-                       pl.n_chunks);
+                       pl.n_chunks, pl.node0, pl.pin_right);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;
@@ -1016,7 +1030,8 @@ int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, co
   }
   {
     ProfSpan span(prof, PC_CHUNK_BACKSUB, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks, trial);
+    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks, pl.node0,
+                       pl.pin_right, trial);
   }
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;

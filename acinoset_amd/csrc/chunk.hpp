@@ -8,11 +8,17 @@ namespace acino {
 // the final one is a SEPARATOR; the others are interior nodes, eliminated in order by one workgroup per run with all
 // operands resident in LDS.  The n_sep = n_chunks - 1 separators form a block-tridiagonal chain with dense couplings
 // that the block cyclic reduction (bcr.hip) solves.
+// Sharded ranks (pinned separators): chain node 0 is the LEFT pin when pin_left (the left neighbour's last three frames: not
+// swept, it is the left separator of run 0 and receives its spike) and the chain's last node is the RIGHT pin when pin_right
+// (the rank's own last three frames: built by the last run as its right separator, never eliminated).  The separator chain
+// is then [left pin] + the runs' separators + [right pin].
 struct ChunkPlan {
   int n_nodes = 0, m = 0, n_chunks = 0, n_sep = 0;
+  int node0 = 0;        // first swept node (= pin_left)
+  int pin_right = 0;
   bool active() const { return n_chunks > 0; }
   // chunk_nodes: nodes per run incl. its separator (>= 2); 0 = automatic; < 0 = no chunking (plain BCR)
-  void build(int nodes, int chunk_nodes);
+  void build(int nodes, int chunk_nodes, bool pin_left = false, bool pin_right = false);
 };
 
 // Separator-side buffers written by the sweep (device views, [n_sep] each).

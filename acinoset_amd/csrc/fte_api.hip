@@ -75,15 +75,16 @@ struct Carver {
   }
 };
 
-static bool use_chunks(const acino_fte_params* p) { return !p->pin_left && !p->pin_right && p->chunk_nodes >= 0; }
+// (sharded ranks - pinned separators - take the chunked solver too since round 4: the pins join the separator chain)
+static bool use_chunks(const acino_fte_params* p) { return p->chunk_nodes >= 0; }
 
 // Host-side layout of a context: the chunk plan and the reduction schedule (of the separator chain when chunked).
 struct Layout {
   ChunkPlan plan;
   BcrSchedule sched;
   void build(const acino_fte_params* p) {
-    plan.build(chain_nodes(p), use_chunks(p) ? p->chunk_nodes : -1);
-    if (plan.active()) sched.build(plan.n_sep, false, false, p->bcr_levels, p->refine_sweeps);
+    plan.build(chain_nodes(p), use_chunks(p) ? p->chunk_nodes : -1, p->pin_left != 0, p->pin_right != 0);
+    if (plan.active()) sched.build(plan.n_sep, p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps);
     else sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps);
   }
 };
@@ -713,6 +714,9 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
                        ctx->sched.pairs.data(), sizeof(int) * ctx->sched.pairs.size(), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
   if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s);
+  // (the runs write the contribution AL of every separator that has a run on its right: a right pin has none - zero once)
+  if (e == hipSuccess && ctx->plan.active() && ctx->plan.n_sep > 0)
+    e = hipMemsetAsync(const_cast<double*>(ctx->sepchain.AL0), 0, sizeof(double) * (size_t)ctx->plan.n_sep * BS * BS, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     set_error("context upload failed: %s", hipGetErrorString(e));
@@ -914,8 +918,9 @@ int acino_fte_export_separators(acino_fte_ctx* ctx, double* d_sep, int rank, int
                 "pins must match the rank position");
   double* rec_left = ctx->h.pin_left ? d_sep + (size_t)(rank - 1) * ACINO_SEP_DOUBLES : nullptr;
   double* rec_right = ctx->h.pin_right ? d_sep + (size_t)rank * ACINO_SEP_DOUBLES : nullptr;
-  hipLaunchKernelGGL(k_export_sep, dim3(8), dim3(256), 0, (hipStream_t)stream, ctx->chain, 0,
-                     ctx->chain.n_nodes - 1, rec_left, rec_right);
+  // (chunked solver: the pins are the first / last node of the separator chain)
+  const BcrChain& pc = ctx->plan.active() ? ctx->sepchain : ctx->chain;
+  hipLaunchKernelGGL(k_export_sep, dim3(8), dim3(256), 0, (hipStream_t)stream, pc, 0, pc.n_nodes - 1, rec_left, rec_right);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }
@@ -1022,13 +1027,14 @@ int acino_fte_backsub_local(acino_fte_ctx* ctx, const double* d_sep_x, int rank,
   hipStream_t s = (hipStream_t)stream;
   if (ctx->h.pin_left) {
     ACINO_REQUIRE(d_sep_x && rank >= 1, "separator solution");
-    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, ctx->chain, 0, d_sep_x + (size_t)(rank - 1) * BS);
+    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, ctx->plan.active() ? ctx->sepchain : ctx->chain, 0,
+                       d_sep_x + (size_t)(rank - 1) * BS);
     ACINO_LAUNCH_CHECK();
   }
   if (ctx->h.pin_right) {
     ACINO_REQUIRE(d_sep_x && rank + 1 < world, "separator solution");
-    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, ctx->chain, ctx->chain.n_nodes - 1,
-                       d_sep_x + (size_t)rank * BS);
+    const BcrChain& pc = ctx->plan.active() ? ctx->sepchain : ctx->chain;
+    hipLaunchKernelGGL(k_set_node_x, dim3(1), dim3(128), 0, s, pc, pc.n_nodes - 1, d_sep_x + (size_t)rank * BS);
     ACINO_LAUNCH_CHECK();
   }
   if (ctx->plan.active())
