@@ -131,7 +131,7 @@ def test_window_plan_and_params_host_logic():
     mk = lambda n, **kw: fte.make_params(n, 6, 1 / 120, **kw)
     assert fte.solver_plan(mk(10000)) == dict(m=14, n_chunks=239, n_sep=238, levels=8)
     assert fte.solver_plan(mk(10000, chunk_nodes=-1)) == dict(m=0, n_chunks=0, n_sep=0, levels=12)
-    assert fte.solver_plan(mk(9999, pin_right=True, n_global=20000))["m"] == 0        # sharded contexts: whole-chain reduction
+    assert fte.solver_plan(mk(9999, pin_right=True, n_global=20000)) == dict(m=14, n_chunks=238, n_sep=238, levels=8)   # sharded contexts: chunked too (round 4); the pin joins the separators and, 3 333 = 238 x 14 + 1, the last run takes 15 nodes
     assert fte.solver_plan(mk(9, chunk_nodes=5)) == dict(m=5, n_chunks=1, n_sep=0, levels=0)
     assert fte.auto_bcr_levels(mk(10000), 160) == 2 and fte.auto_bcr_levels(mk(10000), 384) == 4      # 42 * 2^K frames
     assert fte.auto_bcr_levels(mk(10000, chunk_nodes=-1), 384) == 7 and fte.auto_bcr_levels(mk(700, chunk_nodes=-1), 384) == 0
@@ -173,3 +173,19 @@ def test_bench_baseline_bookkeeping():
     assert set(probe["probe"]) == {"cv2", "pyomo", "ipopt"}
     if not (probe["probe"]["pyomo"] and probe["probe"]["ipopt"]):
         assert probe["available"] is False and "oracle/pyomo_model.py" in probe["note"]
+
+
+def test_chunk_plan_of_sharded_ranks():
+    """Pinned (sharded) contexts take the chunked solver since round 4: the pins join the separator chain, and a right pin is
+    never a run of its own (acino_fte_plan is host logic: no GPU needed)."""
+    for n, pl, pr in ((5000, True, True), (1251, True, False), (1248, False, True), (30, True, True), (6, True, True), (39, False, True)):
+        if pr:
+            n -= n % 3
+        p = fte.make_params(n, 6, 1 / 120, n_global=3 * n + 300, n_offset=(n // 3) * 3 if pl else 0, pin_left=pl, pin_right=pr)
+        plan = fte.solver_plan(p)
+        nodes = (n + 2) // 3                         # swept nodes (the right pin is the last of them)
+        assert plan["m"] >= 2 and plan["n_sep"] == plan["n_chunks"] - 1 + int(pl) + int(pr), plan
+        last = nodes - (plan["n_chunks"] - 1) * plan["m"]
+        assert 1 <= last <= plan["m"] + 1 and (not pr or last >= 2 or plan["n_chunks"] == 1), (n, plan, last)
+    whole = fte.solver_plan(fte.make_params(999, 6, 1 / 120, n_global=5000, n_offset=999, pin_left=True, pin_right=True, chunk_nodes=-1))
+    assert whole["n_chunks"] == 0
