@@ -267,7 +267,7 @@ class FTEContext:
                         update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
                         backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true, 0>", totals="k_totals", control="k_control",
                         trunc_check="k_bcr_trunc_check", chunk_sweep="k_chunk_sweep", sep_combine="k_sep_combine",
-                        chunk_backsub="k_chunk_backsub", refine="k_bcr_refine")
+                        chunk_backsub="k_chunk_backsub", refine="k_sep_tail")
 
     def profile_begin(self):
         check(lib().acino_fte_profile_begin(self._h))
