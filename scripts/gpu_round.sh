@@ -10,7 +10,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 export TMPDIR=/tmp
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rocprof_pmc_fetch -o fetch -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rocprof_pmc_write -o write -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_write.err
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/rocprof_pmc_sq -o sq -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/rocprof_pmc_sq.err
@@ -18,6 +17,7 @@ cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 # the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
 mkdir -p $R/profiles/round4 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round4/ 2>/dev/null
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err)
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
 # the widened rows and the secondary configs: kernel stats of a bench run WITH the secondary metrics (config 2's fused kernel,
