@@ -15,7 +15,7 @@ def T():
 # ---- EKF + smoother: one long clip, a batch of clips
 rep = {}
 for tag, n, b in (("one_clip_10000_frames", 10000, 1), ("64_clips_x_1000_frames", 1000, 64)):
-    seq = synth.make_sequence(n, "circle" if "circle" in getattr(synth, "KINDS", ("circle",)) else "trot")
+    seq = synth.make_sequence(n, "walk")        # the 2 m/s circle: within reach of the filter's constant-acceleration model
     rig = (seq["K"], seq["D"], seq["R"], seq["t"])
     dets = [torch.as_tensor(seq["det"], device="cuda")] * b
     for _ in range(2):
