@@ -18,6 +18,7 @@ for _ in range(3):
 dbg = torch.zeros(72, dtype=torch.int64, device="cuda")
 dbg[64] = wg
 dbg[65] = kk
+dbg[66] = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 check(lib().acino_fte_debug_stamps(c._h, ptr(dbg)))
 c.step()
 torch.cuda.synchronize()
@@ -38,3 +39,5 @@ for kb in range(4):
 for i in sorted(names, key=lambda i: d[i]):
     if d[i]:
         print(f"{(d[i] - t0) / 100.0:8.2f} us  {names[i]}")
+
+print("SIMD of waves 0..7:", [(int(d[67]) >> (4 * w)) & 3 for w in range(8)], " HW_ID of wave 0: %#x" % int(d[68]), " skip mask", int(d[66]))
