@@ -4,14 +4,16 @@
 // [rvecs, tvecs, points] with a finite-difference Jacobian and one cv2.fisheye.projectPoints call per
 // observation.  Here: analytic Jacobians, Cauchy IRLS weights w = 1/(1 + (r/f)^2), Levenberg-Marquardt on the
 // Schur complement of the point blocks (3x3 per point) onto the camera block (6C x 6C), rotations updated by a
-// left perturbation R <- exp([dw]x) R (same minimiser, no rvec singularities).  One thread per POINT walks its
-// observations (CSR built by the host); camera-block sums go through 16 lane-private copies in LDS (the lanes of a wave
-// are all at the same camera: one shared copy serialises 64 atomics per entry), then one atomic per entry per workgroup.
-// The coupling blocks W_pc (6 x 3) live in a DENSE table [point][camera] (zero where the camera does not see the point), so
-// the Schur complement S = - sum_p (W_p V_p^-1) W_p^T is a tall-skinny GEMM: k_sba_schur_mfma forms it on the fp64 matrix
-// cores, one point per k-step (3 columns + 1 zero), operands built in registers - no LDS, no atomics, partial sums per
-// workgroup reduced in a fixed order (round 4: 4.47 -> 0.3 ms per iteration at 1.28 M points; the previous form added 36
-// entries per observation pair to one LDS copy with atomics).
+// left perturbation R <- exp([dw]x) R (same minimiser, no rvec singularities).
+//
+// Two paths.  FUSED (up to seven cameras - every rig of the reference): one lane per (point, camera) slot, no coupling table
+// in memory; k_sba_fused linearises, forms the point blocks and accumulates the Schur complement on the fp64 matrix cores in
+// one pass, k_sba_backsub_fused back-substitutes and prices the trial iterate in one pass (see the block comment in front
+// of them).  TABLE (more cameras, or ACINO_SBA_UNFUSED=1 as an independent cross-check): one thread per POINT walks its
+// observations (CSR built by the host), the coupling blocks W_pc (6 x 3) live in a dense table [point][camera], camera-block
+// sums go through 16 lane-private copies in LDS, the Schur complement is added with LDS atomics.
+// History (config 5, 1.28 M points, 6.5 M observations, per LM iteration): table + LDS atomics 6.1 ms; table + matrix-core GEMM
+// over the table 2.2 ms (round 4, W written once and read twice: 456 B per observation); fused 1.0 ms of kernels.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -32,22 +34,25 @@ constexpr int SBA_INTR = 16;
 // cv2.fisheye projection of a camera-frame point and d(uv)/d(Xc)
 template <bool JAC>
 __device__ __forceinline__ void fisheye_cam(const SbaIntr& c, const double Xc[3], double uv[2], double J[2][3]) {
+  // (three divisions instead of seven: 1 / z, 1 / r, 1 / (1 + r^2) - an fp64 division is ~12 instructions, four of them at quarter rate)
   const double iz = 1.0 / Xc[2];
   const double a = Xc[0] * iz, b = Xc[1] * iz;
-  const double r = sqrt(a * a + b * b);
+  const double r2 = a * a + b * b;
+  const double r = sqrt(r2);
   const double th = atan(r), th2 = th * th;
   const double thd = th * (1 + th2 * (c.d[0] + th2 * (c.d[1] + th2 * (c.d[2] + th2 * c.d[3]))));
   const bool small = !(r > 1e-8);
-  const double m = small ? 1.0 : thd / r;
+  const double ir = small ? 0.0 : 1.0 / r;
+  const double m = small ? 1.0 : thd * ir;
   uv[0] = c.fx * a * m + c.cx;
   uv[1] = c.fy * b * m + c.cy;
   if (JAC) {
     double dm_da = 0.0, dm_db = 0.0;
     if (!small) {
       const double dthd = 1 + th2 * (3 * c.d[0] + th2 * (5 * c.d[1] + th2 * (7 * c.d[2] + th2 * 9 * c.d[3])));
-      const double dm_dr = (dthd / (1 + r * r) * r - thd) / (r * r);
-      dm_da = dm_dr * a / r;
-      dm_db = dm_dr * b / r;
+      const double dm_dr = (dthd / (1 + r2) * r - thd) * (ir * ir);
+      dm_da = dm_dr * a * ir;
+      dm_db = dm_dr * b * ir;
     }
     const double du_da = c.fx * (m + a * dm_da), du_db = c.fx * a * dm_db;
     const double dv_da = c.fy * b * dm_da, dv_db = c.fy * (m + b * dm_db);
@@ -105,7 +110,9 @@ struct SbaBuf {
   double* gp;            // [P][3]
   double* Vinv;          // [P][6]
   double* Wpc;           // [P][C][18]  (6x3 row-major per (point, camera) slot; zero where the camera does not see the point)
-  double* Spart;         // [n_schur_wg][n n + n] per-workgroup partial sums of k_sba_schur_mfma (null: atomics path)
+                         //             unfused path only (more than 7 cameras, ACINO_SBA_UNFUSED); null otherwise
+  int* slot;             // [P][C] observation id of (point, camera), -1 where the camera does not see the point (fused path)
+  double* Spart;         // [SBA_SCHUR_WG + 32][n n + n + 27 C] per-workgroup partial sums [S | rhs | U | g_c] of k_sba_fused
   double* U;             // [C][21]
   double* gc;            // [C][6]
   double* S;             // [6C][6C]
@@ -296,133 +303,12 @@ __global__ void __launch_bounds__(256) k_sba_schur(SbaBuf B, double lam) {
 }
 
 
-// The Schur complement on the matrix cores (6 C + 1 <= 48, i.e. C <= 7 cameras).  With A_p = [W_p V_p^-1 ; (V_p^-1 g_p)^T]
-// (37 x 3 for six cameras: rows 6 c + a, then the right-hand-side row) and B_p = W_p (36 x 3, zero rows for cameras that do
-// not see the point):  [S ; rhs^T] = - sum_p A_p B_p^T.  One point is one k-step of v_mfma_f64_16x16x4 (k = 0..2 the three
-// point coordinates, k = 3 zero); lane (i, k) builds its operand entries from the rows 16 t + i (t = 0, 1, 2) of the dense
-// W table and the point's V^-1 (every lane inverts the same 3 x 3: uniform loads), the six lower tiles accumulate in
-// registers over the wave's points.  Points are dealt to the waves in contiguous ranges, the next point's values are
-// requested before the current point's products.  Partial sums: wave -> LDS -> one [n n + n] record per workgroup; the
-// reduction kernel adds the records in a fixed order (deterministic, no atomics).
-constexpr int SBA_SCHUR_WG = 1024;      // workgroups (x 4 waves) of k_sba_schur_mfma = records of partial sums
-constexpr int SCH_T = 256, SCH_B = 16;     // threads; points per batch of one wave
-__global__ void __launch_bounds__(SCH_T) k_sba_schur_mfma(SbaBuf B, double lam, int pts_per_wave) {
-  // Each wave streams its points through its own LDS slab in batches of SCH_B: the batch's V (6), g (3) and W (18 C) values
-  // are contiguous in memory - copied with all 64 lanes, the NEXT batch's copy in flight (registers) while this batch's
-  // points go through the matrix cores.  (One point at a time from memory was latency-bound: 1.03 ms for 1.28 M points.)
-  extern __shared__ __attribute__((aligned(16))) char sch_smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int C = B.C, n = 6 * C, wrec = 18 * C, rec = 9 + wrec;            // doubles per point in the slab: V | g | W
-  double* slab = reinterpret_cast<double*>(sch_smem) + (size_t)wave * SCH_B * rec;
-  const int gw = blockIdx.x * 4 + wave;
-  const int p0 = gw * pts_per_wave, p1 = min(p0 + pts_per_wave, B.P);
-  d4 acc[6];
-#pragma unroll
-  for (int t = 0; t < 6; ++t) acc[t] = d4{0, 0, 0, 0};
-  int woff[3], rrow[3];                                                    // rows 16 t + li of [W V^-1 ; (V^-1 g)^T]
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int R = 16 * t + li;
-    woff[t] = R < n ? 3 * R : -1;                                          // (camera R / 6, parameter R % 6: offset 18 c + 3 r = 3 R)
-    rrow[t] = R < n ? 0 : (R == n ? 1 : 2);                                // 0 coupling row, 1 right-hand-side row, 2 padding
-  }
-  // one batch in registers: V (6 nb <= 96 values: 2 per lane), g (3 nb <= 48: 1), W (18 C values per point: 2 per lane and
-  // point for C <= 7).  Every copy is a run of consecutive addresses; no division by a run-time value anywhere (the first
-  // form spent ~200 instructions per point on e / wrec, e % wrec).
-  double sv[2], sg, sw[SCH_B][2];
-  // (every load UNCONDITIONAL on a clamped, valid address: a conditional load compiles to a branch and a full wait per
-  //  element - 35 serialised round trips per batch; what is out of range is simply not stashed)
-  auto fetch = [&](int pb, int nb) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) sv[q] = B.V[6 * (size_t)pb + min(lane + 64 * q, 6 * nb - 1)];
-    sg = B.gp[3 * (size_t)pb + min(lane, 3 * nb - 1)];
-#pragma unroll
-    for (int pt = 0; pt < SCH_B; ++pt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        sw[pt][q] = B.Wpc[(size_t)wrec * (pb + min(pt, nb - 1)) + min(lane + 64 * q, wrec - 1)];
-  };
-  auto stash = [&](int nb) {                                               // registers -> slab, point-major records
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane + 64 * q;
-      if (e < 6 * nb) slab[(e / 6) * rec + e % 6] = sv[q];
-    }
-    if (lane < 3 * nb) slab[(lane / 3) * rec + 6 + lane % 3] = sg;
-#pragma unroll
-    for (int pt = 0; pt < SCH_B; ++pt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int e = lane + 64 * q;
-        if (pt < nb && e < wrec) slab[pt * rec + 9 + e] = sw[pt][q];
-      }
-  };
-  int pb = p0;
-  if (pb < p1) fetch(pb, min(SCH_B, p1 - pb));
-  while (pb < p1) {
-    const int nb = min(SCH_B, p1 - pb);
-    stash(nb);                                                             // (a wave's LDS operations are ordered: no barrier)
-    if (pb + nb < p1) fetch(pb + nb, min(SCH_B, p1 - pb - nb));
-    for (int q = 0; q < nb; ++q) {
-      const double* r = slab + q * rec;
-      // V^-1 of the damped point block (closed form, as k_sba_schur), V^-1 g
-      const double a = r[0] * (1 + lam), b = r[1], c = r[2], d = r[3] * (1 + lam), e = r[4], f = r[5] * (1 + lam);
-      const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-      double det = a * c00 + b * c01 + c * c02;
-      if (!(fabs(det) > 0.0)) det = 1.0;
-      const double id = 1.0 / det;
-      const double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
-      if (lane < 6) B.Vinv[6 * (size_t)(pb + q) + lane] = lane == 0 ? Vi[0] : (lane == 1 ? Vi[1] : (lane == 2 ? Vi[2] : (lane == 3 ? Vi[3] : (lane == 4 ? Vi[4] : Vi[5]))));
-      // column lk of V^-1 (lk = 3: the zero k-step), entry lk of V^-1 g
-      const double v0 = lk == 0 ? Vi[0] : (lk == 1 ? Vi[1] : (lk == 2 ? Vi[2] : 0.0));
-      const double v1 = lk == 0 ? Vi[1] : (lk == 1 ? Vi[3] : (lk == 2 ? Vi[4] : 0.0));
-      const double v2 = lk == 0 ? Vi[2] : (lk == 1 ? Vi[4] : (lk == 2 ? Vi[5] : 0.0));
-      const double vg = v0 * r[6] + v1 * r[7] + v2 * r[8];
-      double Aop[3], Bop[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const double* w = r + 9 + (woff[t] >= 0 ? woff[t] : 0);
-        const double w0 = woff[t] >= 0 ? w[0] : 0.0, w1 = woff[t] >= 0 ? w[1] : 0.0, w2 = woff[t] >= 0 ? w[2] : 0.0;
-        Aop[t] = rrow[t] == 1 ? vg : w0 * v0 + w1 * v1 + w2 * v2;
-        Bop[t] = lk == 0 ? w0 : (lk == 1 ? w1 : (lk == 2 ? w2 : 0.0));
-      }
-      acc[0] = mfma(-Aop[0], Bop[0], acc[0]);
-      acc[1] = mfma(-Aop[1], Bop[0], acc[1]);
-      acc[2] = mfma(-Aop[1], Bop[1], acc[2]);
-      acc[3] = mfma(-Aop[2], Bop[0], acc[3]);
-      acc[4] = mfma(-Aop[2], Bop[1], acc[4]);
-      acc[5] = mfma(-Aop[2], Bop[2], acc[5]);
-    }
-    pb += nb;
-  }
-  // wave -> LDS -> one record per workgroup.  C layout: register q of lane (li, lk) = entry [row lk + 4 q][column li] of a tile
-  __syncthreads();                                                         // (the slabs are free)
-  double* sT = reinterpret_cast<double*>(sch_smem);                        // [4][6][256]
-#pragma unroll
-  for (int t = 0; t < 6; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sT[(wave * 6 + t) * 256 + (lk + 4 * q) * 16 + li] = acc[t][q];
-  __syncthreads();
-  double* out = B.Spart + (size_t)blockIdx.x * (n * n + n);
-  for (int e = tid; e < 6 * 256; e += SCH_T) {
-    const int t = e >> 8, r = (e >> 4) & 15, cc = e & 15;
-    const int ib = t < 1 ? 0 : (t < 3 ? 1 : 2), jb = t < 1 ? 0 : (t < 3 ? t - 1 : t - 3);
-    const int R = 16 * ib + r, Cc = 16 * jb + cc;
-    const double v = (sT[(0 * 6 + t) * 256 + (e & 255)] + sT[(1 * 6 + t) * 256 + (e & 255)]) +
-                     (sT[(2 * 6 + t) * 256 + (e & 255)] + sT[(3 * 6 + t) * 256 + (e & 255)]);
-    if (Cc >= n) continue;
-    if (R < n) {
-      out[R * n + Cc] = v;
-      if (ib != jb) out[Cc * n + R] = v;                 // (diagonal tiles hold both triangles already)
-    } else if (R == n) {
-      out[n * n + Cc] = v;
-    }
-  }
-}
+constexpr int SBA_SCHUR_WG = 1024;      // workgroups (x 4 waves) of k_sba_fused = records of partial sums
 // the records, added in a fixed order in two stages (n_part <= 1024 records of n n + n doubles): stage 0 sums every 32nd record
 // into 32 intermediate records (behind the partial records in Spart), stage 1 sums those into [S | rhs]
-__global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part, int stage) {
-  const int n = 6 * B.C, tot = n * n + n;
+// (fused path: records of n n + n + 27 C doubles, the tail [U | g_c] goes to B.U)
+__global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part, int stage, int tail) {
+  const int n = 6 * B.C, tot = n * n + n + tail;
   const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
   if (e >= tot) return;
   double* mid = B.Spart + (size_t)SBA_SCHUR_WG * tot;
@@ -432,7 +318,466 @@ __global__ void __launch_bounds__(256) k_sba_schur_reduce(SbaBuf B, int n_part, 
     mid[(size_t)g * tot + e] = s;
   } else {
     for (int w = 0; w < 32; ++w) s += mid[(size_t)w * tot + e];
-    B.S[e] = s;                                          // (S | rhs contiguous)
+    if (e < n * n + n) B.S[e] = s;                       // (S | rhs contiguous)
+    else B.U[e - (n * n + n)] = s;                       // (U | g_c contiguous)
+  }
+}
+
+// ================================================================================================================
+// The fused path (6 C + 1 <= 48): no coupling table in memory.
+//
+// k_sba_fused: ONE lane per (point, camera) slot - a wave takes 64 / C points per batch (10 for six cameras, 60 lanes) and the
+// lane's camera never changes, so pose, intrinsics and the lane's share of the camera block U_c, g_c stay in registers for
+// the whole kernel (no LDS atomics).  Per batch: projection, analytic Jacobian, IRLS weight, W_pc (6 x 3) in registers; the
+// point blocks V_p, g_p through a wave-private LDS exchange (fixed summation order over the cameras); every lane inverts its
+// point's damped V_p and forms Y_pc = W_pc V_p^-1; W and Y go to the wave's LDS slab in point-major order and the Schur
+// complement [S ; rhs^T] = - sum_p [Y_p ; (V_p^-1 g_p)^T] W_p^T is accumulated on the fp64 matrix cores from there: the
+// (point, coordinate) pairs of the batch are the k dimension, four per v_mfma_f64_16x16x4 (30 pairs -> 8 k-steps x 6 lower
+// tiles for 10 points; the table form spent one k-step of three per point).  Partial sums [S | rhs | U | g_c] per workgroup,
+// two-stage fixed-order reduction (k_sba_schur_reduce).  HBM traffic per iteration: slots, detections, points in; V, V^-1,
+// g_p out - ~60 B per observation against ~450 for the table form (W written once, read twice).
+//
+// k_sba_backsub_fused: the same lane mapping; recomputes the observation's Jacobian rows, forms W_pc^T dc without W
+// (sum_d w_d J_p[d] (J_c[d] . dc)), the point step, the trial point and - with the trial poses already applied by
+// k_sba_apply_cams - the trial cost of the lane's observation: the separate cost pass over the trial iterate is gone.
+template <int PREC>
+struct SbaObs {
+  typedef typename std::conditional<PREC == ACINO_PREC_F64, double, float>::type acc_t;
+  acc_t Jp[2][3], Jc[2][6], w[2], rs[2];
+  double cost;
+};
+template <int PREC, bool JAC, int MODEL, bool COST = true>
+__device__ __forceinline__ void sba_observe(double fs, const double (&R)[12], const SbaIntr& in, const double (&X)[3],
+                                            double u, double v, SbaObs<PREC>& o) {
+  typedef typename SbaObs<PREC>::acc_t acc_t;
+  const double RX[3] = {R[0] * X[0] + R[1] * X[1] + R[2] * X[2], R[3] * X[0] + R[4] * X[1] + R[5] * X[2],
+                        R[6] * X[0] + R[7] * X[1] + R[8] * X[2]};
+  const double Xc[3] = {RX[0] + R[9], RX[1] + R[10], RX[2] + R[11]};
+  double uvp[2], Jpi[2][3];
+  if (MODEL == 0) fisheye_cam<JAC>(in, Xc, uvp, Jpi);
+  else pinhole_cam<JAC>(in, Xc, uvp, Jpi);
+  const double r0 = uvp[0] - u, r1 = uvp[1] - v;
+  const double ifs2 = 1.0 / (fs * fs);
+  const double z0 = r0 * r0 * ifs2, z1 = r1 * r1 * ifs2;
+  o.cost = COST ? 0.5 * fs * fs * (log1p(z0) + log1p(z1)) : 0.0;
+  if (JAC) {
+    if (PREC == ACINO_PREC_F64) {
+      o.w[0] = 1.0 / (1.0 + z0);
+      o.w[1] = 1.0 / (1.0 + z1);
+      o.rs[0] = r0;
+      o.rs[1] = r1;
+    } else {
+      o.rs[0] = bf16_round((float)r0);
+      o.rs[1] = bf16_round((float)r1);
+      const float fi = (float)ifs2;
+      o.w[0] = 1.0f / (1.0f + (float)o.rs[0] * (float)o.rs[0] * fi);
+      o.w[1] = 1.0f / (1.0f + (float)o.rs[1] * (float)o.rs[1] * fi);
+    }
+    auto st = [](double x) -> acc_t { return PREC == ACINO_PREC_F64 ? (acc_t)x : (acc_t)bf16_round((float)x); };
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.Jp[d][j] = st(Jpi[d][0] * R[j] + Jpi[d][1] * R[3 + j] + Jpi[d][2] * R[6 + j]);
+      o.Jc[d][0] = st(Jpi[d][1] * (-RX[2]) + Jpi[d][2] * RX[1]);      // d(Xc)/d(dw) = -[RX]x ;  d(Xc)/d(dt) = I
+      o.Jc[d][1] = st(Jpi[d][0] * RX[2] - Jpi[d][2] * RX[0]);
+      o.Jc[d][2] = st(-Jpi[d][0] * RX[1] + Jpi[d][1] * RX[0]);
+      o.Jc[d][3] = st(Jpi[d][0]);
+      o.Jc[d][4] = st(Jpi[d][1]);
+      o.Jc[d][5] = st(Jpi[d][2]);
+    }
+  }
+}
+
+// slot[p][c] <- observation id (the table is preset to -1); two observations of one (point, camera) pair raise scal[7]
+__global__ void __launch_bounds__(256) k_sba_slots(SbaBuf B) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= B.P) return;
+  for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
+    const int k = B.pt_obs[o], c = B.cam_idx[k];
+    const bool bad = c < 0 || c >= B.C;
+    const int old = bad ? 0 : atomicExch(&B.slot[(size_t)p * B.C + c], k);
+    if (bad || old != -1) B.scal[7] = 1.0;
+  }
+}
+
+constexpr int FU_T = 256;
+__host__ __device__ inline int fused_slab_doubles(int C) {
+  const int ppp = 64 / C;
+  return 2 * (ppp + 1) * 18 * C + 4 * (ppp + 1);          // W | Y (the V / g exchange lives in the Y part) | V^-1 g; record ppp = zeros
+}
+__host__ __device__ inline size_t fused_lds_bytes(int C) {
+  size_t d = (size_t)4 * fused_slab_doubles(C);
+  if (d < (size_t)4 * 6 * 256) d = (size_t)4 * 6 * 256;  // the tiles of the four waves
+  if (d < (size_t)4 * 64 * 27) d = (size_t)4 * 64 * 27;  // the camera sums of all lanes
+  return d * 8;
+}
+
+// COST: also the cost of the iterate (first evaluation only: afterwards it is the trial cost of the accepted step)
+template <int PREC, int MODEL, bool COST>
+__global__ void __launch_bounds__(FU_T, 2)
+k_sba_fused(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ pts, double lam, int pts_per_wave) {
+  typedef typename SbaObs<PREC>::acc_t acc_t;
+  extern __shared__ __attribute__((aligned(16))) char fu_smem[];
+  __shared__ double sred[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int C = B.C, n = 6 * C, ppp = 64 / C, recp = 18 * C;
+  double* Wc = reinterpret_cast<double*>(fu_smem) + (size_t)wave * fused_slab_doubles(C);
+  double* Yc = Wc + (ppp + 1) * recp;
+  double* vgs = Yc + (ppp + 1) * recp;
+  double* part = Yc;                                     // [ppp][C][9], read by every lane before Y is written
+  const bool lane_on = lane < ppp * C;
+  const int pl = lane_on ? lane / C : 0, c = lane_on ? lane % C : 0;
+  // pose and intrinsics of the lane's camera: staged in LDS, read back per batch (20 registers live only while they are used)
+  __shared__ double sCam[SBA_MAXC][28];
+  for (int e = tid; e < C * 28; e += FU_T) {
+    const int cam = e / 28, q = e % 28;
+    sCam[cam][q] = q < 12 ? Rt[12 * cam + q] : B.intr[SBA_INTR * cam + (q - 12)];
+  }
+  // the zero record behind the batch: what the k-steps read past the last (point, coordinate) pair
+  for (int e = lane; e < recp; e += 64) {
+    Wc[ppp * recp + e] = 0.0;
+    Yc[ppp * recp + e] = 0.0;
+  }
+  if (lane < 4) vgs[4 * ppp + lane] = 0.0;
+  __syncthreads();
+  acc_t Uacc[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) Uacc[q] = 0;
+  double cost = 0.0, gmax = 0.0;
+  d4 acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = d4{0, 0, 0, 0};
+  // operand addresses of k-step s, lane (li, lk): (point, coordinate) pair e = 4 s + lk of the batch, rows 16 t + li of
+  // A = [Y ; (V^-1 g)^T] and B = W.  Plain loads, no selects: slab offset = base[t] + pe * stride[t] + ce - coupling rows read
+  // their record, the right-hand-side row reads V^-1 g, padding rows (and B beyond the coupling rows) read the zero record,
+  // pairs past the batch have pe = ppp: the zero record as well.
+  const int y_off = (ppp + 1) * recp, vg_off = 2 * (ppp + 1) * recp, z_off = ppp * recp;
+  int baseA[3], strA[3], baseB[3], strB[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int Rw = 16 * t + li;
+    baseA[t] = Rw < n ? y_off + 3 * Rw : (Rw == n ? vg_off : y_off + z_off);   // (camera Rw / 6, parameter Rw % 6: 18 c + 3 a = 3 Rw)
+    strA[t] = Rw < n ? recp : (Rw == n ? 4 : 0);
+    baseB[t] = Rw < n ? 3 * Rw : z_off;
+    strB[t] = Rw < n ? recp : 0;
+  }
+  const int ksteps = (3 * ppp + 3) / 4;
+  const int gw = blockIdx.x * 4 + wave;
+  const int p0 = min(gw * pts_per_wave, B.P), p1 = min(p0 + pts_per_wave, B.P);
+  auto ldop = [&](int s_, double (&A)[3], double (&Bo)[3]) {
+    const int e4 = 4 * s_ + lk;
+    const int q3 = (e4 * 21846) >> 16;
+    const int pe = min(q3, ppp), ce = e4 < 3 * ppp ? e4 - 3 * q3 : 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      A[t] = Wc[baseA[t] + pe * strA[t] + ce];
+      Bo[t] = Wc[baseB[t] + pe * strB[t] + ce];
+    }
+  };
+  auto products = [&](const double (&A)[3], const double (&Bo)[3]) {
+    acc[0] = mfma(-A[0], Bo[0], acc[0]);
+    acc[1] = mfma(-A[1], Bo[0], acc[1]);
+    acc[2] = mfma(-A[1], Bo[1], acc[2]);
+    acc[3] = mfma(-A[2], Bo[0], acc[3]);
+    acc[4] = mfma(-A[2], Bo[1], acc[4]);
+    acc[5] = mfma(-A[2], Bo[2], acc[5]);
+  };
+  // the first batch's slot, point and detection; afterwards the next batch's are requested a phase ahead
+  // (every load unconditional on a valid address: a conditional load is a branch and a full wait per element)
+  int kq = 0;
+  double Xq[3] = {0, 0, 0}, uq = 0, vq = 0;
+  if (p0 < p1) {
+    const int p = min(p0 + pl, p1 - 1);
+    kq = B.slot[(size_t)p * C + c];
+    Xq[0] = pts[3 * (size_t)p];
+    Xq[1] = pts[3 * (size_t)p + 1];
+    Xq[2] = pts[3 * (size_t)p + 2];
+    const int kc = max(kq, 0);
+    uq = B.uv[2 * (size_t)kc];
+    vq = B.uv[2 * (size_t)kc + 1];
+  }
+  for (int pb = p0; pb < p1; pb += ppp) {
+    const int nb = min(ppp, p1 - pb);
+    const bool on = lane_on && pl < nb;
+    const int p = pb + (on ? pl : 0);
+    const bool valid = on && kq >= 0;
+    const double X[3] = {Xq[0], Xq[1], Xq[2]};
+    const double u = uq, v = vq;
+    // next batch: slot and point now, the detection (which needs the slot) before the matrix-core phase
+    const int pn = min(pb + ppp + pl, B.P - 1);
+    const int kn = B.slot[(size_t)pn * C + c];
+    const double Xn0 = pts[3 * (size_t)pn], Xn1 = pts[3 * (size_t)pn + 1], Xn2 = pts[3 * (size_t)pn + 2];
+    SbaObs<PREC> o;
+    {
+      double R[12];
+      SbaIntr in;
+      const double* cp = sCam[c];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) R[q] = cp[q];
+      in.fx = cp[12]; in.fy = cp[13]; in.cx = cp[14]; in.cy = cp[15];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) in.d[q] = (MODEL == 0 && q >= 4) ? 0.0 : cp[16 + q];
+      sba_observe<PREC, true, MODEL, COST>(B.fs, R, in, X, u, v, o);
+    }
+    // what a lane without an observation computed is discarded by SELECTS (it may be inf / NaN)
+    const acc_t w0 = valid ? o.w[0] : (acc_t)0, w1 = valid ? o.w[1] : (acc_t)0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.Jp[d][j] = valid ? o.Jp[d][j] : (acc_t)0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) o.Jc[d][a] = valid ? o.Jc[d][a] : (acc_t)0;
+      o.rs[d] = valid ? o.rs[d] : (acc_t)0;
+    }
+    if (COST) cost += valid ? o.cost : 0.0;
+    acc_t W[18];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) W[a * 3 + j] = w0 * o.Jc[0][a] * o.Jp[0][j] + w1 * o.Jc[1][a] * o.Jp[1][j];
+    if (B.opt_cams) {
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bq = a; bq < 6; ++bq) Uacc[q++] += w0 * o.Jc[0][a] * o.Jc[0][bq] + w1 * o.Jc[1][a] * o.Jc[1][bq];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) Uacc[21 + a] += w0 * o.rs[0] * o.Jc[0][a] + w1 * o.rs[1] * o.Jc[1][a];
+    }
+    // the point blocks: every lane's share -> LDS -> every lane of the point sums the C shares in camera order
+    if (lane_on) {
+      double* pp = part + (pl * C + c) * 9;
+      pp[0] = w0 * o.Jp[0][0] * o.Jp[0][0] + w1 * o.Jp[1][0] * o.Jp[1][0];
+      pp[1] = w0 * o.Jp[0][0] * o.Jp[0][1] + w1 * o.Jp[1][0] * o.Jp[1][1];
+      pp[2] = w0 * o.Jp[0][0] * o.Jp[0][2] + w1 * o.Jp[1][0] * o.Jp[1][2];
+      pp[3] = w0 * o.Jp[0][1] * o.Jp[0][1] + w1 * o.Jp[1][1] * o.Jp[1][1];
+      pp[4] = w0 * o.Jp[0][1] * o.Jp[0][2] + w1 * o.Jp[1][1] * o.Jp[1][2];
+      pp[5] = w0 * o.Jp[0][2] * o.Jp[0][2] + w1 * o.Jp[1][2] * o.Jp[1][2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pp[6 + j] = w0 * o.rs[0] * o.Jp[0][j] + w1 * o.rs[1] * o.Jp[1][j];
+    }
+    acc_t Vs[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Vs[q] = 0;
+    for (int cc = 0; cc < C; ++cc) {
+      const double* pp = part + (pl * C + cc) * 9;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Vs[q] += (acc_t)pp[q];
+    }
+    const double V0 = Vs[0], V1 = Vs[1], V2 = Vs[2], V3 = Vs[3], V4 = Vs[4], V5 = Vs[5];
+    const double g0 = Vs[6], g1 = Vs[7], g2 = Vs[8];
+    // V^-1 of the damped point block (closed form)
+    const double a = V0 * (1 + lam), b = V1, cc2 = V2, d = V3 * (1 + lam), e = V4, f = V5 * (1 + lam);
+    const double c00 = d * f - e * e, c01 = cc2 * e - b * f, c02 = b * e - cc2 * d;
+    double det = a * c00 + b * c01 + cc2 * c02;
+    if (!(fabs(det) > 0.0)) det = 1.0;                   // point without observations: harmless (g = 0)
+    const double id = 1.0 / det;
+    const double Vi[6] = {c00 * id, c01 * id, c02 * id, (a * f - cc2 * cc2) * id, (b * cc2 - a * e) * id, (a * d - b * b) * id};
+    if (on && c == 0) {
+      double* Vg = B.V + 6 * (size_t)p;
+      double* Ig = B.Vinv + 6 * (size_t)p;
+      Vg[0] = V0; Vg[1] = V1; Vg[2] = V2; Vg[3] = V3; Vg[4] = V4; Vg[5] = V5;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Ig[q] = Vi[q];
+      B.gp[3 * (size_t)p] = g0;
+      B.gp[3 * (size_t)p + 1] = g1;
+      B.gp[3 * (size_t)p + 2] = g2;
+      gmax = fmax(gmax, fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
+    }
+    // the next batch's detections (its slots have arrived long ago); they arrive behind the matrix-core phase
+    kq = kn;
+    Xq[0] = Xn0;
+    Xq[1] = Xn1;
+    Xq[2] = Xn2;
+    {
+      const int kc = max(kn, 0);
+      uq = B.uv[2 * (size_t)kc];
+      vq = B.uv[2 * (size_t)kc + 1];
+    }
+    if (!B.opt_cams) continue;
+    if (lane_on) {
+      double* wq = Wc + pl * recp + 18 * c;
+      double* yq = Yc + pl * recp + 18 * c;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double x0 = W[r * 3], x1 = W[r * 3 + 1], x2 = W[r * 3 + 2];
+        wq[r * 3] = x0;
+        wq[r * 3 + 1] = x1;
+        wq[r * 3 + 2] = x2;
+        yq[r * 3] = x0 * Vi[0] + x1 * Vi[1] + x2 * Vi[2];
+        yq[r * 3 + 1] = x0 * Vi[1] + x1 * Vi[3] + x2 * Vi[4];
+        yq[r * 3 + 2] = x0 * Vi[2] + x1 * Vi[4] + x2 * Vi[5];
+      }
+      if (c == 0) {
+        vgs[4 * pl] = Vi[0] * g0 + Vi[1] * g1 + Vi[2] * g2;
+        vgs[4 * pl + 1] = Vi[1] * g0 + Vi[3] * g1 + Vi[4] * g2;
+        vgs[4 * pl + 2] = Vi[2] * g0 + Vi[4] * g1 + Vi[5] * g2;
+      }
+    }
+    // the batch on the matrix cores: k = (point, coordinate) pairs, four per instruction; the operands of step s + 1 are
+    // requested before the products of step s
+    double A0[3], B0[3], A1[3], B1[3];
+    ldop(0, A0, B0);
+    for (int s = 0; s < ksteps; s += 2) {
+      ldop(s + 1, A1, B1);                               // (past the last step: the zero record)
+      __builtin_amdgcn_sched_barrier(0);
+      products(A0, B0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < ksteps) {
+        ldop(s + 2, A0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        products(A1, B1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // cost, max |g_p|
+  for (int off = 32; off > 0; off >>= 1) {
+    cost += __shfl_down(cost, off, 64);
+    gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  }
+  if (lane == 0) {
+    sred[wave] = cost;
+    atomicMax(reinterpret_cast<unsigned long long*>(&B.scal[2]), (unsigned long long)__double_as_longlong(gmax));   // gmax >= 0: order-preserving
+  }
+  __syncthreads();                                       // (also: the slabs are free)
+  if (COST && tid == 0) atomicAdd(&B.scal[0], (sred[0] + sred[1]) + (sred[2] + sred[3]));
+  if (!B.opt_cams) return;
+  // tiles: wave -> LDS -> the workgroup's record.  C layout: register q of lane (li, lk) = entry [row lk + 4 q][column li]
+  double* sT = reinterpret_cast<double*>(fu_smem);       // [4][6][256]
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[(wave * 6 + t) * 256 + (lk + 4 * q) * 16 + li] = acc[t][q];
+  __syncthreads();
+  const int tot = n * n + n + 27 * C;
+  double* out = B.Spart + (size_t)blockIdx.x * tot;
+  for (int e = tid; e < 6 * 256; e += FU_T) {
+    const int t = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+    const int ib = t < 1 ? 0 : (t < 3 ? 1 : 2), jb = t < 1 ? 0 : (t < 3 ? t - 1 : t - 3);
+    const int Rw = 16 * ib + r, Cw = 16 * jb + cc;
+    const double v = (sT[(0 * 6 + t) * 256 + (e & 255)] + sT[(1 * 6 + t) * 256 + (e & 255)]) +
+                     (sT[(2 * 6 + t) * 256 + (e & 255)] + sT[(3 * 6 + t) * 256 + (e & 255)]);
+    if (Cw >= n) continue;
+    if (Rw < n) {
+      out[Rw * n + Cw] = v;
+      if (ib != jb) out[Cw * n + Rw] = v;                // (diagonal tiles hold both triangles already)
+    } else if (Rw == n) {
+      out[n * n + Cw] = v;
+    }
+  }
+  __syncthreads();
+  // camera sums: lane -> LDS, then the lanes of one camera (c, c + C, ...) of the four waves in a fixed order
+  double* sU = reinterpret_cast<double*>(fu_smem);       // [4][64][27]
+#pragma unroll
+  for (int q = 0; q < 27; ++q) sU[(wave * 64 + lane) * 27 + q] = lane_on ? (double)Uacc[q] : 0.0;
+  __syncthreads();
+  for (int e = tid; e < 27 * C; e += FU_T) {
+    const int cam = e / 27, q = e % 27;
+    double v = 0.0;
+    for (int w = 0; w < 4; ++w)
+      for (int j = 0; j < ppp; ++j) v += sU[(w * 64 + cam + C * j) * 27 + q];
+    out[n * n + n + (q < 21 ? 21 * cam + q : 21 * C + 6 * cam + (q - 21))] = v;
+  }
+}
+
+template <int PREC, int MODEL>
+__global__ void __launch_bounds__(FU_T)
+k_sba_backsub_fused(SbaBuf B, double lam, const double* __restrict__ Rt, const double* __restrict__ Rt_t,
+                    const double* __restrict__ pts, double* __restrict__ pts_t, int pts_per_wave) {
+  typedef typename SbaObs<PREC>::acc_t acc_t;
+  __shared__ double sx[4][64 * 4];                       // per wave: [ppp][C][3] shares, then [ppp][4] trial points
+  __shared__ double sred[2][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int C = B.C, ppp = 64 / C;
+  double* sh = sx[wave];
+  const bool lane_on = lane < ppp * C;
+  const int pl = lane_on ? lane / C : 0, c = lane_on ? lane % C : 0;
+  double R[12], Rn[12], dc[6];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    R[q] = Rt[12 * c + q];
+    Rn[q] = Rt_t[12 * c + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dc[q] = B.opt_cams ? B.dc[6 * c + q] : 0.0;
+  SbaIntr in;
+  {
+    const double* ip = B.intr + SBA_INTR * c;
+    in.fx = ip[0]; in.fy = ip[1]; in.cx = ip[2]; in.cy = ip[3];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) in.d[q] = (MODEL == 0 && q >= 4) ? 0.0 : ip[4 + q];
+  }
+  double pred = 0.0, cost_t = 0.0;
+  const int gw = blockIdx.x * 4 + wave;
+  const int p0 = min(gw * pts_per_wave, B.P), p1 = min(p0 + pts_per_wave, B.P);
+  for (int pb = p0; pb < p1; pb += ppp) {
+    const int nb = min(ppp, p1 - pb);
+    const bool on = lane_on && pl < nb;
+    const int p = pb + (on ? pl : 0);
+    int k = B.slot[(size_t)p * C + c];
+    const bool valid = on && k >= 0;
+    k = valid ? k : 0;
+    const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+    const double u = B.uv[2 * (size_t)k], v = B.uv[2 * (size_t)k + 1];
+    double s3[3] = {0, 0, 0};
+    if (B.opt_cams) {
+      SbaObs<PREC> o;
+      sba_observe<PREC, true, MODEL>(B.fs, R, in, X, u, v, o);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        acc_t jd = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) jd += o.Jc[d][a] * (acc_t)dc[a];
+        const acc_t wj = o.w[d] * jd;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s3[j] += (double)(wj * o.Jp[d][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s3[j] = valid ? s3[j] : 0.0;
+    }
+    if (lane_on) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh[(pl * C + c) * 3 + j] = s3[j];
+    }
+    double Xt[3] = {X[0], X[1], X[2]};
+    double st[3] = {B.gp[3 * (size_t)p], B.gp[3 * (size_t)p + 1], B.gp[3 * (size_t)p + 2]};
+    const double g0 = st[0], g1 = st[1], g2 = st[2];
+    for (int cc = 0; cc < C; ++cc)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) st[j] += sh[(pl * C + cc) * 3 + j];
+    {
+      const double* Vi = B.Vinv + 6 * (size_t)p;
+      const double d0 = -(Vi[0] * st[0] + Vi[1] * st[1] + Vi[2] * st[2]), d1 = -(Vi[1] * st[0] + Vi[3] * st[1] + Vi[4] * st[2]),
+                   d2 = -(Vi[2] * st[0] + Vi[4] * st[1] + Vi[5] * st[2]);
+      Xt[0] += d0;
+      Xt[1] += d1;
+      Xt[2] += d2;
+      if (on && c == 0) {
+        pts_t[3 * (size_t)p] = Xt[0];
+        pts_t[3 * (size_t)p + 1] = Xt[1];
+        pts_t[3 * (size_t)p + 2] = Xt[2];
+        const double* V = B.V + 6 * (size_t)p;
+        pred += 0.5 * (d0 * (lam * V[0] * d0 - g0) + d1 * (lam * V[3] * d1 - g1) + d2 * (lam * V[5] * d2 - g2));
+      }
+    }
+    // the trial cost of this observation: trial point (every lane of the point formed the same one), trial pose
+    SbaObs<ACINO_PREC_F64> ot;
+    sba_observe<ACINO_PREC_F64, false, MODEL>(B.fs, Rn, in, Xt, u, v, ot);
+    cost_t += valid ? ot.cost : 0.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    pred += __shfl_down(pred, off, 64);
+    cost_t += __shfl_down(cost_t, off, 64);
+  }
+  if (lane == 0) {
+    sred[0][wave] = pred;
+    sred[1][wave] = cost_t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&B.scal[1], (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]));
+    atomicAdd(&B.scal[6], (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]));
   }
 }
 
@@ -577,13 +922,20 @@ extern "C" {
 size_t acino_sizeof_sba_params(void) { return sizeof(acino_sba_params); }
 size_t acino_sizeof_sba_info(void) { return sizeof(acino_sba_info); }
 
+// the fused path: at most seven cameras (6 C + 1 rows fit three 16-row tiles); ACINO_SBA_UNFUSED=1 keeps the table form
+static bool sba_fused(int n_cams) {
+  static const bool unfused = getenv("ACINO_SBA_UNFUSED") != nullptr;
+  return 6 * n_cams + 1 <= 48 && !unfused;
+}
+
 size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs) {
   if (n_cams < 1 || n_points < 0 || n_obs < 0) return 0;
   const size_t P = (size_t)n_points, M = (size_t)n_obs, n = 6 * (size_t)n_cams;
   size_t b = 0;
   (void)M;
-  b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3 + a256(P * n_cams * 18 * 8);        // V, Vinv, gp, dp, pts_t, Wpc [P][C]
-  b += a256((size_t)(SBA_SCHUR_WG + 32) * (n * n + n) * 8);                           // partial sums of the Schur kernel (+ 32 intermediate records)
+  b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3;                                      // V, Vinv, gp, dp, pts_t
+  b += sba_fused(n_cams) ? a256(P * n_cams * 4) : a256(P * n_cams * 18 * 8);           // slot [P][C]  |  Wpc [P][C][18]
+  b += a256((size_t)(SBA_SCHUR_WG + 32) * (n * n + n + 27 * (size_t)n_cams) * 8);      // partial sums (+ 32 intermediate records)
   b += a256(n_cams * 21 * 8) + a256(n * 8) * 3 + a256(n * n * 8) + a256(n_cams * 12 * 8) + a256(64);
   return b + 1024;
 }
@@ -638,10 +990,14 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   B.gp = (double*)take(P * 3 * 8);
   B.dp = (double*)take(P * 3 * 8);
   double* pts_t = (double*)take(P * 3 * 8);
-  B.Wpc = (double*)take(P * C * 18 * 8);
-  B.Spart = (double*)take((size_t)(SBA_SCHUR_WG + 32) * (n * n + n) * 8);
+  const bool fused = sba_fused(C);
+  B.Wpc = nullptr;
+  B.slot = nullptr;
+  if (fused) B.slot = (int*)take(P * C * 4);
+  else B.Wpc = (double*)take(P * C * 18 * 8);
+  B.Spart = (double*)take((size_t)(SBA_SCHUR_WG + 32) * (n * n + n + 27 * (size_t)C) * 8);
   // (the dense W table: slots of cameras that do not see a point are never written - zero them once)
-  if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.Wpc, 0, P * C * 18 * 8, s));
+  if (!fused && B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.Wpc, 0, P * C * 18 * 8, s));
   B.U = (double*)take((C * 21 + n) * 8);      // [U | gc] contiguous: one reduction
   B.gc = B.U + C * 21;
   B.dc = (double*)take(n * 8);
@@ -685,6 +1041,158 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     return ACINO_OK;
   };
 
+  if (fused) {
+    // ---- fused path: per LM iteration ONE pass that linearises and reduces (k_sba_fused + the two-stage sum), the camera
+    //      solve, the trial poses, ONE pass that back-substitutes and prices the trial iterate; one host read-back.
+    ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
+    ACINO_HIP_CHECK(hipMemsetAsync(B.slot, 0xFF, P * C * 4, s));
+    hipLaunchKernelGGL(k_sba_slots, dim3(nblk), dim3(256), 0, s, B);
+    ACINO_LAUNCH_CHECK();
+    {
+      double dup = 0.0;
+      ACINO_HIP_CHECK(hipMemcpyAsync(&dup, B.scal + 7, 8, hipMemcpyDeviceToHost, s));
+      ACINO_HIP_CHECK(hipStreamSynchronize(s));
+      ACINO_REQUIRE(dup == 0.0, "SBA: two observations of one point by one camera, or a camera index out of range");
+    }
+    double hd[4];
+    int rc = ACINO_OK;
+    if (d_res_before) {
+      rc = eval(d_Rt, d_pts, false, d_res_before, hd);
+      if (rc) return rc;
+    }
+    const int ppp = 64 / C;
+    const size_t batches = (P + ppp - 1) / ppp;
+    const int waves = (int)std::min<size_t>((size_t)SBA_SCHUR_WG * 4, batches);
+    const int ppw = (int)((batches + waves - 1) / waves) * ppp, n_wg = (int)((P + (size_t)4 * ppw - 1) / ((size_t)4 * ppw));
+    const size_t lds_f = fused_lds_bytes(C);
+    const int tail = 27 * C;
+    const unsigned rblk = (unsigned)((n * n + n + tail + 255) / 256);
+    auto linearise = [&](double lam, bool with_cost) -> int {
+      ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
+#define ACINO_SBA_FUSED(PRECV, MODELV)                                                                                            \
+  do {                                                                                                                            \
+    if (with_cost) hipLaunchKernelGGL((k_sba_fused<PRECV, MODELV, true>), dim3(n_wg), dim3(FU_T), lds_f, s, B, d_Rt, d_pts, lam, ppw); \
+    else hipLaunchKernelGGL((k_sba_fused<PRECV, MODELV, false>), dim3(n_wg), dim3(FU_T), lds_f, s, B, d_Rt, d_pts, lam, ppw);     \
+  } while (0)
+      if (B.prec == ACINO_PREC_F64) {
+        if (B.model == 0) ACINO_SBA_FUSED(ACINO_PREC_F64, 0);
+        else ACINO_SBA_FUSED(ACINO_PREC_F64, 1);
+      } else {
+        if (B.model == 0) ACINO_SBA_FUSED(ACINO_PREC_BF16_ROWS, 0);
+        else ACINO_SBA_FUSED(ACINO_PREC_BF16_ROWS, 1);
+      }
+#undef ACINO_SBA_FUSED
+      ACINO_LAUNCH_CHECK();
+      if (B.opt_cams) {
+        hipLaunchKernelGGL(k_sba_schur_reduce, dim3(rblk, 32), dim3(256), 0, s, B, n_wg, 0, tail);
+        ACINO_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sba_schur_reduce, dim3(rblk, 1), dim3(256), 0, s, B, n_wg, 1, tail);
+        ACINO_LAUNCH_CHECK();
+      }
+      if (with_cost)
+        if (int e = greduce(B.scal, 1, 0)) return e;
+      if (int e = greduce(B.scal + 2, 1, 1)) return e;
+      if (B.opt_cams) {
+        if (int e = greduce(B.U, C * 21 + n, 0)) return e;
+        if (int e = greduce(B.S, n * n + n, 0)) return e;
+      }
+      return ACINO_OK;
+    };
+    auto read_back = [&](double hs[8], double& gmax) -> int {
+      double hgc[6 * SBA_MAXC];
+      ACINO_HIP_CHECK(hipMemcpyAsync(hs, B.scal, 64, hipMemcpyDeviceToHost, s));
+      if (B.opt_cams) ACINO_HIP_CHECK(hipMemcpyAsync(hgc, B.gc, n * 8, hipMemcpyDeviceToHost, s));
+      ACINO_HIP_CHECK(hipStreamSynchronize(s));
+      gmax = hs[2];
+      if (B.opt_cams)
+        for (size_t i = 0; i < n; ++i) gmax = fmax(gmax, fabs(hgc[i]));
+      return ACINO_OK;
+    };
+    double F = 0.0, lam = prm->lam0, nu = 2.0, gmax = 0.0, hs[8];
+    bool fresh = false;                                   // hs / gmax describe the CURRENT iterate
+    info->iterations = 0;
+    info->accepted = 0;
+    info->status = 0;
+    for (int it = 0; it < prm->max_iter; ++it) {
+      if ((rc = linearise(lam, it == 0))) return rc;
+      if (B.opt_cams) {
+        hipLaunchKernelGGL(k_sba_cam_solve, dim3(1), dim3(256), lds_c, s, B, lam);
+        ACINO_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL(k_sba_apply_cams, dim3(1), dim3(64), 0, s, B, d_Rt, Rt_t);
+      ACINO_LAUNCH_CHECK();
+#define ACINO_SBA_BACK(PRECV, MODELV) \
+  hipLaunchKernelGGL((k_sba_backsub_fused<PRECV, MODELV>), dim3(n_wg), dim3(FU_T), 0, s, B, lam, d_Rt, Rt_t, d_pts, pts_t, ppw)
+      if (B.prec == ACINO_PREC_F64) {
+        if (B.model == 0) ACINO_SBA_BACK(ACINO_PREC_F64, 0);
+        else ACINO_SBA_BACK(ACINO_PREC_F64, 1);
+      } else {
+        if (B.model == 0) ACINO_SBA_BACK(ACINO_PREC_BF16_ROWS, 0);
+        else ACINO_SBA_BACK(ACINO_PREC_BF16_ROWS, 1);
+      }
+#undef ACINO_SBA_BACK
+      ACINO_LAUNCH_CHECK();
+      if (int e = greduce(B.scal + 1, 1, 0)) return e;
+      if (int e = greduce(B.scal + 6, 1, 0)) return e;
+      if ((rc = read_back(hs, gmax))) return rc;
+      fresh = true;
+      if (it == 0) {
+        F = hs[0];
+        info->cost_initial = F;
+      }
+      if (gmax <= prm->gtol) {
+        info->status = 3;
+        break;
+      }
+      info->iterations = it + 1;
+      const double pred = hs[1] + hs[4];
+      // (hs[3] != 0: the damped reduced camera system lost definiteness to round-off along the free gauge - 7 DoF when every
+      //  camera moves -: a rejected step)
+      const double Ft = hs[3] == 0.0 ? hs[6] : INFINITY;
+      const double gain = pred > 0 ? (F - Ft) / pred : -1.0;
+      if (Ft < F) {
+        const double dF = F - Ft;
+        ACINO_HIP_CHECK(hipMemcpyAsync(d_pts, pts_t, P * 3 * 8, hipMemcpyDeviceToDevice, s));
+        ACINO_HIP_CHECK(hipMemcpyAsync(d_Rt, Rt_t, C * 12 * 8, hipMemcpyDeviceToDevice, s));
+        F = Ft;
+        fresh = false;
+        info->accepted += 1;
+        const double t = 2.0 * gain - 1.0;
+        lam *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+        nu = 2.0;
+        if (dF <= prm->ftol * fabs(F)) {
+          info->status = 1;
+          break;
+        }
+      } else {
+        lam *= nu;
+        nu *= 2.0;
+        if (lam > 1e16) {
+          info->status = hs[3] != 0.0 ? 5 : 4;
+          if (info->status == 5) set_error("SBA: reduced camera system not positive definite at any damping");
+          break;
+        }
+      }
+    }
+    if (!fresh) {                                          // gradient norm (and, with max_iter = 0, the cost) of the final iterate
+      const bool first = prm->max_iter == 0;
+      if ((rc = linearise(lam, first))) return rc;
+      if ((rc = read_back(hs, gmax))) return rc;
+      if (first) {
+        F = hs[0];
+        info->cost_initial = F;
+      }
+    }
+    if (d_res_after) {
+      rc = eval(d_Rt, d_pts, false, d_res_after, hd);
+      if (rc) return rc;
+    }
+    info->cost_final = F;
+    info->gnorm_inf = gmax;
+    info->lam = lam;
+    return info->status == 5 ? ACINO_ERR_NUMERIC : ACINO_OK;
+  }
+
   double h[4];
   int rc = eval(d_Rt, d_pts, true, d_res_before, h);
   if (rc) return rc;
@@ -707,21 +1215,8 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     }
     info->iterations = it + 1;
     ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
-    static const bool schur_atomics = getenv("ACINO_SBA_SCHUR_ATOMICS") != nullptr;
-    if (B.opt_cams && 6 * C + 1 <= 48 && !schur_atomics) {
-      // matrix-core Schur complement: contiguous point ranges per wave, as many workgroups as keep >= 64 points per wave
-      const int waves = (int)std::min<size_t>((size_t)SBA_SCHUR_WG * 4, (P + 63) / 64);
-      const int ppw = (int)((P + waves - 1) / waves), n_wg = (waves + 3) / 4;
-      const size_t lds_m = std::max((size_t)4 * SCH_B * (9 + 18 * C), (size_t)4 * 6 * 256) * 8;
-      hipLaunchKernelGGL(k_sba_schur_mfma, dim3(n_wg), dim3(SCH_T), lds_m, s, B, lam, ppw);
-      ACINO_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256), 32), dim3(256), 0, s, B, n_wg, 0);
-      ACINO_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_sba_schur_reduce, dim3((unsigned)((n * n + n + 255) / 256), 1), dim3(256), 0, s, B, n_wg, 1);
-    } else {
-      if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
-      hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
-    }
+    if (B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.S, 0, (n * n + n) * 8, s));
+    hipLaunchKernelGGL(k_sba_schur, dim3(nblk), dim3(256), lds_s, s, B, lam);
     ACINO_LAUNCH_CHECK();
     if (B.opt_cams) {
       if (int e = greduce(B.S, n * n + n, 0)) return e;

@@ -99,8 +99,8 @@ def _solve(points_2d, points_3d, point_3d_indices, camera_indices, k_arr, d_arr,
         raise ValueError("points_2d, point_3d_indices and camera_indices must have one entry per observation")
     if n_obs and (cam_idx.min() < 0 or cam_idx.max() >= n_cams):
         raise ValueError("camera_indices out of range")
-    if optimize_cameras and n_obs:
-        # the point <-> camera coupling blocks live in a dense [point][camera] table (csrc/sba.hip): one observation per pair
+    if n_obs:
+        # one GPU lane per (point, camera) slot (csrc/sba.hip): one observation per pair
         key = np.asarray(point_3d_indices, dtype=np.int64).reshape(-1) * n_cams + cam_idx
         if np.unique(key).size != key.size:
             raise ValueError("a point is observed twice by the same camera: merge the duplicate observations first")

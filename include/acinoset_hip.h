@@ -320,10 +320,12 @@ int acino_fte_export_edges(acino_fte_ctx* ctx, int which, double* d_edge, void* 
  * (src/calib/calib.py:307-341).  Cost = sum over observations and both pixel axes of 0.5 f^2 log1p((r/f)^2),
  * scipy's definition, so costs compare 1:1 with `res.cost`.  Observations arrive flat: uv[M][2], cam_idx[M]; the host
  * also supplies the CSR grouping by point (pt_start[P+1], pt_obs[M]).  Poses are [R row-major 9 | t 3] per camera and
- * are updated in place together with the points.  With optimize_cameras a (point, camera) pair may carry at most ONE
- * observation: the 6 x 3 coupling blocks live in a dense table [point][camera] (workspace: n_points x n_cams x 144 B), which
- * makes the Schur complement onto the cameras a tall-skinny GEMM for the fp64 matrix cores (n_cams <= 7; more cameras take
- * the atomic-accumulation kernel). */
+ * are updated in place together with the points.  A (point, camera) pair may carry at most ONE observation (refused with
+ * ACINO_ERR_INVALID_ARG otherwise).  Up to seven cameras take the fused path: one GPU lane per (point, camera) slot, the
+ * 6 x 3 coupling blocks never leave the chip, the Schur complement onto the cameras is accumulated on the fp64 matrix
+ * cores (workspace: n_points x (n_cams x 4 + 144) B).  More cameras - or the environment variable ACINO_SBA_UNFUSED, an
+ * independent cross-check - take the table path: coupling blocks in a dense table [point][camera] (n_points x n_cams x 144 B),
+ * Schur complement by LDS atomics. */
 typedef struct acino_sba_params {
   int32_t n_cams;
   int32_t optimize_cameras;   /* 0 = points only (calib.py:327), 1 = points + extrinsics (calib.py:369) */
@@ -360,8 +362,9 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
  * "the SBA extrinsic refinement adds a 36x36 camera-block + 36-vector all-reduce per
  * iteration").  Every rank passes its own points and observations and identical camera poses; `reduce` must combine
  * n doubles at d_buf (device memory inside d_ws) over all ranks in place - op 0: sum, op 1: max - and return 0; it is
- * called after the stream has been synchronised, four times per LM iteration (cost + camera blocks + camera gradient;
- * the Schur complement and its right-hand side; the predicted reduction; the trial cost).  All ranks take identical
+ * called after the stream has been synchronised, five times per LM iteration (max point gradient; camera blocks + camera
+ * gradient, 27 n_cams doubles; the Schur complement and its right-hand side, (6 n_cams)^2 + 6 n_cams; the predicted
+ * reduction; the trial cost - and the initial cost once).  All ranks take identical
  * decisions and leave with identical poses.  reduce == NULL is acino_sba_solve. */
 typedef int (*acino_reduce_fn)(void* user, double* d_buf, int64_t n, int op, void* stream);
 int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, double* d_Rt, double* d_pts,

@@ -532,3 +532,52 @@ def test_config5_extrinsic_refinement_at_full_size(gsba, precision):
     assert info["cost_final"] < info["cost_initial"] and info["accepted"] >= 5
     assert info["rms_before"] > 4.0 and info["rms_after"] < 2.2
     assert after[0] < 0.5 * before[0] and after[1] < 0.5 * before[1] and after[2] < 0.5 * before[2], (before, after)
+
+
+_TABLE_PATH_SCRIPT = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from acinoset_amd import fte, sba, synth
+seq = synth.make_sequence(40, "trot")
+K, D, R, t = seq["K"], seq["D"], seq["R"], seq["t"]
+rng = np.random.default_rng(11)
+dw = np.deg2rad(0.4) * rng.standard_normal((6, 3))
+from oracle import camera as ocam
+Rp = np.stack([ocam.rodrigues(dw[c]) @ R[c] for c in range(6)])
+tp = np.asarray(t, dtype=np.float64).reshape(-1, 3, 1) + 0.008 * rng.standard_normal((6, 3, 1))
+X0 = np.asarray(fte.cheetah_fk(seq["q_true"])) + 0.004 * rng.standard_normal((40, 20, 3))
+out = {}
+for prec in ("f64", "bf16"):
+    p, rm, tt, info = sba.bundle_adjust_dense_points_and_extrinsics(seq["det"], X0, K, D, Rp, tp, 0.5, max_iter=12, precision=prec)
+    out[prec] = dict(cost0=info["cost_initial"], cost=info["cost_final"], it=info["iterations"], acc=info["accepted"],
+                     r=np.asarray(rm).tolist(), t=np.asarray(tt).tolist(), p=np.asarray(p)[:50].tolist())
+print("RESULT" + json.dumps(out))
+'''
+
+
+def test_fused_path_equals_the_table_path(gsba):
+    """The fused kernels (one lane per (point, camera) slot, Schur complement on the matrix cores, no coupling table) against
+    the table path (one thread per point, dense W table, LDS atomics; ACINO_SBA_UNFUSED=1) on the same problem: the same
+    LM trajectory - equal iteration / acceptance counts, costs to 1e-10, poses and points to 1e-8 - in both precisions."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, extra in (("fused", {}), ("table", {"ACINO_SBA_UNFUSED": "1"})):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("ACINO_SBA_UNFUSED", None)
+        r = subprocess.run([sys.executable, "-c", _TABLE_PATH_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+    for prec in ("f64", "bf16"):
+        a, b = runs["fused"][prec], runs["table"][prec]
+        assert a["it"] == b["it"] and a["acc"] == b["acc"], (prec, a["it"], b["it"])
+        tol = 1e-10 if prec == "f64" else 1e-5          # (bf16 rows: fp32 accumulation in another order)
+        assert abs(a["cost0"] - b["cost0"]) <= 1e-12 * abs(b["cost0"])
+        assert abs(a["cost"] - b["cost"]) <= tol * abs(b["cost"]), (prec, a["cost"], b["cost"])
+        ptol = 1e-8 if prec == "f64" else 1e-4
+        assert np.abs(np.array(a["r"]) - np.array(b["r"])).max() < ptol and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < ptol
+        assert np.abs(np.array(a["p"]) - np.array(b["p"])).max() < ptol
