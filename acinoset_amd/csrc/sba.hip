@@ -401,10 +401,15 @@ __global__ void __launch_bounds__(256) k_sba_slots(SbaBuf B) {
 }
 
 constexpr int FU_T = 256;
-__host__ __device__ inline int fused_slab_doubles(int C) {
-  const int ppp = 64 / C;
-  return 2 * (ppp + 1) * 18 * C + 4 * (ppp + 1);          // W | Y (the V / g exchange lives in the Y part) | V^-1 g; record ppp = zeros
-}
+// Operand slab of one wave: A = -[Y ; (V^-1 g)^T] and B = W as [16 k entries][48 rows] each (entry = (point, coordinate) pair of
+// a CHUNK of five points, entry 15 and rows beyond 6 C (+ 1) stay zero), + the [64 / C][C][9] exchange of the point blocks.
+// Lane (li, lk) reads row 16 t + li of entry 4 s + lk: one base address per lane, everything else immediate offsets, 48 rows
+// = the stride that spreads the two k-entries of a half-wave over all 64 banks.
+constexpr int FU_PC = 5, FU_E = 16, FU_ROWS = 48;
+#ifndef FU_OCC
+#define FU_OCC 2
+#endif
+__host__ __device__ inline int fused_slab_doubles(int C) { return 2 * FU_E * FU_ROWS + (64 / C) * C * 9; }
 __host__ __device__ inline size_t fused_lds_bytes(int C) {
   size_t d = (size_t)4 * fused_slab_doubles(C);
   if (d < (size_t)4 * 6 * 256) d = (size_t)4 * 6 * 256;  // the tiles of the four waves
@@ -414,31 +419,25 @@ __host__ __device__ inline size_t fused_lds_bytes(int C) {
 
 // COST: also the cost of the iterate (first evaluation only: afterwards it is the trial cost of the accepted step)
 template <int PREC, int MODEL, bool COST>
-__global__ void __launch_bounds__(FU_T, 2)
+__global__ void __launch_bounds__(FU_T, FU_OCC)
 k_sba_fused(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ pts, double lam, int pts_per_wave) {
   typedef typename SbaObs<PREC>::acc_t acc_t;
   extern __shared__ __attribute__((aligned(16))) char fu_smem[];
   __shared__ double sred[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int C = B.C, n = 6 * C, ppp = 64 / C, recp = 18 * C;
-  double* Wc = reinterpret_cast<double*>(fu_smem) + (size_t)wave * fused_slab_doubles(C);
-  double* Yc = Wc + (ppp + 1) * recp;
-  double* vgs = Yc + (ppp + 1) * recp;
-  double* part = Yc;                                     // [ppp][C][9], read by every lane before Y is written
+  const int C = B.C, n = 6 * C, ppp = 64 / C;
+  double* Aop = reinterpret_cast<double*>(fu_smem) + (size_t)wave * fused_slab_doubles(C);
+  double* Bop = Aop + FU_E * FU_ROWS;
+  double* part = Bop + FU_E * FU_ROWS;                   // [ppp][C][9]
   const bool lane_on = lane < ppp * C;
   const int pl = lane_on ? lane / C : 0, c = lane_on ? lane % C : 0;
   // pose and intrinsics of the lane's camera: staged in LDS, read back per batch (20 registers live only while they are used)
-  __shared__ double sCam[SBA_MAXC][28];
+  __shared__ double sCam[7][28];                         // (fused path: at most seven cameras)
   for (int e = tid; e < C * 28; e += FU_T) {
     const int cam = e / 28, q = e % 28;
     sCam[cam][q] = q < 12 ? Rt[12 * cam + q] : B.intr[SBA_INTR * cam + (q - 12)];
   }
-  // the zero record behind the batch: what the k-steps read past the last (point, coordinate) pair
-  for (int e = lane; e < recp; e += 64) {
-    Wc[ppp * recp + e] = 0.0;
-    Yc[ppp * recp + e] = 0.0;
-  }
-  if (lane < 4) vgs[4 * ppp + lane] = 0.0;
+  for (int e = lane; e < 2 * FU_E * FU_ROWS; e += 64) Aop[e] = 0.0;    // (entry 15, the rows beyond 6 C + 1: zero for good)
   __syncthreads();
   acc_t Uacc[27];
 #pragma unroll
@@ -447,40 +446,29 @@ k_sba_fused(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
   d4 acc[6];
 #pragma unroll
   for (int t = 0; t < 6; ++t) acc[t] = d4{0, 0, 0, 0};
-  // operand addresses of k-step s, lane (li, lk): (point, coordinate) pair e = 4 s + lk of the batch, rows 16 t + li of
-  // A = [Y ; (V^-1 g)^T] and B = W.  Plain loads, no selects: slab offset = base[t] + pe * stride[t] + ce - coupling rows read
-  // their record, the right-hand-side row reads V^-1 g, padding rows (and B beyond the coupling rows) read the zero record,
-  // pairs past the batch have pe = ppp: the zero record as well.
-  const int y_off = (ppp + 1) * recp, vg_off = 2 * (ppp + 1) * recp, z_off = ppp * recp;
-  int baseA[3], strA[3], baseB[3], strB[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int Rw = 16 * t + li;
-    baseA[t] = Rw < n ? y_off + 3 * Rw : (Rw == n ? vg_off : y_off + z_off);   // (camera Rw / 6, parameter Rw % 6: 18 c + 3 a = 3 Rw)
-    strA[t] = Rw < n ? recp : (Rw == n ? 4 : 0);
-    baseB[t] = Rw < n ? 3 * Rw : z_off;
-    strB[t] = Rw < n ? recp : 0;
-  }
-  const int ksteps = (3 * ppp + 3) / 4;
   const int gw = blockIdx.x * 4 + wave;
   const int p0 = min(gw * pts_per_wave, B.P), p1 = min(p0 + pts_per_wave, B.P);
+  const int n_chunk = (ppp + FU_PC - 1) / FU_PC;
+  const bool row2 = n + 1 > 32;                          // (five cameras or fewer: tile row 2 is empty)
+  const int pch = pl / FU_PC, pin = pl - FU_PC * pch;    // the lane's chunk and its place in it
+  const double* ordA = Aop + lk * FU_ROWS + li;          // operands of k-step s, tile row t: + s * 4 * 48 + 16 t
+  const double* ordB = Bop + lk * FU_ROWS + li;
   auto ldop = [&](int s_, double (&A)[3], double (&Bo)[3]) {
-    const int e4 = 4 * s_ + lk;
-    const int q3 = (e4 * 21846) >> 16;
-    const int pe = min(q3, ppp), ce = e4 < 3 * ppp ? e4 - 3 * q3 : 0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      A[t] = Wc[baseA[t] + pe * strA[t] + ce];
-      Bo[t] = Wc[baseB[t] + pe * strB[t] + ce];
+      A[t] = ordA[s_ * 4 * FU_ROWS + 16 * t];
+      Bo[t] = ordB[s_ * 4 * FU_ROWS + 16 * t];
     }
   };
   auto products = [&](const double (&A)[3], const double (&Bo)[3]) {
-    acc[0] = mfma(-A[0], Bo[0], acc[0]);
-    acc[1] = mfma(-A[1], Bo[0], acc[1]);
-    acc[2] = mfma(-A[1], Bo[1], acc[2]);
-    acc[3] = mfma(-A[2], Bo[0], acc[3]);
-    acc[4] = mfma(-A[2], Bo[1], acc[4]);
-    acc[5] = mfma(-A[2], Bo[2], acc[5]);
+    acc[0] = mfma(A[0], Bo[0], acc[0]);
+    acc[1] = mfma(A[1], Bo[0], acc[1]);
+    acc[2] = mfma(A[1], Bo[1], acc[2]);
+    if (row2) {
+      acc[3] = mfma(A[2], Bo[0], acc[3]);
+      acc[4] = mfma(A[2], Bo[1], acc[4]);
+      acc[5] = mfma(A[2], Bo[2], acc[5]);
+    }
   };
   // the first batch's slot, point and detection; afterwards the next batch's are requested a phase ahead
   // (every load unconditional on a valid address: a conditional load is a branch and a full wait per element)
@@ -595,40 +583,58 @@ k_sba_fused(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
       vq = B.uv[2 * (size_t)kc + 1];
     }
     if (!B.opt_cams) continue;
-    if (lane_on) {
-      double* wq = Wc + pl * recp + 18 * c;
-      double* yq = Yc + pl * recp + 18 * c;
+    // the batch on the matrix cores, five points (15 k entries = four instructions per tile) at a time: the chunk's lanes write
+    // their rows of B = W and A = -W V^-1 (lane of camera 0 also the right-hand-side row -V^-1 g), then four k-steps with the
+    // operands of step s + 1 requested before the products of step s.  (A wave's LDS operations are ordered: no barrier.)
+    double Yn[18];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double x0 = W[r * 3], x1 = W[r * 3 + 1], x2 = W[r * 3 + 2];
-        wq[r * 3] = x0;
-        wq[r * 3 + 1] = x1;
-        wq[r * 3 + 2] = x2;
-        yq[r * 3] = x0 * Vi[0] + x1 * Vi[1] + x2 * Vi[2];
-        yq[r * 3 + 1] = x0 * Vi[1] + x1 * Vi[3] + x2 * Vi[4];
-        yq[r * 3 + 2] = x0 * Vi[2] + x1 * Vi[4] + x2 * Vi[5];
-      }
-      if (c == 0) {
-        vgs[4 * pl] = Vi[0] * g0 + Vi[1] * g1 + Vi[2] * g2;
-        vgs[4 * pl + 1] = Vi[1] * g0 + Vi[3] * g1 + Vi[4] * g2;
-        vgs[4 * pl + 2] = Vi[2] * g0 + Vi[4] * g1 + Vi[5] * g2;
-      }
+    for (int r = 0; r < 6; ++r) {
+      const double x0 = W[r * 3], x1 = W[r * 3 + 1], x2 = W[r * 3 + 2];
+      Yn[r * 3] = -(x0 * Vi[0] + x1 * Vi[1] + x2 * Vi[2]);
+      Yn[r * 3 + 1] = -(x0 * Vi[1] + x1 * Vi[3] + x2 * Vi[4]);
+      Yn[r * 3 + 2] = -(x0 * Vi[2] + x1 * Vi[4] + x2 * Vi[5]);
     }
-    // the batch on the matrix cores: k = (point, coordinate) pairs, four per instruction; the operands of step s + 1 are
-    // requested before the products of step s
-    double A0[3], B0[3], A1[3], B1[3];
-    ldop(0, A0, B0);
-    for (int s = 0; s < ksteps; s += 2) {
-      ldop(s + 1, A1, B1);                               // (past the last step: the zero record)
+    const double vgn[3] = {-(Vi[0] * g0 + Vi[1] * g1 + Vi[2] * g2), -(Vi[1] * g0 + Vi[3] * g1 + Vi[4] * g2),
+                           -(Vi[2] * g0 + Vi[4] * g1 + Vi[5] * g2)};
+    for (int j = 0; j < n_chunk; ++j) {
+      const int cnt = min(FU_PC, ppp - FU_PC * j);       // points of this chunk (the batch's last chunk may be short)
+      if (cnt < FU_PC)                                   // entries of the points it lacks: zero again
+        for (int e = lane; e < (FU_PC - cnt) * 3 * (n + 1); e += 64) {
+          const int en = 3 * cnt + e / (n + 1), rw = e % (n + 1);
+          Aop[en * FU_ROWS + rw] = 0.0;
+          Bop[en * FU_ROWS + rw] = 0.0;
+        }
+      if (lane_on && pch == j) {
+        double* aq = Aop + 3 * pin * FU_ROWS + 6 * c;
+        double* bq = Bop + 3 * pin * FU_ROWS + 6 * c;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            aq[jj * FU_ROWS + r] = Yn[r * 3 + jj];
+            bq[jj * FU_ROWS + r] = W[r * 3 + jj];
+          }
+        if (c == 0) {
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) Aop[(3 * pin + jj) * FU_ROWS + n] = vgn[jj];
+        }
+      }
+      double A0[3], B0[3], A1[3], B1[3];
+      ldop(0, A0, B0);
+      ldop(1, A1, B1);
       __builtin_amdgcn_sched_barrier(0);
       products(A0, B0);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < ksteps) {
-        ldop(s + 2, A0, B0);
-        __builtin_amdgcn_sched_barrier(0);
-        products(A1, B1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      ldop(2, A0, B0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(A1, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      ldop(3, A1, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(A0, B0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(A1, B1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // cost, max |g_p|

@@ -326,9 +326,13 @@ def secondary_metrics(det, rig, Ts):
             c5[prec] = dict(seconds=dt, iterations=info["iterations"], ms_per_outer_iteration=1e3 * dt / it, n_points=info["n_points"],
                             n_obs=info["n_obs"], observations_per_s=info["n_obs"] * it / dt, rms_before_px=info["rms_before"],
                             rms_after_px=info["rms_after"], cost_initial=info["cost_initial"], cost_final=info["cost_final"],
-                            includes="observation lists built on the device, workspace allocation, 10 LM iterations (two 32-byte read-backs each)")
-        c5["bytes_per_observation"] = dict(algorithmic_survey=200, as_implemented=16 + 8 + 144 * 3,
-                                           note="uv + indices + the 6x3 coupling block W_cp written once and read by the Schur and back-substitution kernels")
+                            hbm_fraction_on_algorithmic_bytes=200.0 * info["n_obs"] * it / dt / 8.0e12,
+                            includes="observation lists built on the device, workspace allocation, slot table, residuals before / after, "
+                                     "10 LM iterations (one 64-byte read-back each)")
+        c5["bytes_per_observation"] = dict(algorithmic_survey=200, as_implemented=112,
+                                           note="fused path, per LM iteration: slot table + detections + points read by both passes, V / V^-1 / g_p written "
+                                                "once and read once, trial points written and copied (728 MB for 6.5 M observations); the 6 x 3 coupling "
+                                                "blocks never leave the chip (the table form of round 4a moved 456 B per observation)")
         c5["all_reduce_doubles_per_iteration_when_sharded"] = (6 * len(r3[2])) ** 2 + 6 * len(r3[2])
         out["config5_sba_extrinsics"] = c5
         del pos64
