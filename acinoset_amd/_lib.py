@@ -120,6 +120,8 @@ SIGNATURES = {
     "acino_project_fisheye": (_I, [_P, _L, _P, _P, _P]),
     "acino_project_pinhole": (_I, [_P, _L, _P, _P, _P]),
     "acino_triangulate_pairs": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "acino_fte_triangulation_init_scratch_bytes": (_Z, [_L]),
+    "acino_fte_triangulation_init": (_I, [_P, _L, _I, _P, _I, _I, _P, _Z, _P, _P]),
     "acino_reproject_residuals": (_I, [_P, _P, _L, _I, _I, _D, _P, _P, _P, _P]),
     "acino_triangulate_reproject": (_I, [_P, _L, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
     "acino_cheetah_fk": (_I, [_P, _L, _P, _P]),

@@ -637,3 +637,164 @@ extern "C" int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angl
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }
+
+// ---- initial guess of the FTE solve from the per-frame triangulation, on the device --------------------------------
+// (acinoset_amd.fte.triangulation_init: root position = mean of the triangulated eyes and nose, yaw = unwrapped heading of
+//  neck_base -> nose, both linearly interpolated over the frames that lack them and held flat at the ends - the same
+//  arithmetic as the numpy / torch forms, one launch instead of ~60 small ones and three host synchronisations.)
+namespace acino {
+constexpr int TI_T = 1024;
+// inclusive scan over the workgroup's 1024 values (one per thread); OP: 0 max, 1 min, 2 sum.  carry joins from the left
+// (OP 0, 2) or from the right (OP 1, reverse order handled by the caller's indexing).
+template <typename T, int OP>
+__device__ __forceinline__ T ti_op(T a, T b) {
+  return OP == 0 ? (a > b ? a : b) : (OP == 1 ? (a < b ? a : b) : a + b);
+}
+template <typename T, int OP>
+__device__ __forceinline__ T ti_block_scan(T v, T ident, T* sh /*[16]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const T o = __shfl_up(v, off, 64);
+    if (lane >= off) v = ti_op<T, OP>(v, o);
+  }
+  __syncthreads();                                       // (sh is reused between calls)
+  if (lane == 63) sh[wave] = v;
+  __syncthreads();
+  T pre = ident;
+  for (int w = 0; w < wave; ++w) pre = ti_op<T, OP>(pre, sh[w]);
+  return ti_op<T, OP>(pre, v);
+}
+
+__global__ void __launch_bounds__(TI_T)
+k_tri_init(const double* __restrict__ tri, int n_frames, int n_markers, double* __restrict__ xa, int n_active, int psi_col,
+           int* __restrict__ P, int* __restrict__ Nx, double* __restrict__ val, double* __restrict__ cum, int* __restrict__ flag) {
+  __shared__ int shi[16];
+  __shared__ double shd[16];
+  __shared__ int s_carry_i;
+  __shared__ double s_carry_d;
+  const int tid = threadIdx.x, N = n_frames;
+  const double TWO_PI = 6.283185307179586476925286766559;
+  // every other active state starts at 0
+  for (long e = tid; e < (long)N * n_active; e += TI_T) xa[e] = 0.0;
+  __syncthreads();
+  for (int ch = 0; ch < 4; ++ch) {
+    // value and validity of the channel per frame: 0..2 head coordinate (mean of the finite ones among markers 0, 1, 2),
+    // 3 heading atan2 of marker 2 - marker 3 (all three coordinates finite)
+    for (int n = tid; n < N; n += TI_T) {
+      const double* t = tri + (size_t)n * n_markers * 3;
+      double v = 0.0;
+      bool ok;
+      if (ch < 3) {
+        double s = 0.0;
+        int cnt = 0;
+        for (int m = 0; m < 3; ++m) {
+          const double x = t[3 * m + ch];
+          if (!(x != x)) {                               // (torch.nanmean: NaN is skipped, inf is not)
+            s += x;
+            ++cnt;
+          }
+        }
+        v = cnt ? s / cnt : 0.0;
+        ok = cnt > 0 && m_finite(v);
+      } else {
+        const double fx = t[6] - t[9], fy = t[7] - t[10], fz = t[8] - t[11];
+        ok = m_finite(fx) && m_finite(fy) && m_finite(fz);
+        v = ok ? atan2(fy, fx) : 0.0;
+      }
+      val[n] = v;
+      P[n] = ok ? n : -1;
+      Nx[n] = ok ? n : 0x7fffffff;
+    }
+    __syncthreads();
+    // P[n] <- last valid frame <= n  (forward max-scan, tile by tile with a carry)
+    if (tid == 0) s_carry_i = -1;
+    __syncthreads();
+    for (int base = 0; base < N; base += TI_T) {
+      const int n = base + tid;
+      int v = n < N ? P[n] : -1;
+      v = ti_block_scan<int, 0>(v, -1, shi);
+      const int c = s_carry_i;
+      v = v > c ? v : c;
+      if (n < N) P[n] = v;
+      __syncthreads();
+      if (tid == TI_T - 1) s_carry_i = v;
+      __syncthreads();
+    }
+    // Nx[n] <- first valid frame >= n  (backward min-scan: the tiles from the right, thread order reversed)
+    if (tid == 0) s_carry_i = 0x7fffffff;
+    __syncthreads();
+    for (int base = 0; base < N; base += TI_T) {
+      const int n = N - 1 - (base + tid);
+      int v = n >= 0 ? Nx[n] : 0x7fffffff;
+      v = ti_block_scan<int, 1>(v, 0x7fffffff, shi);
+      const int c = s_carry_i;
+      v = v < c ? v : c;
+      if (n >= 0) Nx[n] = v;
+      __syncthreads();
+      if (tid == TI_T - 1) s_carry_i = v;
+      __syncthreads();
+    }
+    if (ch == 3) {
+      // np.unwrap over the valid frames: k = round((a_i - a_prev) / 2 pi) per valid frame after the first, a_i -= 2 pi cumsum(k)
+      if (tid == 0) s_carry_d = 0.0;
+      __syncthreads();
+      for (int base = 0; base < N; base += TI_T) {
+        const int n = base + tid;
+        double k = 0.0;
+        if (n < N && n > 0 && P[n] == n) {
+          const int pv = P[n - 1];
+          if (pv >= 0) k = rint((val[n] - val[pv]) / TWO_PI);
+        }
+        k = ti_block_scan<double, 2>(k, 0.0, shd);
+        k += s_carry_d;
+        if (n < N) cum[n] = k;
+        __syncthreads();
+        if (tid == TI_T - 1) s_carry_d = k;
+        __syncthreads();
+      }
+      for (int n = tid; n < N; n += TI_T)
+        if (P[n] == n) val[n] -= TWO_PI * cum[n];
+      __syncthreads();
+    }
+    // np.interp(arange(N), valid frames, values): b = first valid >= n (the last valid one behind the end), a = the valid frame
+    // before b (b itself when there is none), weight clamped to [0, 1]
+    const int last = P[N - 1];
+    if (last < 0) {
+      if (ch < 3 && tid == 0) *flag = 1;                 // no triangulated head marker in the whole sequence
+    } else {
+      const int col = ch < 3 ? ch : psi_col;
+      for (int n = tid; n < N; n += TI_T) {
+        int b = Nx[n];
+        if (b == 0x7fffffff) b = last;
+        int a = b > 0 ? P[b - 1] : -1;
+        if (a < 0) a = b;
+        double w = 0.0;
+        if (b > a) w = fmin(fmax((double)(n - a) / fmax((double)(b - a), 1.0), 0.0), 1.0);
+        const double va = val[a], vb = val[b];
+        xa[(size_t)n * n_active + col] = va + w * (vb - va);
+      }
+    }
+    __syncthreads();
+  }
+}
+}  // namespace acino
+
+extern "C" {
+size_t acino_fte_triangulation_init_scratch_bytes(int64_t n_frames) { return n_frames > 0 ? (size_t)n_frames * 24 + 256 : 0; }
+int acino_fte_triangulation_init(const double* d_tri, int64_t n_frames, int n_markers, double* d_xa, int n_active,
+                                 int psi_column, void* d_scratch, size_t scratch_bytes, int32_t* d_flag, void* stream) {
+  ACINO_REQUIRE(n_frames >= 1 && n_frames < (1ll << 30), "n_frames");
+  ACINO_REQUIRE(n_markers >= 4 && n_active >= 4 && psi_column >= 3 && psi_column < n_active, "markers / states");
+  ACINO_REQUIRE(d_tri && d_xa && d_scratch && d_flag, "null buffer");
+  ACINO_REQUIRE(((uintptr_t)d_scratch & 7) == 0 && scratch_bytes >= acino_fte_triangulation_init_scratch_bytes(n_frames), "scratch");
+  const size_t N = (size_t)n_frames;
+  double* val = (double*)d_scratch;
+  double* cum = val + N;
+  int* P = (int*)(cum + N);
+  int* Nx = P + N;
+  hipLaunchKernelGGL(acino::k_tri_init, dim3(1), dim3(acino::TI_T), 0, (hipStream_t)stream, d_tri, (int)n_frames, n_markers, d_xa,
+                     n_active, psi_column, P, Nx, val, cum, d_flag);
+  ACINO_LAUNCH_CHECK();
+  return ACINO_OK;
+}
+}  // extern "C"

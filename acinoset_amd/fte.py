@@ -391,43 +391,26 @@ def _context_for(det, k_arr, d_arr, r_arr, t_arr, Ts, reuse, kw):
     return ctx, True
 
 
-def _interp_rows(valid, values):
-    """Linear interpolation over the frame index of ``values[N]`` where ``valid[N]`` (held flat at the ends), on the device:
-    ``np.interp(arange(N), idx[valid], values[valid])`` without leaving the GPU."""
-    n = values.shape[0]
-    idx = torch.arange(n, device=values.device)
-    vi = idx[valid]
-    vv = values[valid]
-    hi = torch.searchsorted(vi, idx).clamp(max=vi.numel() - 1)
-    lo = (hi - 1).clamp(min=0)
-    x0, x1 = vi[lo].to(values.dtype), vi[hi].to(values.dtype)
-    w = torch.where(x1 > x0, (idx.to(values.dtype) - x0) / (x1 - x0).clamp(min=1.0), torch.zeros_like(x0))
-    w = w.clamp(0.0, 1.0)
-    return vv[lo] + w * (vv[hi] - vv[lo])
-
-
-def triangulation_init_active(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh):
+def triangulation_init_active(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, raise_now=True):
     """``triangulation_init`` for a detections tensor that lives on the GPU: the same initial guess, formed on the device and
-    returned as the 25 active states [N, 25] (no host round trip of the 4.8 MB triangulation of a 10 000-frame sequence: that
-    copy and the numpy interpolation were 3 ms of a 15 ms end-to-end solve)."""
+    returned as the 25 active states [N, 25].  Two launches (pairwise triangulation, ``acino_fte_triangulation_init``: head
+    mean, unwrapped heading, interpolation over the frames that lack them) and no host round trip - the numpy form copied
+    the 4.8 MB triangulation of a 10 000-frame sequence to the host (3 ms of a 15 ms solve), a torch form of the same
+    arithmetic took ~60 small launches and three synchronisations (2 ms).  ``raise_now=False`` returns ``(xa, flag)`` with the
+    "no head marker in the whole sequence" flag left on the device for the caller to test later."""
     tri = calib.triangulate_pairs_dense(det, dlc_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
-    n = tri.shape[0]
-    head = torch.nanmean(tri[:, 0:3], dim=1)                 # eyes + nose
-    fwd = tri[:, 2] - tri[:, 3]                              # neck_base -> nose
-    xa = torch.zeros((n, N_ACTIVE), dtype=torch.float64, device=tri.device)
-    okh = torch.isfinite(head)
-    okf = torch.isfinite(fwd).all(1)
-    if not bool((okh.sum(0) > 0).all()):
+    n = int(tri.shape[0])
+    xa = torch.empty((n, N_ACTIVE), dtype=torch.float64, device=tri.device)
+    nbytes = int(lib().acino_fte_triangulation_init_scratch_bytes(n))
+    scratch = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=tri.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=tri.device)
+    psi_col = int(np.nonzero(ACTIVE == PSI + 0)[0][0])
+    check(lib().acino_fte_triangulation_init(ptr(tri), n, int(tri.shape[1]), ptr(xa), N_ACTIVE, psi_col, ptr(scratch),
+                                                scratch.numel() * 8, ptr(flag), stream_ptr()))
+    if not raise_now:
+        return xa, flag
+    if int(flag.item()):
         raise ValueError("no triangulated head marker in the whole sequence")
-    for j in range(3):
-        xa[:, j] = _interp_rows(okh[:, j], head[:, j])
-    if bool(okf.any()):
-        ang = torch.atan2(fwd[okf, 1], fwd[okf, 0])
-        d = torch.diff(ang)
-        ang = torch.cat([ang[:1], ang[1:] - 2 * np.pi * torch.cumsum(torch.round(d / (2 * np.pi)), 0)])     # np.unwrap
-        full = torch.zeros(n, dtype=torch.float64, device=tri.device)
-        full[okf] = ang
-        xa[:, int(np.nonzero(ACTIVE == PSI + 0)[0][0])] = _interp_rows(okf, full)
     return xa
 
 
@@ -446,12 +429,12 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     det = torch.cat([meas_t.to(torch.float64), lik_t.to(torch.float64).unsqueeze(-1).to(meas_t.device)], dim=-1)
     _lib.require_gpu()
     det = det.to(torch.device("cuda", torch.cuda.current_device()))
-    xa0 = None
+    xa0 = init_flag = None
     if x0 is None:
         if init == "nose_line":
             x0 = nose_line_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, start_frame=start_frame)
         elif init == "triangulation":
-            xa0 = triangulation_init_active(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh)     # (stays on the device)
+            xa0, init_flag = triangulation_init_active(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh, raise_now=False)   # (stays on the device)
         else:
             raise ValueError("init must be 'nose_line' or 'triangulation'")
     if xa0 is None:
@@ -471,6 +454,8 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
     finally:
         if not cached:
             ctx.close()
+    if init_flag is not None and int(init_flag.item()):        # (tested after the solve: no synchronisation in front of it)
+        raise ValueError("no triangulated head marker in the whole sequence")
     if info["status"] == 5:
         raise RuntimeError("FTE: block factorisation hit a non-positive pivot")
     conv = (lambda a: a.cpu().numpy()) if return_numpy else (lambda a: a)

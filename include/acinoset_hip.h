@@ -95,6 +95,15 @@ int acino_project_pinhole(const double* d_obj, int64_t m, const double* d_cam32,
 int acino_triangulate_pairs(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                             const double* d_cams24, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,
                             void* stream);
+/* Initial iterate of the FTE solve from the dense triangulation d_tri[N][n_markers][3] (NaN = no pair), formed on the device
+ * (acinoset_amd.fte.triangulation_init; the reference's own initialisation is the nose line, all_optimizations.py:268-277,
+ * which acinoset_amd.fte.nose_line_init restates): d_xa[N][n_active] <- 0 except columns 0..2 = mean of the finite ones among
+ * markers 0, 1, 2 (eyes, nose) and column psi_column = np.unwrap(atan2) of marker 2 - marker 3 (neck_base -> nose), each
+ * np.interp'ed over the frames that lack it (held flat at the ends).  *d_flag (preset to 0 by the caller) <- 1 when no frame
+ * has a head marker.  One launch; d_scratch: acino_fte_triangulation_init_scratch_bytes(N), 8-byte aligned. */
+size_t acino_fte_triangulation_init_scratch_bytes(int64_t n_frames);
+int acino_fte_triangulation_init(const double* d_tri, int64_t n_frames, int n_markers, double* d_xa, int n_active,
+                                 int psi_column, void* d_scratch, size_t scratch_bytes, int32_t* d_flag, void* stream);
 /* The same index path with the injected pinhole pair (calib.py:52-61): d_cams32 = C pinhole records. */
 int acino_triangulate_pairs_pinhole(const double* d_det, int64_t n_frames, int n_cams, int n_markers, double thresh,
                                     const double* d_cams32, double* d_tri, uint8_t* d_npairs, uint8_t* d_pairmask,

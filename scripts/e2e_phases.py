@@ -8,9 +8,9 @@ d = torch.as_tensor(seq["det"], device="cuda")
 def T():
     torch.cuda.synchronize(); return time.perf_counter()
 for reuse in (False, True, True):
-    t0 = T(); x0 = fte.triangulation_init(d, *rig, 0.5); t1 = T()
+    t0 = T(); xa = fte.triangulation_init_active(d, *rig, 0.5); t1 = T()
     ctx, cached = fte._context_for(d, *rig, seq["Ts"], reuse, dict(dlc_thresh=0.5)); t2 = T()
-    ctx.set_x(x0[:, fte.ACTIVE]); t3 = T()
+    ctx.set_x(xa); t3 = T()
     info = ctx.solve(200); t4 = T()
     out = ctx.result(); t5 = T()
     if not cached: ctx.close()

@@ -1088,9 +1088,26 @@ def test_device_side_initial_guess_and_context_reuse(mods):
     det = torch.as_tensor(seq["det"], device="cuda").clone()
     det[100:140, :, 0:4, 2] = 0.0                      # 40 frames without any head marker: interpolated
     det[:7, :, 0:4, 2] = 0.0                           # ... and a gap at the start: held flat
+    det[-5:, :, 3, 2] = 0.0                            # ... no heading in the last frames (neck_base missing): held flat
+    det[300:303, :, 0:2, 2] = 0.0                      # ... head from the nose alone
     want = fte.triangulation_init(det, *rig, 0.5)[:, fte.ACTIVE]
     got = fte.triangulation_init_active(det, *rig, 0.5).cpu().numpy()
     assert np.abs(got - want).max() < 1e-11
+    assert np.ptp(want[:, 20]) > 4 * np.pi             # (the heading of the loop is unwrapped over several turns)
+    for n in (1, 5, 1023, 1024, 1025, 2500):           # the scans' tile boundaries (1 024 frames per tile)
+        sq = synth.make_sequence(n, "loop", seed=3)
+        dn = torch.as_tensor(sq["det"], device="cuda").clone()
+        if n > 5:
+            dn[n // 2:n // 2 + 3, :, 0:4, 2] = 0.0
+        w_n = fte.triangulation_init(dn, *rig, 0.5)[:, fte.ACTIVE]
+        g_n = fte.triangulation_init_active(dn, *rig, 0.5).cpu().numpy()
+        assert np.abs(g_n - w_n).max() < 1e-11, n
+    blind = det.clone()
+    blind[:, :, 0:3, 2] = 0.0
+    with pytest.raises(ValueError, match="no triangulated head marker"):
+        fte.triangulation_init_active(blind, *rig, 0.5)
+    with pytest.raises(ValueError, match="no triangulated head marker"):
+        fte.fte_solve(blind[:60, ..., :2], blind[:60, ..., 2], *rig, seq["Ts"], init="triangulation", max_iter=2)
     seq2 = synth.make_sequence(600, "loop", seed=7)
     outs = []
     for reuse in (False, True, True):
