@@ -792,15 +792,16 @@ __global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
                 int n_chunks, int node0, int pin_right, TrialOut trial) {
   if (status && *status != 0) return;
-  __shared__ double Gs[BS * LD], u[BS], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
+  __shared__ double Gs[BS * LD], u[BK_P * BK_W], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
   const int tid = threadIdx.x;
+  if (tid >= BS && tid < BK_P * BK_W) u[tid] = 0.0;      // (the padding behind u stays zero: see product)
   const int c = blockIdx.x, first = node0 + c * m;
   const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
   const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;
   const int n_int = hasR ? len - 1 : len;
   const int sL = c - 1 + node0, sR = c + node0;
   const size_t MB = (size_t)BS * BS;
-  const int row = tid % BS, part = tid / BS, c0 = BK_W * part, nc = min(BK_W, BS - c0);
+  const int row = tid % BS, part = tid / BS, c0 = BK_W * part;
   const bool uni_tables = coupling_tables_uniform(*cst, first, first + n_int - 1);   // (one fill serves every node of the run)
   // ---- the trial iterate of the run's frames (fte_api.hip k_trial, same arithmetic): thread r < 75 owns row r of every node
   const int t_cur = ch.st->cur, t_nf = cst->n_frames, t_own_lo = cst->own_lo, t_own_hi = cst->own_hi;
@@ -868,10 +869,11 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   };
   auto product = [&]() {                                // ysc <- partial sums of Gs u (BK_P per row)
     if (tid < BK_P * BS) {
+      // (all BK_W loads unconditional - u is zero behind its 80 entries, the matrix row is clamped -: the last part's four
+      //  missing columns as `if (kk < nc)` compiled to four masked blocks with an LDS round trip each)
       double s0 = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < BK_W; ++kk)
-        if (kk < nc) s0 += Gs[(c0 + kk) * LD + row] * u[c0 + kk];
+      for (int kk = 0; kk < BK_W; ++kk) s0 += Gs[min(c0 + kk, BS - 1) * LD + row] * u[c0 + kk];
       ysc[tid] = s0;
     }
   };
