@@ -30,6 +30,11 @@ rm -rf $OUT/rocprof_all
 timeout 600 python scripts/extras_report.py $OUT/summary > $OUT/extras.log 2>&1
 timeout 900 bash scripts/pmc_waits.sh > /dev/null 2>&1; cp $R/gpurun_out/waits/waits.txt $OUT/summary/pmc_wait_states.txt 2>/dev/null
 timeout 600 python scripts/shard_model.py > $OUT/summary/shard_model.txt 2>&1
+# config 5's SBA half at full size: kernel stats and wait states of the fused kernels
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_sba -o sba -- python $R/scripts/sba_config5.py f64 10 > /dev/null 2> $OUT/rocprof_sba.err)
+find $OUT/rocprof_sba -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/sba_config5_kernel_stats.csv; rm -rf $OUT/rocprof_sba
+timeout 600 bash scripts/pmc_waits_sba.sh > /dev/null 2>&1; cp $R/gpurun_out/waits_sba/waits.txt $OUT/summary/pmc_wait_states_sba.txt 2>/dev/null; rm -rf $R/gpurun_out/waits_sba/p1 $R/gpurun_out/waits_sba/p2
+timeout 300 python scripts/e2e_phases.py > $OUT/summary/e2e_phases.txt 2>&1
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
 # keep the merge-back small: the raw counter dumps are not needed once summarised

@@ -562,7 +562,8 @@ def test_fused_path_equals_the_table_path(gsba):
     """The fused kernels (one lane per (point, camera) slot, Schur complement on the matrix cores, no coupling table) against
     the table path (one thread per point, dense W table, LDS atomics; ACINO_SBA_UNFUSED=1) on the same problem: the same
     LM trajectory in fp64 - equal iteration / acceptance counts, costs to 1e-10, poses and points to 1e-8; with bf16 rows
-    (fp32 sums in another order: accept / reject decisions at the noise floor differ) the same end cost to 1e-2 (12 iterations, not converged)."""
+    (fp32 sums in another order: accept / reject decisions at the noise floor differ, the free rig drifts along its gauge)
+    the same end cost to 1e-2 (12 iterations, not converged)."""
     import json
     import subprocess
     import sys
@@ -582,6 +583,6 @@ def test_fused_path_equals_the_table_path(gsba):
         tol = 1e-10 if prec == "f64" else 1e-2
         assert abs(a["cost0"] - b["cost0"]) <= 1e-12 * abs(b["cost0"])
         assert abs(a["cost"] - b["cost"]) <= tol * abs(b["cost"]), (prec, a["cost"], b["cost"])
-        ptol = 1e-8 if prec == "f64" else 1e-2
-        assert np.abs(np.array(a["r"]) - np.array(b["r"])).max() < ptol and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < ptol
-        assert np.abs(np.array(a["p"]) - np.array(b["p"])).max() < ptol
+        if prec == "f64":                                  # (bf16 rows: the iterates drift along the 7 gauge directions of a free rig)
+            assert np.abs(np.array(a["r"]) - np.array(b["r"])).max() < 1e-8 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-8
+            assert np.abs(np.array(a["p"]) - np.array(b["p"])).max() < 1e-8
