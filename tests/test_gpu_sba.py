@@ -241,6 +241,65 @@ def test_first_lm_step_equals_a_dense_numpy_step(gsba, model):
     assert np.abs(pts - (X0 + dp.reshape(P, 3))).max() < 1e-6
 
 
+@pytest.mark.parametrize("n_cams", [2, 4, 5, 6, 7])
+def test_first_lm_step_with_ragged_visibility_for_every_camera_count(gsba, n_cams):
+    """The fused kernels deal 64 / C points to a wave and feed the matrix cores in chunks of five points: every camera count
+    of the fused path (two tile rows up to five cameras, three from six on; a short last chunk for 4, 5 and 7 cameras), a
+    point count that fills neither the last batch nor the last wave, and points that some cameras do not see - one LM step
+    against the dense numpy step built from central differences, as above."""
+    sba, calib = gsba
+    from acinoset_amd import synth
+    rng = np.random.default_rng(100 + n_cams)
+    K6, D6, R6, t6 = synth.make_rig()
+    C, P, fs, lam = n_cams, 37, 1.0, 1e-3
+    sel = np.arange(C) % 6                                  # (a seventh camera: a copy of the first one, moved)
+    K, D, R, t = K6[sel], D6[sel], R6[sel].copy(), t6[sel].reshape(C, 3, 1).copy()
+    if C == 7:
+        R[6] = ocam.rodrigues(np.array([0.02, -0.05, 0.03])) @ R[6]
+        t[6] = t[6] + np.array([[0.3], [-0.2], [0.1]])
+    ofun, proj = ocam.project_points_fisheye, calib.project_points_fisheye
+    X = np.array([2.0, 6.5, 0.7]) + rng.normal(0, 0.6, (P, 3))
+    pi, ci = [], []
+    for p in range(P):
+        cams = np.sort(rng.choice(C, size=rng.integers(2, C + 1), replace=False))
+        pi += [p] * len(cams)
+        ci += list(cams)
+    pi, ci = np.array(pi), np.array(ci)
+    uv = np.stack([ofun(X[p:p + 1], K[c], D[c], R[c], t[c])[0] for p, c in zip(pi, ci)]) + rng.normal(0, 1.0, (len(pi), 2))
+    uv[rng.choice(len(uv), 5, replace=False)] += rng.uniform(-15, 15, (5, 2))
+    X0 = X + rng.normal(0, 0.03, X.shape)
+    R0 = np.array([ocam.rodrigues(rng.normal(0, 0.01, 3)) @ R[c] for c in range(C)])
+    t0 = t + rng.normal(0, 0.01, t.shape)
+
+    def resid(Xp, Rm, tv):
+        return osba.residuals(Xp, Rm, tv, K, D, pi, ci, uv, project_func=ofun)
+
+    def apply(dc, dp):
+        Rn = np.array([ocam.rodrigues(dc[6 * c:6 * c + 3]) @ R0[c] for c in range(C)])
+        return X0 + dp.reshape(P, 3), Rn, t0 + dc.reshape(C, 6)[:, 3:].reshape(C, 3, 1)
+
+    r0 = resid(X0, R0, t0)
+    n = 6 * C + 3 * P
+    J, h = np.zeros((r0.size, n)), 1e-6
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = h
+        J[:, k] = (resid(*apply(e[:6 * C], e[6 * C:])) - resid(*apply(-e[:6 * C], -e[6 * C:]))) / (2 * h)
+    w = 1.0 / (1.0 + (r0 / fs) ** 2)
+    A = J.T @ (w[:, None] * J)
+    delta = -np.linalg.solve(A + lam * np.diag(np.diag(A)), J.T @ (w * r0))
+    Xn, Rn, tn = apply(delta[:6 * C], delta[6 * C:])
+    c0 = 0.5 * np.log1p(r0 ** 2).sum()
+    c1 = 0.5 * np.log1p(resid(Xn, Rn, tn) ** 2).sum()
+    pts, rm, tt, _res = sba.bundle_adjust_points_and_extrinsics(uv, X0, pi, ci, K, D, R0, t0, proj, max_iter=1)
+    info = dict(sba.last_info)
+    assert info["iterations"] == 1 and info["accepted"] == (1 if c1 < c0 else 0)
+    assert abs(info["cost_initial"] - c0) < 1e-9 * c0
+    if c1 < c0:
+        assert abs(info["cost_final"] - c1) < 1e-6 * c1, (info, c0, c1)
+        assert np.abs(pts - Xn).max() < 1e-6 and np.abs(rm - Rn).max() < 1e-6 and np.abs(tt - tn).max() < 1e-6
+
+
 def test_pinhole_model_bundle_adjustment(gsba):
     """The reference's second SBA call site (sba_board_points, app.py:215-218) injects the cv2.projectPoints pinhole
     model (rational + tangential distortion, calibrated with CALIB_RATIONAL_MODEL, calib.py:18)."""
