@@ -645,3 +645,39 @@ def test_fused_path_equals_the_table_path(gsba):
         if prec == "f64":                                  # (bf16 rows: the iterates drift along the 7 gauge directions of a free rig)
             assert np.abs(np.array(a["r"]) - np.array(b["r"])).max() < 1e-8 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-8
             assert np.abs(np.array(a["p"]) - np.array(b["p"])).max() < 1e-8
+
+
+def test_fused_path_edge_cases(gsba):
+    """max_iter = 0 (evaluation only: the cost of the start, its gradient norm, nothing moved), three points (less than one
+    batch of a wave), a point seen by ONE camera (its 3 x 3 block is singular without the damping), a point the lists never
+    mention, duplicates and bad camera indices (refused before anything runs)."""
+    sba, calib = gsba
+    from acinoset_amd import synth
+    rng = np.random.default_rng(23)
+    K, D, R, t = synth.make_rig()
+    t = t.reshape(6, 3, 1)
+    X = np.array([2.0, 6.5, 0.7]) + rng.normal(0, 0.4, (4, 3))
+    pi = np.array([0, 0, 0, 1, 1, 2, 2, 2, 2])            # point 3 has no observation at all; point 1 two; ...
+    ci = np.array([0, 1, 2, 1, 4, 0, 2, 3, 5])
+    uv = np.stack([ocam.project_points_fisheye(X[p:p + 1], K[c], D[c], R[c], t[c])[0] for p, c in zip(pi, ci)]) + rng.normal(0, 0.5, (9, 2))
+    X0 = X + rng.normal(0, 0.02, X.shape)
+    r0 = osba.residuals(X0, R, t, K, D, pi, ci, uv)
+    c0 = 0.5 * np.log1p(r0 ** 2).sum()
+    pts, rm, tt, res = sba.bundle_adjust_points_and_extrinsics(uv, X0, pi, ci, K, D, R, t, max_iter=0)
+    info = dict(sba.last_info)
+    assert info["iterations"] == 0 and abs(info["cost_initial"] - c0) < 1e-9 * c0 and info["cost_final"] == info["cost_initial"]
+    assert info["gnorm_inf"] > 0 and np.array_equal(pts, X0) and np.abs(rm - R).max() < 1e-12
+    assert np.abs(res["before"] - r0).max() < 1e-9
+    # a few iterations: the cost falls, the unobserved point stays where it was
+    pts, rm, tt, res = sba.bundle_adjust_points_and_extrinsics(uv, X0, pi, ci, K, D, R, t, max_iter=15)
+    info = dict(sba.last_info)
+    assert info["cost_final"] < info["cost_initial"] and np.array_equal(pts[3], X0[3]) and np.isfinite(pts).all()
+    # one camera only for a point: points-only solve, the damping carries the rank-2 block
+    pi1, ci1 = np.array([0, 0, 1]), np.array([0, 1, 3])
+    uv1 = np.stack([ocam.project_points_fisheye(X[p:p + 1], K[c], D[c], R[c], t[c])[0] for p, c in zip(pi1, ci1)])
+    pts1, _res = sba.bundle_adjust_points_only(uv1, X0[:2], pi1, ci1, K, D, R, t, max_iter=20)
+    assert np.isfinite(pts1).all() and dict(sba.last_info)["cost_final"] <= dict(sba.last_info)["cost_initial"]
+    with pytest.raises(ValueError, match="observed twice"):
+        sba.bundle_adjust_points_and_extrinsics(np.vstack([uv, uv[:1]]), X0, np.append(pi, 0), np.append(ci, 0), K, D, R, t, max_iter=2)
+    with pytest.raises(ValueError, match="out of range"):
+        sba.bundle_adjust_points_and_extrinsics(uv, X0, pi, np.where(ci == 5, 6, ci), K, D, R, t, max_iter=2)
