@@ -847,6 +847,88 @@ __global__ void __launch_bounds__(256) k_sba_cam_solve(SbaBuf B, double lam) {
   }
 }
 
+// The same solve by ONE wave (n <= 48: up to eight cameras): lane i holds row i of the matrix and entry i of the vectors in
+// REGISTERS; column j of the factor reaches the other lanes through v_readlane with a constant lane index (a scalar
+// broadcast: no LDS, no barrier), the whole factorisation is straight-line code.  (36 columns x 3 workgroup barriers and
+// two single-thread substitutions made the 256-thread form 67 us; a one-wave form with the rows in LDS 58 us - a dependent
+// LDS round trip per term of the trailing update.)
+constexpr int CS_N = 48;
+__device__ __forceinline__ double lane_bcast(double v, int lane_const) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
+  return __hiloint2double(hi, lo);
+}
+__global__ void __launch_bounds__(64) k_sba_cam_solve_wave(SbaBuf B, double lam) {
+  __shared__ double sL[CS_N * (CS_N + 1)];
+  const int n = 6 * B.C, i = threadIdx.x;
+  const bool on = i < n;
+  const int ic = on ? i : 0;
+  // (every load unconditional on a clamped address, the selects afterwards: 48 conditional loads were 48 serialised round trips)
+  double a[CS_N], ub[6];
+  {
+    const int cam = ic / 6, p = ic % 6;
+#pragma unroll
+    for (int q0 = 0; q0 < 6; ++q0) {
+      const int lo = p < q0 ? p : q0, hi = p < q0 ? q0 : p;
+      ub[q0] = B.U[21 * cam + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+    }
+#pragma unroll
+    for (int c = 0; c < CS_N; ++c) a[c] = B.S[ic * n + min(c, n - 1)];
+#pragma unroll
+    for (int c = 0; c < CS_N; ++c) {
+      double v = a[c];
+      const double u = ub[c % 6];
+      if (c / 6 == cam) v += (c % 6 == p) ? u + lam * u + 1e-300 : u;
+      a[c] = (on && c < n) ? v : (c == i ? 1.0 : 0.0);   // (identity on the padding: lanes >= n never touch the live part)
+    }
+  }
+  double bi = on ? -(B.gc[ic] + B.rhs[ic]) : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < CS_N; ++j) {
+    if (j < n) {
+      double d = lane_bcast(a[j], j);
+      if (!(d > 0.0)) {
+        bad = true;
+        d = 1.0;
+      }
+      const double dj = sqrt(d), idj = 1.0 / dj;
+      const double lij = i == j ? dj : (i > j ? a[j] * idj : 0.0);
+      a[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < CS_N; ++k) a[k] -= lij * lane_bcast(lij, k);     // (used for k <= i only; harmless elsewhere)
+    }
+  }
+  // L y = b by columns (row i's L[i][j] is in register a[j]); then the factor to LDS and L^T x = y by rows of L
+#pragma unroll
+  for (int j = 0; j < CS_N; ++j)
+    if (j < n) {
+      const double yj = lane_bcast(bi, j) / lane_bcast(a[j], j);
+      bi = i == j ? yj : (i > j ? bi - a[j] * yj : bi);
+    }
+#pragma unroll
+  for (int c = 0; c < CS_N; ++c)
+    if (i < CS_N) sL[i * (CS_N + 1) + c] = a[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = CS_N - 1; j >= 0; --j)
+    if (j < n) {
+      const double xj = lane_bcast(bi, j) / lane_bcast(a[j], j);
+      const double lji = sL[j * (CS_N + 1) + (i < CS_N ? i : 0)];
+      bi = i == j ? xj : (i < j ? bi - lji * xj : bi);
+    }
+  double pred = 0.0;
+  if (on) {
+    B.dc[i] = bi;
+    const int cam = i / 6, p = i % 6, q = p * 6 - (p * (p - 1)) / 2;
+    pred = 0.5 * bi * (lam * B.U[21 * cam + q] * bi - B.gc[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) pred += __shfl_down(pred, off, 64);
+  if (i == 0) B.scal[4] = pred;
+  if (bad && i == 0) B.scal[3] = 1.0;                    // (d is wave-uniform: every lane sees the same flag)
+}
+
 // dp = -Vinv (gp + sum_c W_pc^T dc); trial points; predicted reduction
 __global__ void __launch_bounds__(256)
 k_sba_backsub(SbaBuf B, double lam, const double* __restrict__ pts, double* __restrict__ pts_t) {
@@ -1122,7 +1204,8 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     for (int it = 0; it < prm->max_iter; ++it) {
       if ((rc = linearise(lam, it == 0))) return rc;
       if (B.opt_cams) {
-        hipLaunchKernelGGL(k_sba_cam_solve, dim3(1), dim3(256), lds_c, s, B, lam);
+        if (n <= (size_t)CS_N) hipLaunchKernelGGL(k_sba_cam_solve_wave, dim3(1), dim3(64), 0, s, B, lam);
+        else hipLaunchKernelGGL(k_sba_cam_solve, dim3(1), dim3(256), lds_c, s, B, lam);
         ACINO_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(k_sba_apply_cams, dim3(1), dim3(64), 0, s, B, d_Rt, Rt_t);
