@@ -111,6 +111,7 @@ struct SbaBuf {
   double* Vinv;          // [P][6]
   double* Wpc;           // [P][C][18]  (6x3 row-major per (point, camera) slot; zero where the camera does not see the point)
                          //             unfused path only (more than 7 cameras, ACINO_SBA_UNFUSED); null otherwise
+  double* part3;         // [SBA_SCHUR_WG][4] per-workgroup partial sums of the fused kernels: cost | predicted reduction | trial cost
   int* slot;             // [P][C] observation id of (point, camera), -1 where the camera does not see the point (fused path)
   double* Spart;         // [SBA_SCHUR_WG + 32][n n + n + 27 C] per-workgroup partial sums [S | rhs | U | g_c] of k_sba_fused
   double* U;             // [C][21]
@@ -647,7 +648,7 @@ k_sba_fused(SbaBuf B, const double* __restrict__ Rt, const double* __restrict__ 
     atomicMax(reinterpret_cast<unsigned long long*>(&B.scal[2]), (unsigned long long)__double_as_longlong(gmax));   // gmax >= 0: order-preserving
   }
   __syncthreads();                                       // (also: the slabs are free)
-  if (COST && tid == 0) atomicAdd(&B.scal[0], (sred[0] + sred[1]) + (sred[2] + sred[3]));
+  if (tid == 0) B.part3[4 * blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // (summed in a fixed order by k_sba_sum_parts)
   if (!B.opt_cams) return;
   // tiles: wave -> LDS -> the workgroup's record.  C layout: register q of lane (li, lk) = entry [row lk + 4 q][column li]
   double* sT = reinterpret_cast<double*>(fu_smem);       // [4][6][256]
@@ -782,8 +783,34 @@ k_sba_backsub_fused(SbaBuf B, double lam, const double* __restrict__ Rt, const d
   }
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&B.scal[1], (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]));
-    atomicAdd(&B.scal[6], (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]));
+    B.part3[4 * blockIdx.x + 1] = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
+    B.part3[4 * blockIdx.x + 2] = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
+  }
+}
+
+// scal[dst] <- sum over the workgroups of part3[.][src], in a fixed order (same launch geometry -> same bits): the cost and
+// the predicted reduction decide accept / reject, so a solve repeats bit for bit only if they do.  (up to two sums per launch)
+__global__ void __launch_bounds__(256) k_sba_sum_parts(SbaBuf B, int n_wg, int src0, int dst0, int src1, int dst1) {
+  __shared__ double sh[2][256];
+  const int tid = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int w = tid; w < n_wg; w += 256) {
+    a0 += B.part3[4 * w + src0];
+    if (src1 >= 0) a1 += B.part3[4 * w + src1];
+  }
+  sh[0][tid] = a0;
+  sh[1][tid] = a1;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      sh[0][tid] += sh[0][tid + off];
+      sh[1][tid] += sh[1][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    B.scal[dst0] = sh[0][0];
+    if (src1 >= 0) B.scal[dst1] = sh[1][0];
   }
 }
 
@@ -1024,6 +1051,7 @@ size_t acino_sba_workspace_bytes(int n_cams, int64_t n_points, int64_t n_obs) {
   b += a256(P * 6 * 8) * 2 + a256(P * 3 * 8) * 3;                                      // V, Vinv, gp, dp, pts_t
   b += sba_fused(n_cams) ? a256(P * n_cams * 4) : a256(P * n_cams * 18 * 8);           // slot [P][C]  |  Wpc [P][C][18]
   b += a256((size_t)(SBA_SCHUR_WG + 32) * (n * n + n + 27 * (size_t)n_cams) * 8);      // partial sums (+ 32 intermediate records)
+  b += a256((size_t)SBA_SCHUR_WG * 4 * 8);                                               // cost / prediction / trial-cost partials
   b += a256(n_cams * 21 * 8) + a256(n * 8) * 3 + a256(n * n * 8) + a256(n_cams * 12 * 8) + a256(64);
   return b + 1024;
 }
@@ -1084,6 +1112,7 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
   if (fused) B.slot = (int*)take(P * C * 4);
   else B.Wpc = (double*)take(P * C * 18 * 8);
   B.Spart = (double*)take((size_t)(SBA_SCHUR_WG + 32) * (n * n + n + 27 * (size_t)C) * 8);
+  B.part3 = (double*)take((size_t)SBA_SCHUR_WG * 4 * 8);
   // (the dense W table: slots of cameras that do not see a point are never written - zero them once)
   if (!fused && B.opt_cams) ACINO_HIP_CHECK(hipMemsetAsync(B.Wpc, 0, P * C * 18 * 8, s));
   B.U = (double*)take((C * 21 + n) * 8);      // [U | gc] contiguous: one reduction
@@ -1171,6 +1200,10 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
       }
 #undef ACINO_SBA_FUSED
       ACINO_LAUNCH_CHECK();
+      if (with_cost) {
+        hipLaunchKernelGGL(k_sba_sum_parts, dim3(1), dim3(256), 0, s, B, n_wg, 0, 0, -1, 0);
+        ACINO_LAUNCH_CHECK();
+      }
       if (B.opt_cams) {
         hipLaunchKernelGGL(k_sba_schur_reduce, dim3(rblk, 32), dim3(256), 0, s, B, n_wg, 0, tail);
         ACINO_LAUNCH_CHECK();
@@ -1220,6 +1253,8 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
         else ACINO_SBA_BACK(ACINO_PREC_BF16_ROWS, 1);
       }
 #undef ACINO_SBA_BACK
+      ACINO_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_sba_sum_parts, dim3(1), dim3(256), 0, s, B, n_wg, 1, 1, 2, 6);
       ACINO_LAUNCH_CHECK();
       if (int e = greduce(B.scal + 1, 1, 0)) return e;
       if (int e = greduce(B.scal + 6, 1, 0)) return e;
