@@ -130,7 +130,8 @@ class FTEContext:
     # "truncation" otherwise, on which solve() continues with one more level).  bcr_levels = 0 asks for the complete
     # reduction, chunk_nodes = -1 for block cyclic reduction over the whole chain (the round-1/2 solver).
     TRUNC_DISTANCE = 160
-    REFINE_SWEEPS = 3
+    REFINE_SWEEPS = 3     # (2 sweeps: -7 us per iteration and a measured bound <= 1.2e-14 on every probe sequence - scripts/refine_probe.py -,
+                          #  i.e. above rounding: solves that must walk the exact path decision for decision keep the third, <= 1.5e-18)
     TRUNC_TOL = 1e-12
 
     @classmethod
