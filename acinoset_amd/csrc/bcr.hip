@@ -555,21 +555,37 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
   if (role == 0) {
     if (im < 0 && ip < 0 && !AL) return;
     double* Dj = ch.D + j * MB;
-    d4 dt[4];
+    // (the run's contribution: loaded UNCONDITIONALLY beside the tile - from D_j itself when there is none - and masked
+    //  afterwards; `if (AL && r < 75 && c < 75) dt += AL[..]` compiled to a masked load with s_waitcnt vmcnt(0) per element:
+    //  16 serialised round trips in front of the products the tiles were "requested first" for)
+    const double* Aj = AL ? AL + j * MB : Dj;
+    d4 dt[4], da[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {    // this wave's output tiles of D_j, requested first, consumed last
-      const int t = sub + S * (wave + 4 * q);
-      if (t < 15) {
+      const int t = min(sub + S * (wave + 4 * q), 14);
+      const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r_ = ib * 16 + lk + 4 * rr, c_ = jb * 16 + li;
+        dt[q][rr] = Dj[r_ * BS + c_];
+        da[q][rr] = Aj[r_ * BS + c_];
+      }
+    }
+    auto fold_al = [&]() {                               // (at the point of use: the tiles are "requested first, consumed last")
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = min(sub + S * (wave + 4 * q), 14);
         const int ib = tri_i(t), jb = tri_j(t);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int r_ = ib * 16 + lk + 4 * rr, c_ = jb * 16 + li;
-          dt[q][rr] = Dj[r_ * BS + c_];
-          if (AL && r_ < 3 * NP && c_ < 3 * NP) dt[q][rr] += AL[j * MB + (size_t)r_ * BS + c_];
+          asm volatile("" : "+v"(da[q][rr]));            // (the load stays a load: no sinking into the select)
+          dt[q][rr] += (AL && r_ < 3 * NP && c_ < 3 * NP) ? da[q][rr] : 0.0;
         }
       }
-    }
+    };
     if (im < 0 && ip < 0) {          // (no eliminated neighbour: only the run's contribution is added)
+      fold_al();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int t = sub + S * (wave + 4 * q);
@@ -585,6 +601,7 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
     if (both) load_mat2(Wb, ch.Wr + im * MB, Wb2, ch.Wl + ip * MB, tid);
     else load_mat(Wb, im >= 0 ? ch.Wr + im * MB : ch.Wl + ip * MB, tid);
     __syncthreads();
+    fold_al();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = sub + S * (wave + 4 * q);

@@ -330,12 +330,18 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
 template <int NQ>
 __device__ __forceinline__ void syrk_load_n(d4 (&acc)[NQ], const double* __restrict__ Ag, bool load, const int (&ib)[NQ],
                                             const int (&jb)[NQ], int li, int lk) {
-  // (loads unconditional, THEN the select: a conditional load compiles to a branch per element with a full wait in front)
+  // (loads unconditional; the select - syrk_mask_n - where the values are first needed, behind the W strip: a conditional
+  //  load compiles to a branch per element with a full wait in front, and a select right behind the loads made the wave
+  //  wait for them - three serialised round trips - before its W strip instead of after it)
+  (void)load;
   const double* base = Ag + lk * BS + li;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) acc[q][rr] = base[(ib[q] * 16 + 4 * rr) * BS + jb[q] * 16];
+}
+template <int NQ>
+__device__ __forceinline__ void syrk_mask_n(d4 (&acc)[NQ], bool load) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -663,7 +669,10 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
       SW_STAMP(16 + 4 * sw);
       sub_barrier(sync + 1, t5, n_spike, ln);          // every strip of W is in Y
       SW_STAMP(17 + 4 * sw);
-      if (hasL) syrk_run_n<3>(accL, Y, Ag, sib, sjb, li, lk);
+      if (hasL) {
+        syrk_mask_n<3>(accL, k > 0);
+        syrk_run_n<3>(accL, Y, Ag, sib, sjb, li, lk);
+      }
       SW_STAMP(18 + 4 * sw);
       d4 town[NT];
       strip_product<false>(Xc, Y, sw, town, li, lk);   // T strip = U W strip (reads its own strip of W only)
