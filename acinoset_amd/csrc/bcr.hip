@@ -1557,6 +1557,27 @@ int bcr_set_func_attributes() {
   return ACINO_OK;
 }
 
+// k_sep_tail's isolated workgroups spin-wait on each other's flags, the levels above them on lower block indices: the launch
+// is only safe when ALL of its workgroups are resident at once.  blocks = workgroups the schedule would launch (0: the
+// kernel does not apply), capacity = what the current device holds of them (occupancy query x compute units - a CU-masked
+// or partitioned device, CPX mode, answers with what it really has).
+int bcr_sep_tail_fit(const BcrSchedule& sch, int* blocks, int* capacity) {
+  *blocks = 0;
+  *capacity = 0;
+  const int top = (int)sch.levels.size() - 1;
+  if (!(sch.refine > 0 && top >= 0 && sch.levels[top].isolated && top <= 12 && sch.levels[top].n_elim <= 128)) return ACINO_OK;
+  int n = 0;
+  for (int k = top; k >= 0; --k) n += sch.levels[k].n_elim;
+  *blocks = n;
+  int dev = 0, cus = 0, per_cu = 0;
+  ACINO_HIP_CHECK(hipGetDevice(&dev));
+  ACINO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  ACINO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_sep_tail), ST_T,
+                                                               kBacksubTailLds));
+  *capacity = cus * per_cu;
+  return ACINO_OK;
+}
+
 // Debug (ACINO_DEBUG_SYNC=1): after every launch of the reduction, synchronise and report the first kernel after which
 // the numeric-error flag is set or the level's outputs hold a NaN.
 static bool dbg_check(const char* what, int level, const BcrChain& ch, const int* ent, int n_ent, int stride, int* d_err,

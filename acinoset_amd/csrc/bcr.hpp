@@ -69,6 +69,9 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof = nullptr, int* d_numeric_err = nullptr);
 int bcr_set_func_attributes();
+// the single-launch back-substitution of an incomplete reduction with refinement (k_sep_tail) needs every one of its
+// workgroups resident: blocks it would launch (0 = not applicable) and the device's capacity for them
+int bcr_sep_tail_fit(const BcrSchedule& sch, int* blocks, int* capacity);
 // true when level 0 of the schedule runs the narrow-level kernels, which can add the chunk sweep's left-run contributions
 // (BcrChain::AL0) themselves - no k_sep_combine launch
 bool bcr_level0_adds_al(const BcrSchedule& sch);

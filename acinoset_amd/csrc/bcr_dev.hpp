@@ -160,6 +160,7 @@ static __device__ void fill_coupling_coef(double* coefL, double* coefR, const Ft
   const int64_t f_i = K.n_offset + (int64_t)loc_i;
   for (int e = tid; e < 2 * 9 * NP; e += NTH) {
     const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
+    if (side == 0 && !coefL) continue;                         // (a caller that only wants the right tables)
     double v = 0.0;
     if (ii <= jj) {
       const int k = 3 + ii - jj;

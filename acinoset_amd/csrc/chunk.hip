@@ -231,8 +231,16 @@ __device__ __forceinline__ int gram8_tile(int wave, int q) {
 // chol80 by THREE waves: role 0 = pivot chains + look-ahead (never waits for a helper inside a step), roles 1, 2 = the
 // other panel tiles (2 + 1) and the trailing products (alternate entries of the step's list).
 // sync[0]: barrier of the three, sync[2]: barrier of the two helpers, sync[3]: one-way flag "role 0's panel tile posted".
+// busy (helpers of the two-team sweep only, else null): the word a helper keeps at 1 while it has work - lowered in front of every
+// wait, raised behind it - for the strip wave that shares its SIMD to yield to
+__device__ __forceinline__ void helper_wait_begin(int* busy, int lane) {
+  if (busy && lane == 0) __hip_atomic_store(busy, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void helper_wait_end(int* busy, int lane) {
+  if (busy && lane == 0) __hip_atomic_store(busy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int* err, int* sync, int& t3, int& t2, int& posted,
-                                            long long* dbg = nullptr) {
+                                            long long* dbg = nullptr, int* busy = nullptr) {
   const int li = lane & 15, lk = lane >> 4;
   if (role == 0) {
     __builtin_amdgcn_s_setprio(3);                     // the chain's VALU wins the issue arbitration against its SIMD mate
@@ -240,7 +248,9 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
   } else {
     __builtin_amdgcn_s_setprio(2);                     // a helper's short bursts go ahead of its SIMD mate's strip products
   }
+  helper_wait_begin(busy, lane);
   sub_barrier(sync, t3, 3, lane);
+  helper_wait_end(busy, lane);
 #pragma unroll 1
   for (int kb = 0; kb < NT; ++kb) {
     {  // panel: tile(t, kb) <- tile(t, kb) U_kk
@@ -283,7 +293,9 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
     }
     if (kb == NT - 1) {
       __builtin_amdgcn_s_setprio(0);
+      helper_wait_begin(busy, lane);
       sub_barrier(sync, t3, 3, lane);
+      helper_wait_end(busy, lane);
       break;
     }
     ++posted;
@@ -305,9 +317,12 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
       chol16_inv_acc(Cc, a, lane, err);
       if (dbg && lane == 0) dbg[41 + 2 * kb] = (long long)wall_clock64();
     } else {
+      helper_wait_begin(busy, lane);
       sub_barrier(sync + 2, t2, 2, lane);              // the helpers' three panel tiles
       while (__hip_atomic_load(sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < posted) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      helper_wait_end(busy, lane);
+      if (dbg && lane == 0 && role == 1) dbg[56 + kb] = (long long)wall_clock64();
       if (role == 1) {
         if (kb == 0) trail_step<0, 0, 2>(Lm, li, lk);
         else if (kb == 1) trail_step<1, 0, 2>(Lm, li, lk);
@@ -321,8 +336,427 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
       }
       if (dbg && lane == 0) dbg[48 + 4 * (role - 1) + kb] = (long long)wall_clock64();
     }
+    helper_wait_begin(busy, lane);
     sub_barrier(sync, t3, 3, lane);
+    helper_wait_end(busy, lane);
   }
+}
+
+// ---- the three-wave Cholesky, round-5 protocol -------------------------------------------------------------------------------
+// chol80_trio meets in a three-wave barrier after every block column: the pivot-chain wave waits for ALL trailing products of
+// step kb before it may touch block column kb + 1, so whatever slows a helper (the strip wave it shares a SIMD with: matrix
+// instructions of the younger wave slip into every stall of the older one, 64 cycles each) lands on the chain.  But the chain
+// needs only TWO of those products - (kb+2, kb+1), its next panel tile, and (kb+2, kb+2), its next look-ahead tile, the first
+// entries of the step's list, one per helper - and nothing else the helpers write until the last block column.  Here the
+// helpers signal those two ("crit") and the chain waits for nothing else; the helpers follow the chain's posts (U_kk stored,
+// panel tile stored) and meet each other at the end of a step.  They may fall a block column behind without the chain noticing.
+//   sync[12]: crit (2 per step kb = 0, 1, 2)   sync[13]: the chain's posts (U_00, then panel kb / U_kb+1,kb+1 for kb = 0 .. 3)
+struct TrioSync {
+  int t3 = 0, t2 = 0, posts = 0, crit = 0;             // rounds / counts so far (the counters are never reset)
+};
+template <int KB, int PART, int NPARTS, int Q0, int NQ>
+__device__ __forceinline__ void trail_group(double* Lm, const double (&P)[NT][4], int li, int lk) {
+  constexpr TrailList<KB> TL{};
+  d4 a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int ti = TL.ti[PART + NPARTS * (Q0 + q)], tj = TL.tj[PART + NPARTS * (Q0 + q)];
+    const double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) a[q][rr] = ti == KB ? 0.0 : Cc[(lk + 4 * rr) * LD + li];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ti = TL.ti[PART + NPARTS * (Q0 + q)], tj = TL.tj[PART + NPARTS * (Q0 + q)];
+      a[q] = mfma(-P[ti][s], P[tj][s], a[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int ti = TL.ti[PART + NPARTS * (Q0 + q)], tj = TL.tj[PART + NPARTS * (Q0 + q)];
+    double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+  }
+}
+// the step's products of one helper; CRIT: the first one on its own, stored and signalled before the others start
+template <int KB, int PART, bool CRIT>
+__device__ __forceinline__ void trail_step2(double* Lm, int li, int lk, int* ccrit, int lane) {
+  double P[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P[t][s] = Lm[(t * 16 + li) * LD + KB * 16 + 4 * s + lk];
+  constexpr TrailList<KB> TL{};
+  constexpr int NTOT = (TL.n - PART + 1) / 2;
+  constexpr int F = CRIT ? 1 : 0;
+  if constexpr (CRIT) {
+    trail_group<KB, PART, 2, 0, 1>(Lm, P, li, lk);
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ccrit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  }
+  if constexpr (NTOT - F >= 1) trail_group<KB, PART, 2, F, (NTOT - F < 4 ? NTOT - F : 4)>(Lm, P, li, lk);
+  if constexpr (NTOT - F > 4) trail_group<KB, PART, 2, F + 4, NTOT - F - 4>(Lm, P, li, lk);
+}
+__device__ __forceinline__ void spin_until(int* f, int target) {
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void post_one(int* f, int lane) {
+  asm volatile("" ::: "memory");                       // (LDS performs a wave's operations in issue order: the stores in front are visible first)
+  if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void bar_n(int* cnt, int& target, int n, int lane) {
+  target += n;
+  post_one(cnt, lane);
+  spin_until(cnt, target);
+}
+__device__ __forceinline__ void chol80_trio2(double* Lm, int role, int lane, int* err, int* sync, TrioSync& ts,
+                                             long long* dbg = nullptr) {
+  const int li = lane & 15, lk = lane >> 4;
+  int* const c3 = sync;
+  int* const c2 = sync + 2;
+  int* const ccrit = sync + 12;
+  int* const cpost = sync + 13;
+  const int post0 = ts.posts, crit0 = ts.crit;
+  if (role == 0) {
+    __builtin_amdgcn_s_setprio(3);                     // the chain's VALU wins the issue arbitration against its SIMD mate
+    chol16_inv(Lm, lane, err);
+    post_one(cpost, lane);                             // U_00
+  } else {
+    __builtin_amdgcn_s_setprio(2);
+  }
+#pragma unroll 1
+  for (int kb = 0; kb < NT; ++kb) {
+    if (kb == NT - 1) {
+      bar_n(c3, ts.t3, 3, lane);                       // U_44 stored, every trailing product of step 3 stored
+    } else if (role == 0) {
+      if (kb > 0) spin_until(ccrit, crit0 + 2 * kb);   // tiles (kb+1, kb) and (kb+1, kb+1) carry the update of step kb - 1
+    } else {
+      spin_until(cpost, post0 + 2 * kb + 1);           // U_kk
+    }
+    {  // panel: tile(t, kb) <- tile(t, kb) U_kk
+      const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+      double bq[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
+      if (role != 1) {
+        double* A = Lm + (panel_tile(kb, role == 0 ? 0 : 3) * 16) * LD + kb * 16;
+        double av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bq[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
+      } else {
+        double av[2][4];
+        d4 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
+          acc[q] = d4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          double* A = Lm + (panel_tile(kb, q + 1) * 16) * LD + kb * 16;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
+        }
+      }
+    }
+    if (kb == NT - 1) {
+      __builtin_amdgcn_s_setprio(0);
+      bar_n(c3, ts.t3, 3, lane);
+      break;
+    }
+    if (role == 0) {
+      post_one(cpost, lane);                           // panel tile (kb+1, kb)
+      if (dbg && lane == 0) dbg[40 + 2 * kb] = (long long)wall_clock64();
+      // next diagonal tile, then its 16-pivot chain
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      chol16_inv_acc(Cc, a, lane, err);
+      post_one(cpost, lane);                           // U_kb+1,kb+1
+      if (dbg && lane == 0) dbg[41 + 2 * kb] = (long long)wall_clock64();
+    } else {
+      bar_n(c2, ts.t2, 2, lane);                       // the helpers' three panel tiles
+      spin_until(cpost, post0 + 2 * kb + 2);           // the chain's panel tile
+      if (dbg && lane == 0 && role == 1) dbg[56 + kb] = (long long)wall_clock64();
+      if (role == 1) {
+        if (kb == 0) trail_step2<0, 0, true>(Lm, li, lk, ccrit, lane);
+        else if (kb == 1) trail_step2<1, 0, true>(Lm, li, lk, ccrit, lane);
+        else if (kb == 2) trail_step2<2, 0, true>(Lm, li, lk, ccrit, lane);
+        else trail_step2<3, 0, false>(Lm, li, lk, ccrit, lane);
+      } else {
+        if (kb == 0) trail_step2<0, 1, true>(Lm, li, lk, ccrit, lane);
+        else if (kb == 1) trail_step2<1, 1, true>(Lm, li, lk, ccrit, lane);
+        else if (kb == 2) trail_step2<2, 1, true>(Lm, li, lk, ccrit, lane);
+        else trail_step2<3, 1, false>(Lm, li, lk, ccrit, lane);
+      }
+      if (dbg && lane == 0) dbg[48 + 4 * (role - 1) + kb] = (long long)wall_clock64();
+      bar_n(c2, ts.t2, 2, lane);                       // every product of the step stored: the next panel column is complete
+    }
+  }
+  ts.posts = post0 + 9;
+  ts.crit = crit0 + 6;
+}
+
+// ---- the three-wave Cholesky, split by what the pivot chain needs ----------------------------------------------------------------
+// chol80_trio2 lets the helpers fall behind, but both still carry half of EVERYTHING, and everything includes the 30 tile
+// products that only build U = L^-T (needed when the factorisation is over, for G): a step's worth of work per helper stays
+// longer than the chain's step, the lag grows and the chain ends up waiting all the same.  Here the helpers are split by
+// deadline:
+//   helper L (role 1, the OLDER wave of its SIMD: it wins the issue arbitration): the panel tiles below the chain's and the
+//     LOWER trailing products - 12 / 7 / 3 / 0 tile products at block column 0 / 1 / 2 / 3 against the chain's ~2 us per column;
+//     the chain's two tiles first, signalled (crit);
+//   helper U (role 2): the panel and trailing products of the strictly-upper tiles (U), 4 / 7 / 8 / 7 products, in the gaps the
+//     first leaves on their common matrix pipe; it follows the chain's posts and helper L's "panel of column kb stored" and
+//     has no deadline before the last block column.
+// Last block column: the four tiles (t, 4) U_44 wait for U_44 and for helper U's last products, then one barrier of the three.
+//   sync[12]: crit (1 per block column 0 .. 2)   [13]: chain posts   [14]: helper L's panel columns   [15]: helper U done with step 3
+template <int KB>
+struct LowerList {                                     // (r, c), r = KB+2 .. 4, c = KB+1 .. r: row KB+2 first (the chain's tiles)
+  int ti[9], tj[9], n;
+  constexpr LowerList() : ti{}, tj{}, n(0) {
+    for (int r = KB + 2; r < NT; ++r)
+      for (int c = KB + 1; c <= r; ++c) {
+        ti[n] = r;
+        tj[n] = c;
+        ++n;
+      }
+  }
+};
+template <int KB>
+struct UpperList {                                     // (r, c), r = 0 .. KB, c = KB+1 .. 4: tiles of U, first written at r == KB
+  int ti[16], tj[16], n;
+  constexpr UpperList() : ti{}, tj{}, n(0) {
+    for (int r = 0; r <= KB; ++r)
+      for (int c = KB + 1; c < NT; ++c) {
+        ti[n] = r;
+        tj[n] = c;
+        ++n;
+      }
+  }
+};
+// products Q0 .. Q0 + NQ - 1 of a list: C(ti, tj) -= P(ti) P(tj)^T, P = the panel tiles of block column KB (registers)
+template <class LIST, int KB, int Q0, int NQ>
+__device__ __forceinline__ void trail_run(double* Lm, const double (&P)[NT][4], int li, int lk) {
+  constexpr LIST TL{};
+  d4 a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int ti = TL.ti[Q0 + q], tj = TL.tj[Q0 + q];
+    const double* Cc = Lm + (ti * 16) * LD + tj * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) a[q][rr] = ti == KB ? 0.0 : Cc[(lk + 4 * rr) * LD + li];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = mfma(-P[TL.ti[Q0 + q]][s], P[TL.tj[Q0 + q]][s], a[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double* Cc = Lm + (TL.ti[Q0 + q] * 16) * LD + TL.tj[Q0 + q] * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+  }
+}
+template <class LIST, int KB, int Q0>
+__device__ __forceinline__ void trail_rest(double* Lm, const double (&P)[NT][4], int li, int lk) {
+  constexpr LIST TL{};
+  if constexpr (Q0 < TL.n) {
+    constexpr int NQ = TL.n - Q0 < 4 ? TL.n - Q0 : 4;
+    trail_run<LIST, KB, Q0, NQ>(Lm, P, li, lk);
+    trail_rest<LIST, KB, Q0 + NQ>(Lm, P, li, lk);
+  }
+}
+template <int KB>
+__device__ __forceinline__ void load_panel(double (&P)[NT][4], const double* Lm, int li, int lk) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P[t][s] = Lm[(t * 16 + li) * LD + KB * 16 + 4 * s + lk];
+}
+// helper L, block column KB: the lower trailing products; the first two (the chain's next panel and look-ahead tiles) signalled.
+// Every operand of the step - the panel column and all accumulator tiles - is requested before the first product: one LDS round trip.
+template <int KB>
+__device__ __forceinline__ void helperL_trailing(double* Lm, int li, int lk, int* ccrit, int lane) {
+  constexpr LowerList<KB> TL{};
+  double P[NT][4];
+  d4 a[TL.n];
+  load_panel<KB>(P, Lm, li, lk);
+#pragma unroll
+  for (int q = 0; q < TL.n; ++q) {
+    const double* Cc = Lm + (TL.ti[q] * 16) * LD + TL.tj[q] * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) a[q][rr] = Cc[(lk + 4 * rr) * LD + li];
+  }
+  constexpr int NC = TL.n < 2 ? TL.n : 2;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) a[q] = mfma(-P[TL.ti[q]][s], P[TL.tj[q]][s], a[q]);
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    double* Cc = Lm + (TL.ti[q] * 16) * LD + TL.tj[q] * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+  }
+  post_one(ccrit, lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = NC; q < TL.n; ++q) a[q] = mfma(-P[TL.ti[q]][s], P[TL.tj[q]][s], a[q]);
+#pragma unroll
+  for (int q = NC; q < TL.n; ++q) {
+    double* Cc = Lm + (TL.ti[q] * 16) * LD + TL.tj[q] * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[q][rr];
+  }
+}
+template <int KB>
+__device__ __forceinline__ void helperU_trailing(double* Lm, int li, int lk) {
+  double P[NT][4];
+  load_panel<KB>(P, Lm, li, lk);
+  trail_rest<UpperList<KB>, KB, 0>(Lm, P, li, lk);
+}
+// NQ panel tiles t0 .. t0 + NQ - 1 of block column kb: tile(t, kb) <- tile(t, kb) U_kk
+template <int NQ>
+__device__ __forceinline__ void panel_tiles(double* Lm, int kb, int t0, int li, int lk) {
+  const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
+  double bq[4], av[NQ][4];
+  d4 acc[NQ];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) bq[s] = Ukk[(4 * s + lk) * LD + li];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double* A = Lm + ((t0 + q) * 16) * LD + kb * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) av[q][s] = A[li * LD + 4 * s + lk];
+    acc[q] = d4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = mfma(av[q][s], bq[s], acc[q]);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double* A = Lm + ((t0 + q) * 16) * LD + kb * 16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[q][rr];
+  }
+}
+struct Trio3Sync {
+  int t3 = 0, posts = 0, crit = 0, lpan = 0, udone = 0;
+};
+__device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int* err, int* sync, Trio3Sync& ts,
+                                             long long* dbg = nullptr) {
+  const int li = lane & 15, lk = lane >> 4;
+  int* const c3 = sync;
+  int* const ccrit = sync + 12;
+  int* const cpost = sync + 13;
+  int* const clpan = sync + 14;
+  int* const cudone = sync + 15;
+  const int post0 = ts.posts, crit0 = ts.crit, lp0 = ts.lpan;
+  if (role == 0) {
+    // ---------------- the pivot chains ----------------
+    __builtin_amdgcn_s_setprio(3);
+    chol16_inv(Lm, lane, err);
+    post_one(cpost, lane);                             // U_00
+#pragma unroll 1
+    for (int kb = 0; kb < NT - 1; ++kb) {
+      if (kb > 0) spin_until(ccrit, crit0 + kb);       // tiles (kb+1, kb) and (kb+1, kb+1) carry the update of step kb - 1
+      panel_tiles<1>(Lm, kb, kb + 1, li, lk);
+      post_one(cpost, lane);                           // panel tile (kb+1, kb)
+      if (dbg && lane == 0) dbg[40 + 2 * kb] = (long long)wall_clock64();
+      double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
+      const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
+      d4 a;
+      double av[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LD + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) av[s] = A[li * LD + 4 * s + lk];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+      chol16_inv_acc(Cc, a, lane, err);
+      post_one(cpost, lane);                           // U_kb+1,kb+1
+      if (dbg && lane == 0) dbg[41 + 2 * kb] = (long long)wall_clock64();
+    }
+    spin_until(cudone, ts.udone + 1);                  // every tile of U carries the update of step 3
+    panel_tiles<1>(Lm, NT - 1, 0, li, lk);             // (0, 4) U_44
+    __builtin_amdgcn_s_setprio(0);
+  } else if (role == 1) {
+    // ---------------- helper L ----------------
+    __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+    for (int kb = 0; kb < NT - 1; ++kb) {
+      spin_until(cpost, post0 + 2 * kb + 1);           // U_kk
+      if (kb == 0) panel_tiles<3>(Lm, 0, 2, li, lk);
+      else if (kb == 1) panel_tiles<2>(Lm, 1, 3, li, lk);
+      else if (kb == 2) panel_tiles<1>(Lm, 2, 4, li, lk);
+      post_one(clpan, lane);                           // panel tiles (kb+2 .., kb) stored
+      spin_until(cpost, post0 + 2 * kb + 2);           // the chain's panel tile (kb+1, kb)
+      if (dbg && lane == 0) dbg[56 + kb] = (long long)wall_clock64();
+      if (kb == 0) helperL_trailing<0>(Lm, li, lk, ccrit, lane);
+      else if (kb == 1) helperL_trailing<1>(Lm, li, lk, ccrit, lane);
+      else if (kb == 2) helperL_trailing<2>(Lm, li, lk, ccrit, lane);
+      else post_one(ccrit, lane);
+      if (dbg && lane == 0) dbg[48 + kb] = (long long)wall_clock64();
+    }
+    spin_until(cpost, post0 + 2 * (NT - 1) + 1);       // U_44
+    spin_until(cudone, ts.udone + 1);
+    panel_tiles<2>(Lm, NT - 1, 1, li, lk);             // (1, 4), (2, 4)
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    // ---------------- helper U ----------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+    for (int kb = 0; kb < NT - 1; ++kb) {
+      spin_until(cpost, post0 + 2 * kb + 1);           // U_kk
+      if (kb == 1) panel_tiles<1>(Lm, 1, 0, li, lk);
+      else if (kb == 2) panel_tiles<2>(Lm, 2, 0, li, lk);
+      else if (kb == 3) panel_tiles<3>(Lm, 3, 0, li, lk);
+      spin_until(cpost, post0 + 2 * kb + 2);           // the chain's panel tile
+      spin_until(clpan, lp0 + kb + 1);                 // helper L's panel tiles
+      if (kb == 0) helperU_trailing<0>(Lm, li, lk);
+      else if (kb == 1) helperU_trailing<1>(Lm, li, lk);
+      else if (kb == 2) helperU_trailing<2>(Lm, li, lk);
+      else helperU_trailing<3>(Lm, li, lk);
+      if (dbg && lane == 0) dbg[52 + kb] = (long long)wall_clock64();
+    }
+    post_one(cudone, lane);
+    spin_until(cpost, post0 + 2 * (NT - 1) + 1);       // U_44
+    panel_tiles<1>(Lm, NT - 1, 3, li, lk);             // (3, 4)
+    __builtin_amdgcn_s_setprio(0);
+  }
+  bar_n(c3, ts.t3, 3, lane);
+  ts.posts = post0 + 9;
+  ts.crit = crit0 + 4;
+  ts.lpan = lp0 + 4;
+  ts.udone += 1;
 }
 
 // The NQ tiles (ib[q], jb[q]) of the left separator's update D_L -= W^T W that one spike wave owns: accumulators
@@ -747,6 +1181,975 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   publish_gmax<SW_T>(gmax_run, red, ch.gn_part, c, tid);
 }
 
+// ================================================================================================================
+// The sweep kernel, round-5 form.  Same elimination, same outputs; what changed is the SPIKE algebra and the buffer roles:
+//   T_k = G_k F_k               (G_k = D~_k^-1 is formed anyway for the next node: the spike no longer goes through
+//   D_L -= F_k^T T_k             W = U^T F, W^T W, T = U W - 160 matrix instructions per strip instead of 180, ONE barrier of
+//   F_k+1 = -E^T T_k             the strip waves per node instead of two, no W written back and read again)
+// A strip wave keeps its strip of F in registers (the accumulator layout of a 16 x 16 tile IS the B-operand layout of the
+// four k-steps over it), reads G - symmetric, stored in full - from LDS, and keeps the finished T strip in registers as
+// the B operand of its three tiles of F^T T (tile pairs {j, j}, {j, j + 1}, {j, j + 2} mod 5: every unordered pair of strips
+// once, 60 instructions per wave; the other operand is a strip of F, read-only in Y until the one barrier).
+// Buffers: Xf = the factorisation's workspace (D~_k -> [L \ U_k]; after G_k is formed U_k is dead and D~_k+1 is built
+// straight into it), Xg = G_k for the whole node (stencil pass, spike, and the store to HBM - by the spike waves, off the
+// factor chain's path), Y = the spike.  No buffer swap, one barrier fewer in the serial part (the stencil reads Xg and
+// writes Xf).
+__device__ __forceinline__ void spike_gf(const double* G, const double (&bF)[NT][4], d4 (&acc)[NT], int li, int lk, int mode = 0) {
+  constexpr int NSTEP = 4 * NT;
+  double a[3][NT];
+  const double* gb = G + lk * LD + li;                 // A(ib, kb)[li][4 s + lk] = G[kb 16 + 4 s + lk][ib 16 + li] (symmetric)
+  auto fetch = [&](int buf, int step) {
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) a[buf][ib] = mode == 1 ? 1e-3 * (li + step) : gb[(4 * step) * LD + ib * 16];
+  };
+#pragma unroll
+  for (int ib = 0; ib < NT; ++ib) acc[ib] = d4{0, 0, 0, 0};
+  fetch(0, 0);
+  fetch(1, 1);
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    if (step + 2 < NSTEP) fetch((step + 2) % 3, step + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) {
+      if (mode == 2) acc[ib][0] += a[step % 3][ib];
+      else acc[ib] = mfma(a[step % 3][ib], bF[step >> 2][step & 3], acc[ib]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// acc[q] -= F(:, as[q])^T T(:, own strip): A operand = the strip as[q] of F in Y (column pattern), B = the T tiles in registers
+template <int NQ>
+__device__ __forceinline__ void spike_ftt(d4 (&acc)[NQ], const double* Yf, const d4 (&T)[NT], const int (&as)[NQ], int li, int lk, int mode = 0) {
+  constexpr int NSTEP = 4 * NT;
+  const double* p = Yf + lk * LD + li;
+  double a0[NQ], a1[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a0[q] = mode == 1 ? 1e-3 * li : p[as[q] * 16];
+#pragma unroll
+  for (int st = 0; st < NSTEP; st += 2) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a1[q] = mode == 1 ? 1e-3 * (li + st) : p[(4 * (st + 1)) * LD + as[q] * 16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { if (mode == 2) acc[q][0] += a0[q]; else acc[q] = mfma(-a0[q], T[st >> 2][st & 3], acc[q]); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (st + 2 < NSTEP) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) a0[q] = mode == 1 ? 1e-3 * (li - st) : p[(4 * (st + 2)) * LD + as[q] * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { if (mode == 2) acc[q][0] += a1[q]; else acc[q] = mfma(-a1[q], T[(st + 1) >> 2][(st + 1) & 3], acc[q]); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ void __launch_bounds__(SW_T)
+k_chunk_sweep2(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+                int m, int n_chunks, int node0, int pin_right) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* const Xf = reinterpret_cast<double*>(smem_raw);   // D~_k -> [L \ U_k] -> D~_k+1
+  double* const Xg = Xf + MAT;                               // G_k
+  double* const Y = Xg + MAT;                                // spike: F_k -> T_k -> F_k+1; column 79 = right-hand side
+  double* cL = Y + MAT;                                // coupling tables of the current node
+  double* cR = cL + 9 * NP;
+  double* bv = cR + 9 * NP;                            // [80] right-hand side of the node built last
+  double* red = bv + BS;                               // [8]
+  int* sync = reinterpret_cast<int*>(red + 8);         // [0] factor trio | [1] spike waves | [2] helper pair | [3] flag
+  double* kq = red + 16;                               // [25] each: copies of K.q_w, K.lo, K.hi
+  double* klo = kq + NP;
+  double* khi = klo + NP;
+  long long* lst = reinterpret_cast<long long*>(khi + NP);   // [64] debug stamps, copied out at the end of the stamped node
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const FteConst& K = *cst;
+  const int c = blockIdx.x;
+  const int first = node0 + c * m;
+  const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
+  const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;       // (the last run: whatever is left, m + 1 at most)
+  const int n_int = hasR ? len - 1 : len;
+  const int sL = c - 1 + node0, sR = c + node0;                    // separator-chain indices of the run's two ends
+  const size_t MB = (size_t)BS * BS;
+  const int role = __builtin_amdgcn_readfirstlane(role8(wave));
+  const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
+  const int n_spike = hasL ? 5 : 1;          // first run: only the right-hand side column (strip 4) is alive
+  int t3 = 0, t2 = 0, tflag = 0, t5 = 0;     // rounds of the wave-subset barriers
+  double gmax_run = 0.0;
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64]) ? ch.dbg : nullptr;
+  const int dbg_k = dbgp ? (int)ch.dbg[65] : -1;
+  // (experiment knobs of the stamped workgroup: dbg[66] = mask of spike roles that skip their matrix-core work; dbg[67] <- SIMD
+  //  index of every wave, four bits each, from HW_ID)
+  const int dbg_skip = dbgp ? (int)ch.dbg[66] : 0;
+  if (dbgp && lane == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    atomicOr(reinterpret_cast<unsigned long long*>(ch.dbg + 67), (unsigned long long)((hw >> 4) & 3) << (4 * wave));
+    if (wave == 0) ch.dbg[68] = hw;
+  }
+#define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
+  if (tid < 4) sync[tid] = 0;
+  if (tid < 64) lst[tid] = 0;
+  if (c == 0 && node0) {                               // the left pin owns no frames here: its block starts from zero, the
+    for (int e = tid; e < BS * BS; e += SW_T) sp.D[e] = 0.0;       // run's spike contribution AL is added by the reduction
+    if (tid < BS) sp.b[tid] = 0.0;
+  }
+  if (tid < NP) {
+    kq[tid] = K.q_w[tid];
+    klo[tid] = K.lo[tid];
+    khi[tid] = K.hi[tid];
+  }
+  __syncthreads();
+
+  {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
+    NodeFetch f;
+    build_fetch<SW_T>(f, ch, K, first, tid);
+    fill_coupling_coef<SW_T>(cL, cR, K, first, tid, kq);
+    for (int e = tid; e < MAT; e += SW_T) Y[e] = 0.0;
+    gmax_run = build_finish<SW_T>(Xf, bv, f, K, first, tid, kq, klo, khi);
+    __syncthreads();                                   // node, bv, tables, zeros complete
+    if (hasL)
+      for (int e = tid; e < 9 * NP; e += SW_T) {
+        const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
+        if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
+      }
+    if (tid < BS) Y[tid * LD + (BS - 1)] = bv[tid];
+    __syncthreads();
+    if (role < 3) chol80_trio(Xf, role, lane, numeric_err, sync, t3, t2, tflag);
+    __syncthreads();
+  }
+
+#pragma unroll 1
+  for (int k = 0; k < n_int; ++k) {
+    const int node = first + k, next = node + 1;
+    const bool last = k + 1 == n_int;
+    const bool has_next = !last || hasR;
+    // ================= serial part (all eight waves): G_k, then the next node =================
+    const int tid_ = opaque(tid);
+    const int fb_next = 3 * (next - node0);            // (node t holds the local frames 3 (t - pin_left) ..)
+    double hq[2][3] = {{0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, cvq[3] = {0, 0, 0}, lamq = 0.0;
+    bool liveq[3] = {false, false, false}, ownq[3] = {false, false, false};
+    const int e1 = tid_ + SW_T;
+    const bool own1 = e1 < NP * NP;
+    const int pd0 = tid_ / NP, pc0 = tid_ % NP, pd1 = own1 ? e1 / NP : 0, pc1 = own1 ? e1 % NP : 0;
+    const bool diag0 = pd0 == pc0, diag1 = own1 && pd1 == pc1;
+    const int pdg = diag1 ? pd1 : pd0;                 // (a thread owns at most one diagonal pair)
+    if (has_next) {
+      const int cur = ch.st->cur;
+      const double* Hg = cur ? ch.H1 : ch.H0;
+      lamq = ch.st->lam;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (fb_next + j < K.n_frames) {
+          hq[0][j] = Hg[(size_t)(fb_next + j) * NP * NP + tid_];
+          if (own1) hq[1][j] = Hg[(size_t)(fb_next + j) * NP * NP + e1];
+        }
+      if (diag0 || diag1) {
+        const double* xg = cur ? ch.x1 : ch.x0;
+        const double* gg = cur ? ch.g1 : ch.g0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (fb_next + j < K.n_frames) {
+            xq[j] = xg[(size_t)(fb_next + j + HALO) * NP + pdg];
+            gq[j] = gg[(size_t)(fb_next + j) * NP + pdg];
+          }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          const int j = pr == 2 ? 1 : 0, jp = pr == 0 ? 1 : 2;
+          if (fb_next + jp < K.n_frames)
+            cvq[pr] = 2.0 * kq[pdg] * band_coef_clip(K.n_offset + fb_next + j, jp - j, K.n_global, K.clip_len);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        liveq[j] = fb_next + j < K.n_frames;
+        ownq[j] = fb_next + j >= K.own_lo && fb_next + j < K.own_hi;
+      }
+    }
+    if (wave == 0) SW_STAMP(0);
+    {
+      const int gi = opaque(lane & 15), gk = opaque(lane >> 4);
+      d4 g[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = gram8_tile(wave, q);
+        if (t >= 0) g[q] = tile_u_ut(Xf, tri_i(t), tri_j(t), gi, gk);
+      }
+      asm volatile("" : "+v"(g[0][0]), "+v"(g[1][0]), "+v"(g[2][0]));
+      SW_STAMP(32 + wave);
+      if (k > 0 && !uni_tables) fill_coupling_coef<SW_T>(cL, cR, K, node, tid_, kq);   // (beside the matrix-core work above)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = gram8_tile(wave, q);
+        if (t >= 0) {
+          const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            Xg[(ib * 16 + gk + 4 * rr) * LD + jb * 16 + gi] = g[q][rr];
+            if (ib != jb) Xg[(jb * 16 + gi) * LD + ib * 16 + gk + 4 * rr] = g[q][rr];
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // G in Xg, every read of U_k (Xf) done, tables of this node visible
+    if (wave == 0) SW_STAMP(1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(hq[0][j]), "+v"(hq[1][j]), "+v"(xq[j]), "+v"(gq[j]));
+    asm volatile("" : "+v"(lamq));
+    if (wave == 0) SW_STAMP(2);
+    if (has_next) {
+      // S = E^T G_k E on the thread's blocks (reads Xg), the next node written straight into Xf
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int pr = sl ? pd1 : pd0, pc = sl ? pc1 : pc0;
+        const bool dg = sl ? diag1 : diag0;
+        if (sl == 0 || own1) {
+          const double a00 = cR[0 * NP + pr], a01 = cR[1 * NP + pr], a02 = cR[2 * NP + pr];
+          const double a11 = cR[4 * NP + pr], a12 = cR[5 * NP + pr], a22 = cR[8 * NP + pr];
+          const double b00 = cR[0 * NP + pc], b01 = cR[1 * NP + pc], b02 = cR[2 * NP + pc];
+          const double b11 = cR[4 * NP + pc], b12 = cR[5 * NP + pc], b22 = cR[8 * NP + pc];
+          double mm[3][3], S[3][3];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) {
+            const double* gp = Xg + (jj * NP + pr) * LD + pc;
+            const double g0 = gp[0], g1 = gp[NP], g2 = gp[2 * NP];
+            mm[jj][0] = g0 * b00 + g1 * b01 + g2 * b02;
+            mm[jj][1] = g1 * b11 + g2 * b12;
+            mm[jj][2] = g2 * b22;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 3; ++ii) {
+            S[0][ii] = a00 * mm[0][ii] + a01 * mm[1][ii] + a02 * mm[2][ii];
+            S[1][ii] = a11 * mm[1][ii] + a12 * mm[2][ii];
+            S[2][ii] = a22 * mm[2][ii];
+          }
+          double v[3][3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) v[j][jp] = (j == jp ? hq[sl][j] : 0.0);
+          if (dg) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              double d = 1.0, bb = 0.0;
+              if (liveq[j]) {
+                d = hq[sl][j];
+                const double gtol = GRAD_ZERO_REL * d;
+                const bool fixed = (xq[j] <= klo[pr] && gq[j] > gtol) || (xq[j] >= khi[pr] && gq[j] < -gtol);
+                d = d + lamq * fmax(d, DIAG_FLOOR);
+                if (fixed) d *= FIX_SCALE;
+                bb = fixed ? 0.0 : -gq[j];
+                if (ownq[j]) gmax_run = fmax(gmax_run, fabs(bb));   // (window sharding: owned frames only)
+              }
+              v[j][j] = d;
+              bv[j * NP + pr] = bb;
+            }
+            v[0][1] = v[1][0] = cvq[0];
+            v[0][2] = v[2][0] = cvq[1];
+            v[1][2] = v[2][1] = cvq[2];
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) Xf[(j * NP + pr) * LD + jp * NP + pc] = v[j][jp] - S[j][jp];
+        }
+      }
+      // (padding rows / columns 75 .. 79: the factorisation left an identity block there - L and U of an identity block are
+      //  the identity, the blocks beside it exact zeros -; the diagonal is rewritten all the same: five stores)
+      if (tid_ < BS - 3 * NP) Xf[(3 * NP + tid_) * LD + 3 * NP + tid_] = 1.0;
+      if (wave == 0) SW_STAMP(3);
+    }
+    __syncthreads();
+    if (wave == 0) SW_STAMP(4);
+    // ================= parallel part =================
+    if (role < 3) {
+      if (!last)
+        chol80_trio(Xf, role, opaque(lane), numeric_err, sync, t3, t2, tflag, (dbgp && k == dbg_k) ? lst : nullptr);
+      SW_STAMP(8 + wave);
+    } else {
+      const int sw = __builtin_amdgcn_readfirstlane(opaque(role)) - 3;
+      const int ln = opaque(lane);
+      const int li = ln & 15, lk = ln >> 4;
+      {
+        // G_k -> HBM, lower tiles only (G is symmetric: the back-substitution mirrors them); 1920 items over the five waves
+        double* Gg = ch.D + node * MB;
+#pragma unroll
+        for (int q = 0; q < LOWER_ITEMS / 320; ++q) {
+          const int idx = sw * 64 + ln + 320 * q;
+          int r, cc;
+          lower_item(idx, r, cc);
+          *reinterpret_cast<double2*>(Gg + r * BS + cc) = make_double2(Xg[r * LD + cc], Xg[r * LD + cc + 1]);
+        }
+      }
+      if (hasL || sw == 4) {
+        // the strip's three tiles of the left separator's update: pairs (a, sw), a = sw, sw + 1, sw + 2 mod 5; kept in the lower
+        // tiles of AL (a < sw: stored transposed)
+        int sa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sa[q] = (sw + q) % NT;
+        double* Ag = sp.AL + (size_t)(hasL ? opaque(sL) : 0) * MB;
+        auto al_at = [&](int q, int rr) -> double* {
+          return sa[q] >= sw ? Ag + (size_t)(sa[q] * 16 + 4 * rr + lk) * BS + sw * 16 + li
+                             : Ag + (size_t)(sw * 16 + li) * BS + sa[q] * 16 + 4 * rr + lk;
+        };
+        d4 accL[3] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+        if (hasL) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) accL[q][rr] = *al_at(q, rr);
+        }
+        d4 T[NT];
+        {
+          double bF[NT][4];
+          const double* yb = Y + lk * LD + sw * 16 + li;
+#pragma unroll
+          for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bF[kb][s] = yb[(kb * 16 + 4 * s) * LD];
+          SW_STAMP(59 + sw);
+          if (!((dbg_skip >> role) & 1)) spike_gf(Xg, bF, T, li, lk, (dbg_skip >> 8) & 3);
+        }
+        SW_STAMP(16 + 4 * sw);
+        if (hasL) {
+          syrk_mask_n<3>(accL, k > 0);
+          if (!((dbg_skip >> role) & 1)) spike_ftt<3>(accL, Y, T, sa, li, lk, (dbg_skip >> 8) & 3);
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) *al_at(q, rr) = accL[q][rr];
+        }
+        SW_STAMP(17 + 4 * sw);
+        sub_barrier(sync + 1, t5, n_spike, ln);          // nobody reads F_k any more
+        SW_STAMP(18 + 4 * sw);
+#pragma unroll
+        for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, sw, T[ib], li, lk);
+        SW_STAMP(19 + 4 * sw);
+        const int c_lo = 16 * sw;
+        if (sw == 4) {
+          ch.b[(size_t)node * BS + ln] = Y[ln * LD + (BS - 1)];
+          if (ln < 16) ch.b[(size_t)node * BS + 64 + ln] = Y[(64 + ln) * LD + (BS - 1)];
+        }
+        if (has_next) {
+          const int p = ln % NP, cg = ln / NP;        // cg 0, 1 (lanes 50..63 idle)
+          if (cg < 2) {
+            const double e00 = cR[(0 * 3 + 0) * NP + p], e01 = cR[(0 * 3 + 1) * NP + p], e02 = cR[(0 * 3 + 2) * NP + p];
+            const double e11 = cR[(1 * 3 + 1) * NP + p], e12 = cR[(1 * 3 + 2) * NP + p], e22 = cR[(2 * 3 + 2) * NP + p];
+            const double b0 = bv[p], b1 = bv[NP + p], b2 = bv[2 * NP + p];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int cc = c_lo + cg + 2 * q;
+              const double f0 = Y[p * LD + cc], f1 = Y[(NP + p) * LD + cc], f2 = Y[(2 * NP + p) * LD + cc];
+              double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
+              if (cc == BS - 1) {
+                o0 += b0;
+                o1 += b1;
+                o2 += b2;
+              }
+              Y[p * LD + cc] = o0;
+              Y[(NP + p) * LD + cc] = o1;
+              Y[(2 * NP + p) * LD + cc] = o2;
+            }
+          }
+          if (ln < 16)
+            for (int r = 3 * NP; r < BS; ++r) Y[r * LD + c_lo + ln] = 0.0;     // padding rows couple to nothing
+        }
+      }
+      SW_STAMP(8 + wave);
+    }
+    __syncthreads();                                   // next node factored, F_k+1 complete, G_k no longer read
+    if (wave == 0) SW_STAMP(7);
+    if (dbgp && k == dbg_k) {
+      __syncthreads();
+      if (tid < 64 && lst[tid]) dbgp[tid] = lst[tid];
+    }
+    if (last && hasR) {                                // the node built last is the right separator
+      {
+        double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)sR * MB);
+        for (int idx = tid; idx < BS * BS / 2; idx += SW_T) {
+          const int e = 2 * idx, r = e / BS, cc = e % BS;
+          d2[idx] = make_double2(Xf[r * LD + cc], Xf[r * LD + cc + 1]);
+        }
+      }
+      if (tid < BS) sp.b[(size_t)sR * BS + tid] = Y[tid * LD + (BS - 1)];
+      if (hasL) {
+        double* Cg = sp.Cpl + (size_t)sL * MB;         // block(R, L): rows R, columns L
+        for (int e = tid; e < BS * BS; e += SW_T) {
+          const int r = e / BS, cc = e % BS;
+          Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
+        }
+      }
+    }
+  }
+#undef SW_STAMP
+  publish_gmax<SW_T>(gmax_run, red, ch.gn_part, c, tid);
+}
+
+// ================================================================================================================
+// The sweep kernel as TWO TEAMS of waves that run their own loops over the nodes of the run and meet only through counters
+// in LDS (round 5; the algebra is k_chunk_sweep2's: T_k = G_k F_k, D_L -= F_k^T T_k, F_k+1 = -E^T T_k).
+//   D team (waves 0, 1, 2 and 4): the chain  U_k -> G_k = U_k U_k^T -> D~_k+1 = D_k+1 - E^T G_k E -> Cholesky -> U_k+1.
+//     Per node: the 15 tiles of G_k into Xg (wave 1 / 2: 48 matrix instructions each, wave 0 / 4: 24 / 20 - these two share a
+//     SIMD), the next node built by state pairs straight into Xf (256 threads, <= 3 pairs each), then the three-wave blocked
+//     Cholesky (chol80_trio: wave 0 pivot chains, waves 1, 2 panels and trailing products) while wave 4 - the pivot chain's
+//     SIMD mate, which therefore carries no matrix work during the chains - streams G_k to HBM.
+//   S team (waves 5, 6, 3, 7): the spike of node k as soon as G_k is published.  Wave 5 / 6 hold strip 1 / 2 of the spike
+//     (16 columns), wave 3 strips 3 and 0, wave 7 strip 4 (waves 3 and 7 share the SIMD that hosts no D wave: it carries five
+//     twelfths of the spike's matrix work).  T strips by spike_gf (F strip in registers, G from Xg), then the tiles of F^T T
+//     dealt so that every one is computed where its T strip lives: wave 3 {3,3} {0,3} {0,0}, wave 7 {4,4} {0,4} {3,4},
+//     wave 5 {1,1} {0,1} {1,3} {1,4} {1,2}, wave 6 {2,2} {0,2} {2,3} {2,4}; ONE barrier of the four waves, then T -> Y and the
+//     stencil pass in place.  Waves 5 and 6 share their SIMDs with the factor helpers and YIELD to them: a helper raises
+//     busy[] while it has work and lowers it before every wait, the strip wave polls the word between groups of matrix
+//     instructions (the older wave wins the issue arbitration anyway, but every instruction of the younger one that slips
+//     into a stall of the helper holds the pipe for 64 cycles).
+// Hand-offs (monotonic counters, LDS): gready (G_k in Xg) D -> S; gfdone (a strip wave is through with Xg) S -> D, which then
+// overwrites Xg with G_k+1; bvready (next node built: its right-hand side bv[(k+1) & 1] is there) D -> S for the stencil pass;
+// fready (a wave's strips of F_k+1 are complete) among the S waves before F^T T reads across strips.  No workgroup barrier
+// inside the node loop: the S team's tail (T -> Y, stencil) runs under the D team's G_k+1, the D team's build under the S
+// team's T = G F.  LDS-only protocol: the LDS performs one wave's operations in issue order, so a counter update issued behind
+// a wave's reads / writes releases them and nothing has to wait for the wave's GLOBAL stores (sub_barrier's fence does).
+__device__ __forceinline__ void lds_signal(int* f, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_wait(int* f, int target) {
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_barrier(int* cnt, int& target, int n, int lane) {
+  target += n;
+  lds_signal(cnt, lane);
+  lds_wait(cnt, target);
+}
+// (k-step 19 - rows 76 .. 79 of F and of T - is skipped everywhere: those rows are exact zeros)
+constexpr int SP_STEPS = 4 * NT - 1;
+__device__ __forceinline__ void spike_gf3(const double* G, const double (&bF)[NT][4], d4 (&acc)[NT], int li, int lk) {
+  double a[3][NT];
+  const double* gb = G + lk * LD + li;                 // A(ib, kb)[li][4 s + lk] = G[kb 16 + 4 s + lk][ib 16 + li] (symmetric)
+  auto fetch = [&](int buf, int step) {
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) a[buf][ib] = gb[(4 * step) * LD + ib * 16];
+  };
+#pragma unroll
+  for (int ib = 0; ib < NT; ++ib) acc[ib] = d4{0, 0, 0, 0};
+  fetch(0, 0);
+  fetch(1, 1);
+#pragma unroll
+  for (int step = 0; step < SP_STEPS; ++step) {
+    if (step + 2 < SP_STEPS) fetch((step + 2) % 3, step + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) acc[ib] = mfma(a[step % 3][ib], bF[step >> 2][step & 3], acc[ib]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void spike_ftt3(d4 (&acc)[NQ], const double* Yf, const d4 (&T)[NT], const int (&as)[NQ], int li, int lk) {
+  constexpr int DEPTH = NQ >= 3 ? 2 : (NQ == 2 ? 3 : 6);   // operands requested ~6 matrix instructions ahead of their use
+  const double* p = Yf + lk * LD + li;
+  double a[DEPTH + 1][NQ];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[d][q] = p[(4 * d) * LD + as[q] * 16];
+#pragma unroll
+  for (int st = 0; st < SP_STEPS; ++st) {
+    if (st + DEPTH < SP_STEPS) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) a[(st + DEPTH) % (DEPTH + 1)][q] = p[(4 * (st + DEPTH)) * LD + as[q] * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = mfma(-a[st % (DEPTH + 1)][q], T[st >> 2][st & 3], acc[q]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// NQ tiles (as[q], j) of F^T T against one T strip, accumulated in the lower tiles of AL (a < j: stored transposed).  The
+// accumulators are REQUESTED by al_fetch long before they are needed (ahead of the wave's T = G F: an L2 round trip) and
+// folded in by al_run.
+template <int NQ>
+struct AlTiles {
+  d4 acc[NQ];
+  int as[NQ], j;
+  double* Ag;
+  __device__ __forceinline__ double* at(int q, int rr, int li, int lk) const {
+    return as[q] >= j ? Ag + (size_t)(as[q] * 16 + 4 * rr + lk) * BS + j * 16 + li
+                      : Ag + (size_t)(j * 16 + li) * BS + as[q] * 16 + 4 * rr + lk;
+  }
+  __device__ __forceinline__ void fetch(int li, int lk) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[q][rr] = *at(q, rr, li, lk);
+  }
+  __device__ __forceinline__ void run(bool load, const double* Yf, const d4 (&T)[NT], int li, int lk) {
+    syrk_mask_n<NQ>(acc, load);
+    spike_ftt3<NQ>(acc, Yf, T, as, li, lk);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) *at(q, rr, li, lk) = acc[q][rr];
+  }
+};
+// roles of the two-team sweep by wave (waves w and w + 4 share a SIMD): the pivot-chain wave with a wave that carries no matrix work
+// during the chains (0, 4), the two factor helpers together (1, 5), the four strip waves on the other two SIMDs (2, 6 | 3, 7) -
+// a wave that streams fp64 matrix instructions holds its SIMD 64 cycles at a time, and every instruction of its SIMD mate,
+// vector or matrix, waits for the slot: latency-bound work and matrix streams do not share a SIMD
+__device__ __forceinline__ int role8b(int wave) { return (0x75236410u >> (4 * wave)) & 15; }   // {0, 1, 4, 6, 3, 2, 5, 7}
+// G = U U^T over the four D waves (0 chain, 1, 2 helpers, 3 the chain's SIMD mate): {0,3,10} {2,4,12,13} {5,8,9,14} {1,6,7,11}:
+// 36 | 36 | 32 | 36 matrix instructions, 72 | 68 per SIMD
+__device__ __forceinline__ int gram4_tile(int dw, int q) {
+  const unsigned v = dw == 0 ? 0xFA30u : (dw == 1 ? 0xDC42u : (dw == 2 ? 0xE985u : 0xB761u));
+  const int t = (v >> (4 * q)) & 15;
+  return t == 15 ? -1 : t;
+}
+// G = U U^T over the six builder waves (bw = 0 chain, 1, 2 helpers, 3 the chain's SIMD mate, 4, 5 the strip waves that share
+// the helpers' SIMDs): tiles in the nibbles, 15 = none.  {0,10} {1,7} {2,9} {3,6,11} {4,8,12} {5,13,14}: 24 matrix
+// instructions each (20 the last), 48 | 48 | 44 per SIMD
+__device__ __forceinline__ int gram6_tile(int bw, int q) {
+  const unsigned v = bw == 0 ? 0xFA0u : (bw == 1 ? 0xF71u : (bw == 2 ? 0xF92u : (bw == 3 ? 0xB63u : (bw == 4 ? 0xC84u : 0xED5u))));
+  const int t = (v >> (4 * q)) & 15;
+  return t == 15 ? -1 : t;
+}
+// The spike of one node on one strip wave (ROLE 4: wave 2, strip 1 | 5: wave 6, strips 2 and 0 | 6: wave 3, strip 3 | 7: wave 7,
+// strip 4), a function per role so that each gets its own register allocation.  Tiles of F^T T: role 4 {1,1} {0,1} {1,2},
+// role 5 {2,2} {0,2} | {0,0}, role 6 {3,3} {0,3} {1,3} {2,3} {3,4}, role 7 {4,4} {0,4} {1,4} {2,4}.
+struct SpikeArgs {
+  const double* Xg;
+  double* Y;
+  double* Ag;
+  const double* cRk;
+  const double* bvn;
+  double* zk;
+  int *c_gready, *c_gfdone, *c_fready, *c_bv, *cS;
+  int k, n_s;
+  bool hasL, has_next;
+  long long* stamps;
+};
+template <int ROLE>
+__device__ __forceinline__ void spike_node(const SpikeArgs& A, int& tsb, int ln) {
+  constexpr bool two = ROLE == 5;
+  constexpr int j0 = ROLE == 4 ? 1 : (ROLE == 5 ? 2 : (ROLE == 6 ? 3 : 4));
+  constexpr int NA = ROLE == 4 ? 3 : (ROLE == 5 ? 2 : (ROLE == 6 ? 5 : 4));
+  const int li = ln & 15, lk = ln >> 4;
+  double* const Y = A.Y;
+  auto stamp = [&](int i) { if (A.stamps && ln == 0) A.stamps[i] = (long long)wall_clock64(); };
+  AlTiles<NA> al;                                      // tiles against T strip j0
+  AlTiles<1> al0;                                      // role 5 only: {0, 0} against T strip 0
+  al.Ag = A.Ag;
+  al.j = j0;
+  if (ROLE == 4) { al.as[0] = 1; al.as[1] = 0; al.as[2 % NA] = 2; }
+  if (ROLE == 5) { al.as[0] = 2; al.as[1] = 0; }
+  if (ROLE == 6) { al.as[0] = 3; al.as[1] = 0; al.as[2 % NA] = 1; al.as[3 % NA] = 2; al.as[4 % NA] = 4; }
+  if (ROLE == 7) { al.as[0] = 4; al.as[1] = 0; al.as[2 % NA] = 1; al.as[3 % NA] = 2; }
+  al0.Ag = A.Ag;
+  al0.j = 0;
+  al0.as[0] = 0;
+  if (A.hasL) {
+    al.fetch(li, lk);
+    if (two) al0.fetch(li, lk);
+  }
+  lds_wait(A.c_gready, A.k + 1);
+  stamp(16 + 4 * (ROLE - 4));
+  d4 T0[NT], T1[NT];
+  {
+    double bF[NT][4];
+    const double* yb = Y + lk * LD + j0 * 16 + li;
+#pragma unroll
+    for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bF[kb][s] = (4 * kb + s < SP_STEPS) ? yb[(kb * 16 + 4 * s) * LD] : 0.0;
+    spike_gf3(A.Xg, bF, T0, li, lk);
+  }
+  if (two) {
+    double bF[NT][4];
+    const double* yb = Y + lk * LD + li;               // strip 0
+#pragma unroll
+    for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bF[kb][s] = (4 * kb + s < SP_STEPS) ? yb[(kb * 16 + 4 * s) * LD] : 0.0;
+    spike_gf3(A.Xg, bF, T1, li, lk);
+  }
+  lds_signal(A.c_gfdone, ln);                          // this wave is through with G_k
+  stamp(17 + 4 * (ROLE - 4));
+  if (A.hasL) {
+    lds_wait(A.c_fready, A.n_s * A.k);                 // every strip of F_k is complete
+    al.run(A.k > 0, Y, T0, li, lk);
+    if (two) al0.run(A.k > 0, Y, T1, li, lk);
+  }
+  stamp(18 + 4 * (ROLE - 4));
+  lds_barrier(A.cS, tsb, A.n_s, ln);                   // nobody reads F_k any more
+  // ---- T_k -> Y (own strips), z_k (column 79 of T) -> HBM, then F_k+1 = -E^T T_k in place, column 79 += the next node's
+  //      right-hand side
+#pragma unroll
+  for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, j0, T0[ib], li, lk);
+  if (two) {
+#pragma unroll
+    for (int ib = 0; ib < NT; ++ib) tile_store(Y, ib, 0, T1[ib], li, lk);
+  }
+  if (ROLE == 7) {
+    A.zk[ln] = Y[ln * LD + (BS - 1)];
+    if (ln < 16) A.zk[64 + ln] = Y[(64 + ln) * LD + (BS - 1)];
+  }
+  if (A.has_next) {
+    lds_wait(A.c_bv, A.k + 1);                         // the next node's right-hand side is there
+    const double* const cRk = A.cRk;
+    const double* const bvn = A.bvn;
+    const int p = ln % NP, cg = ln / NP;               // cg 0, 1 (lanes 50..63 idle)
+#pragma unroll
+    for (int h = 0; h < (two ? 2 : 1); ++h) {
+      const int c_lo = 16 * (h ? 0 : j0);
+      if (cg < 2) {
+        const double e00 = cRk[(0 * 3 + 0) * NP + p], e01 = cRk[(0 * 3 + 1) * NP + p], e02 = cRk[(0 * 3 + 2) * NP + p];
+        const double e11 = cRk[(1 * 3 + 1) * NP + p], e12 = cRk[(1 * 3 + 2) * NP + p], e22 = cRk[(2 * 3 + 2) * NP + p];
+        const double b0 = bvn[p], b1 = bvn[NP + p], b2 = bvn[2 * NP + p];
+        double fv[8][3];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int cc = c_lo + cg + 2 * q;
+          fv[q][0] = Y[p * LD + cc];
+          fv[q][1] = Y[(NP + p) * LD + cc];
+          fv[q][2] = Y[(2 * NP + p) * LD + cc];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int cc = c_lo + cg + 2 * q;
+          const double f0 = fv[q][0], f1 = fv[q][1], f2 = fv[q][2];
+          double o0 = -(e00 * f0 + e01 * f1 + e02 * f2), o1 = -(e11 * f1 + e12 * f2), o2 = -(e22 * f2);
+          if (cc == BS - 1) {
+            o0 += b0;
+            o1 += b1;
+            o2 += b2;
+          }
+          Y[p * LD + cc] = o0;
+          Y[(NP + p) * LD + cc] = o1;
+          Y[(2 * NP + p) * LD + cc] = o2;
+        }
+      }
+      if (ln < 16)
+        for (int r = 3 * NP; r < BS; ++r) Y[r * LD + c_lo + ln] = 0.0;     // padding rows couple to nothing
+    }
+  }
+  lds_signal(A.c_fready, ln);
+  stamp(19 + 4 * (ROLE - 4));
+}
+
+constexpr int SW3_VEC = SW_VEC + BS;        // + the second right-hand-side buffer
+static constexpr size_t kSweep3Lds = (3 * MAT + SW3_VEC) * sizeof(double);
+
+__global__ void __launch_bounds__(SW_T)
+k_chunk_sweep3(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* numeric_err, const int* __restrict__ status,
+                int m, int n_chunks, int node0, int pin_right) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (status && *status != 0) return;
+  double* const Xf = reinterpret_cast<double*>(smem_raw);   // D~_k -> [L \ U_k] -> D~_k+1
+  double* const Xg = Xf + MAT;                               // G_k
+  double* const Y = Xg + MAT;                                // spike: F_k -> T_k -> F_k+1; column 79 = right-hand side
+  double* const cL = Y + MAT;                          // left tables of the first node; afterwards the odd nodes' right tables
+  double* const cR0 = cL + 9 * NP;                     // right tables of the even nodes (of every node when they are uniform)
+  double* const bvb = cR0 + 9 * NP;                    // [2][80] right-hand side of the node built last, by node parity
+  double* const red = bvb + 2 * BS;                    // [8]
+  int* const sync = reinterpret_cast<int*>(red + 8);   // [0] factor trio | [2] helper pair | [12] crit | [13] posts | below
+  int* const cB = sync + 4;                            // barrier of the six builder waves
+  int* const cS = sync + 5;                            // barrier of the strip waves
+  int* const c_gready = sync + 6;
+  int* const c_gfdone = sync + 7;
+  int* const c_fready = sync + 8;
+  int* const c_bv = sync + 9;
+  double* const kq = red + 16;                         // [25] each: copies of K.q_w, K.lo, K.hi
+  double* const klo = kq + NP;
+  double* const khi = klo + NP;
+  long long* const lst = reinterpret_cast<long long*>(khi + NP);   // [64] debug stamps, copied out at the end of the kernel
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const FteConst& K = *cst;
+  const int c = blockIdx.x;
+  const int first = node0 + c * m;
+  const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
+  const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;       // (the last run: whatever is left, m + 1 at most)
+  const int n_int = hasR ? len - 1 : len;
+  const int sL = c - 1 + node0, sR = c + node0;                    // separator-chain indices of the run's two ends
+  const size_t MB = (size_t)BS * BS;
+  const int role = __builtin_amdgcn_readfirstlane(role8b(wave));   // 0 chain, 1 / 2 helpers, 3 chain's mate, 4 .. 7 strip waves
+  const bool uni_tables = coupling_tables_uniform(K, first, first + n_int - 1);   // (then the tables of `first` serve every node)
+  const int n_s = hasL ? 4 : 1;              // first run: only the right-hand side column (strip 4, role 7) is alive
+  const bool builder = role <= 3;            // the D team
+  const bool strips = role >= 4 && (hasL || role == 7);
+  double gmax_run = 0.0;
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64]) ? ch.dbg : nullptr;
+  const int dbg_k = dbgp ? (int)ch.dbg[65] : -1;
+  if (dbgp && lane == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    atomicOr(reinterpret_cast<unsigned long long*>(ch.dbg + 67), (unsigned long long)((hw >> 4) & 3) << (4 * wave));
+    if (wave == 0) ch.dbg[68] = hw;
+  }
+#define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
+  if (tid < 16) sync[tid] = 0;
+  if (tid < 64) lst[tid] = 0;
+  if (c == 0 && node0) {                               // the left pin owns no frames here: its block starts from zero, the
+    for (int e = tid; e < BS * BS; e += SW_T) sp.D[e] = 0.0;       // run's spike contribution AL is added by the reduction
+    if (tid < BS) sp.b[tid] = 0.0;
+  }
+  if (tid < NP) {
+    kq[tid] = K.q_w[tid];
+    klo[tid] = K.lo[tid];
+    khi[tid] = K.hi[tid];
+  }
+  __syncthreads();
+
+  Trio3Sync tsy;
+  {  // ---- first node of the run, its spike F_0 = E_l (dense form) with the right-hand side in column 79
+    NodeFetch f;
+    build_fetch<SW_T>(f, ch, K, first, tid);
+    fill_coupling_coef<SW_T>(cL, cR0, K, first, tid, kq);
+    for (int e = tid; e < MAT; e += SW_T) Y[e] = 0.0;
+    gmax_run = build_finish<SW_T>(Xf, bvb, f, K, first, tid, kq, klo, khi);
+    __syncthreads();                                   // node, bv, tables, zeros complete
+    if (hasL)
+      for (int e = tid; e < 9 * NP; e += SW_T) {
+        const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
+        if (ii <= jj) Y[(ii * NP + p) * LD + jj * NP + p] = cL[e];
+      }
+    if (tid < BS) Y[tid * LD + (BS - 1)] = bvb[tid];
+    __syncthreads();
+    if (role < 3) chol80_trio3(Xf, role, lane, numeric_err, sync, tsy);
+    __syncthreads();
+  }
+
+  int tb = 0, tsb = 0;                       // rounds of the builders' / the strip waves' barrier
+#pragma unroll 1
+  for (int k = 0; k < n_int; ++k) {
+    const int node = first + k, next = node + 1;
+    const bool last = k + 1 == n_int;
+    const bool has_next = !last || hasR;
+    const int ln = opaque(lane);
+    const int li = ln & 15, lk = ln >> 4;
+    double* const cRk = (uni_tables || !(k & 1)) ? cR0 : cL;
+    if (builder) {
+      // ============================== G_k and the next node: the four D waves ==============================
+      const int bw = role;                             // 0 chain, 1, 2 helpers, 3 the chain's SIMD mate (wave 4)
+      const int bt = bw * 64 + ln;                     // builder thread: state pairs bt, bt + 256, bt + 512 (< 625)
+      const int fb_next = 3 * (next - node0);          // (node t holds the local frames 3 (t - pin_left) ..)
+      double hq[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0}, gq[3] = {0, 0, 0}, cvq[3] = {0, 0, 0}, lamq = 0.0;
+      bool liveq[3] = {false, false, false}, ownq[3] = {false, false, false};
+      int pdq[3], pcq[3];
+      bool ownp[3], dgp[3];
+      int pdg = 0;
+      bool anydg = false;
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int e = bt + 256 * sl;
+        ownp[sl] = e < NP * NP;
+        pdq[sl] = ownp[sl] ? e / NP : 0;
+        pcq[sl] = ownp[sl] ? e % NP : 0;
+        dgp[sl] = ownp[sl] && pdq[sl] == pcq[sl];
+        if (dgp[sl]) pdg = pdq[sl];                    // (a thread owns at most one diagonal pair: 256 and 512 are no multiples of 26)
+        anydg = anydg || dgp[sl];
+      }
+      if (has_next) {
+        const int cur = ch.st->cur;
+        const double* Hg = cur ? ch.H1 : ch.H0;
+        lamq = ch.st->lam;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (fb_next + j < K.n_frames) {
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl)
+              if (ownp[sl]) hq[sl][j] = Hg[(size_t)(fb_next + j) * NP * NP + bt + 256 * sl];
+          }
+        if (anydg) {
+          const double* xg = cur ? ch.x1 : ch.x0;
+          const double* gg = cur ? ch.g1 : ch.g0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (fb_next + j < K.n_frames) {
+              xq[j] = xg[(size_t)(fb_next + j + HALO) * NP + pdg];
+              gq[j] = gg[(size_t)(fb_next + j) * NP + pdg];
+            }
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr) {
+            const int j = pr == 2 ? 1 : 0, jp = pr == 0 ? 1 : 2;
+            if (fb_next + jp < K.n_frames)
+              cvq[pr] = 2.0 * kq[pdg] * band_coef_clip(K.n_offset + fb_next + j, jp - j, K.n_global, K.clip_len);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          liveq[j] = fb_next + j < K.n_frames;
+          ownq[j] = fb_next + j >= K.own_lo && fb_next + j < K.own_hi;
+        }
+      }
+      if (bw == 0) SW_STAMP(0);
+      // U_k complete (the trio came out of the factorisation), wave 4 through with the store of G_k-1; then every strip wave
+      // through with Xg
+      lds_barrier(cB, tb, 4, ln);
+      lds_wait(c_gfdone, n_s * k);
+      if (bw == 0) SW_STAMP(1);
+      {
+        d4 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = gram4_tile(bw, q);
+          if (t >= 0) g[q] = tile_u_ut(Xf, tri_i(t), tri_j(t), li, lk);
+        }
+        asm volatile("" : "+v"(g[0][0]), "+v"(g[1][0]), "+v"(g[2][0]), "+v"(g[3][0]));
+        SW_STAMP(32 + wave);
+        if (k > 0 && !uni_tables) fill_coupling_coef<256>(nullptr, cRk, K, node, bt, kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = gram4_tile(bw, q);
+          if (t >= 0) {
+            const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              Xg[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = g[q][rr];
+              if (ib != jb) Xg[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = g[q][rr];
+            }
+          }
+        }
+      }
+      lds_barrier(cB, tb, 4, ln);                      // G_k in Xg, every read of U_k (Xf) done, tables of this node in place
+      if (bt == 0) __hip_atomic_fetch_add(c_gready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (bw == 0) SW_STAMP(2);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(hq[0][j]), "+v"(hq[1][j]), "+v"(hq[2][j]), "+v"(xq[j]), "+v"(gq[j]));
+      asm volatile("" : "+v"(lamq));
+      SW_STAMP(24 + wave);
+      if (has_next) {
+        double* const bvn = bvb + ((k + 1) & 1) * BS;
+        // S = E^T G_k E on the thread's blocks (reads Xg), the next node written straight into Xf.  Every LDS read of the three
+        // slots first (unconditional: a slot the thread does not own reads pair (0, 0)), then the arithmetic, the stores guarded
+        double ca[3][6], cb[3][6], gv[3][3][3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+          const int pr = pdq[sl], pc = pcq[sl];
+          ca[sl][0] = cRk[0 * NP + pr]; ca[sl][1] = cRk[1 * NP + pr]; ca[sl][2] = cRk[2 * NP + pr];
+          ca[sl][3] = cRk[4 * NP + pr]; ca[sl][4] = cRk[5 * NP + pr]; ca[sl][5] = cRk[8 * NP + pr];
+          cb[sl][0] = cRk[0 * NP + pc]; cb[sl][1] = cRk[1 * NP + pc]; cb[sl][2] = cRk[2 * NP + pc];
+          cb[sl][3] = cRk[4 * NP + pc]; cb[sl][4] = cRk[5 * NP + pc]; cb[sl][5] = cRk[8 * NP + pc];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) {
+            const double* gp = Xg + (jj * NP + pr) * LD + pc;
+            gv[sl][jj][0] = gp[0];
+            gv[sl][jj][1] = gp[NP];
+            gv[sl][jj][2] = gp[2 * NP];
+          }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+          const int pr = pdq[sl], pc = pcq[sl];
+          const bool dg = dgp[sl];
+          const double a00 = ca[sl][0], a01 = ca[sl][1], a02 = ca[sl][2], a11 = ca[sl][3], a12 = ca[sl][4], a22 = ca[sl][5];
+          const double b00 = cb[sl][0], b01 = cb[sl][1], b02 = cb[sl][2], b11 = cb[sl][3], b12 = cb[sl][4], b22 = cb[sl][5];
+          double mm[3][3], S[3][3];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) {
+            const double g0 = gv[sl][jj][0], g1 = gv[sl][jj][1], g2 = gv[sl][jj][2];
+            mm[jj][0] = g0 * b00 + g1 * b01 + g2 * b02;
+            mm[jj][1] = g1 * b11 + g2 * b12;
+            mm[jj][2] = g2 * b22;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 3; ++ii) {
+            S[0][ii] = a00 * mm[0][ii] + a01 * mm[1][ii] + a02 * mm[2][ii];
+            S[1][ii] = a11 * mm[1][ii] + a12 * mm[2][ii];
+            S[2][ii] = a22 * mm[2][ii];
+          }
+          double v[3][3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) v[j][jp] = (j == jp ? hq[sl][j] : 0.0);
+          if (dg) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              double d = 1.0, bb = 0.0;
+              if (liveq[j]) {
+                d = hq[sl][j];
+                const double gtol = GRAD_ZERO_REL * d;
+                const bool fixed = (xq[j] <= klo[pr] && gq[j] > gtol) || (xq[j] >= khi[pr] && gq[j] < -gtol);
+                d = d + lamq * fmax(d, DIAG_FLOOR);
+                if (fixed) d *= FIX_SCALE;
+                bb = fixed ? 0.0 : -gq[j];
+                if (ownq[j]) gmax_run = fmax(gmax_run, fabs(bb));   // (window sharding: owned frames only)
+              }
+              v[j][j] = d;
+              bvn[j * NP + pr] = bb;
+            }
+            v[0][1] = v[1][0] = cvq[0];
+            v[0][2] = v[2][0] = cvq[1];
+            v[1][2] = v[2][1] = cvq[2];
+          }
+          if (ownp[sl]) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int jp = 0; jp < 3; ++jp) Xf[(j * NP + pr) * LD + jp * NP + pc] = v[j][jp] - S[j][jp];
+          }
+        }
+        // (padding rows / columns 75 .. 79: the factorisation left an identity block there; the diagonal is rewritten all the same,
+        //  and the padding of the right-hand side is zero in both buffers)
+        if (bt < BS - 3 * NP) {
+          Xf[(3 * NP + bt) * LD + 3 * NP + bt] = 1.0;
+          bvn[3 * NP + bt] = 0.0;
+        }
+      }
+      SW_STAMP(60 + (wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 5 ? 2 : 3))));
+      lds_barrier(cB, tb, 4, ln);                      // next node complete in Xf
+      if (bt == 0) __hip_atomic_fetch_add(c_bv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (bw == 0) SW_STAMP(4);
+      if (bw < 3) {
+        if (!last) chol80_trio3(Xf, bw, ln, numeric_err, sync, tsy, (dbgp && k == dbg_k) ? lst : nullptr);
+        SW_STAMP(8 + wave);
+      } else if (bw == 3) {
+        // G_k -> HBM, lower tiles only (G is symmetric: the back-substitution mirrors them): the chain's SIMD mate, 30 items per lane
+        double* Gg = ch.D + node * MB;
+#pragma unroll 6
+        for (int q = 0; q < LOWER_ITEMS / 64; ++q) {
+          const int idx = ln + 64 * q;
+          int r, cc;
+          lower_item(idx, r, cc);
+          *reinterpret_cast<double2*>(Gg + r * BS + cc) = make_double2(Xg[r * LD + cc], Xg[r * LD + cc + 1]);
+        }
+        SW_STAMP(8 + wave);
+      }
+    }
+    if (strips) {
+      // ============================== the spike of node k ==============================
+      SpikeArgs sa;
+      sa.Xg = Xg; sa.Y = Y; sa.Ag = sp.AL + (size_t)(hasL ? opaque(sL) : 0) * MB; sa.cRk = cRk; sa.bvn = bvb + ((k + 1) & 1) * BS;
+      sa.zk = ch.b + (size_t)node * BS; sa.c_gready = c_gready; sa.c_gfdone = c_gfdone; sa.c_fready = c_fready; sa.c_bv = c_bv; sa.cS = cS;
+      sa.k = k; sa.n_s = n_s; sa.hasL = hasL; sa.has_next = has_next; sa.stamps = (dbgp && k == dbg_k) ? lst : nullptr;
+      if (role == 4) spike_node<4>(sa, tsb, ln);
+      else if (role == 5) spike_node<5>(sa, tsb, ln);
+      else if (role == 6) spike_node<6>(sa, tsb, ln);
+      else spike_node<7>(sa, tsb, ln);
+    }
+  }
+  __syncthreads();                                     // both teams through
+  if (dbgp) {
+    if (tid < 64 && lst[tid]) dbgp[tid] = lst[tid];
+  }
+  if (hasR) {                                          // the node built last is the right separator
+    {
+      double2* d2 = reinterpret_cast<double2*>(sp.D + (size_t)sR * MB);
+      for (int idx = tid; idx < BS * BS / 2; idx += SW_T) {
+        const int e = 2 * idx, r = e / BS, cc = e % BS;
+        d2[idx] = make_double2(Xf[r * LD + cc], Xf[r * LD + cc + 1]);
+      }
+    }
+    if (tid < BS) sp.b[(size_t)sR * BS + tid] = Y[tid * LD + (BS - 1)];
+    if (hasL) {
+      double* Cg = sp.Cpl + (size_t)sL * MB;           // block(R, L): rows R, columns L
+      for (int e = tid; e < BS * BS; e += SW_T) {
+        const int r = e / BS, cc = e % BS;
+        Cg[e] = cc < 3 * NP ? Y[r * LD + cc] : 0.0;
+      }
+    }
+  }
+#undef SW_STAMP
+  publish_gmax<SW_T>(gmax_run, red, ch.gn_part, c, tid);
+}
+
 // Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as
 // column 79 of the spike, so row 79 of AL holds -(sum W^T y) = the update of b, and rows / columns >= 75 of AL are not
 // part of the Schur update.  (A launch of its own: folding it into the sweep - the later of a separator's two runs adds AL -
@@ -1007,6 +2410,10 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
 int chunk_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep2),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep3),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweep3Lds));
   return ACINO_OK;
 }
 
@@ -1015,8 +2422,16 @@ int chunk_reduce(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, con
                  Profiler* prof) {
   {
     ProfSpan span(prof, PC_CHUNK_SWEEP, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(SW_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
-                       pl.n_chunks, pl.node0, pl.pin_right);
+    static const int variant = [] { const char* e = getenv("ACINO_SWEEP"); return e ? atoi(e) : 3; }();
+    if (variant == 3)
+      hipLaunchKernelGGL(k_chunk_sweep3, dim3(pl.n_chunks), dim3(SW_T), kSweep3Lds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                         pl.n_chunks, pl.node0, pl.pin_right);
+    else if (variant == 1)
+      hipLaunchKernelGGL(k_chunk_sweep, dim3(pl.n_chunks), dim3(SW_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                         pl.n_chunks, pl.node0, pl.pin_right);
+    else
+      hipLaunchKernelGGL(k_chunk_sweep2, dim3(pl.n_chunks), dim3(SW_T), kSweepLds, s, ch, sp, d_c, d_numeric_err, d_status, pl.m,
+                         pl.n_chunks, pl.node0, pl.pin_right);
   }
   ACINO_LAUNCH_CHECK();
   if (pl.n_sep == 0) return ACINO_OK;

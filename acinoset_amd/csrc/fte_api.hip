@@ -724,23 +724,36 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     return ACINO_ERR_HIP;
   }
   {
-    BcrChain& rc = ctx->plan.active() ? ctx->sepchain : ctx->chain;   // the chain the schedule reduces
-    rc.d_elim = ctx->b.sched;
-    rc.d_remain = ctx->b.sched + ctx->sched.elim.size();
+    BcrChain& red = ctx->plan.active() ? ctx->sepchain : ctx->chain;   // the chain the schedule reduces
+    red.d_elim = ctx->b.sched;
+    red.d_remain = ctx->b.sched + ctx->sched.elim.size();
     if (!ctx->sched.tail.empty() && !p->shared_gpu) {
-      rc.d_tail = rc.d_remain + ctx->sched.remain.size();
-      rc.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() +
+      red.d_tail = red.d_remain + ctx->sched.remain.size();
+      red.d_done = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() +
                   ctx->sched.pairs.size();
     }
     if (!ctx->sched.pairs.empty()) {
-      rc.d_pairs = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
-      rc.n_pairs = (int)(ctx->sched.pairs.size() / 2);
+      red.d_pairs = ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size();
+      red.n_pairs = (int)(ctx->sched.pairs.size() / 2);
     }
-    ctx->n_trunc = rc.n_pairs;
-    rc.refine_buf = ctx->b.refine_buf;
+    ctx->n_trunc = red.n_pairs;
+    red.refine_buf = ctx->b.refine_buf;
     // one persistent launch for the separator chain's back-substitution: its isolated workgroups wait for each other, so it
     // is kept off GPUs that other spin-waiting kernels may share (shared_gpu: batched clips, several ranks on one device)
-    rc.st_flags = (ctx->plan.active() && !p->shared_gpu && !getenv("ACINO_NO_SEP_TAIL")) ? ctx->b.st_flags : nullptr;
+    // - and off devices that cannot hold all of its workgroups at once (occupancy x compute units of THIS device: a CU mask, a
+    // partitioned GPU): those take the per-level kernels
+    red.st_flags = nullptr;
+    if (ctx->plan.active() && !p->shared_gpu && !getenv("ACINO_NO_SEP_TAIL") && ctx->b.st_flags) {
+      int blocks = 0, capacity = 0;
+      int rc = bcr_set_func_attributes();                // (the occupancy query needs the kernel's LDS attribute in place)
+      if (!rc) rc = bcr_sep_tail_fit(ctx->sched, &blocks, &capacity);
+      if (rc) {
+        delete ctx;
+        return rc;
+      }
+      if (const char* e = getenv("ACINO_SEP_TAIL_CAPACITY")) capacity = atoi(e);   // (tests: pretend a smaller device)
+      if (blocks > 0 && blocks <= capacity) red.st_flags = ctx->b.st_flags;
+    }
   }
   if (ctx->plan.active()) {
     ctx->sep = SepView{ctx->sepchain.D, ctx->sepchain.Cpl, const_cast<double*>(ctx->sepchain.AL0), ctx->sepchain.b};
@@ -1239,6 +1252,26 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
   }
   int rc = acino_fte_get_state(ctx, &st, stream);
   if (rc) return rc;
+  if (st.status == 6 && ctx->sepchain.st_flags && max_iter > 0) {
+    // the single-launch back-substitution of the separator chain waited in vain for a lower workgroup (something else holds
+    // the compute units it counted on): the refused step changed nothing but the counters - fall back to the per-level
+    // kernels for the rest of this context's life and go on from the same iterate
+    ctx->sepchain.st_flags = nullptr;
+    ctx->sep.flags = nullptr;
+    ctx->sep.n_flags = 0;
+    if (ctx->gexec) {
+      (void)hipGraphExecDestroy(ctx->gexec);
+      ctx->gexec = nullptr;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    st.status = 0;
+    st.iter -= 1;
+    ACINO_HIP_CHECK(hipMemcpyAsync(ctx->b.state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+    ACINO_HIP_CHECK(hipMemsetAsync(ctx->b.numeric_err, 0, sizeof(int), s));
+    ACINO_HIP_CHECK(hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    return acino_fte_solve(ctx, max_iter > st.iter ? max_iter - st.iter : 1, out, stream);
+  }
   if (out) *out = st;
   if (st.status == 5) {
     set_error("non-positive pivot in the block factorisation (system not positive definite)");
