@@ -101,37 +101,57 @@ def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_f
     d_arr = d_arr.reshape((-1, 4))                                           # :100
     if dlc_tables is None:
         paths = sorted(glob.glob(os.path.join(project_dir, "data", "*.h5")))  # :106
-        dlc_tables = [io.read_dlc_table(p)[:2] for p in paths]
+        dlc_tables = [io.read_dlc_table(p) for p in paths]
     C_ = len(k_arr)
     if len(dlc_tables) != C_:
         raise ValueError(f"{len(dlc_tables)} detection tables for {C_} cameras")
-    n_tot = min(int(v.shape[0]) for _, v in dlc_tables)
-    if start_frame + n_frames > n_tot:
-        raise ValueError("frame window outside the detection tables")
+    # a table is (bodyparts, values[rows, K, 3]) or (bodyparts, values, frame index[rows]): the reference looks a detection up by
+    # the VALUE of its frame index (utils.py:105-120 -> `frame == n - 1`), not by its row number, and every table by its own
+    # body-part order
+    tabs = []
+    for tb in dlc_tables:
+        parts, vals = list(tb[0]), np.asarray(tb[1], dtype=np.float64)
+        idx = np.arange(vals.shape[0], dtype=np.int64) if len(tb) < 3 or tb[2] is None else np.asarray(tb[2], dtype=np.int64)
+        if idx.shape != (vals.shape[0],) or np.unique(idx).size != idx.size:
+            raise ValueError("a detection table needs one distinct frame index per row")
+        tabs.append((parts, vals, idx))
+    want = np.arange(start_frame, start_frame + n_frames, dtype=np.int64)
+    rows = []
+    for parts, vals, idx in tabs:
+        order = np.argsort(idx)
+        pos = np.searchsorted(idx[order], want)
+        if (pos >= idx.size).any() or (idx[order][np.minimum(pos, idx.size - 1)] != want).any():
+            raise ValueError("frame window outside the detection tables")
+        rows.append(order[pos])
     # ---- measurements and weights per pose slot (:113-128, :184-206)
     pair = marker_pairing(skel_dict, names, pairing)
     Lp = len(names)
     meas = np.full((n_frames, C_, Lp, 2), np.nan)
     w = np.zeros((n_frames, C_, Lp))
-    for c, (parts, vals) in enumerate(dlc_tables):
+    for c, (parts, vals, _idx) in enumerate(tabs):
         for l, mk in enumerate(pair):
             if mk is None or mk not in parts:
                 continue
-            k = list(parts).index(mk)
-            sl = vals[start_frame:start_frame + n_frames, k]
+            sl = vals[rows[c], parts.index(mk)]
             meas[:, c, l] = sl[:, :2]
             w[:, c, l] = np.where(sl[:, 2] > lik_thresh, 1.0 / r_meas, 0.0)
-    # ---- initial point: line through the triangulated "forehead" over ALL frames (:143-166), evaluated at 0 .. N-1 (:157)
+    # ---- initial point: line through the triangulated "forehead" over ALL frames the cameras share (:143-166), a regression
+    #      against the frame VALUE, evaluated at 0 .. N-1 (:157)
     init_x = np.zeros((n_frames, 3 + 3 * prog["n_angles"]))
-    parts0 = list(dlc_tables[0][0])
-    if "forehead" in parts0 and C_ >= 2:
-        fk = parts0.index("forehead")
-        det = np.stack([np.asarray(v[:n_tot, fk], dtype=np.float64)[:, None, :] for _, v in dlc_tables], axis=1)   # [F, C, 1, 3]
+    if all("forehead" in parts for parts, _v, _i in tabs) and C_ >= 2:
+        common = tabs[0][2]
+        for _p, _v, idx in tabs[1:]:
+            common = np.intersect1d(common, idx)
+        cols = []
+        for parts, vals, idx in tabs:
+            order = np.argsort(idx)
+            cols.append(vals[order[np.searchsorted(idx[order], common)], parts.index("forehead")][:, None, :])
+        det = np.stack(cols, axis=1)                                                                            # [F, C, 1, 3]
         tri = calib.triangulate_pairs_dense(det, lik_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
         tri = np.asarray(tri.cpu().numpy() if isinstance(tri, torch.Tensor) else tri)[:, 0]
         ok = np.isfinite(tri).all(1)
         if ok.sum() >= 2:
-            f = np.arange(n_tot, dtype=np.float64)[ok]
+            f = common.astype(np.float64)[ok]
             coef, *_ = np.linalg.lstsq(np.stack([f, np.ones_like(f)], 1), tri[ok], rcond=None)
             fe = np.arange(n_frames, dtype=np.float64)
             init_x[:, 0:3] = fe[:, None] * coef[0][None, :] + coef[1][None, :]

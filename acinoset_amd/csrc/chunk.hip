@@ -535,11 +535,14 @@ __device__ __forceinline__ void chol80_trio2(double* Lm, int role, int lane, int
 //     has no deadline before the last block column.
 // Last block column: the four tiles (t, 4) U_44 wait for U_44 and for helper U's last products, then one barrier of the three.
 //   sync[12]: crit (1 per block column 0 .. 2)   [13]: chain posts   [14]: helper L's panel columns   [15]: helper U done with step 3
-template <int KB>
-struct LowerList {                                     // (r, c), r = KB+2 .. 4, c = KB+1 .. r: row KB+2 first (the chain's tiles)
+// (block column 0 is the long one - 3 panel tiles + 9 lower products against helper U's 4 - and sets the distance the helper
+//  keeps to the chain for the rest of the factorisation: there row 4 of the lower products goes to helper U, who has them stored
+//  and signalled (culow) before helper L touches row 4 of block column 1)
+template <int KB, int R0 = KB + 2, int R1 = NT - 1>
+struct LowerList {                                     // (r, c), r = R0 .. R1, c = KB+1 .. r: row KB+2 first (the chain's tiles)
   int ti[9], tj[9], n;
   constexpr LowerList() : ti{}, tj{}, n(0) {
-    for (int r = KB + 2; r < NT; ++r)
+    for (int r = R0; r <= R1; ++r)
       for (int c = KB + 1; c <= r; ++c) {
         ti[n] = r;
         tj[n] = c;
@@ -601,9 +604,9 @@ __device__ __forceinline__ void load_panel(double (&P)[NT][4], const double* Lm,
 }
 // helper L, block column KB: the lower trailing products; the first two (the chain's next panel and look-ahead tiles) signalled.
 // Every operand of the step - the panel column and all accumulator tiles - is requested before the first product: one LDS round trip.
-template <int KB>
+template <int KB, class LIST = LowerList<KB>>
 __device__ __forceinline__ void helperL_trailing(double* Lm, int li, int lk, int* ccrit, int lane) {
-  constexpr LowerList<KB> TL{};
+  constexpr LIST TL{};
   double P[NT][4];
   d4 a[TL.n];
   load_panel<KB>(P, Lm, li, lk);
@@ -669,7 +672,7 @@ __device__ __forceinline__ void panel_tiles(double* Lm, int kb, int t0, int li, 
   }
 }
 struct Trio3Sync {
-  int t3 = 0, posts = 0, crit = 0, lpan = 0, udone = 0;
+  int t3 = 0, posts = 0, crit = 0, lpan = 0, udone = 0, ulow = 0;
 };
 __device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int* err, int* sync, Trio3Sync& ts,
                                              long long* dbg = nullptr) {
@@ -679,6 +682,7 @@ __device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int
   int* const cpost = sync + 13;
   int* const clpan = sync + 14;
   int* const cudone = sync + 15;
+  int* const culow = sync + 11;                        // helper U: row 4 of block column 0's lower products stored
   const int post0 = ts.posts, crit0 = ts.crit, lp0 = ts.lpan;
   if (role == 0) {
     // ---------------- the pivot chains ----------------
@@ -714,13 +718,14 @@ __device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int
 #pragma unroll 1
     for (int kb = 0; kb < NT - 1; ++kb) {
       spin_until(cpost, post0 + 2 * kb + 1);           // U_kk
+      if (kb == 1) spin_until(culow, ts.ulow + 1);     // row 4 carries the update of step 0
       if (kb == 0) panel_tiles<3>(Lm, 0, 2, li, lk);
       else if (kb == 1) panel_tiles<2>(Lm, 1, 3, li, lk);
       else if (kb == 2) panel_tiles<1>(Lm, 2, 4, li, lk);
       post_one(clpan, lane);                           // panel tiles (kb+2 .., kb) stored
       spin_until(cpost, post0 + 2 * kb + 2);           // the chain's panel tile (kb+1, kb)
       if (dbg && lane == 0) dbg[56 + kb] = (long long)wall_clock64();
-      if (kb == 0) helperL_trailing<0>(Lm, li, lk, ccrit, lane);
+      if (kb == 0) helperL_trailing<0, LowerList<0, 2, 3>>(Lm, li, lk, ccrit, lane);
       else if (kb == 1) helperL_trailing<1>(Lm, li, lk, ccrit, lane);
       else if (kb == 2) helperL_trailing<2>(Lm, li, lk, ccrit, lane);
       else post_one(ccrit, lane);
@@ -741,8 +746,13 @@ __device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int
       else if (kb == 3) panel_tiles<3>(Lm, 3, 0, li, lk);
       spin_until(cpost, post0 + 2 * kb + 2);           // the chain's panel tile
       spin_until(clpan, lp0 + kb + 1);                 // helper L's panel tiles
-      if (kb == 0) helperU_trailing<0>(Lm, li, lk);
-      else if (kb == 1) helperU_trailing<1>(Lm, li, lk);
+      if (kb == 0) {
+        double P[NT][4];
+        load_panel<0>(P, Lm, li, lk);
+        trail_rest<LowerList<0, 4, 4>, 0, 0>(Lm, P, li, lk);     // (4, 1) .. (4, 4)
+        post_one(culow, lane);
+        trail_rest<UpperList<0>, 0, 0>(Lm, P, li, lk);
+      } else if (kb == 1) helperU_trailing<1>(Lm, li, lk);
       else if (kb == 2) helperU_trailing<2>(Lm, li, lk);
       else helperU_trailing<3>(Lm, li, lk);
       if (dbg && lane == 0) dbg[52 + kb] = (long long)wall_clock64();
@@ -757,6 +767,7 @@ __device__ __forceinline__ void chol80_trio3(double* Lm, int role, int lane, int
   ts.crit = crit0 + 4;
   ts.lpan = lp0 + 4;
   ts.udone += 1;
+  ts.ulow += 1;
 }
 
 // The NQ tiles (ib[q], jb[q]) of the left separator's update D_L -= W^T W that one spike wave owns: accumulators
@@ -2034,6 +2045,11 @@ k_chunk_sweep3(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* n
             gv[sl][jj][2] = gp[2 * NP];
           }
         }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) asm volatile("" : "+v"(gv[sl][jj][0]), "+v"(gv[sl][jj][1]), "+v"(gv[sl][jj][2]), "+v"(ca[sl][jj]), "+v"(cb[sl][jj + 3]));
+        if (bw == 0) SW_STAMP(3);
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl) {
           const int pr = pdq[sl], pc = pcq[sl];

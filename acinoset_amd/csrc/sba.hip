@@ -389,6 +389,26 @@ __device__ __forceinline__ void sba_observe(double fs, const double (&R)[12], co
   }
 }
 
+// Input check of BOTH paths: a camera index out of range, or two observations of one point by one camera (the table path keeps
+// ONE coupling block per (point, camera): a second observation would overwrite it and leave the Schur complement inconsistent
+// with U and V), raise scal[7].  One thread per point, the cameras seen so far as a bit mask (at most 16 cameras).
+__global__ void __launch_bounds__(256) k_sba_check(SbaBuf B) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= B.P) return;
+  unsigned seen = 0;
+  bool bad = false;
+  for (int o = B.pt_start[p]; o < B.pt_start[p + 1]; ++o) {
+    const int c = B.cam_idx[B.pt_obs[o]];
+    if (c < 0 || c >= B.C) {
+      bad = true;
+    } else {
+      bad = bad || ((seen >> c) & 1u);
+      seen |= 1u << c;
+    }
+  }
+  if (bad) B.scal[7] = 1.0;
+}
+
 // slot[p][c] <- observation id (the table is preset to -1); two observations of one (point, camera) pair raise scal[7]
 __global__ void __launch_bounds__(256) k_sba_slots(SbaBuf B) {
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -1158,6 +1178,18 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     return ACINO_OK;
   };
 
+  {
+    // ---- input check, both paths; the flag is combined over the ranks (max) BEFORE anyone returns: a rank that left early
+    //      would leave the others waiting in the first reduction of the solve
+    ACINO_HIP_CHECK(hipMemsetAsync(B.scal, 0, 64, s));
+    hipLaunchKernelGGL(k_sba_check, dim3(nblk), dim3(256), 0, s, B);
+    ACINO_LAUNCH_CHECK();
+    if (int e = greduce(B.scal + 7, 1, 1)) return e;
+    double dup = 0.0;
+    ACINO_HIP_CHECK(hipMemcpyAsync(&dup, B.scal + 7, 8, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    ACINO_REQUIRE(dup == 0.0, "SBA: two observations of one point by one camera, or a camera index out of range");
+  }
   if (fused) {
     // ---- fused path: per LM iteration ONE pass that linearises and reduces (k_sba_fused + the two-stage sum), the camera
     //      solve, the trial poses, ONE pass that back-substitutes and prices the trial iterate; one host read-back.
@@ -1165,12 +1197,6 @@ int acino_sba_solve_sharded(const acino_sba_params* prm, const double* d_intr, d
     ACINO_HIP_CHECK(hipMemsetAsync(B.slot, 0xFF, P * C * 4, s));
     hipLaunchKernelGGL(k_sba_slots, dim3(nblk), dim3(256), 0, s, B);
     ACINO_LAUNCH_CHECK();
-    {
-      double dup = 0.0;
-      ACINO_HIP_CHECK(hipMemcpyAsync(&dup, B.scal + 7, 8, hipMemcpyDeviceToHost, s));
-      ACINO_HIP_CHECK(hipStreamSynchronize(s));
-      ACINO_REQUIRE(dup == 0.0, "SBA: two observations of one point by one camera, or a camera index out of range");
-    }
     double hd[4];
     int rc = ACINO_OK;
     if (d_res_before) {

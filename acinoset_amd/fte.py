@@ -121,6 +121,8 @@ class FTEContext:
         if self.cams.shape[0] != self.C:
             raise ValueError("camera count mismatch between det and the rig")
         self._kw = self._resolve_defaults(dict(kw))
+        self._kw0 = dict(self._kw)                # as asked for: an escalation (status 7 -> one more level) edits self._kw
+        self._escalated = False
         self._graph = False
         self._create()
 
@@ -191,7 +193,17 @@ class FTEContext:
         self._kw = dict(self._kw, bcr_levels=levels, refine_sweeps=int(self.params.refine_sweeps) or
                         int(self._kw.get("refine_sweeps", 0)), trunc_tol=float(self.params.trunc_tol))
         self._kw.pop("trunc_distance", None)
+        self._escalated = True
         self._create()
+
+    def reset_solver(self):
+        """Back to the solver settings the context was created with, if an escalation changed them (contexts kept by
+        ``reuse_context``: what a solve does must not depend on what earlier solves in the same context ran into)."""
+        if self._escalated:
+            self.close()
+            self._kw = dict(self._kw0)
+            self._escalated = False
+            self._create()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -344,7 +356,10 @@ def triangulation_init(det, k_arr, d_arr, r_arr, t_arr, dlc_thresh):
     tri = calib.triangulate_pairs_dense(det, dlc_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
     tri = tri if isinstance(tri, np.ndarray) else tri.cpu().numpy()
     N = tri.shape[0]
-    head = np.nanmean(tri[:, 0:3], axis=1)               # eyes + nose
+    seen = np.isfinite(tri[:, 0:3]).all(-1)              # eyes + nose: mean of the ones that were triangulated
+    cnt = seen.sum(1)
+    head = np.where(seen[..., None], tri[:, 0:3], 0.0).sum(1) / np.maximum(cnt, 1)[:, None]
+    head[cnt == 0] = np.nan                              # (no np.nanmean: frames without any head marker are expected, not a warning)
     fwd = tri[:, 2] - tri[:, 3]                          # neck_base -> nose
     idx = np.arange(N)
     x0 = np.zeros((N, N_STATES))
@@ -388,6 +403,7 @@ def _context_for(det, k_arr, d_arr, r_arr, t_arr, Ts, reuse, kw):
         ctx.enable_graph(True)
         _CTX_CACHE[key] = ctx
     else:
+        ctx.reset_solver()                                # (a no-op unless an earlier solve escalated the reduction levels)
         ctx.det.copy_(det)                                # (the library reads the detections through this tensor's pointer)
     return ctx, True
 
@@ -452,10 +468,16 @@ def fte_solve(meas, likelihood, k_arr, d_arr, r_arr, t_arr, Ts, x0=None, dlc_thr
         ctx.set_x(xa0)
         info = ctx.solve(max_iter)
         x, pos, dx, ddx = ctx.result()
+    except Exception:
+        # (the initial guess's flag is read after the solve - no synchronisation in front of it -, but whatever a solve from an
+        #  all-zero start ran into must not hide the real cause)
+        if init_flag is not None and int(init_flag.item()):
+            raise ValueError("no triangulated head marker in the whole sequence") from None
+        raise
     finally:
         if not cached:
             ctx.close()
-    if init_flag is not None and int(init_flag.item()):        # (tested after the solve: no synchronisation in front of it)
+    if init_flag is not None and int(init_flag.item()):
         raise ValueError("no triangulated head marker in the whole sequence")
     if info["status"] == 5:
         raise RuntimeError("FTE: block factorisation hit a non-positive pivot")

@@ -371,7 +371,9 @@ int acino_sba_solve(const acino_sba_params* prm, const double* d_intr, double* d
  * "the SBA extrinsic refinement adds a 36x36 camera-block + 36-vector all-reduce per
  * iteration").  Every rank passes its own points and observations and identical camera poses; `reduce` must combine
  * n doubles at d_buf (device memory inside d_ws) over all ranks in place - op 0: sum, op 1: max - and return 0; it is
- * called after the stream has been synchronised, five times per LM iteration (max point gradient; camera blocks + camera
+ * called after the stream has been synchronised, once at entry (max of the input-check flag: a rank with a duplicate (point,
+ * camera) pair or a camera index out of range makes EVERY rank return ACINO_ERR_INVALID_ARG together) and five times per LM
+ * iteration (max point gradient; camera blocks + camera
  * gradient, 27 n_cams doubles; the Schur complement and its right-hand side, (6 n_cams)^2 + 6 n_cams; the predicted
  * reduction; the trial cost - and the initial cost once).  All ranks take identical
  * decisions and leave with identical poses.  reduce == NULL is acino_sba_solve. */

@@ -41,7 +41,7 @@ for kb in range(4):
 import os
 if os.environ.get("ACINO_SWEEP", "3") == "3":          # the two-team kernel: other phases behind the same slots
     names.update({0: "D: iteration starts (loads of the next node requested)", 1: "D: U_k complete, strip waves through with Xg", 2: "D: G_k published",
-                  4: "D: next node built", 7: ""})
+                  4: "D: next node built", 7: "", 3: "D wave 0: the LDS reads of its state pairs have arrived"})
     who = ["wave 2 (strip 1)", "wave 6 (strips 2, 0)", "wave 3 (strip 3)", "wave 7 (strip 4)"]
     for r in range(4):
         names[16 + 4 * r] = f"S {who[r]}: sees G_k"; names[17 + 4 * r] = f"S {who[r]}: T = G F done"

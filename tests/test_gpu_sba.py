@@ -683,6 +683,34 @@ def test_fused_path_edge_cases(gsba):
         sba.bundle_adjust_points_and_extrinsics(uv, X0, pi, np.where(ci == 5, 6, ci), K, D, R, t, max_iter=2)
 
 
+@pytest.mark.parametrize("n_cams", [6, 8])
+def test_library_refuses_duplicate_observations_on_both_paths(gsba, n_cams):
+    """The C ABI's own input check (k_sba_check), without the Python wrapper's: two observations of one (point, camera) pair
+    and a camera index out of range answer ACINO_ERR_INVALID_ARG on the fused path (6 cameras) AND on the table path (8
+    cameras: one coupling block per pair, a duplicate would silently overwrite it); a clean list still solves."""
+    sba, calib = gsba
+    from acinoset_amd import synth
+    rng = np.random.default_rng(5)
+    K6, D6, R6, t6 = synth.make_rig()
+    idx = np.arange(n_cams) % 6
+    K, D, R = K6[idx], D6[idx], R6[idx]
+    t = t6.reshape(6, 3, 1)[idx] + rng.normal(0, 0.05, (n_cams, 3, 1)) * (np.arange(n_cams) >= 6)[:, None, None]
+    X = np.array([2.0, 6.5, 0.7]) + rng.normal(0, 0.4, (12, 3))
+    pi = np.repeat(np.arange(12), n_cams)
+    ci = np.tile(np.arange(n_cams), 12)
+    uv = np.stack([ocam.project_points_fisheye(X[p:p + 1], K[c], D[c], R[c], t[c])[0] for p, c in zip(pi, ci)])
+    X0 = X + rng.normal(0, 0.02, X.shape)
+    args = dict(optimize_cameras=True, f_scale=1.0, max_iter=3, ftol=1e-10, gtol=1e-12, host_checks=False)
+    out = sba._solve(uv, X0, pi, ci, K, D, R, t, **args)
+    assert np.isfinite(out[0]).all()
+    with pytest.raises(ValueError, match="two observations"):
+        sba._solve(np.vstack([uv, uv[:1]]), X0, np.append(pi, 0), np.append(ci, 0), K, D, R, t, **args)
+    with pytest.raises(ValueError, match="two observations|out of range"):
+        sba._solve(uv, X0, pi, np.where(ci == n_cams - 1, n_cams, ci), K, D, R, t, **args)
+    out = sba._solve(uv, X0, pi, ci, K, D, R, t, **args)                 # the library is still usable
+    assert np.isfinite(out[0]).all()
+
+
 def test_fused_solve_repeats_bit_for_bit(gsba):
     """Every sum that decides accept / reject (cost, predicted reduction, trial cost) and every block of the normal equations
     is reduced in a fixed order: the same problem solved three times gives the same bits - points, poses, costs, counts."""
