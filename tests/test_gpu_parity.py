@@ -990,7 +990,7 @@ def test_bf16_rows_solve_against_the_oracle(mods):
     calib, fte, synth = mods
     from oracle import fk as ofk
     from oracle import fte as ofte
-    worst = {"bf16": 0.0, "f64": 0.0}
+    worst = {"bf16": 0.0, "f64": 0.0, "bf16_raw": 0.0}
     for b in range(4):
         seq = synth.make_sequence(30, "trot", seed=700 + b)
         rig = (seq["K"], seq["D"], seq["R"], seq["t"])
@@ -1002,12 +1002,18 @@ def test_bf16_rows_solve_against_the_oracle(mods):
         for prec in ("f64", "bf16"):
             kw = dict(precision="bf16") if prec == "bf16" else {}
             res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=x0, max_iter=80, **kw)
-            if prec == "bf16":                           # polish: fp64 iterations from the mixed end state
+            if prec == "bf16":
+                # the RAW end state of the mode first (what a caller of precision="bf16" gets), then the polish: fp64
+                # iterations from the mixed end state
+                worst["bf16_raw"] = max(worst["bf16_raw"], float(np.abs(res["positions"] - pos_o).max()))
                 res, info = fte.fte_solve(det[..., :2], det[..., 2], *rig, seq["Ts"], x0=_full_state(fte, res["x"]), max_iter=80)
             assert info["status_name"] in ("ftol", "xtol", "gtol"), (prec, info)
             worst[prec] = max(worst[prec], float(np.abs(res["positions"] - pos_o).max()))
-    print(f"bf16 rows vs the oracle: max |dpos| {worst['bf16']:.3e} m; fp64 vs the oracle {worst['f64']:.3e} m")
-    assert worst["f64"] < 1e-7 and worst["bf16"] < 1e-3
+    print(f"bf16 rows vs the oracle: RAW end state max |dpos| {worst['bf16_raw']:.3e} m, after the fp64 polish {worst['bf16']:.3e} m; "
+          f"fp64 vs the oracle {worst['f64']:.3e} m")
+    # the mode's own error (bf16 rows shift the minimiser itself: the polish number only says "same basin") against the
+    # north star's 1e-3 m, with the spread of the flat valleys on top (two fp64 solves differ by 1.4e-3 m there)
+    assert worst["f64"] < 1e-7 and worst["bf16"] < 1e-3 and worst["bf16_raw"] < 3e-3
 
 
 def _full_state(fte, x_active):
