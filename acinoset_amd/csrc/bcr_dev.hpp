@@ -152,15 +152,17 @@ static __device__ void publish_gmax(double gmax, double* red, double* gn_part, i
 //   right (neighbour i+1): W_r[r][(ii,p)] = sum_{jj>=ii} U[(jj,p)][r] * 2 q_p band(f_i+jj,   3+ii-jj)
 // coef[(ii*3 + jj) * NP + p], ii <= jj: the two constant coupling blocks of node i (left: columns in node i-1,
 // right: columns in node i+1).  450 doubles, filled once per workgroup.
-template <int NTH = 256>
-static __device__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid,
-                                          const double* qw = nullptr) {
-  if (!qw) qw = K.q_w;
+// (QW: state -> weight, a callable so that the weights may come from K.q_w or from a copy in LDS WITHOUT a pointer select: a
+//  pointer that may be either is a generic pointer, its loads are FLAT loads, and one pending FLAT load anywhere on a path makes
+//  every later wait of the kernel a wait for ALL memory operations in flight - vmcnt(0) lgkmcnt(0).)
+template <int NTH, class QW>
+static __device__ __forceinline__ void fill_coupling_coef_q(double* coefL, double* coefR, const FteConst& K, int node_i,
+                                                            int tid, QW qw) {
   const int loc_i = 3 * (node_i - K.pin_left);                 // local index of the node's first frame
   const int64_t f_i = K.n_offset + (int64_t)loc_i;
   for (int e = tid; e < 2 * 9 * NP; e += NTH) {
     const int side = e / (9 * NP), q = e % (9 * NP), pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
-    if (side == 0 && !coefL) continue;                         // (a caller that only wants the right tables)
+    if (side == 0 ? !coefL : !coefR) continue;                 // (a caller that only wants one side)
     double v = 0.0;
     if (ii <= jj) {
       const int k = 3 + ii - jj;
@@ -169,11 +171,21 @@ static __device__ void fill_coupling_coef(double* coefL, double* coefR, const Ft
       // frames) is an identity row of the chain and must not be coupled, whatever the global band says there.
       const int hi = side == 0 ? loc_i + ii : loc_i + 3 + ii;
       if (hi < K.n_frames)
-        v = 2.0 * qw[p] * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
-                                              : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
+        v = 2.0 * qw(p) * (side == 0 ? band_coef_clip(f_i - 3 + jj, k, K.n_global, K.clip_len)
+                                             : band_coef_clip(f_i + jj, k, K.n_global, K.clip_len));
     }
-    (side == 0 ? coefL : coefR)[q] = v;
+    if (side == 0) coefL[q] = v;
+    else coefR[q] = v;
   }
+}
+template <int NTH = 256>
+static __device__ __forceinline__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid) {
+  fill_coupling_coef_q<NTH>(coefL, coefR, K, node_i, tid, [&](int p) { return K.q_w[p]; });
+}
+template <int NTH = 256>
+static __device__ __forceinline__ void fill_coupling_coef(double* coefL, double* coefR, const FteConst& K, int node_i, int tid,
+                                                          const double* qw) {
+  fill_coupling_coef_q<NTH>(coefL, coefR, K, node_i, tid, [&](int p) { return qw[p]; });
 }
 
 // True when the coupling tables of every node first .. last are those of an interior node of one long sequence - no clip
@@ -185,6 +197,24 @@ static __device__ __forceinline__ bool coupling_tables_uniform(const FteConst& K
   const int64_t lo = K.n_offset + 3 * (int64_t)(first - K.pin_left) - 3;   // first frame a left table of `first` refers to
   const int64_t hi = K.n_offset + 3 * (int64_t)(last - K.pin_left) + 5;    // last frame a right table of `last` refers to
   return lo >= 3 && hi + 3 <= K.n_global - 4 && 3 * (last - K.pin_left) + 5 < K.n_frames;
+}
+
+// True when the RIGHT table of one node is that of an interior node (every frame of the node and of its right neighbour alive, in
+// one clip, no third-difference row cut by an end of the sequence / clip): the entry (ii, jj), ii <= jj, is then
+// 2 q_p {-1, 6, -15}[jj - ii] - what right_table_interior writes.
+static __device__ __forceinline__ bool right_table_is_interior(const FteConst& K, int node) {
+  const int loc = 3 * (node - K.pin_left);
+  const int64_t f = K.n_offset + (int64_t)loc;
+  const int64_t len = K.clip_len > 0 ? K.clip_len : K.n_global;
+  const int64_t r = K.clip_len > 0 ? f % K.clip_len : f;
+  return f >= 0 && r <= len - 6 && f + 5 < K.n_global && loc + 5 < K.n_frames;
+}
+template <int NTH, class QW>
+static __device__ __forceinline__ void right_table_interior(double* coefR, int tid, QW qw) {
+  for (int q = tid; q < 9 * NP; q += NTH) {
+    const int pair = q / NP, p = q % NP, ii = pair / 3, jj = pair % 3;
+    coefR[q] = ii <= jj ? 2.0 * qw(p) * (jj == ii ? -1.0 : (jj - ii == 1 ? 6.0 : -15.0)) : 0.0;
+  }
 }
 
 }  // namespace acino

@@ -665,7 +665,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   const bool builder = role <= 3;            // the D team
   const bool strips = role >= 4 && (hasL || role == 7);
   double gmax_run = 0.0;
-  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64]) ? ch.dbg : nullptr;
+  long long* const dbgp = (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[66] == 0) ? ch.dbg : nullptr;
   const int dbg_k = dbgp ? (int)ch.dbg[65] : -1;
   if (dbgp && lane == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -970,224 +970,395 @@ __global__ void __launch_bounds__(256) k_sep_combine(SepView sp, const int* __re
 // Back-substitution, one workgroup per run.  x_k = z_k - G_k (E x_k+1) - T_k x_L with T_k = D~_k^-1 F_k; T_k is not
 // stored.  Its action on the left separator's solution obeys the recurrence of the spike itself,
 //     f_0 = F_0 x_L = E_l x_L,    t_k = T_k x_L = G_k f_k,    f_k+1 = F_k+1 x_L = -E^T t_k,
-// so the run is walked twice over the same 31 KB per node (the lower tiles of G_k, mirrored into a symmetric LDS copy):
+// so the run is walked twice over the same 31 KB per node (the lower tiles of G_k):
 //   forward  k = 0 .. n-2 :  t_k = G_k f_k, f_k+1 = -E^T t_k            (f_k kept: 80 doubles per node, ch.Wl)
 //   backward k = n-1 .. 0 :  x_k = z_k - G_k (E x_k+1 + f_k)
-// i.e. <= 61 KB of HBM reads per node instead of the 102 KB of G_k and T_k^T - and no T_k^T store in the sweep (51 KB per node).
-// The next node's tiles are requested (registers) before the current node's products and staged into LDS afterwards.
-constexpr int BK_T = 512;
-constexpr int BK_P = BK_T / BS, BK_W = (BS + BK_P - 1) / BK_P;      // 6 partial sums per row, <= 14 columns each
-constexpr int BK_Q = (LOWER_ITEMS + BK_T - 1) / BK_T;      // 4 items per thread (the last round is mostly empty)
+// i.e. 2 n - 1 DEPENDENT 80 x 80 matrix-vector products per run ("steps"), 61 KB of HBM reads per node.  Until round 4 a step
+// took 2.1 us - three barriers of eight waves around the product (partial sums through LDS, row sums, stencil by 80 threads) -
+// and a prefetch distance of one step.  Now the workgroup is two teams that meet only through LDS counters:
+//   * FOUR PRODUCT WAVES, one per SIMD, which touch no global memory but their stores.  Lane (p, part) - p = 8 wave + lane / 8
+//     one of the 25 states, part = lane % 8 - multiplies the THREE rows (a, p), a = 0 .. 2 (the state's entry in the node's three
+//     frames) by the columns part + 8 j, j = 0 .. 9: 30 multiply-adds, then a three-step butterfly over the 8 lanes of the state
+//     (DPP; every lane ends with the three complete sums, bit-identical).  The stencils E couple only the three frames of ONE
+//     state, so lanes part = 0 .. 2 turn the sums into the next step's vector entries (a, p) with no further exchange, store
+//     x_k / f_k+1 and form the trial iterate of their row; the new vector goes to the other of two LDS buffers, the four waves
+//     meet at a counter, next step.
+//   * FOUR LOADER WAVES, each with one whole node in flight (its 1920 two-double items = 30 per lane, the row operands z_k and
+//     the trial row's x / g / diag H, f_k of far nodes, the step's coupling table where the tables change from node to node):
+//     HBM -> registers -> one of two LDS stages when the product waves are through with it -> "ready".  A loader may sit in
+//     s_waitcnt vmcnt(0) for as long as HBM takes - nobody waits for IT at a barrier - and the four of them keep 120 KB per CU in
+//     flight, which is what the stream needs (the compiler turns a register ring of prefetches inside ONE wave's loop into
+//     vmcnt(0 .. 1) waits: measured 66 us against the 51 us of the round-4 kernel).
+// The LDS image of a node: lower tiles only, leading dimension 82 (16-byte rows for ds_write_b128; the transposed reads
+// G[c][r] of the upper part - stride 164 words - spread over the banks).  f_k of the eight nodes before the turning point come
+// from a ring in LDS written by the row lanes themselves (they are read back sooner than a loader could fetch them).
+constexpr int BK_PW = 4;                                     // product waves (waves 0 .. 3)
+constexpr int BK_NL = 4;                                     // loader waves: step t is loader t % 4's
+constexpr int BK_T = 64 * (BK_PW + BK_NL);
+constexpr int BK_NB = 2;                                     // LDS stages
+constexpr int BLD = 82;
+constexpr int BK_Q = LOWER_ITEMS / 64;                       // 30 two-double items per loader lane
+constexpr int BK_FL = 8;                                     // f_k of the last BK_FL nodes of the forward pass stay in LDS
+static_assert(LOWER_ITEMS == 64 * NT * (NT + 1), "30 rounds of 64 items: 2 (ib + 1) per tile row");
+static_assert(BK_FL >= BK_NL + BK_NB + 2, "a far f_k must have been stored (and waited for) before a loader asks for it");
+// one stage: the node's tiles | z x g diagH f rows [5][80] | right table of the step's node [225] (+ 1: even size)
+constexpr int BK_OPS = BS * BLD, BK_TAB = BK_OPS + 5 * BS, BK_STAGE = BK_TAB + 9 * NP + 1;
+static constexpr size_t kBacksubLds =
+    (BK_NB * BK_STAGE + 2 * BS + BK_FL * BS + 2 * 9 * NP + 16 + NP + 1) * sizeof(double) + 16 * sizeof(int);
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {      // v + (v of the lane CTRL names)
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 8 lanes of a state (i <-> 7 - i, then i <-> i ^ 1, i <-> i ^ 2): every lane receives the same bits (a + b and
+// b + a at every level)
+__device__ __forceinline__ double lanes8_sum(double v) {
+  v = dpp_add<0x141>(v);                                     // row_half_mirror
+  v = dpp_add<0xB1>(v);                                      // quad_perm [1, 0, 3, 2]
+  return dpp_add<0x4E>(v);                                   // quad_perm [2, 3, 0, 1]
+}
 __global__ void __launch_bounds__(BK_T)
 k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const int* __restrict__ status, int m,
                 int n_chunks, int node0, int pin_right, TrialOut trial) {
-  if (status && *status != 0) return;
-  __shared__ double Gs[BS * LD], u[BK_P * BK_W], xn[BS], xl[BS], ysc[BK_P * BS], cL[9 * NP], cR[9 * NP];
-  const int tid = threadIdx.x;
-  if (tid >= BS && tid < BK_P * BK_W) u[tid] = 0.0;      // (the padding behind u stays zero: see product)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* const stg = reinterpret_cast<double*>(smem_raw);   // [BK_NB][BK_STAGE]
+  double* const ub = stg + BK_NB * BK_STAGE;                   // [2][80] the product's vector, by step parity
+  double* const fl = ub + 2 * BS;                              // [BK_FL][80] f_k of the nodes before the turning point
+  double* const cL0 = fl + BK_FL * BS;                         // left table of the first node
+  double* const cRl = cL0 + 9 * NP;                            // right table of the last interior node
+  double* const red = cRl + 9 * NP;                            // [16]
+  double* const kq = red + 16;                                 // [25] copy of K.q_w (+ 1 pad)
+  int* const sync = reinterpret_cast<int*>(kq + NP + 1);       // ready, per loader | stage read | vector written
+  int* const c_ready = sync;
+  int* const c_rd = sync + BK_NL;
+  int* const c_u = sync + BK_NL + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x, first = node0 + c * m;
   const bool hasL = c > 0 || node0 > 0, hasR = c + 1 < n_chunks || pin_right;
   const int len = c + 1 < n_chunks ? m : ch.n_nodes - first;
   const int n_int = hasR ? len - 1 : len;
   const int sL = c - 1 + node0, sR = c + node0;
   const size_t MB = (size_t)BS * BS;
-  const int row = tid % BS, part = tid / BS, c0 = BK_W * part;
-  const bool uni_tables = coupling_tables_uniform(*cst, first, first + n_int - 1);   // (one fill serves every node of the run)
-  // ---- the trial iterate of the run's frames (fte_api.hip k_trial, same arithmetic): thread r < 75 owns row r of every node
-  const int t_cur = ch.st->cur, t_nf = cst->n_frames, t_own_lo = cst->own_lo, t_own_hi = cst->own_hi;
-  const double t_lam = ch.st->lam;
+  const int nf = hasL && n_int > 0 ? n_int - 1 : 0;         // forward steps; then n_int backward steps
+  const int ns = nf + n_int;
+  auto node_at = [&](int s) __attribute__((always_inline)) { return s < nf ? s : n_int - 1 - (s - nf); };   // local node of step s
+  // ---- loader waves: the tiles of their first node are requested before anything else is looked at (the status word, the
+  //      iterate's buffer index, the tables: three dependent round trips to memory that the first tiles now share)
+  // Round q of a node's 30 rounds of 64 two-double items: eight rows of one tile row x eight items (one 128-byte line per row),
+  // q -> (tile row ib, half h of its rows, 16-column chunk jc <= ib) at compile time.  The lane's part of every address is the
+  // same in all rounds (row lane / 8 of the eight, item lane % 8 of the line): two registers, the rest are immediates.
+  struct Rounds {
+    int row0[BK_Q], col0[BK_Q];
+    constexpr Rounds() : row0{}, col0{} {
+      int q = 0;
+      for (int ib = 0; ib < NT; ++ib)
+        for (int h = 0; h < 2; ++h)
+          for (int jc = 0; jc <= ib; ++jc) {
+            row0[q] = 16 * ib + 8 * h;
+            col0[q] = 16 * jc;
+            ++q;
+          }
+    }
+  };
+  constexpr Rounds RD{};
+  const int gl = (lane >> 3) * BS + 2 * (lane & 7), ll = (lane >> 3) * BLD + 2 * (lane & 7);
+  d2 g[BK_Q];
+  // (rows 75 .. 79 of G_k are rows of the identity - padding - and are never read as rows: the lanes that would fetch them ask
+  //  for row 74 again, which costs no traffic: 10 % of the node's bytes)
+  const int gl74 = ((lane >> 3) < 3 ? (lane >> 3) : 2) * BS + 2 * (lane & 7);
+  auto tile_fetch = [&](int k) __attribute__((always_inline)) {
+    const double* G = ch.D + (size_t)(first + k) * MB;
+#pragma unroll
+    for (int q = 0; q < BK_Q; ++q)
+      g[q] = *reinterpret_cast<const d2*>(G + (RD.row0[q] * BS + RD.col0[q]) + (RD.row0[q] + 8 > 3 * NP ? gl74 : gl));
+  };
+  // Loader lw's jobs: steps lw, lw + BK_NL, ..
+  const int lw = wave - BK_PW;
+  if (lw >= 0 && lw < ns) tile_fetch(node_at(lw));
+  if (status && *status != 0) return;
+  const FteConst& K = *cst;
+  const bool uni = coupling_tables_uniform(K, first, first + n_int - 1);   // (one table serves every node of the run)
+  // the node whose right table step s uses: its own (forward: f_k+1 = -E_k^T t_k) or the next one's (backward: u_k-1 = .. E_k-1 x_k)
+  auto table_node = [&](int s) __attribute__((always_inline)) {
+    const int k = node_at(s);
+    return s < nf ? k : (k > 0 ? k - 1 : 0);
+  };
+  const int t_cur = ch.st->cur, t_nf = K.n_frames;
   const double* t_x = t_cur ? ch.x1 : ch.x0;
-  double* t_xt = const_cast<double*>(t_cur ? ch.x0 : ch.x1);   // (the other iterate buffer: the chain view holds both read-only)
   const double* t_g = t_cur ? ch.g1 : ch.g0;
   const double* t_hd = t_cur ? trial.hd1 : trial.hd0;
-  const bool t_thr = tid < 3 * NP;
-  const int t_p = tid % NP, t_a = tid / NP;
-  const double t_lo = t_thr ? cst->lo[t_p] : 0.0, t_hi = t_thr ? cst->hi[t_p] : 0.0;
-  double t_pred = 0.0, t_step = 0.0;
-  double t_xv = 0.0, t_gv = 0.0, t_d0 = 0.0;            // operands of the node being solved (requested a node ahead)
-  double s_xv = 0.0, s_gv = 0.0, s_d0 = 0.0, s_dx = 0.0;  // ... and of the run's right separator
-  auto trial_fetch = [&](int node) {
-    const int n = 3 * (node - node0) + t_a;
-    if (t_thr && n < t_nf) {
-      t_xv = t_x[(size_t)(n + HALO) * NP + t_p];
-      t_gv = t_g[(size_t)n * NP + t_p];
-      t_d0 = t_hd[(size_t)n * NP + t_p];
-    }
-  };
-  auto trial_row = [&](int node, double delta) {        // (a bound-active variable takes a step of exactly 0: see k_trial)
-    const int n = 3 * (node - node0) + t_a;
-    if (t_thr && n < t_nf) {
-      const double gtol = GRAD_ZERO_REL * t_d0;
-      const bool fixed = (t_xv <= t_lo && t_gv > gtol) || (t_xv >= t_hi && t_gv < -gtol);
-      const double d = fixed ? 0.0 : delta, pg = fixed ? 0.0 : t_gv;
-      const double xnew = fmin(fmax(t_xv + d, t_lo), t_hi);
-      t_xt[(size_t)(n + HALO) * NP + t_p] = xnew;
-      if (n >= t_own_lo && n < t_own_hi) {              // (window sharding: only owned frames enter the global sums)
-        t_pred += 0.5 * d * (t_lam * fmax(t_d0, DIAG_FLOOR) * d - pg);
-        t_step = fmax(t_step, fabs(xnew - t_xv));
-      }
-    }
-  };
-  double2 gq[BK_Q];
-  auto fetch = [&](int node) {                          // lower tiles of G_node -> registers
-    const double* G = ch.D + node * MB;
-#pragma unroll
-    for (int q = 0; q < BK_Q; ++q) {
-      const int idx = tid + BK_T * q;
-      if (idx < LOWER_ITEMS) {
-        int r, cc;
-        lower_item(idx, r, cc);
-        gq[q] = *reinterpret_cast<const double2*>(G + r * BS + cc);
-      }
-    }
-  };
-  auto stage = [&]() {                                  // registers -> symmetric matrix in LDS (strictly-lower tiles mirrored)
-#pragma unroll
-    for (int q = 0; q < BK_Q; ++q) {
-      const int idx = tid + BK_T * q;
-      if (idx < LOWER_ITEMS) {
-        int r, cc;
-        lower_item(idx, r, cc);
-        Gs[r * LD + cc] = gq[q].x;
-        Gs[r * LD + cc + 1] = gq[q].y;
-        if ((cc >> 4) < (r >> 4)) {
-          Gs[cc * LD + r] = gq[q].x;
-          Gs[(cc + 1) * LD + r] = gq[q].y;
-        }
-      }
-    }
-  };
-  auto product = [&]() {                                // ysc <- partial sums of Gs u (BK_P per row)
-    if (tid < BK_P * BS) {
-      // (all BK_W loads unconditional - u is zero behind its 80 entries, the matrix row is clamped -: the last part's four
-      //  missing columns as `if (kk < nc)` compiled to four masked blocks with an LDS round trip each)
-      double s0 = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < BK_W; ++kk) s0 += Gs[min(c0 + kk, BS - 1) * LD + row] * u[c0 + kk];
-      ysc[tid] = s0;
-    }
-  };
-  auto row_sum = [&](int r) {                           // fixed order
-    double v = ysc[r];
-#pragma unroll
-    for (int q = 1; q < BK_P; ++q) v += ysc[q * BS + r];
-    return v;
-  };
-  if (c == 0 && sp.flags)                               // (k_sep_tail's hand-off flags: clean for the next iteration)
+  double* const fst = ch.Wl + (size_t)first * BS;           // f_k of this run's nodes
+  if (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[66] == 1 && tid == 0) ch.dbg[61] = (long long)wall_clock64();
+  if (c == 0 && sp.flags)                                   // (k_sep_tail's hand-off flags: clean for the next iteration)
     for (int e = tid; e < sp.n_flags; e += BK_T) sp.flags[e] = 0;
-  if (tid < BS) {
-    xl[tid] = hasL ? sp.b[(size_t)sL * BS + tid] : 0.0;
-    const double xr = hasR ? sp.b[(size_t)sR * BS + tid] : 0.0;
-    xn[tid] = xr;
-    if (hasR) ch.b[(size_t)(first + n_int) * BS + tid] = xr;      // the separator's solution joins the chain's vector
-    if (hasR) {                                         // (the separator's trial row: operands requested here, used at the end)
-      trial_fetch(first + n_int);
-      s_xv = t_xv;
-      s_gv = t_gv;
-      s_d0 = t_d0;
-      s_dx = xr;
-    }
-  }
-  double* fst = ch.Wl + (size_t)first * BS;             // f_k of this run's nodes
-  if (hasL) {
-    // ---------------- forward: t_k = G_k f_k, f_k+1 = -E^T t_k ----------------
-    fetch(first);
-    fill_coupling_coef<BK_T>(cL, cR, *cst, first, tid);
-    __syncthreads();                                   // xl, tables
-    if (tid < BS) {
-      double v = 0.0;
-      if (tid < 3 * NP) {
-        const int a = tid / NP, p = tid % NP;
-        for (int jj = a; jj < 3; ++jj) v += cL[(a * 3 + jj) * NP + p] * xl[jj * NP + p];    // (E_l x_L)[(a, p)]
+  if (tid < 16) sync[tid] = 0;
+  if (tid < 2 * BS) ub[tid] = 0.0;
+  if (tid < NP) kq[tid] = K.q_w[tid];
+  fill_coupling_coef<BK_T>(cL0, nullptr, K, first, tid);
+  fill_coupling_coef<BK_T>(nullptr, cRl, K, first + (n_int > 0 ? n_int - 1 : 0), tid);
+  double t_pred = 0.0, t_step = 0.0;
+  if (wave >= BK_PW) {
+    // ================================ loader waves ================================
+    // row operands of a backward step: [5][75] values (z, x, g, diag H, f_k-1), entry lane + 64 j; requested a job ahead, with
+    // the tiles
+    constexpr int NRO = (5 * 3 * NP + 63) / 64;
+    double ro[NRO];
+    auto ro_fetch = [&](int t) __attribute__((always_inline)) {
+      if (t < nf) return;
+      const int k = node_at(t), node = first + k;
+      const bool far = hasL && k >= 1 && n_int - k >= BK_FL;   // f_k-1 is no longer in the LDS ring
+      const int ln = opaque(lane);                          // (the address arithmetic stays inside the loop: registers)
+#pragma unroll
+      for (int j = 0; j < NRO; ++j) {
+        const int e = ln + 64 * j < 5 * 3 * NP ? ln + 64 * j : 5 * 3 * NP - 1, o = e / (3 * NP), r = e % (3 * NP);
+        int n = 3 * (node - node0) + r / NP;
+        n = n < t_nf ? n : t_nf - 1;
+        const size_t nr = (size_t)n * NP + r % NP;
+        const double* src = o == 0 ? ch.b + (size_t)node * BS + r
+                          : o == 1 ? t_x + nr + (size_t)HALO * NP
+                          : o == 2 ? t_g + nr
+                          : o == 3 ? t_hd + nr
+                                   : fst + (size_t)(far ? k - 1 : 0) * BS + r;
+        ro[j] = *src;
       }
-      u[tid] = v;
-      fst[tid] = v;
-    }
-    stage();
-    for (int k = 0; k + 1 < n_int; ++k) {              // (f_n is not needed: the last node takes no forward product)
-      const int node = first + k;
-      __syncthreads();                                 // Gs, u
-      fetch(node + 1);
-      if (k > 0 && !uni_tables) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);     // (cR of this node: read after the next barrier)
-      product();
-      __syncthreads();                                 // ysc, cR; every read of Gs and u done
-      if (tid < BS) xn[tid] = row_sum(tid);              // t_k (xn is free until the backward pass)
-      stage();
-      __syncthreads();
-      if (tid < BS) {
-        double v = 0.0;
-        if (tid < 3 * NP) {
-          const int a = tid / NP, p = tid % NP;
-          for (int bb = a; bb < 3; ++bb) v -= cR[(a * 3 + bb) * NP + p] * xn[bb * NP + p];   // -(E^T t_k)[(a, p)]
+      if (lane < BS - 3 * NP) ch.b[(size_t)node * BS + 3 * NP + lane] = 0.0;   // (padding rows of the solution)
+    };
+    if (lw < ns) ro_fetch(lw);
+    __syncthreads();                                        // counters, kq
+    for (int t = lw; t < ns; t += BK_NL) {
+      const bool bwd = t >= nf;
+      long long* const ldbg = (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[66] == 1 && lane == 0 && t >= 10 && t < 14) ? ch.dbg + 48 + 4 * (t - 10) : nullptr;
+      if (ldbg) ldbg[0] = (long long)wall_clock64();
+      if (t >= BK_NB) lds_wait(c_rd, BK_PW * (t - BK_NB + 1));   // the product waves are through with the stage
+      if (ldbg) { __builtin_amdgcn_s_waitcnt(0x0F70); ldbg[1] = (long long)wall_clock64(); }
+      double* const St = stg + (t % BK_NB) * BK_STAGE;
+#pragma unroll
+      for (int q = 0; q < BK_Q; ++q) *reinterpret_cast<d2*>(St + ll + (RD.row0[q] * BLD + RD.col0[q])) = g[q];
+      if (bwd) {
+        const int ln = opaque(lane);
+#pragma unroll
+        for (int j = 0; j < NRO; ++j) {
+          const int e = ln + 64 * j;
+          if (e < 5 * 3 * NP) St[BK_OPS + (e / (3 * NP)) * BS + e % (3 * NP)] = ro[j];
         }
-        u[tid] = v;
-        fst[(size_t)(k + 1) * BS + tid] = v;
+      }
+      // the step's table: the first node's serves every step of a uniform run (the product waves read it in steps 0 and 1);
+      // elsewhere most nodes still have the interior table
+      if (uni) {
+        if (t < BK_NB) right_table_interior<64>(St + BK_TAB, lane, [&](int p) { return kq[p]; });
+      } else if (right_table_is_interior(K, first + table_node(t))) {
+        right_table_interior<64>(St + BK_TAB, lane, [&](int p) { return kq[p]; });
+      } else {
+        fill_coupling_coef<64>(nullptr, St + BK_TAB, K, first + table_node(t), lane, kq);
+      }
+      if (ldbg) { __builtin_amdgcn_s_waitcnt(0xC07F); ldbg[2] = (long long)wall_clock64(); }
+      lds_signal(c_ready + lw, lane);
+      if (t + BK_NL < ns) {                                 // the next job's tiles and row operands
+        tile_fetch(node_at(t + BK_NL));
+        ro_fetch(t + BK_NL);
       }
     }
-    __syncthreads();
-    if (tid < BS) xn[tid] = hasR ? sp.b[(size_t)sR * BS + tid] : 0.0;
-  }
-  // ---------------- backward: x_k = z_k - G_k (E x_k+1 + f_k) ----------------
-  // (the last node's tiles are still in LDS after the forward pass; the first run has no forward pass)
-  if (!hasL) {
-    fetch(first + n_int - 1);
-    stage();
-  }
-  for (int k = n_int - 1; k >= 0; --k) {
-    const int node = first + k;
-    if (!uni_tables || !hasL) fill_coupling_coef<BK_T>(cL, cR, *cst, node, tid);   // (uniform: filled by the forward pass)
-    const double zi = tid < BS ? ch.b[(size_t)node * BS + tid] : 0.0;
-    const double fi = (hasL && tid < BS) ? fst[(size_t)k * BS + tid] : 0.0;
-    double xtr = 0.0;
-    trial_fetch(node);
-    if (k > 0) fetch(node - 1);
-    __syncthreads();                                   // tables, xn of the previous round, Gs
-    if (tid < BS) {
-      double v = fi;
-      if (tid < 3 * NP) {
-        const int a = tid / NP, p = tid % NP;
-        for (int ii = 0; ii <= a; ++ii) v += cR[(ii * 3 + a) * NP + p] * xn[ii * NP + p];   // (E_r x_k+1)[(a, p)]
+  } else {
+    // ================================ product waves ================================
+    const int pg = lane >> 3, part = lane & 7;
+    const int p = 8 * wave + pg, pc = p < NP ? p : NP - 1;
+    const int a = part < 3 ? part : 2, ra = a * NP + pc;    // the lane's row of the triple (lanes part >= 3 shadow row 2)
+    const bool rowl = p < NP && part < 3;
+    const int t_own_lo = K.own_lo, t_own_hi = K.own_hi;
+    const double t_lam = ch.st->lam;
+    double* t_xt = const_cast<double*>(t_cur ? ch.x0 : ch.x1);   // (the other iterate buffer: the chain view holds both read-only)
+    const double t_lo = K.lo[pc], t_hi = K.hi[pc];
+    // trial iterate (fte_api.hip k_trial, same arithmetic): a row lane owns row (a, p) of every node of the run
+    auto trial_row = [&](int node, double delta, double xv, double gv, double d0) __attribute__((always_inline)) {
+      const int n = 3 * (node - node0) + a;
+      if (rowl && n < t_nf) {
+        const double gtol = GRAD_ZERO_REL * d0;
+        const bool fixed = (xv <= t_lo && gv > gtol) || (xv >= t_hi && gv < -gtol);   // (a bound-active variable takes a step of 0)
+        const double d = fixed ? 0.0 : delta, pg_ = fixed ? 0.0 : gv;
+        const double xnew = fmin(fmax(xv + d, t_lo), t_hi);
+        t_xt[(size_t)(n + HALO) * NP + pc] = xnew;
+        if (n >= t_own_lo && n < t_own_hi) {                // (window sharding: only owned frames enter the global sums)
+          t_pred += 0.5 * d * (t_lam * fmax(d0, DIAG_FLOOR) * d - pg_);
+          t_step = fmax(t_step, fabs(xnew - xv));
+        }
       }
-      u[tid] = v;
+    };
+    // LDS offsets of the lane's 30 entries: G[(a, p)][part + 8 j] lies in a stored tile when j / 2 <= tile row of (a, p), else it
+    // is read as G[part + 8 j][(a, p)]: two bases per row, the rest immediates (30 offsets kept in registers would not fit
+    // beside the loaders' 120 registers of tiles: 12 waves share the CU's register file)
+    constexpr int NJ = BS / 8;
+    int gdir[3], gtrn[3], gtile[3];
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa) {
+      const int r = aa * NP + pc;
+      gdir[aa] = r * BLD + part;
+      gtrn[aa] = part * BLD + r;
+      gtile[aa] = r >> 4;
     }
-    __syncthreads();
-    product();
-    __syncthreads();                                   // ysc; every read of Gs done
-    if (tid < BS) {
-      const double x = zi - row_sum(tid);
-      xn[tid] = x;
-      ch.b[(size_t)node * BS + tid] = x;
-      xtr = x;
+    // the two separator solutions, the right separator's trial row, the first vector
+    double xr[3] = {0, 0, 0}, xl[3] = {0, 0, 0};
+    if (hasR) {
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii) xr[ii] = sp.b[(size_t)sR * BS + ii * NP + pc];
+      if (tid < BS) ch.b[(size_t)(first + n_int) * BS + tid] = sp.b[(size_t)sR * BS + tid];   // the separator's solution joins the chain's vector
     }
-    if (k > 0) stage();
-    trial_row(node, xtr);                              // (after the staging: nothing on the node chain waits for it)
+    if (hasL) {
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) xl[jj] = sp.b[(size_t)sL * BS + jj * NP + pc];
+    }
+    double s_xv, s_gv, s_d0;
+    {
+      int n = 3 * (first + n_int - node0) + a;
+      n = n < t_nf ? n : t_nf - 1;
+      s_xv = t_x[(size_t)(n + HALO) * NP + pc];
+      s_gv = t_g[(size_t)n * NP + pc];
+      s_d0 = t_hd[(size_t)n * NP + pc];
+    }
+    __syncthreads();                                        // tables, zeros, counters
+    double wR = 0.0, f0 = 0.0;                              // (E_r x_R)[(a, p)] for the last interior node, (E_l x_L)[(a, p)]
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii)
+      if (ii <= a) wR += cRl[(ii * 3 + a) * NP + pc] * xr[ii];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      if (jj >= a) f0 += cL0[(a * 3 + jj) * NP + pc] * xl[jj];
+    if (rowl) {
+      ub[ra] = nf > 0 ? f0 : f0 + wR;
+      if (hasL) {
+        fst[ra] = f0;
+        fl[ra] = f0;
+      }
+    }
+    lds_signal(c_u, lane);                                  // (the vector of step 0: c_u counts from BK_PW)
+    // debug stamps (scripts/backsub_stamps.py): wave 0 of the selected workgroup, per step "stage ready" / "vector ready"
+    long long* const bdbg = (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[66] == 1 && tid == 0) ? ch.dbg : nullptr;
+    if (bdbg) bdbg[62] = (long long)wall_clock64();
+    double cf[6] = {0, 0, 0, 0, 0, 0};                      // c00 c01 c02 c11 c12 c22 of the step's table for state p
+    bool pend = false;                                      // a backward step's stores and trial row, done under the next step's reads
+    int p_node = 0;
+    double p_xa = 0.0, p_xv = 0.0, p_gv = 0.0, p_d0 = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+      const int b = s & 1;
+      const bool fwd = s < nf;
+      const int k = node_at(s), node = first + k;
+      const double* const St = stg + (s % BK_NB) * BK_STAGE;
+      lds_wait(c_ready + (s % BK_NL), s / BK_NL + 1);       // the node's stage
+#define BK_STAMP(i) do { if (bdbg && s >= 8 && s < 16) { __builtin_amdgcn_s_waitcnt(0xC07F); bdbg[6 * (s - 8) + (i)] = (long long)wall_clock64(); } } while (0)
+      BK_STAMP(0);
+      lds_wait(c_u, BK_PW * (s + 1));                       // the vector (every product wave through with step s - 1)
+      BK_STAMP(1);
+      double uv[NJ], gv[3][NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) uv[j] = ub[b * BS + part + 8 * j];
+#pragma unroll
+      for (int aa = 0; aa < 3; ++aa) {
+        const int gd = opaque(gdir[aa]), gt = opaque(gtrn[aa]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gv[aa][j] = St[(j >> 1) <= gtile[aa] ? gd + 8 * j : gt + 8 * j * BLD];
+      }
+      if (!uni || s < BK_NB) {
+        const double* T = St + BK_TAB;
+        cf[0] = T[0 * NP + pc]; cf[1] = T[1 * NP + pc]; cf[2] = T[2 * NP + pc];
+        cf[3] = T[4 * NP + pc]; cf[4] = T[5 * NP + pc]; cf[5] = T[8 * NP + pc];
+      }
+      const double z0 = St[BK_OPS + pc], z1 = St[BK_OPS + NP + pc], z2 = St[BK_OPS + 2 * NP + pc];
+      const double o_xv = St[BK_OPS + BS + ra], o_gv = St[BK_OPS + 2 * BS + ra], o_d0 = St[BK_OPS + 3 * BS + ra];
+      const double o_f = St[BK_OPS + 4 * BS + ra];
+      const double fnear = fl[((k > 0 ? k - 1 : 0) % BK_FL) * BS + ra];
+      lds_signal(c_rd, lane);                               // (behind the reads: the LDS serves a wave's requests in order)
+      // the previous step's solution row and trial row, while this step's operands are on their way from the LDS
+      if (pend) {
+        if (rowl) ch.b[(size_t)p_node * BS + ra] = p_xa;
+        trial_row(p_node, p_xa, p_xv, p_gv, p_d0);
+        pend = false;
+      }
+      BK_STAMP(2);
+      double y[3];
+#pragma unroll
+      for (int aa = 0; aa < 3; ++aa) {
+        double v0 = gv[aa][0] * uv[0], v1 = gv[aa][1] * uv[1];
+#pragma unroll
+        for (int j = 2; j < NJ; j += 2) {
+          v0 = fma(gv[aa][j], uv[j], v0);
+          v1 = fma(gv[aa][j + 1], uv[j + 1], v1);
+        }
+        y[aa] = lanes8_sum(v0 + v1);
+      }
+      if (bdbg && s >= 8 && s < 16) { asm volatile("" :: "v"(y[0]), "v"(y[1]), "v"(y[2])); bdbg[6 * (s - 8) + 3] = (long long)wall_clock64(); }
+      if (fwd) {
+        // t_k = y;  f_k+1 = -E^T t_k:  row (a, p) = -sum_{bb >= a} c[a][bb] t[(bb, p)]
+        const double f0_ = -(cf[0] * y[0] + cf[1] * y[1] + cf[2] * y[2]);
+        const double f1_ = -(cf[3] * y[1] + cf[4] * y[2]);
+        const double f2_ = -(cf[5] * y[2]);
+        const double fn = a == 0 ? f0_ : (a == 1 ? f1_ : f2_);
+        if (rowl) {
+          ub[(b ^ 1) * BS + ra] = s + 1 == nf ? fn + wR : fn;
+          fl[((k + 1) % BK_FL) * BS + ra] = fn;
+          fst[(size_t)(k + 1) * BS + ra] = fn;
+        }
+        // every f_k of the run stored (at L2) before a loader may ask for one: the loaders start on far f_k only after the product
+        // waves have read two stages beyond the turning point
+        if (s + 1 == nf) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        lds_signal(c_u, lane);
+        BK_STAMP(4);
+      } else {
+        const double x0 = z0 - y[0], x1 = z1 - y[1], x2 = z2 - y[2];
+        const double xa = a == 0 ? x0 : (a == 1 ? x1 : x2);
+        // u_k-1 = f_k-1 + E_r(k-1) x_k:  row (a, p) = sum_{ii <= a} c[ii][a] x[(ii, p)]
+        const double e0 = cf[0] * x0, e1 = cf[1] * x0 + cf[3] * x1, e2 = cf[2] * x0 + cf[4] * x1 + cf[5] * x2;
+        const double fk = hasL ? (n_int - k < BK_FL ? fnear : o_f) : 0.0;
+        if (rowl && k > 0) ub[(b ^ 1) * BS + ra] = fk + (a == 0 ? e0 : (a == 1 ? e1 : e2));
+        lds_signal(c_u, lane);                              // (the next step's vector is complete: the rest is stores)
+        BK_STAMP(4);
+        pend = true;
+        p_node = node;
+        p_xa = xa;
+        p_xv = o_xv;
+        p_gv = o_gv;
+        p_d0 = o_d0;
+      }
+      if (bdbg && s >= 8 && s < 16) bdbg[6 * (s - 8) + 5] = (long long)wall_clock64();
+    }
+#undef BK_STAMP
+    if (pend) {
+      if (rowl) ch.b[(size_t)p_node * BS + ra] = p_xa;
+      trial_row(p_node, p_xa, p_xv, p_gv, p_d0);
+    }
+    if (bdbg) bdbg[63] = (long long)wall_clock64();
+    if (hasR) trial_row(first + n_int, a == 0 ? xr[0] : (a == 1 ? xr[1] : xr[2]), s_xv, s_gv, s_d0);
   }
-  if (hasR) {
-    t_xv = s_xv;
-    t_gv = s_gv;
-    t_d0 = s_d0;
-    trial_row(first + n_int, s_dx);
-  }
-  // the run's share of the predicted reduction (sum) and of the step length (max): waves 0 and 1 hold the 75 rows
+  // the run's share of the predicted reduction (sum) and of the step length (max), fixed order
   for (int off = 32; off > 0; off >>= 1) {
     t_pred += __shfl_down(t_pred, off, 64);
     t_step = fmax(t_step, __shfl_down(t_step, off, 64));
   }
-  __syncthreads();                                     // (ysc is free)
-  if ((tid & 63) == 0 && tid < 128) {
-    ysc[2 * (tid >> 6)] = t_pred;
-    ysc[2 * (tid >> 6) + 1] = t_step;
+  if (lane == 0 && wave < BK_PW) {
+    red[2 * wave] = t_pred;
+    red[2 * wave + 1] = t_step;
   }
   __syncthreads();
   if (tid == 0) {
-    trial.pred_part[c] = ysc[0] + ysc[2];
-    trial.step_part[c] = fmax(ysc[1], ysc[3]);
+    double sp_ = 0.0, sm = 0.0;
+#pragma unroll
+    for (int w = 0; w < BK_PW; ++w) {
+      sp_ += red[2 * w];
+      sm = fmax(sm, red[2 * w + 1]);
+    }
+    trial.pred_part[c] = sp_;
+    trial.step_part[c] = sm;
   }
 }
 
 int chunk_set_func_attributes() {
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_sweep),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLds));
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chunk_backsub),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubLds));
   return ACINO_OK;
 }
 
@@ -1222,7 +1393,7 @@ int chunk_backsub(const BcrChain& ch, const ChunkPlan& pl, const SepView& sp, co
   }
   {
     ProfSpan span(prof, PC_CHUNK_BACKSUB, s, pl.n_nodes - pl.n_sep);
-    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), 0, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks, pl.node0,
+    hipLaunchKernelGGL(k_chunk_backsub, dim3(pl.n_chunks), dim3(BK_T), kBacksubLds, s, ch, sp, d_c, d_status, pl.m, pl.n_chunks, pl.node0,
                        pl.pin_right, trial);
   }
   ACINO_LAUNCH_CHECK();

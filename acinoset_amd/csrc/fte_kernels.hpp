@@ -49,11 +49,13 @@ struct FteConst {
 __host__ __device__ inline double band_coef(int64_t n, int k, int64_t ng) {
   if (n < 0 || n + k >= ng) return 0.0;
   if (n + k >= 3 && n <= ng - 4) return k == 0 ? 20.0 : (k == 1 ? -15.0 : (k == 2 ? 6.0 : -1.0));   // interior rows
-  const double c[4] = {-1.0, 3.0, -3.0, 1.0};
+  // (the stencil by selects, not from a table: a table is a load from constant memory, and a kernel that evaluates this
+  //  between two prefetches would have to wait for every load in flight)
+  auto c = [](int64_t i) { return i == 0 ? -1.0 : (i == 1 ? 3.0 : (i == 2 ? -3.0 : 1.0)); };
   int64_t jlo = n + k - 3 > 0 ? n + k - 3 : 0;
   int64_t jhi = n < ng - 4 ? n : ng - 4;
   double tot = 0.0;
-  for (int64_t j = jlo; j <= jhi; ++j) tot += c[n - j] * c[n + k - j];
+  for (int64_t j = jlo; j <= jhi; ++j) tot += c(n - j) * c(n + k - j);
   return tot;
 }
 
