@@ -178,8 +178,11 @@ SIGNATURES = {
     "acino_sizeof_skel_fte_params": (_Z, []),
     "acino_sizeof_skel_fte_info": (_Z, []),
     "acino_skel_fte_workspace_bytes": (_Z, [C.POINTER(SkelFteParams)]),
+    "acino_skel_fte_workspace_bytes_batch": (_Z, [C.POINTER(SkelFteParams), _I]),
     "acino_skel_fte_solve": (_I, [C.POINTER(SkelFteParams), C.POINTER(SkelOp), C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P,
                                   _P, _Z, C.POINTER(SkelFteInfo), _P]),
+    "acino_skel_fte_solve_batch": (_I, [C.POINTER(SkelFteParams), _I, C.POINTER(SkelOp), C.POINTER(C.c_int32), _P, _P, _P, _P, _P,
+                                        _P, _P, _P, _Z, C.POINTER(SkelFteInfo), _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
     "acino_debug_poison_lds": (_I, [_I, _I, _P]),
 }

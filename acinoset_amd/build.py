@@ -174,43 +174,9 @@ def _ops_array(prog):
     return ops
 
 
-def solve_model(model, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-10, gtol=1e-8, l1_eps=1e-2, lam_max=1e16):
-    """The GPU solve of a ``SkeletonModel`` (acino_skel_fte_solve).  Returns (results, info): ``results`` has the layout of
-    ``convert_to_dict`` (positions [N, n_pose, 3], x / dx / ddx [N, P]); states outside ``model.active`` keep their initial
-    values - which must be 0, as in the reference's initialisation (:215-222)."""
-    _lib.require_gpu()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    act = np.asarray(model.active, dtype=np.int32)
-    x_full = np.array(model.init_x if x0 is None else x0, dtype=np.float64, copy=True)
-    N, P = x_full.shape
-    if (N, P) != (model.N, model.P):
-        raise ValueError(f"x0 must be [{model.N}, {model.P}]")
-    inactive = np.setdiff1d(np.arange(P), act)
-    if np.any(x_full[:, inactive] != 0):
-        raise ValueError("states that move no pose must start (and stay) at 0")
-    prog = model.prog
-    p = SkelFteParams()
-    p.n_frames, p.n_cams, p.n_pose, p.n_ops = N, int(model.meas.shape[1]), len(model.names), len(prog["ops"])
-    p.n_angles, p.n_active, p.max_iter = prog["n_angles"], len(act), int(max_iter)
-    p.h, p.model_weight, p.l1_eps = float(model.h), float(model.model_weight), float(l1_eps)
-    p.lam0, p.ftol, p.xtol, p.gtol, p.lam_max = float(lam0), float(ftol), float(xtol), float(gtol), float(lam_max)
-    nbytes = lib().acino_skel_fte_workspace_bytes(C.byref(p))
-    if nbytes == 0:
-        raise ValueError("problem outside the kernel limits (n_active <= 64)")
-    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)   # noqa: E731
-    meas, w = t(np.nan_to_num(model.meas, nan=0.0)), t(np.where(np.isfinite(model.meas).all(-1), model.weights, 0.0))
-    cams = torch.as_tensor(calib.fisheye_records(model.K, model.D, model.R, model.t), device=dev)
-    lo, hi = t(model.lo[:, act]), t(model.hi[:, act])
-    x = t(x_full[:, act])
-    pos = torch.empty((N, len(model.names), 3), dtype=torch.float64, device=dev)
-    info = SkelFteInfo()
-    act_c = (C.c_int32 * len(act))(*[int(a) for a in act])
-    check(lib().acino_skel_fte_solve(C.byref(p), _ops_array(prog), act_c, ptr(meas), ptr(w), ptr(cams), ptr(lo), ptr(hi),
-                                     ptr(x), ptr(pos), C.c_void_p(ws_ptr), nbytes, C.byref(info), stream_ptr()))
-    x_full[:, act] = x.cpu().numpy()
-    hh = float(model.h)
+def _finite_diff_states(x_full, hh):
+    """dx / ddx of convert_to_dict (build.py:343-365 takes them from the model's backward-Euler variables)."""
+    N = x_full.shape[0]
     dx, ddx = np.zeros_like(x_full), np.zeros_like(x_full)
     if N >= 2:
         dx[1:] = (x_full[1:] - x_full[:-1]) / hh
@@ -218,8 +184,133 @@ def solve_model(model, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-10,
         ddx[2:] = (dx[2:] - dx[1:-1]) / hh
         ddx[1] = ddx[0] = ddx[2]
         dx[0] = dx[1] - hh * ddx[1]
-    results = dict(positions=pos.cpu().numpy(), x=x_full, dx=dx, ddx=ddx)
-    return results, info.as_dict()
+    return dx, ddx
+
+
+def solve_models(models, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-10, gtol=1e-8, l1_eps=1e-2, lam_max=1e16):
+    """The GPU solve of SEVERAL ``SkeletonModel`` s of the same skeleton, cameras and length in one call
+    (acino_skel_fte_solve_batch: one workgroup per clip in the banded factorisation, a Levenberg-Marquardt controller per clip
+    on the device).  ``x0``: None or one [N, P] array per model.  Returns ``[(results, info), ...]`` in the order of ``models``."""
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m0 = models[0]
+    B, N, P = len(models), m0.N, m0.P
+    act = np.asarray(m0.active, dtype=np.int32)
+    prog = m0.prog
+    for m in models:
+        if (m.N, m.P) != (N, P) or repr(m.prog["ops"]) != repr(prog["ops"]) or list(m.active) != list(m0.active) or m.meas.shape != m0.meas.shape:
+            raise ValueError("the models of one batch share skeleton, active states, cameras and length")
+        if not all(np.array_equal(np.asarray(getattr(m, k)), np.asarray(getattr(m0, k))) for k in ("K", "D", "R", "t")):
+            raise ValueError("the models of one batch share the cameras")
+        if (m.h, m.model_weight) != (m0.h, m0.model_weight):
+            raise ValueError("the models of one batch share h and the model weight")
+    xs = [np.array(m.init_x if x0 is None or x0[i] is None else x0[i], dtype=np.float64, copy=True) for i, m in enumerate(models)]
+    inactive = np.setdiff1d(np.arange(P), act)
+    for xf in xs:
+        if xf.shape != (N, P):
+            raise ValueError(f"x0 must be [{N}, {P}]")
+        if np.any(xf[:, inactive] != 0):
+            raise ValueError("states that move no pose must start (and stay) at 0")
+    p = SkelFteParams()
+    p.n_frames, p.n_cams, p.n_pose, p.n_ops = N, int(m0.meas.shape[1]), len(m0.names), len(prog["ops"])
+    p.n_angles, p.n_active, p.max_iter = prog["n_angles"], len(act), int(max_iter)
+    p.h, p.model_weight, p.l1_eps = float(m0.h), float(m0.model_weight), float(l1_eps)
+    p.lam0, p.ftol, p.xtol, p.gtol, p.lam_max = float(lam0), float(ftol), float(xtol), float(gtol), float(lam_max)
+    nbytes = lib().acino_skel_fte_workspace_bytes_batch(C.byref(p), B)
+    if nbytes == 0:
+        raise ValueError("problem outside the kernel limits (n_active <= 64)")
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)   # noqa: E731
+    meas = t(np.stack([np.nan_to_num(m.meas, nan=0.0) for m in models]))
+    w = t(np.stack([np.where(np.isfinite(m.meas).all(-1), m.weights, 0.0) for m in models]))
+    cams = torch.as_tensor(calib.fisheye_records(m0.K, m0.D, m0.R, m0.t), device=dev)
+    lo, hi = t(np.stack([m.lo[:, act] for m in models])), t(np.stack([m.hi[:, act] for m in models]))
+    x = t(np.stack([xf[:, act] for xf in xs]))
+    pos = torch.empty((B, N, len(m0.names), 3), dtype=torch.float64, device=dev)
+    infos = (SkelFteInfo * B)()
+    act_c = (C.c_int32 * len(act))(*[int(a) for a in act])
+    check(lib().acino_skel_fte_solve_batch(C.byref(p), B, _ops_array(prog), act_c, ptr(meas), ptr(w), ptr(cams), ptr(lo), ptr(hi),
+                                           ptr(x), ptr(pos), C.c_void_p(ws_ptr), nbytes, infos, stream_ptr()))
+    xh, ph = x.cpu().numpy(), pos.cpu().numpy()
+    out = []
+    for i, (m, xf) in enumerate(zip(models, xs)):
+        xf[:, act] = xh[i]
+        dx, ddx = _finite_diff_states(xf, float(m.h))
+        out.append((dict(positions=ph[i], x=xf, dx=dx, ddx=ddx), infos[i].as_dict()))
+    return out
+
+
+def solve_model(model, x0=None, **solver_kw):
+    """The GPU solve of a ``SkeletonModel`` (acino_skel_fte_solve).  Returns (results, info): ``results`` has the layout of
+    ``convert_to_dict`` (positions [N, n_pose, 3], x / dx / ddx [N, P]); states outside ``model.active`` keep their initial
+    values - which must be 0, as in the reference's initialisation (:215-222)."""
+    return solve_models([model], None if x0 is None else [x0], **solver_kw)[0]
+
+
+def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, first_frame=None, last_frame=None, window=N_FRAMES,
+                overlap=20, **kw):
+    """A whole video as the reference would have to do it - windows of ``window`` frames (build.py:131-133: N = 100), here
+    ALL of them in one batched GPU solve: consecutive windows overlap by ``overlap`` frames and every frame is taken from
+    the window in which it lies deepest.  An extension (the reference solves one window per run): the initial point of a
+    window is the triangulated forehead of its OWN frames, gaps interpolated (the reference fits one straight line through the
+    forehead of the whole video and evaluates it at 0 .. N-1 whatever ``start_frame`` is, :143-166 - fine for its one window
+    near the start, metres away for a window later in a video in which the subject turns round).  ``kw``: build_model's (``pairing``, ``h``,
+    ...) and solve_models' (``max_iter``, ...) keywords.  Returns ``(results, infos, starts)``: ``results`` as convert_to_dict
+    over frames first_frame .. last_frame, one info per window."""
+    build_kw = {k: kw.pop(k) for k in ("h", "pairing", "lik_thresh", "r_meas", "model_weight") if k in kw}
+    if dlc_tables is None:
+        paths = sorted(glob.glob(os.path.join(project_dir, "data", "*.h5")))
+        dlc_tables = [io.read_dlc_table(p) for p in paths]
+    idx = [np.arange(np.asarray(tb[1]).shape[0]) if len(tb) < 3 or tb[2] is None else np.asarray(tb[2]) for tb in dlc_tables]
+    f0 = max(int(i.min()) for i in idx) if first_frame is None else int(first_frame)
+    f1 = min(int(i.max()) for i in idx) if last_frame is None else int(last_frame)
+    total = f1 - f0 + 1
+    if total < window:
+        raise ValueError(f"{total} frames, windows of {window}")
+    stride = window - overlap
+    starts = list(range(f0, f1 - window + 2, stride))
+    if starts[-1] + window - 1 < f1:
+        starts.append(f1 - window + 1)
+    # the forehead of every frame, triangulated once (the reference's initial point uses the same marker, build.py:143-166)
+    head = None
+    tabs3 = [(list(tb[0]), np.asarray(tb[1], dtype=np.float64), ix) for tb, ix in zip(dlc_tables, idx)]
+    if all("forehead" in parts for parts, _v, _i in tabs3) and len(tabs3) >= 2:
+        if scene is None:
+            scene = io.load_scene(os.path.join(project_dir, "data", "4_cam_scene_static_sba.json"))[:4]
+        k_arr, d_arr, r_arr, t_arr = (np.asarray(a, dtype=np.float64) for a in scene)
+        want = np.arange(f0, f1 + 1)
+        cols = []
+        for parts, vals, ix in tabs3:
+            order = np.argsort(ix)
+            cols.append(vals[order[np.searchsorted(ix[order], want)], parts.index("forehead")][:, None, :])
+        tri = calib.triangulate_pairs_dense(np.stack(cols, axis=1), build_kw.get("lik_thresh", LIK_THRESH), k_arr,
+                                            d_arr.reshape((-1, 4)), r_arr, t_arr, return_masks=False)
+        tri = np.asarray(tri.cpu().numpy() if isinstance(tri, torch.Tensor) else tri)[:, 0]
+        ok = np.isfinite(tri).all(1)
+        if ok.sum() >= 2:
+            fr = np.arange(total, dtype=np.float64)
+            head = np.stack([np.interp(fr, fr[ok], tri[ok, j]) for j in range(3)], axis=1)
+    models, x0s = [], []
+    for st in starts:
+        m, _ = build_model(skel_dict, project_dir, scene=scene, dlc_tables=dlc_tables, n_frames=window, start_frame=st, **build_kw)
+        x0 = m.init_x.copy()
+        if head is not None:
+            x0[:, :3] = head[st - f0:st - f0 + window]
+        models.append(m)
+        x0s.append(x0)
+    solved = solve_models(models, x0s, **kw)
+    Lp, P = len(models[0].names), models[0].P
+    pos, x = np.zeros((total, Lp, 3)), np.zeros((total, P))
+    depth = np.full(total, -1.0)
+    for st, (res, _info) in zip(starts, solved):
+        d = np.minimum(np.arange(window), window - 1 - np.arange(window)).astype(np.float64)
+        sl = slice(st - f0, st - f0 + window)
+        take = d > depth[sl]
+        pos[sl][take], x[sl][take] = res["positions"][take], res["x"][take]
+        depth[sl] = np.maximum(depth[sl], d)
+    dx, ddx = _finite_diff_states(x, float(models[0].h))
+    return dict(positions=pos, x=x, dx=dx, ddx=ddx, start_frame=f0), [i for _r, i in solved], starts
 
 
 def convert_to_dict(m, poses=None):

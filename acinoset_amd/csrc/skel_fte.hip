@@ -16,8 +16,12 @@
 //                    16 x 16 tiles by the register-resident pivot chain of dense80.hpp, panel / trailing / window updates
 //                    as fp64 MFMA tile products - with the forward substitution folded in, then the backward substitution
 //   k_skel_trial, k_skel_reduce   trial iterate, predicted reduction, the sums the controller needs
-// The controller itself runs on the host (four doubles read back per iteration): these are sequences of 10^2 .. 10^3 frames,
-// the path is latency-bound by construction and not the benchmark path.
+//   k_skel_control   the Levenberg-Marquardt controller, one workgroup per clip (the sums above, accept / reject, damping)
+// A call solves n_clips independent clips of n_frames frames each (same skeleton, same cameras): every kernel but the solve
+// runs over all frames of all clips, the solve is one workgroup PER CLIP, every clip has its own controller state on the
+// device (the host reads the clips' status words back once per iteration and stops when all are done; finished clips are
+// skipped by the kernels).  One clip is latency-bound by construction (34 us per frame and iteration in the banded
+// factorisation); the reference's own use is windows of 100 frames (build.py:131-133), and a video is many of them.
 #include <algorithm>
 #include <cstddef>
 #include <cstring>
@@ -40,15 +44,30 @@ struct SkelDev {                   // device-resident description of one problem
   Cam cams[ACINO_MAX_CAMS];
 };
 
+struct SkelClip {                  // controller state of one clip (device)
+  double F, lam, nu, gnorm, cost0, Ft, pred, step;
+  int32_t cur, status, it, accepted, pivot_err, pad;
+};
+
 // ---- assembly ---------------------------------------------------------------------------------------------------
+// (frame index n runs over the frames of all clips; `which` = 0: the clips' current iterate, 1: their trial iterate)
 template <bool JAC>
 __global__ void __launch_bounds__(256)
-k_skel_assemble(const SkelDev* __restrict__ dev, const double* __restrict__ x, const double* __restrict__ meas,
-                const double* __restrict__ wgt, double* __restrict__ H, double* __restrict__ g, double* __restrict__ hd,
-                double* __restrict__ cost_part) {
+k_skel_assemble(const SkelDev* __restrict__ dev, const SkelClip* __restrict__ clip, int which, const double* __restrict__ x0,
+                const double* __restrict__ x1, const double* __restrict__ meas, const double* __restrict__ wgt,
+                double* __restrict__ H0, double* __restrict__ H1, double* __restrict__ g0, double* __restrict__ g1,
+                double* __restrict__ hd0, double* __restrict__ hd1, double* __restrict__ c0, double* __restrict__ c1) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const SkelDev& D = *dev;
   const int tid = threadIdx.x, n = blockIdx.x;
+  const SkelClip& cs = clip[n / D.n_frames];
+  if (cs.status != 0) return;                               // (the clip is finished)
+  const int buf = cs.cur ^ which;
+  const double* __restrict__ x = buf ? x1 : x0;
+  double* __restrict__ H = buf ? H1 : H0;
+  double* __restrict__ g = buf ? g1 : g0;
+  double* __restrict__ hd = buf ? hd1 : hd0;
+  double* __restrict__ cost_part = buf ? c1 : c0;
   const int P = D.n_act, C = D.n_cams, NPOSE = D.n_pose, NOPS = D.n_ops, R = D.n_rows, lda = P | 1;
   double* xs = reinterpret_cast<double*>(smem_raw);          // [64] active states of this frame
   double* opv = xs + SK_MAXP;                                 // [n_ops][4][3]: M off, dM/dphi off, dM/dtheta off, dM/dpsi off
@@ -184,7 +203,7 @@ k_skel_assemble(const SkelDev* __restrict__ dev, const double* __restrict__ x, c
     }
     __syncthreads();
     // H_n = A^T W A (upper pairs, mirrored), g_n = A^T gs (+ the smoothness terms, as the cheetah assembly)
-    const double b0 = band_coef(n, 0, D.n_frames);
+    const double b0 = band_coef(n % D.n_frames, 0, D.n_frames);      // (position inside the clip)
     for (int e = tid; e < P * P; e += 256) {
       const int p = e / P, pc = e % P;
       if (pc < p) continue;
@@ -200,7 +219,8 @@ k_skel_assemble(const SkelDev* __restrict__ dev, const double* __restrict__ x, c
   }
   if (tid < P) {
     const double* xc = x + (size_t)n * P + tid;
-    if (n >= 3) {
+    const int nl = n % D.n_frames;                            // position inside the clip: no coupling across clips
+    if (nl >= 3) {
       const double d3 = xc[0] - 3.0 * xc[-P] + 3.0 * xc[-2 * P] - xc[-3 * P];
       my_cost += D.q * d3 * d3;
     }
@@ -208,9 +228,9 @@ k_skel_assemble(const SkelDev* __restrict__ dev, const double* __restrict__ x, c
       double gs = 0.0;
 #pragma unroll
       for (int k = -3; k <= 3; ++k) {
-        const int nn = n + k;
+        const int nn = nl + k;
         if (nn < 0 || nn >= D.n_frames) continue;
-        const double bc = k >= 0 ? band_coef(n, k, D.n_frames) : band_coef(nn, -k, D.n_frames);
+        const double bc = k >= 0 ? band_coef(nl, k, D.n_frames) : band_coef(nn, -k, D.n_frames);
         gs += bc * xc[k * P];
       }
       double gm = 0.0;
@@ -231,19 +251,27 @@ __device__ __forceinline__ bool skel_fixed(double xv, double gv, double d0, doub
   return (xv <= lo && gv > gtol) || (xv >= hi && gv < -gtol);
 }
 __global__ void __launch_bounds__(256)
-k_skel_build(const SkelDev* __restrict__ dev, const double* __restrict__ x, const double* __restrict__ g,
-             const double* __restrict__ H, const double* __restrict__ hd, const double* __restrict__ lo,
-             const double* __restrict__ hi, double lam, double* __restrict__ band, double* __restrict__ rhs,
-             double* __restrict__ gn_part) {
+k_skel_build(const SkelDev* __restrict__ dev, const SkelClip* __restrict__ clip, const double* __restrict__ x0,
+             const double* __restrict__ x1, const double* __restrict__ g0, const double* __restrict__ g1,
+             const double* __restrict__ H0, const double* __restrict__ H1, const double* __restrict__ hd0,
+             const double* __restrict__ hd1, const double* __restrict__ lo, const double* __restrict__ hi,
+             double* __restrict__ band, double* __restrict__ rhs, double* __restrict__ gn_part, int final_pass) {
   const SkelDev& D = *dev;
-  const int tid = threadIdx.x, n = blockIdx.x, P = D.n_act, PT = D.PT, N = D.n_frames;
+  const int tid = threadIdx.x, n = blockIdx.x, P = D.n_act, PT = D.PT, N = D.n_frames, nl = n % N;
+  const SkelClip& cs = clip[n / N];
+  if (cs.status != 0 && !final_pass) return;                // (finished; the final pass only wants the gradient norms)
+  const double* __restrict__ x = cs.cur ? x1 : x0;
+  const double* __restrict__ g = cs.cur ? g1 : g0;
+  const double* __restrict__ H = cs.cur ? H1 : H0;
+  const double* __restrict__ hd = cs.cur ? hd1 : hd0;
+  const double lam = cs.lam;
   __shared__ unsigned char fx[4][SK_MAXP];
   __shared__ double red[4];
   for (int e = tid; e < 4 * P; e += 256) {
-    const int j = e / P, p = e % P, nn = n + j;
+    const int j = e / P, p = e % P;
     bool f = false;
-    if (nn < N) {
-      const size_t q = (size_t)nn * P + p;
+    if (nl + j < N) {
+      const size_t q = (size_t)(n + j) * P + p;
       f = skel_fixed(x[q], g[q], hd[q], lo[q], hi[q]);
     }
     fx[j][p] = f ? 1 : 0;
@@ -264,7 +292,7 @@ k_skel_build(const SkelDev* __restrict__ dev, const double* __restrict__ x, cons
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
       double c = 0.0;
-      if (p == pc && p < P && n + j < N && !fx[0][p] && !fx[j][p]) c = 2.0 * D.q * band_coef(n, j, N);
+      if (p == pc && p < P && nl + j < N && !fx[0][p] && !fx[j][p]) c = 2.0 * D.q * band_coef(nl, j, N);
       B[(size_t)j * PT * PT + e] = c;
     }
   }
@@ -291,10 +319,41 @@ k_skel_build(const SkelDev* __restrict__ dev, const double* __restrict__ x, cons
 constexpr int SK_ST = 512, SK_SW = SK_ST / 64;      // threads / waves of the solve kernel
 template <int PT>
 __global__ void __launch_bounds__(SK_ST)
-k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const double* __restrict__ rhs,
-             double* __restrict__ yv, double* __restrict__ delta, int* __restrict__ numeric_err) {
+k_skel_solve(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, double gtol, double* __restrict__ band_all,
+             const double* __restrict__ rhs_all, double* __restrict__ yv_all, double* __restrict__ delta_all,
+             const double* __restrict__ gn_part) {
   constexpr int LDP = PT + 1, NTP = PT / 16, RT = 4 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // ---- the clip's iteration starts here: count it, and stop before any work when the projected gradient is small already
+  //      (what the oracle's controller does at the top of an iteration)
+  SkelClip& cs = clip[blockIdx.x];
+  if (cs.status != 0) return;
+  {
+    __shared__ double gred[SK_ST / 64];
+    __shared__ int stop;
+    const int nfr = dev->n_frames;
+    double gm = 0.0;
+    for (int i = threadIdx.x; i < nfr; i += SK_ST) gm = fmax(gm, gn_part[(size_t)blockIdx.x * nfr + i]);
+    for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+    if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SK_ST / 64; ++w) gm = fmax(gm, gred[w]);
+      cs.gnorm = gm;
+      cs.it += 1;
+      cs.pivot_err = 0;
+      stop = gm <= gtol;
+      if (stop) cs.status = 3;
+    }
+    __syncthreads();
+    if (stop) return;
+  }
+  int* const numeric_err = &cs.pivot_err;
+  const size_t fr0 = (size_t)blockIdx.x * dev->n_frames;      // the clip's first frame
+  double* const band = band_all + fr0 * 4 * PT * PT;
+  const double* const rhs = rhs_all + fr0 * PT;
+  double* const yv = yv_all + fr0 * PT;
+  double* const delta = delta_all + fr0 * PT;
   double* Pn = reinterpret_cast<double*>(smem_raw);       // [4 PT][LDP]
   double* ring = Pn + 4 * PT * LDP;                        // [4][PT] right-hand sides / solutions of frames n .. n + 3
   double* tv = ring + 4 * PT;                              // [PT]
@@ -470,12 +529,25 @@ k_skel_solve(const SkelDev* __restrict__ dev, double* __restrict__ band, const d
 
 // ---- trial iterate and the controller's sums -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_skel_trial(const SkelDev* __restrict__ dev, const double* __restrict__ x, double* __restrict__ xt,
-             const double* __restrict__ g, const double* __restrict__ hd, const double* __restrict__ lo,
-             const double* __restrict__ hi, const double* __restrict__ delta, double lam, double* __restrict__ pred_part,
+k_skel_trial(const SkelDev* __restrict__ dev, const SkelClip* __restrict__ clip, double* __restrict__ xb0,
+             double* __restrict__ xb1, const double* __restrict__ g0, const double* __restrict__ g1,
+             const double* __restrict__ hd0, const double* __restrict__ hd1, const double* __restrict__ lo_all,
+             const double* __restrict__ hi_all, const double* __restrict__ delta_all, double* __restrict__ pred_part,
              double* __restrict__ step_part) {
+  // grid (blocks per clip, clips): the partial sums of clip b are pred_part[b * gridDim.x ..]
   const SkelDev& D = *dev;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const SkelClip& cs = clip[b];
+  if (cs.status != 0) return;
+  const size_t off = (size_t)b * D.n_frames * D.n_act;
+  const double* __restrict__ x = (cs.cur ? xb1 : xb0) + off;
+  double* __restrict__ xt = (cs.cur ? xb0 : xb1) + off;
+  const double* __restrict__ g = (cs.cur ? g1 : g0) + off;
+  const double* __restrict__ hd = (cs.cur ? hd1 : hd0) + off;
+  const double* __restrict__ lo = lo_all + off;
+  const double* __restrict__ hi = hi_all + off;
+  const double* __restrict__ delta = delta_all + (size_t)b * D.n_frames * D.PT;
+  const double lam = cs.lam;
   const int64_t e = (int64_t)blockIdx.x * 256 + tid;
   double pred = 0.0, step = 0.0;
   if (e < (int64_t)D.n_frames * D.n_act) {
@@ -499,24 +571,35 @@ k_skel_trial(const SkelDev* __restrict__ dev, const double* __restrict__ x, doub
   }
   __syncthreads();
   if (tid == 0) {
-    pred_part[blockIdx.x] = (rp[0] + rp[1]) + (rp[2] + rp[3]);
-    step_part[blockIdx.x] = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+    pred_part[(size_t)b * gridDim.x + blockIdx.x] = (rp[0] + rp[1]) + (rp[2] + rp[3]);
+    step_part[(size_t)b * gridDim.x + blockIdx.x] = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
   }
 }
 
-// totals = {cost, pred, step_inf, gnorm_inf}; fixed order
-__global__ void __launch_bounds__(1024)
-k_skel_reduce(const double* __restrict__ cost_part, int n_cost, const double* __restrict__ pred_part,
-              const double* __restrict__ step_part, int n_trial, const double* __restrict__ gn_part, int n_gn,
-              double* __restrict__ totals) {
-  __shared__ double sh[16][4];
+// The controller of one clip (lm_control_local of fte_api.hip / oracle.fte.lm_solve): sums in a fixed order, then thread 0
+// decides.  mode 0: the cost of the initial iterate; 1: an iteration's trial (cost of the trial buffer, predicted reduction,
+// step length); 2: only the gradient norm of the final iterate (gn_part from a final k_skel_build).
+// A failed factorisation (non-positive pivot at this damping) is a rejected step: lambda goes up, as in the cheetah path; only
+// when lambda runs out is it reported as a numeric failure (status 5).
+__global__ void __launch_bounds__(256)
+k_skel_control(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, int mode, const double* __restrict__ c0,
+               const double* __restrict__ c1, const double* __restrict__ pred_part, const double* __restrict__ step_part,
+               int n_trial, const double* __restrict__ gn_part, double lam0, double ftol, double xtol, double lam_max) {
+  __shared__ double sh[4][4];
+  const int b = blockIdx.x, N = dev->n_frames;
+  SkelClip& cs = clip[b];
+  if (mode == 1 && cs.status != 0) return;
+  const double* cost_part = ((mode == 1 ? cs.cur ^ 1 : cs.cur) ? c1 : c0) + (size_t)b * N;
   double c = 0.0, p = 0.0, s = 0.0, g = 0.0;
-  for (int i = threadIdx.x; i < n_cost; i += 1024) c += cost_part[i];
-  for (int i = threadIdx.x; i < n_trial; i += 1024) {
-    p += pred_part[i];
-    s = fmax(s, step_part[i]);
-  }
-  for (int i = threadIdx.x; i < n_gn; i += 1024) g = fmax(g, gn_part[i]);
+  if (mode != 2)
+    for (int i = threadIdx.x; i < N; i += 256) c += cost_part[i];
+  if (mode == 1)
+    for (int i = threadIdx.x; i < n_trial; i += 256) {
+      p += pred_part[(size_t)b * n_trial + i];
+      s = fmax(s, step_part[(size_t)b * n_trial + i]);
+    }
+  if (mode == 2)
+    for (int i = threadIdx.x; i < N; i += 256) g = fmax(g, gn_part[(size_t)b * N + i]);
   for (int off = 32; off > 0; off >>= 1) {
     c += __shfl_down(c, off, 64);
     p += __shfl_down(p, off, 64);
@@ -531,33 +614,59 @@ k_skel_reduce(const double* __restrict__ cost_part, int n_cost, const double* __
     w[3] = g;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    c = p = s = g = 0.0;
-    for (int w = 0; w < 16; ++w) {
-      c += sh[w][0];
-      p += sh[w][1];
-      s = fmax(s, sh[w][2]);
-      g = fmax(g, sh[w][3]);
-    }
-    totals[0] = c;
-    totals[1] = p;
-    totals[2] = s;
-    totals[3] = g;
+  if (threadIdx.x != 0) return;
+  c = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+  p = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+  s = fmax(fmax(sh[0][2], sh[1][2]), fmax(sh[2][2], sh[3][2]));
+  g = fmax(fmax(sh[0][3], sh[1][3]), fmax(sh[2][3], sh[3][3]));
+  if (mode == 0) {
+    cs.F = cs.cost0 = c;
+    cs.lam = lam0;
+    cs.nu = 2.0;
+    return;
+  }
+  if (mode == 2) {
+    cs.gnorm = g;
+    return;
+  }
+  cs.Ft = c;
+  cs.pred = p;
+  cs.step = s;
+  const double F = cs.F, Ft = c;
+  if (cs.pivot_err == 0 && Ft < F) {
+    const double gain = p > 0.0 ? (F - Ft) / p : -1.0, dF = F - Ft, t = 2.0 * gain - 1.0;
+    cs.cur ^= 1;
+    cs.F = Ft;
+    cs.accepted += 1;
+    cs.lam = cs.lam * fmax(1.0 / 3.0, 1.0 - t * t * t);
+    cs.nu = 2.0;
+    if (dF <= ftol * fabs(Ft)) cs.status = 1;
+    else if (s <= xtol) cs.status = 2;
+  } else {
+    cs.lam *= cs.nu;
+    cs.nu *= 2.0;
+    if (cs.lam > lam_max) cs.status = cs.pivot_err ? 5 : 4;
   }
 }
 
-__global__ void k_skel_clip(const SkelDev* __restrict__ dev, const double* __restrict__ src, const double* __restrict__ lo,
-                            const double* __restrict__ hi, double* __restrict__ dst) {
+__global__ void k_skel_clip(const double* __restrict__ src, const double* __restrict__ lo, const double* __restrict__ hi,
+                            double* __restrict__ dst, int64_t n_total) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < (int64_t)dev->n_frames * dev->n_act) dst[e] = fmin(fmax(src[e], lo[e]), hi[e]);
+  if (e < n_total) dst[e] = fmin(fmax(src[e], lo[e]), hi[e]);
+}
+// the clips' final iterates (each from its own current buffer) -> out[clips][N][P]
+__global__ void k_skel_gather(const SkelDev* __restrict__ dev, const SkelClip* __restrict__ clip, const double* __restrict__ x0,
+                              const double* __restrict__ x1, double* __restrict__ out, int64_t n_total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n_total) out[e] = (clip[e / ((int64_t)dev->n_frames * dev->n_act)].cur ? x1 : x0)[e];
 }
 
 // poses of active-state rows: pos[N][n_pose][3]
 __global__ void __launch_bounds__(256)
-k_skel_poses(const SkelDev* __restrict__ dev, const double* __restrict__ x, double* __restrict__ pos) {
+k_skel_poses(const SkelDev* __restrict__ dev, const double* __restrict__ x, double* __restrict__ pos, int64_t n_total) {
   const SkelDev& D = *dev;
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= D.n_frames) return;
+  if (n >= n_total) return;
   const double* xs = x + n * D.n_act;
   double* out = pos + n * D.n_pose * 3;
   for (int s = 0; s < D.n_pose; ++s)
@@ -597,10 +706,11 @@ k_skel_poses(const SkelDev* __restrict__ dev, const double* __restrict__ x, doub
 }
 
 struct SkelLayout {
-  size_t dev, x[2], g[2], H[2], hd[2], cost[2], band, rhs, yv, delta, pred, step, gn, totals, err, total;
+  size_t dev, clip, x[2], g[2], H[2], hd[2], cost[2], band, rhs, yv, delta, pred, step, gn, total;
 };
 static size_t sk_align(size_t v) { return (v + 255) / 256 * 256; }
-static SkelLayout skel_layout(int N, int P, int PT) {
+// (N: frames of ALL clips)
+static SkelLayout skel_layout(size_t N, int n_clips, int frames_per_clip, int P, int PT) {
   SkelLayout L;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -609,21 +719,20 @@ static SkelLayout skel_layout(int N, int P, int PT) {
     return o;
   };
   L.dev = take(sizeof(SkelDev));
-  for (int k = 0; k < 2; ++k) L.x[k] = take(sizeof(double) * (size_t)N * P);
-  for (int k = 0; k < 2; ++k) L.g[k] = take(sizeof(double) * (size_t)N * P);
-  for (int k = 0; k < 2; ++k) L.H[k] = take(sizeof(double) * (size_t)N * P * P);
-  for (int k = 0; k < 2; ++k) L.hd[k] = take(sizeof(double) * (size_t)N * P);
-  for (int k = 0; k < 2; ++k) L.cost[k] = take(sizeof(double) * (size_t)N);
-  L.band = take(sizeof(double) * (size_t)N * 4 * PT * PT);
-  L.rhs = take(sizeof(double) * (size_t)(N + 4) * PT);
-  L.yv = take(sizeof(double) * (size_t)N * PT);
-  L.delta = take(sizeof(double) * (size_t)N * PT);
-  const size_t nt = ((size_t)N * P + 255) / 256 + 1;
+  L.clip = take(sizeof(SkelClip) * (size_t)n_clips);
+  for (int k = 0; k < 2; ++k) L.x[k] = take(sizeof(double) * N * P);
+  for (int k = 0; k < 2; ++k) L.g[k] = take(sizeof(double) * N * P);
+  for (int k = 0; k < 2; ++k) L.H[k] = take(sizeof(double) * N * P * P);
+  for (int k = 0; k < 2; ++k) L.hd[k] = take(sizeof(double) * N * P);
+  for (int k = 0; k < 2; ++k) L.cost[k] = take(sizeof(double) * N);
+  L.band = take(sizeof(double) * N * 4 * PT * PT);
+  L.rhs = take(sizeof(double) * (N + 4) * PT);
+  L.yv = take(sizeof(double) * N * PT);
+  L.delta = take(sizeof(double) * N * PT);
+  const size_t nt = (((size_t)frames_per_clip * P + 255) / 256) * (size_t)n_clips + 1;
   L.pred = take(sizeof(double) * nt);
   L.step = take(sizeof(double) * nt);
-  L.gn = take(sizeof(double) * (size_t)N);
-  L.totals = take(sizeof(double) * 8);
-  L.err = take(sizeof(int) * 4);
+  L.gn = take(sizeof(double) * N);
   L.total = off;
   return L;
 }
@@ -652,24 +761,28 @@ extern "C" {
 size_t acino_sizeof_skel_fte_params(void) { return sizeof(acino_skel_fte_params); }
 size_t acino_sizeof_skel_fte_info(void) { return sizeof(acino_skel_fte_info); }
 
-size_t acino_skel_fte_workspace_bytes(const acino_skel_fte_params* p) {
-  if (!p || p->n_frames < 1 || p->n_active < 3 || p->n_active > SK_MAXP) return 0;
+size_t acino_skel_fte_workspace_bytes_batch(const acino_skel_fte_params* p, int n_clips) {
+  if (!p || p->n_frames < 1 || p->n_active < 3 || p->n_active > SK_MAXP || n_clips < 1) return 0;
   const int PT = (p->n_active + 15) / 16 * 16;
-  return skel_layout(p->n_frames, p->n_active, PT).total + 256;
+  return skel_layout((size_t)p->n_frames * n_clips, n_clips, p->n_frames, p->n_active, PT).total + 256;
 }
+size_t acino_skel_fte_workspace_bytes(const acino_skel_fte_params* p) { return acino_skel_fte_workspace_bytes_batch(p, 1); }
 
-int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_ops, const int32_t* h_active,
-                         const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
-                         const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
-                         acino_skel_fte_info* info, void* stream) {
+int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, const acino_skel_op* h_ops, const int32_t* h_active,
+                               const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
+                               const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
+                               acino_skel_fte_info* infos, void* stream) {
   int rc = skel_validate(p);
   if (rc) return rc;
+  ACINO_REQUIRE(n_clips >= 1 && n_clips <= 65535, "n_clips in 1..65535");
   ACINO_REQUIRE(h_ops && h_active && d_meas && d_w && d_cams24 && d_lo && d_hi && d_x && d_workspace, "null buffer");
   ACINO_REQUIRE(((uintptr_t)d_workspace & 255) == 0, "workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int N = p->n_frames, P = p->n_active, PT = (P + 15) / 16 * 16, L = p->n_angles;
-  const SkelLayout lay = skel_layout(N, P, PT);
-  ACINO_REQUIRE(workspace_bytes >= lay.total, "workspace too small (acino_skel_fte_workspace_bytes)");
+  const int N = p->n_frames, B = n_clips, P = p->n_active, PT = (P + 15) / 16 * 16, L = p->n_angles;
+  const size_t NT = (size_t)N * B;                           // frames of all clips
+  ACINO_REQUIRE(NT < (size_t)1 << 31, "n_clips * n_frames < 2^31");
+  const SkelLayout lay = skel_layout(NT, B, N, P, PT);
+  ACINO_REQUIRE(workspace_bytes >= lay.total, "workspace too small (acino_skel_fte_workspace_bytes_batch)");
   // ---- the program: active index of every op's parent angles, the ops on every pose's path
   std::vector<SkelDev> hv(1);
   SkelDev& h = hv[0];
@@ -710,11 +823,11 @@ int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_
   char* base = (char*)d_workspace;
   auto D = [&](size_t off) { return reinterpret_cast<double*>(base + off); };
   SkelDev* d_dev = reinterpret_cast<SkelDev*>(base + lay.dev);
-  int* d_err = reinterpret_cast<int*>(base + lay.err);
+  SkelClip* d_clip = reinterpret_cast<SkelClip*>(base + lay.clip);
   ACINO_HIP_CHECK(hipMemcpyAsync(d_dev, &h, sizeof(SkelDev), hipMemcpyHostToDevice, s));
   ACINO_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(d_dev) + offsetof(SkelDev, cams), d_cams24,
                                  sizeof(double) * ACINO_CAM_STRIDE * p->n_cams, hipMemcpyDeviceToDevice, s));
-  ACINO_HIP_CHECK(hipMemsetAsync(d_err, 0, 4 * sizeof(int), s));
+  ACINO_HIP_CHECK(hipMemsetAsync(d_clip, 0, sizeof(SkelClip) * (size_t)B, s));
   ACINO_HIP_CHECK(hipStreamSynchronize(s));                // (h lives on this frame)
   const size_t lds_asm = sizeof(double) * (SK_MAXP + ACINO_SKEL_MAX_OPS * 12 + (ACINO_SKEL_MAX_OPS + 1) * 3 + SK_MAXROWS * 5 + 8 +
                                            (size_t)h.n_rows * (P | 1));
@@ -722,127 +835,111 @@ int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_
   {
     static PerDeviceOnce attr;
     if (attr.first()) {
-      const int big = 160 * 1024;
+      const int big = 160 * 1024, big_solve = 160 * 1024 - 1024;   // (the solve kernel also has a few static words)
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_assemble<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, big));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_assemble<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, big));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<48>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
     }
   }
   ACINO_REQUIRE(lds_asm <= 160 * 1024, "residual rows x active states do not fit the assembly's LDS");
-  const int n_trial = (int)(((size_t)N * P + 255) / 256);
-  auto assemble = [&](int buf, bool jac) -> int {
-    if (jac)
-      hipLaunchKernelGGL(k_skel_assemble<true>, dim3(N), dim3(256), lds_asm, s, d_dev, D(lay.x[buf]), d_meas, d_w,
-                         D(lay.H[buf]), D(lay.g[buf]), D(lay.hd[buf]), D(lay.cost[buf]));
-    else
-      hipLaunchKernelGGL(k_skel_assemble<false>, dim3(N), dim3(256), lds_asm, s, d_dev, D(lay.x[buf]), d_meas, d_w,
-                         D(lay.H[buf]), D(lay.g[buf]), D(lay.hd[buf]), D(lay.cost[buf]));
+  const int n_trial = (int)(((size_t)N * P + 255) / 256);    // blocks per clip
+  const int64_t n_el = (int64_t)NT * P;
+  const double lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
+  auto assemble = [&](int which) -> int {
+    hipLaunchKernelGGL(k_skel_assemble<true>, dim3((unsigned)NT), dim3(256), lds_asm, s, d_dev, d_clip, which, D(lay.x[0]),
+                       D(lay.x[1]), d_meas, d_w, D(lay.H[0]), D(lay.H[1]), D(lay.g[0]), D(lay.g[1]), D(lay.hd[0]), D(lay.hd[1]),
+                       D(lay.cost[0]), D(lay.cost[1]));
     ACINO_LAUNCH_CHECK();
     return ACINO_OK;
   };
-  double tot[8];
-  int herr[4] = {0, 0, 0, 0};
-  auto read_totals = [&](int cost_buf, bool with_step) -> int {
-    hipLaunchKernelGGL(k_skel_reduce, dim3(1), dim3(1024), 0, s, D(lay.cost[cost_buf]), N, D(lay.pred), D(lay.step),
-                       with_step ? n_trial : 0, D(lay.gn), with_step ? N : 0, D(lay.totals));
+  auto build = [&](int final_pass) -> int {
+    hipLaunchKernelGGL(k_skel_build, dim3((unsigned)NT), dim3(256), 0, s, d_dev, d_clip, D(lay.x[0]), D(lay.x[1]), D(lay.g[0]),
+                       D(lay.g[1]), D(lay.H[0]), D(lay.H[1]), D(lay.hd[0]), D(lay.hd[1]), d_lo, d_hi, D(lay.band), D(lay.rhs),
+                       D(lay.gn), final_pass);
     ACINO_LAUNCH_CHECK();
-    ACINO_HIP_CHECK(hipMemcpyAsync(tot, D(lay.totals), sizeof(double) * 4, hipMemcpyDeviceToHost, s));
-    ACINO_HIP_CHECK(hipMemcpyAsync(herr, d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    ACINO_HIP_CHECK(hipStreamSynchronize(s));
     return ACINO_OK;
   };
-  hipLaunchKernelGGL(k_skel_clip, dim3(n_trial), dim3(256), 0, s, d_dev, d_x, d_lo, d_hi, D(lay.x[0]));
+  auto control = [&](int mode) -> int {
+    hipLaunchKernelGGL(k_skel_control, dim3(B), dim3(256), 0, s, d_dev, d_clip, mode, D(lay.cost[0]), D(lay.cost[1]), D(lay.pred),
+                       D(lay.step), n_trial, D(lay.gn), p->lam0, p->ftol, p->xtol, lam_max);
+    ACINO_LAUNCH_CHECK();
+    return ACINO_OK;
+  };
+  hipLaunchKernelGGL(k_skel_clip, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, d_x, d_lo, d_hi, D(lay.x[0]), n_el);
   ACINO_LAUNCH_CHECK();
-  int cur = 0;
-  if ((rc = assemble(0, true))) return rc;
-  if ((rc = read_totals(0, false))) return rc;
-  // ---- the controller (lm_control_local of fte_api.hip / oracle.fte.lm_solve, on the host)
-  double F = tot[0], lam = p->lam0, nu = 2.0, gnorm = 0.0;
-  const double cost0 = F, lam_max = p->lam_max > 0 ? p->lam_max : 1e16;
-  int status = 0, it = 0, accepted = 0;
-  for (it = 1; it <= p->max_iter; ++it) {
-    hipLaunchKernelGGL(k_skel_build, dim3(N), dim3(256), 0, s, d_dev, D(lay.x[cur]), D(lay.g[cur]), D(lay.H[cur]),
-                       D(lay.hd[cur]), d_lo, d_hi, lam, D(lay.band), D(lay.rhs), D(lay.gn));
-    ACINO_LAUNCH_CHECK();
+  if ((rc = assemble(0))) return rc;
+  if ((rc = control(0))) return rc;
+  // ---- the iterations: every clip's controller is on the device; the host reads the status words to know when to stop
+  std::vector<SkelClip> hc(B);
+  for (int it = 1; it <= p->max_iter; ++it) {
+    if ((rc = build(0))) return rc;
     switch (PT) {
-      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
-      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(1), dim3(SK_ST), lds_solve, s, d_dev, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), d_err); break;
+      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
     }
     ACINO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_skel_trial, dim3(n_trial), dim3(256), 0, s, d_dev, D(lay.x[cur]), D(lay.x[cur ^ 1]), D(lay.g[cur]),
-                       D(lay.hd[cur]), d_lo, d_hi, D(lay.delta), lam, D(lay.pred), D(lay.step));
+    hipLaunchKernelGGL(k_skel_trial, dim3(n_trial, B), dim3(256), 0, s, d_dev, d_clip, D(lay.x[0]), D(lay.x[1]), D(lay.g[0]),
+                       D(lay.g[1]), D(lay.hd[0]), D(lay.hd[1]), d_lo, d_hi, D(lay.delta), D(lay.pred), D(lay.step));
     ACINO_LAUNCH_CHECK();
-    if ((rc = assemble(cur ^ 1, true))) return rc;
-    if ((rc = read_totals(cur ^ 1, true))) return rc;
-    const double Ft = tot[0], pred = tot[1], step = tot[2];
-    gnorm = tot[3];
-    if (herr[0]) {
-      status = 5;
-      break;
-    }
-    if (gnorm <= p->gtol) {
-      status = 3;
-      break;
-    }
-    const double gain = pred > 0.0 ? (F - Ft) / pred : -1.0;
-    if (Ft < F) {
-      const double dF = F - Ft;
-      cur ^= 1;
-      F = Ft;
-      ++accepted;
-      const double t = 2.0 * gain - 1.0;
-      lam = lam * std::max(1.0 / 3.0, 1.0 - t * t * t);
-      nu = 2.0;
-      if (dF <= p->ftol * fabs(Ft)) {
-        status = 1;
-        break;
-      }
-      if (step <= p->xtol) {
-        status = 2;
-        break;
-      }
-    } else {
-      lam *= nu;
-      nu *= 2.0;
-      if (lam > lam_max) {
-        status = 4;
-        break;
-      }
-    }
+    if ((rc = assemble(1))) return rc;
+    if ((rc = control(1))) return rc;
+    ACINO_HIP_CHECK(hipMemcpyAsync(hc.data(), d_clip, sizeof(SkelClip) * (size_t)B, hipMemcpyDeviceToHost, s));
+    ACINO_HIP_CHECK(hipStreamSynchronize(s));
+    bool running = false;
+    for (int b = 0; b < B; ++b) running = running || hc[b].status == 0;
+    if (!running) break;
   }
-  if (it > p->max_iter) it = p->max_iter;
-  ACINO_HIP_CHECK(hipMemcpyAsync(d_x, D(lay.x[cur]), sizeof(double) * (size_t)N * P, hipMemcpyDeviceToDevice, s));
+  // ---- the gradient norm of the final iterates (a clip that stopped on ftol / xtol / max_iter holds the norm of the iterate
+  //      BEFORE its last step; at max_iter = 0 none was ever computed), the results
+  if ((rc = build(1))) return rc;
+  if ((rc = control(2))) return rc;
+  hipLaunchKernelGGL(k_skel_gather, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, d_dev, d_clip, D(lay.x[0]), D(lay.x[1]),
+                     d_x, n_el);
+  ACINO_LAUNCH_CHECK();
   if (d_pos) {
-    hipLaunchKernelGGL(k_skel_poses, dim3((N + 255) / 256), dim3(256), 0, s, d_dev, D(lay.x[cur]), d_pos);
+    hipLaunchKernelGGL(k_skel_poses, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, d_dev, d_x, d_pos, (int64_t)NT);
     ACINO_LAUNCH_CHECK();
   }
+  ACINO_HIP_CHECK(hipMemcpyAsync(hc.data(), d_clip, sizeof(SkelClip) * (size_t)B, hipMemcpyDeviceToHost, s));
   ACINO_HIP_CHECK(hipStreamSynchronize(s));
-  if (info) {
-    info->cost_initial = cost0;
-    info->cost_final = F;
-    info->gnorm_inf = gnorm;
-    info->lam = lam;
-    info->iterations = it;
-    info->accepted = accepted;
-    info->status = status;
-    info->pad0 = 0;
+  bool numeric = false;
+  for (int b = 0; b < B; ++b) {
+    numeric = numeric || hc[b].status == 5;
+    if (infos) {
+      infos[b].cost_initial = hc[b].cost0;
+      infos[b].cost_final = hc[b].F;
+      infos[b].gnorm_inf = hc[b].gnorm;
+      infos[b].lam = hc[b].lam;
+      infos[b].iterations = hc[b].it;
+      infos[b].accepted = hc[b].accepted;
+      infos[b].status = hc[b].status;
+      infos[b].pad0 = 0;
+    }
   }
-  if (status == 5) {
-    set_error("non-positive pivot in the banded factorisation (system not positive definite)");
+  if (numeric) {
+    set_error("non-positive pivot in the banded factorisation at every damping up to lam_max (system not positive definite)");
     return ACINO_ERR_NUMERIC;
   }
   return ACINO_OK;
+}
+
+int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_ops, const int32_t* h_active,
+                         const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
+                         const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
+                         acino_skel_fte_info* info, void* stream) {
+  return acino_skel_fte_solve_batch(p, 1, h_ops, h_active, d_meas, d_w, d_cams24, d_lo, d_hi, d_x, d_pos, d_workspace,
+                                    workspace_bytes, info, stream);
 }
 
 }  // extern "C"

@@ -409,7 +409,8 @@ int acino_skeleton_fk(const double* d_q, int64_t n_frames, int n_angles, int n_p
  * the skeleton's marker list, build.py:113-128,288-292) and sets w = 1/R where likelihood > threshold, else 0.
  * d_x[N][n_active]: initial iterate in, solution out.  d_pos[N][n_pose][3] (may be NULL): poses of the solution.
  * Solved by the projected Levenberg-Marquardt of the cheetah path (L1 loss: IRLS curvature w^2 / max(|e|, l1_eps), cost
- * and gradient those of |e|); the controller runs on the host.  Limits: n_active <= 64, 2 n_pose C <= 256. */
+ * and gradient those of |e|); the controller runs on the device (one status word per clip read back per iteration).
+ * Limits: n_active <= 64, 2 n_pose C <= 256. */
 typedef struct acino_skel_fte_params {
   int32_t n_frames, n_cams, n_pose, n_ops, n_angles, n_active;
   int32_t max_iter, pad0;
@@ -431,6 +432,16 @@ int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_
                          const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
                          const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
                          acino_skel_fte_info* info, void* stream);
+/* The same for n_clips independent clips of n_frames frames each in one call (same skeleton, same cameras; the reference
+ * solves windows of N = 100 frames, build.py:131-133 - a video is many of them): every array gains a leading clip index
+ * (d_meas[n_clips][N][C][n_pose][2], d_x[n_clips][N][n_active], ..., infos[n_clips]); no coupling across clips; one
+ * workgroup per clip walks its banded factorisation, every clip has its own Levenberg-Marquardt controller on the device
+ * and stops on its own criteria. */
+size_t acino_skel_fte_workspace_bytes_batch(const acino_skel_fte_params* p, int n_clips);
+int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, const acino_skel_op* h_ops, const int32_t* h_active,
+                               const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
+                               const double* d_hi, double* d_x, double* d_pos, void* d_workspace, size_t workspace_bytes,
+                               acino_skel_fte_info* infos, void* stream);
 
 /* ---- extended Kalman filter + RTS smoother (src/all_optimizations.py:569-865) ---------
  * One call filters and smooths n_seq independent sequences of n_frames frames (same rig).  States are the reference's

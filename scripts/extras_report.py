@@ -48,6 +48,8 @@ for prec in ("f64", "bf16"):
     it = max(info["iterations"], 1)
     srep["config5_64x1000_" + prec] = dict(seconds=dt, ms_per_outer_iteration=1e3 * dt / it, n_points=info["n_points"], n_obs=info["n_obs"],
                                            rms_before_px=info["rms_before"], rms_after_px=info["rms_after"],
-                                           algorithmic_bytes_per_observation=200, hbm_fraction_on_algorithmic_bytes=200.0 * info["n_obs"] * it / dt / 8e12)
+                                           bytes_moved_per_observation=112, compulsory_bytes_per_observation=40,
+                                           hbm_fraction_on_bytes_moved=112.0 * info["n_obs"] * it / dt / 8e12,
+                                           fp64_flop_fraction=2.6e3 * info["n_obs"] * it / dt / 78.6e12)
 json.dump(srep, open(os.path.join(dst, "sba_report.json"), "w"), indent=1)
 print("sba:", srep)

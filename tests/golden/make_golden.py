@@ -552,6 +552,11 @@ def gen_skel_fte():
     tabs = [osf.read_dlc_h5(f)[1] for f in sorted(glob.glob(os.path.join(REF, "data", "*.h5")))]
     np.savez_compressed(os.path.join(OUT, "human_dlc_slice.npz"), det=np.stack([t[:460] for t in tabs], 1).astype(np.float32),
                         parts=out["parts"], note=np.array("rows 0..459 of data/Ex1Cam{3,4}...h5 (x, y, likelihood), float32 as stored by DeepLabCut"))
+    # ... and the whole shipped video (every row of both tables): the full-length real-data workload (build.solve_video)
+    np.savez_compressed(os.path.join(OUT, "human_dlc_full.npz"), parts=out["parts"],
+                        note=np.array("every row of data/Ex1Cam{3,4}...h5 (x, y, likelihood), float32 as stored by DeepLabCut; one array "
+                                      "per camera (the tables differ in length), row i = frame i"),
+                        **{f"det{c}": t.astype(np.float32) for c, t in enumerate(tabs)})
     print("skel_fte_model.npz: obj", out["case_obj"], "max equality residual", out["case_max_eq_residual"],
           "bounded entries", int(np.isfinite(out["bounds_lo"]).sum()), "weights > 0:", int((out["meas_err_weight"] > 0).sum()))
 
