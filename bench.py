@@ -41,7 +41,7 @@ ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0
-PROFILE_DIR = "round4"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
+PROFILE_DIR = "round5"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
 
 
 def _log(msg):

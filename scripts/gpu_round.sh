@@ -16,7 +16,7 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64
 cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 # the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
-mkdir -p $R/profiles/round4 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round4/ 2>/dev/null
+mkdir -p $R/profiles/round5 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round5/ 2>/dev/null
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err)
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
@@ -35,6 +35,11 @@ timeout 600 python scripts/shard_model.py > $OUT/summary/shard_model.txt 2>&1
 find $OUT/rocprof_sba -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/sba_config5_kernel_stats.csv; rm -rf $OUT/rocprof_sba
 timeout 600 bash scripts/pmc_waits_sba.sh > /dev/null 2>&1; cp $R/gpurun_out/waits_sba/waits.txt $OUT/summary/pmc_wait_states_sba.txt 2>/dev/null; rm -rf $R/gpurun_out/waits_sba/p1 $R/gpurun_out/waits_sba/p2
 timeout 300 python scripts/e2e_phases.py > $OUT/summary/e2e_phases.txt 2>&1
+# the widened rows' kernels (k_ekf_*, k_skel_*, k_triangulate_*): kernel stats, wait states, HBM bytes per launch
+timeout 1500 bash scripts/pmc_waits_any.sh extras python $R/scripts/extras_workload.py > /dev/null 2>&1
+cp $R/gpurun_out/waits_extras/waits.txt $OUT/summary/pmc_wait_states_extras.txt 2>/dev/null; cp $R/gpurun_out/waits_extras/kernel_stats.csv $OUT/summary/extras_kernel_stats.csv 2>/dev/null
+timeout 120 python scripts/backsub_stamps.py 100 2>&1 | grep -v amdgpu.ids > $OUT/summary/backsub_step_stamps.txt
+timeout 120 python scripts/sweep_stamps.py 100 3 2>&1 | grep -v amdgpu.ids > $OUT/summary/sweep_node_stamps.txt
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
 # keep the merge-back small: the raw counter dumps are not needed once summarised
