@@ -442,6 +442,28 @@ def secondary_metrics(det, rig, Ts):
     return out
 
 
+def _shard_model_figures(world, halo):
+    """What profiles/<PROFILE_DIR>/shard_model.txt (scripts/shard_model.py: real pinned / windowed contexts of every rank stepped
+    in lock step on ONE GPU, collectives emulated and not timed) predicts for this rank count: the per-rank ms of both drivers
+    before collectives, to hold the measured line against."""
+    import re
+    out = dict(source=f"profiles/{PROFILE_DIR}/shard_model.txt", note="per-rank ms per iteration on one GPU, collectives not included")
+    try:
+        for line in open(os.path.join(ROOT, "profiles", PROFILE_DIR, "shard_model.txt")):
+            m = re.match(r"world 1: .* single-GPU step ([0-9.]+) ms", line)
+            if m:
+                out["single_gpu_ms"] = float(m.group(1))
+            m = re.match(rf"world {world}: .*chunked sweep.* = ([0-9.]+) ms per iteration", line)
+            if m:
+                out["separators_ms"] = float(m.group(1))
+            m = re.match(rf"windows: world {world}, halo (\d+): .*default.*: step ([0-9.]+) ms", line)
+            if m and (int(m.group(1)) == int(halo) or "windows_ms" not in out):
+                out["windows_ms"], out["windows_halo"] = float(m.group(2)), int(m.group(1))
+    except OSError as exc:
+        out["error"] = repr(exc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -738,7 +760,7 @@ def main():
         }
         if world > 1:
             out["drivers"] = {"headline": "windows" if windows else "separators", "windows": other if not windows else None,
-                              "replicas": replicas}
+                              "replicas": replicas, "modelled_on_one_gpu": _shard_model_figures(world, args.halo)}
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
                                   "payload_bytes": ({"all_gather_edge_slabs": world * 2 * (args.halo + 3) * 25 * 8, "all_gather_scalars": world * 8 * 8}
