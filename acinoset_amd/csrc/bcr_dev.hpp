@@ -52,7 +52,7 @@ static __device__ __forceinline__ void build_fetch(NodeFetch& f, const BcrChain&
     f.hv[k] = 0.0;
     if (!sep_left && idx < 3 * NP * NP) {
       const int n = fbase + idx / (NP * NP);
-      if (n < K.n_frames) f.hv[k] = H[(size_t)n * NP * NP + idx % (NP * NP)];
+      if (n < K.n_frames) f.hv[k] = H[(size_t)n * HPAIRS + hpair((idx % (NP * NP)) / NP, idx % NP)];   // (stored as unordered pairs)
     }
   }
   f.xv = 0.0;

@@ -748,7 +748,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
           if (fb_next + j < K.n_frames) {
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl)
-              if (ownp[sl]) hq[sl][j] = Hg[(size_t)(fb_next + j) * NP * NP + pdq[sl] * NP + pcq[sl]];
+              if (ownp[sl]) hq[sl][j] = Hg[(size_t)(fb_next + j) * HPAIRS + bt + 256 * sl];   // (pair e = 13 p + d: as stored)
           }
         if (anydg) {
           const double* xg = cur ? ch.x1 : ch.x0;

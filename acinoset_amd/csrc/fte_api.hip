@@ -99,7 +99,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.state = c.take<acino_fte_state>(1);
   for (int k = 0; k < 2; ++k) b.x[k] = c.take<double>((N + 2 * HALO) * NP);
   for (int k = 0; k < 2; ++k) b.g[k] = c.take<double>(N * NP);
-  for (int k = 0; k < 2; ++k) b.H[k] = c.take<double>(N * NP * NP);
+  for (int k = 0; k < 2; ++k) b.H[k] = c.take<double>(N * HPAIRS);
   for (int k = 0; k < 2; ++k) b.hd[k] = c.take<double>(N * NP);
   b.cost_part = c.take<double>(n_assemble_blocks((int)N) + 1);
   const size_t n_pred = std::max((N * NP + 255) / 256, (size_t)std::max(lay.plan.n_chunks, 0)) + 1;
@@ -233,7 +233,9 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
          const double* step_part, int n_trial, const double* gn_part, int n_nodes, int* nbehind, double* totals,
          int with_step, const FteConst* __restrict__ cst, const int* __restrict__ numeric_err, int fused_control,
          const double* __restrict__ trunc_eps2, int n_trunc) {
-  if (st->status != 0) return;
+  // (the status word is LOADED first and TESTED behind the loads of the partial sums: tested here, every other load of this
+  //  single-workgroup kernel would wait a round trip for it)
+  const int st_status = st->status;
   int* numeric_err_rw = const_cast<int*>(numeric_err);
   // the four reductions run together: strided per-thread partials, one shuffle tree per wave, the sixteen waves
   // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
@@ -276,6 +278,7 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     }
     for (int i = threadIdx.x; i < n_nodes; i += 64 * NW) g = fmax(g, gn_part[i]);
   }
+  if (st_status != 0) return;
   for (int off = 32; off > 0; off >>= 1) {
     c += __shfl_down(c, off, 64);
     p += __shfl_down(p, off, 64);
@@ -498,7 +501,10 @@ __global__ void k_export_HG(const acino_fte_state* __restrict__ st, const double
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (dg && e < n * NP) dg[e] = g[e];
   if (dh)
-    for (int64_t k = e; k < n * NP * NP; k += (int64_t)gridDim.x * 256) dh[k] = H[k];
+    for (int64_t k = e; k < n * NP * NP; k += (int64_t)gridDim.x * 256) {      // (out: the full [25][25] block)
+      const int rem = (int)(k % (NP * NP));
+      dh[k] = H[(k / (NP * NP)) * HPAIRS + hpair(rem / NP, rem % NP)];
+    }
 }
 
 __global__ void k_export_edges(const acino_fte_state* __restrict__ st, int which, const double* x0, const double* x1,

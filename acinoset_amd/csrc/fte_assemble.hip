@@ -386,7 +386,7 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       for (int i = 0; i < 6; ++i) gm += xb[i] * S[21 + i];
       gout[(int64_t)n * NP + bq] = gm + 2.0 * q * gs;
       // Hessian column bq of this frame's 25x25 block
-      double* Dn = D0 + (int64_t)n * NP * NP;
+      double* Dn = D0 + (int64_t)n * HPAIRS;          // the frame's 325 unordered state pairs (fte_kernels.hpp: hpair)
       const unsigned ancb = g < 0 ? 0u : c_ancmask[g];
 #pragma unroll
       for (int a = 0; a < NP; ++a) {
@@ -394,7 +394,9 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
         // a is ancestor-or-same of bq ?   (root is an ancestor of everything; root-root only with itself)
         bool a_anc_b = ga < 0 ? true : (g >= 0 && ((ancb >> ga) & 1u));
         bool b_anc_a = g < 0 ? true : (ga >= 0 && ((c_ancmask[ga] >> g) & 1u));
-        if (a_anc_b) {
+        // (two ROOT states are each other's "ancestor": the pair has two candidate writers whose values agree only to rounding -
+        //  the thread of the larger state writes, so the stored value does not depend on which store lands last)
+        if (a_anc_b && !(b_anc_a && a > bq)) {
           double val;
           if (a < 3) {
             val = Y[a];
@@ -406,10 +408,9 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
             val += 2.0 * q * b0;
             hdout[(int64_t)n * NP + bq] = val;
           }
-          Dn[a * NP + bq] = val;
-          if (!b_anc_a) Dn[bq * NP + a] = val;   // strict ancestor: mirror
-        } else if (!b_anc_a) {
-          Dn[a * NP + bq] = 0.0;                   // unrelated branches
+          Dn[hpair(a, bq)] = val;                 // (the pair of a state with an ancestor-or-self: written by the descendant's thread)
+        } else if (!b_anc_a && a < bq) {
+          Dn[hpair(a, bq)] = 0.0;                 // unrelated branches (one writer)
         }
       }
     }

@@ -123,6 +123,17 @@ struct ProfSpan {
 // x iterate buffers carry 3 halo frames on each side: row (i + 3) holds local frame i.
 constexpr int HALO = 3;
 
+// The Gauss-Newton block of a frame is symmetric: the assembly stores its 325 UNORDERED state pairs {p, p'} only, pair
+// e = 13 p + d with p' = (p + d) mod 25, d = 0 .. 12 (every cyclic distance once: 25 is odd) - the order in which the chunk
+// sweep builds a node from state pairs, so its 256 builder threads read consecutive doubles (round 5; before: [25][25], both
+// triangles written, 5 000 B per frame written and read back instead of 2 600).
+constexpr int HPAIRS = 13 * NP;
+__host__ __device__ inline int hpair(int p, int pc) {
+  int d = pc - p;
+  if (d < 0) d += NP;
+  return d <= NP / 2 ? 13 * p + d : 13 * pc + (NP - d);
+}
+
 int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_state* d_st, int which,
                     const double* d_det, double* const x[2], double* const H[2], double* const g[2],
                     double* const hd[2], double* d_cost_partials, int* d_nbehind, bool need_jac, bool respect_status, hipStream_t s);
