@@ -97,6 +97,16 @@ __device__ __forceinline__ void lds_wait(int* f, int target) {
   while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
+// two conditions in one poll: both counters are requested together (one LDS round trip per look instead of two loops)
+__device__ __forceinline__ void lds_wait2(int* f0, int t0, int* f1, int t1) {
+  for (;;) {
+    const int a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int b = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (a >= t0 && b >= t1) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
 // barrier among the n waves that share cnt: every participant adds one and waits for the n-th arrival of this round
 __device__ __forceinline__ void lds_barrier(int* cnt, int& target, int n, int lane) {
   target += n;
@@ -259,6 +269,8 @@ __device__ __forceinline__ void panel_tiles(double* Lm, int kb, int t0, int li, 
 struct TrioSync {
   int t3 = 0, posts = 0, crit = 0, lpan = 0, udone = 0, ulow = 0;
 };
+// (MEET = false: no closing barrier of the three - the caller's next synchronisation point includes them all)
+template <bool MEET = true>
 __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int* err, int* sync, TrioSync& ts,
                                              long long* dbg = nullptr) {
   const int li = lane & 15, lk = lane >> 4;
@@ -347,7 +359,7 @@ __device__ __forceinline__ void chol80_trio(double* Lm, int role, int lane, int*
     panel_tiles<1>(Lm, NT - 1, 3, li, lk);             // (3, 4)
     __builtin_amdgcn_s_setprio(0);
   }
-  lds_barrier(c3, ts.t3, 3, lane);
+  if (MEET) lds_barrier(c3, ts.t3, 3, lane);
   ts.posts = post0 + 9;
   ts.crit = crit0 + 4;
   ts.lpan = lp0 + 4;
@@ -675,6 +687,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
 #define SW_STAMP(i) do { if (dbgp && k == dbg_k && lane == 0) lst[i] = (long long)wall_clock64(); } while (0)
   if (tid < 16) sync[tid] = 0;
   if (tid < 64) lst[tid] = 0;
+  if (dbgp && tid == 0) dbgp[70] = (long long)wall_clock64();    // (run-level stamps: 70 start, 60 first node built, 61 factored, 62 loop done, 71 end)
   if (c == 0 && node0) {                               // the left pin owns no frames here: its block starts from zero, the
     for (int e = tid; e < BS * BS; e += SW_T) sp.D[e] = 0.0;       // run's spike contribution AL is added by the reduction
     if (tid < BS) sp.b[tid] = 0.0;
@@ -694,6 +707,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     for (int e = tid; e < MAT; e += SW_T) Y[e] = 0.0;
     gmax_run = build_finish<SW_T>(Xf, bvb, f, K, first, tid, kq, klo, khi);
     __syncthreads();                                   // node, bv, tables, zeros complete
+    if (dbgp && tid == 0) lst[60] = (long long)wall_clock64();
     if (hasL)
       for (int e = tid; e < 9 * NP; e += SW_T) {
         const int pair = e / NP, p = e % NP, ii = pair / 3, jj = pair % 3;
@@ -703,6 +717,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
     __syncthreads();
     if (role < 3) chol80_trio(Xf, role, lane, numeric_err, sync, tsy);
     __syncthreads();
+    if (dbgp && tid == 0) lst[61] = (long long)wall_clock64();
   }
 
   int tb = 0, tsb = 0;                       // rounds of the builders' barrier
@@ -876,7 +891,8 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
       if (bt == 0) __hip_atomic_fetch_add(c_bv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (bw == 0) SW_STAMP(4);
       if (bw < 3) {
-        if (!last) chol80_trio(Xf, bw, ln, numeric_err, sync, tsy, (dbgp && k == dbg_k) ? lst : nullptr);
+        // (no closing barrier of the trio: the four D waves meet at the top of the next iteration, before anyone reads the factor)
+        if (!last) chol80_trio<false>(Xf, bw, ln, numeric_err, sync, tsy, (dbgp && k == dbg_k) ? lst : nullptr);
         SW_STAMP(8 + wave);
       } else if (bw == 3) {
         // G_k -> HBM, lower tiles only (G is symmetric: the back-substitution mirrors them): the chain's SIMD mate, 30 items per lane
@@ -905,6 +921,8 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   }
   __syncthreads();                                     // both teams through
   if (dbgp) {
+    if (tid == 0) lst[62] = (long long)wall_clock64();
+    __syncthreads();
     if (tid < 64 && lst[tid]) dbgp[tid] = lst[tid];
   }
   if (hasR) {                                          // the node built last is the right separator
@@ -926,6 +944,7 @@ k_chunk_sweep(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, int* nu
   }
 #undef SW_STAMP
   publish_gmax<SW_T>(gmax_run, red, ch.gn_part, c, tid);
+  if (dbgp && tid == 0) dbgp[71] = (long long)wall_clock64();
 }
 
 // Separator q: D += AL (the run on its right; lower tiles - the factorisation reads no others).  The right-hand side rode as
@@ -1247,10 +1266,10 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
       const bool fwd = s < nf;
       const int k = node_at(s), node = first + k;
       const double* const St = stg + (s % BK_NB) * BK_STAGE;
-      lds_wait(c_ready + (s % BK_NL), s / BK_NL + 1);       // the node's stage
 #define BK_STAMP(i) do { if (bdbg && s >= 8 && s < 16) { __builtin_amdgcn_s_waitcnt(0xC07F); bdbg[6 * (s - 8) + (i)] = (long long)wall_clock64(); } } while (0)
+      // the node's stage and the vector (every product wave through with step s - 1), one poll for both
+      lds_wait2(c_ready + (s % BK_NL), s / BK_NL + 1, c_u, BK_PW * (s + 1));
       BK_STAMP(0);
-      lds_wait(c_u, BK_PW * (s + 1));                       // the vector (every product wave through with step s - 1)
       BK_STAMP(1);
       double uv[NJ], gv[3][NJ];
 #pragma unroll

@@ -41,4 +41,7 @@ for kb in range(4):
 for i in sorted(names, key=lambda i: d[i]):
     if d[i]:
         print(f"{(d[i] - t0) / 100.0:8.2f} us  {names[i]}")
+if d[70]:
+    print(f"run-level (us from the workgroup's start): first node built {(d[60] - d[70]) / 100.0:.2f}, factored {(d[61] - d[70]) / 100.0:.2f}, "
+          f"node loop done {(d[62] - d[70]) / 100.0:.2f}, workgroup done {(d[71] - d[70]) / 100.0:.2f}")
 print("SIMD of waves 0..7:", [(int(d[67]) >> (4 * w)) & 3 for w in range(8)], " HW_ID of wave 0: %#x" % int(d[68]))
