@@ -248,6 +248,19 @@ def solve_model(model, x0=None, **solver_kw):
     return solve_models([model], None if x0 is None else [x0], **solver_kw)[0]
 
 
+def video_windows(first_frame, last_frame, window, overlap):
+    """First frames of the windows ``solve_video`` cuts first_frame .. last_frame into: ``window`` frames each, consecutive
+    windows ``overlap`` frames apart from abutting, the last one pulled back so that it ends on ``last_frame``."""
+    if not 0 <= overlap < window:
+        raise ValueError("0 <= overlap < window")
+    if last_frame - first_frame + 1 < window:
+        raise ValueError(f"{last_frame - first_frame + 1} frames, windows of {window}")
+    starts = list(range(first_frame, last_frame - window + 2, window - overlap))
+    if starts[-1] + window - 1 < last_frame:
+        starts.append(last_frame - window + 1)
+    return starts
+
+
 def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, first_frame=None, last_frame=None, window=N_FRAMES,
                 overlap=20, **kw):
     """A whole video as the reference would have to do it - windows of ``window`` frames (build.py:131-133: N = 100), here
@@ -268,10 +281,7 @@ def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, fir
     total = f1 - f0 + 1
     if total < window:
         raise ValueError(f"{total} frames, windows of {window}")
-    stride = window - overlap
-    starts = list(range(f0, f1 - window + 2, stride))
-    if starts[-1] + window - 1 < f1:
-        starts.append(f1 - window + 1)
+    starts = video_windows(f0, f1, window, overlap)
     # the forehead of every frame, triangulated once (the reference's initial point uses the same marker, build.py:143-166)
     head = None
     tabs3 = [(list(tb[0]), np.asarray(tb[1], dtype=np.float64), ix) for tb, ix in zip(dlc_tables, idx)]

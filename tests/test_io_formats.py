@@ -53,3 +53,30 @@ def test_tri_scatter_and_fte_pickle(tmp_path):
     assert set(raw) == {"positions", "x", "dx", "ddx", "start_frame"} and isinstance(raw["x"], list) and len(raw["x"][0]) == 25
     back = aio.load_fte(path)
     assert back["x"].shape == (4, 25) and back["positions"].shape == (4, 20, 3) and back["start_frame"] == 7
+
+
+def test_video_windows_cover_every_frame_once_deep_enough():
+    """build.video_windows (host logic of build.solve_video): windows of the reference's length, consecutive ones overlapping,
+    the last one pulled back to end on the last frame; every frame lies in a window, and - away from the two ends of the
+    video - at least overlap / 2 frames deep in one of them (the stitching takes a frame from the window in which it lies
+    deepest)."""
+    from acinoset_amd import build
+    for f0, f1, w, ov in ((0, 6239, 100, 20), (60, 459, 100, 20), (0, 99, 100, 20), (5, 250, 100, 0), (0, 1000, 64, 63)):
+        st = build.video_windows(f0, f1, w, ov)
+        assert st[0] == f0 and st[-1] + w - 1 == f1 and all(b > a for a, b in zip(st, st[1:]))
+        assert all(b - a <= w - ov for a, b in zip(st, st[1:]))
+        depth = np.full(f1 - f0 + 1, -1)
+        for s in st:
+            d = np.minimum(np.arange(w), w - 1 - np.arange(w))
+            sl = slice(s - f0, s - f0 + w)
+            depth[sl] = np.maximum(depth[sl], d)
+        assert (depth >= 0).all()
+        inner = depth[w // 2: len(depth) - w // 2]
+        assert inner.size == 0 or inner.min() >= ov // 2 - 1
+    assert build.video_windows(0, 6239, 100, 20)[:3] == [0, 80, 160] and len(build.video_windows(0, 6239, 100, 20)) == 78
+    for bad in ((0, 50, 100, 20), (0, 500, 100, 100)):
+        try:
+            build.video_windows(*bad)
+        except ValueError:
+            continue
+        raise AssertionError(bad)
