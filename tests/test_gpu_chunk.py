@@ -205,3 +205,22 @@ def test_soak_thousands_of_steps_bit_reproducible_under_foreign_load(mods, n, st
 def C_void(v):
     import ctypes
     return ctypes.c_void_p(v)
+
+
+def test_separator_tail_falls_back_to_the_per_level_kernels_on_a_device_that_cannot_hold_it(mods, monkeypatch):
+    """Round-4 advisor: the one-launch back-substitution of the separator chain (k_sep_tail) needs every one of its workgroups
+    resident, so a context is only given it where occupancy x compute units of the device hold them all; elsewhere (a CU mask, a
+    partitioned GPU - here: ACINO_SEP_TAIL_CAPACITY pretends a device with room for one workgroup) the per-level kernels
+    run.  Same LM path either way: decisions equal, trial iterates to rounding."""
+    calib, fte, synth = mods
+    n = 3331
+    seq = synth.make_sequence(n, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    xa = _start(fte, seq, n, 11)
+    ref = _walk(fte, seq["det"], rig, seq["Ts"], xa, 4)
+    monkeypatch.setenv("ACINO_SEP_TAIL_CAPACITY", "1")
+    got = _walk(fte, seq["det"], rig, seq["Ts"], xa, 4)
+    for it, (r, g) in enumerate(zip(ref, got)):
+        assert g[3] == 0 and r[3] == 0 and g[1] == r[1], (it, g[3], r[3])
+        assert abs(g[0] - r[0]) <= 1e-11 * abs(r[0]), (it, g[0], r[0])
+        assert np.abs(g[4] - r[4]).max() < 1e-10, (it, float(np.abs(g[4] - r[4]).max()))
