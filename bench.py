@@ -378,6 +378,19 @@ def secondary_metrics(det, rig, Ts):
             mean_abs_residual_px=sinfo["cost_final"] * _build.R_MEAS / max(n_w, 1), ms_per_iteration=1e3 * (t2 - t1) / max(sinfo["iterations"], 1),
             data="rows 60..459 of the reference's data/Ex1Cam{3,4}...h5, skeletons/new_human.pickle, data/4_cam_scene_static_sba.json",
             note="L1 measurement loss, constant model weight 0.002 (src/build.py:186-191, 299); csrc/skel_fte.hip")
+        # ... the same 400-frame clip with every compute unit: alternating Schwarz over half-overlapping windows (build.solve_model_parallel)
+        _log("secondary: skeleton FTE, one clip on every CU (alternating Schwarz over windows)")
+        for _rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _pres, pinfo = _build.solve_model_parallel(model)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        out["skeleton_fte_human_real_detections"]["alternating_schwarz_over_windows"] = dict(
+            seconds_solve=t1 - t0, outer_iterations=pinfo["outer_iterations"], windows=pinfo["windows"], status=pinfo["status_name"],
+            cost_final=pinfo["cost_final"], gnorm_inf=pinfo["gnorm_inf"], cost_final_single_workgroup=sinfo["cost_final"],
+            note="whole-clip cost and projected gradient of the outer iteration's end point; the single-workgroup solve above is the exact "
+                 "banded factorisation of the same clip")
         # ... and the WHOLE shipped video (6 240 frames): 78 windows of the reference's 100 frames (build.py:131-133), overlapping
         # by 20, as ONE batched solve - one workgroup and one device-side controller per window (acino_skel_fte_solve_batch)
         full = np.load(os.path.join(gd, "human_dlc_full.npz"))
