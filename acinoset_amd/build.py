@@ -89,7 +89,7 @@ class SkeletonModel:
 
 
 def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_frames=N_FRAMES, start_frame=START_FRAME,
-                h=H_STEP, pairing="reference", lik_thresh=LIK_THRESH, r_meas=R_MEAS, model_weight=MODEL_WEIGHT):
+                h=H_STEP, pairing="reference", lik_thresh=LIK_THRESH, r_meas=R_MEAS, model_weight=MODEL_WEIGHT, initial_line=True):
     """build.py:28-304.  ``project_dir`` is the reference's: ``data/4_cam_scene_static_sba.json`` and ``data/*.h5`` are read
     from it (:97-109); alternatively pass ``scene = (k_arr, d_arr, r_arr, t_arr)`` and ``dlc_tables`` = one
     ``(bodyparts, values[frames, K, 3])`` per camera.  Returns ``(model, pose_to_3d)`` as the reference does."""
@@ -138,7 +138,7 @@ def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_f
     # ---- initial point: line through the triangulated "forehead" over ALL frames the cameras share (:143-166), a regression
     #      against the frame VALUE, evaluated at 0 .. N-1 (:157)
     init_x = np.zeros((n_frames, 3 + 3 * prog["n_angles"]))
-    if all("forehead" in parts for parts, _v, _i in tabs) and C_ >= 2:
+    if initial_line and all("forehead" in parts for parts, _v, _i in tabs) and C_ >= 2:   # (initial_line=False: the caller brings x0)
         common = tabs[0][2]
         for _p, _v, idx in tabs[1:]:
             common = np.intersect1d(common, idx)
@@ -363,7 +363,8 @@ def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, fir
             head = np.stack([np.interp(fr, fr[ok], tri[ok, j]) for j in range(3)], axis=1)
     models, x0s = [], []
     for st in starts:
-        m, _ = build_model(skel_dict, project_dir, scene=scene, dlc_tables=dlc_tables, n_frames=window, start_frame=st, **build_kw)
+        m, _ = build_model(skel_dict, project_dir, scene=scene, dlc_tables=dlc_tables, n_frames=window, start_frame=st,
+                           initial_line=head is None, **build_kw)
         x0 = m.init_x.copy()
         if head is not None:
             x0[:, :3] = head[st - f0:st - f0 + window]
