@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the FTE hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) the ranks
+are taken as given; started as a plain `python bench.py --gpus N` the script launches its own N ranks (self_launch()) and
+forwards rank 0's JSON line.  Either way stdout carries exactly ONE JSON line; everything else (progress, Gloo / c10d /
+RCCL banners) goes to stderr.
 
 A "step" is ONE Levenberg-Marquardt iteration over the whole synthetic sequence: damped block system ->
 block-cyclic-reduction solve -> trial iterate -> reprojection residuals + analytic Jacobians + normal-
@@ -477,6 +482,109 @@ def _shard_model_figures(world, halo):
     return out
 
 
+_JSON_OUT = None
+
+
+def _claim_stdout():
+    """stdout carries exactly one JSON line: keep a private handle on the real stdout and point fd 1 at stderr, so that
+    whatever else writes to fd 1 - Python prints, the C++ banners of Gloo / c10d / RCCL - cannot land in front of it."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
+def _emit(obj):
+    out = _claim_stdout()
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line_of(text):
+    """The last line of `text` that parses as a JSON object with a "metric" key (None if there is none); the other lines."""
+    found, rest = None, []
+    for line in text.splitlines():
+        obj = None
+        if line.startswith("{"):
+            try:
+                obj = json.loads(line)
+            except ValueError:
+                obj = None
+        if isinstance(obj, dict) and "metric" in obj:
+            if found is not None:
+                rest.append(found)
+            found = line
+        else:
+            rest.append(line)
+    return found, rest
+
+
+def self_launch(n_ranks, argv, extra_env=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run on
+    127.0.0.1 (a free port), pass rank 0's JSON line through to stdout, everything else to stderr.  If the sharded run
+    dies (it has never met a multi-GPU node: a failing collective must not leave the caller without a number) the
+    collective-free placement is run instead - N replicas, weak scaling - and the line says so (`fallback`)."""
+    import subprocess
+    me = os.path.abspath(__file__)
+
+    def run(more):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), me] + list(argv) + more
+        _log("self-launch: " + " ".join(cmd))
+        env = dict(os.environ, ACINO_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        env.update(extra_env or {})
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+        line, rest = _json_line_of(pr.stdout)
+        for other in rest:
+            print(other, file=sys.stderr)
+        return pr.returncode, line
+
+    rc, line = run([])
+    if line is None and "--shard" not in argv and "--dry-run" not in argv:
+        _log(f"self-launch: the sharded run ended with rc {rc} and no JSON line; running {n_ranks} replicas instead")
+        rc2, line = run(["--shard", "replicas"])
+        if line is not None:
+            obj = json.loads(line)
+            obj["fallback"] = f"the frame-sharded run ended with rc {rc} before printing; this line is --shard replicas"
+            line, rc = json.dumps(obj), rc2
+    if line is None:
+        raise SystemExit(rc or 1)
+    _emit(json.loads(line))
+    return rc
+
+
+def _dry_run(rank, world, backend, dev_seen):
+    """--dry-run: everything around the measurement - launch, rendezvous, one all-reduce, one all-gather, the single JSON
+    line - without touching a GPU (what the CPU test of the launch path runs)."""
+    import torch.distributed as dist
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        seen = [None] * world
+        dist.all_gather_object(seen, dev_seen)
+    else:
+        seen = [dev_seen]
+    if rank == 0:
+        _emit({"metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint", "value": None, "unit": "frames/s",
+               "n_gpus": world, "dry_run": True, "world": world, "backend": backend, "devices_seen": seen,
+               "all_reduce_check": float(t.item()) == world * (world + 1) / 2,
+               "self_launched": os.environ.get("ACINO_BENCH_SELF_LAUNCHED") == "1"})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,11 +595,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / solve-to-tolerance extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
-    ap.add_argument("--shard", choices=("both", "windows", "separators"), default="both",
+    ap.add_argument("--dry-run", action="store_true", help="launch, rendezvous, one collective and the JSON line only (no GPU work)")
+    ap.add_argument("--shard", choices=("both", "windows", "separators", "replicas"), default="both",
                     help="N > 1: 'both' (default) = the headline is the separator system - the north star's RCCL all-reduce on the "
                          "temporal-coupling rows, exact step - and the overlapping-window driver is timed in the same run "
                          "(drivers.windows); or one of: overlapping windows (two all-gathers per step, step exact to the decay over --halo frames) or "
-                         "exact separator system (one all-reduce + two all-gathers)")
+                         "exact separator system (one all-reduce + two all-gathers); 'replicas' = every rank solves its own copy of the "
+                         "whole sequence (weak scaling, no data-path collective)")
     ap.add_argument("--halo", type=int, default=192, help="--shard windows: frames of overlap on either side")
     ap.add_argument("--bcr-levels", type=int, default=None,
                     help="reduction levels before the remaining nodes are solved on their own + refined (default: the library's "
@@ -503,19 +613,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (how the driver starts N = 1): be the launcher
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: start one rank per GPU "
+                         "(torch.distributed.run --nproc-per-node N), or run `python bench.py --gpus N` and let it launch them")
+    _claim_stdout()
     # ACINO_DIST_BACKEND=gloo ACINO_FORCE_DEVICE=0 lets several ranks share one GPU (functional check of the
     # multi-process path on a single-GPU box); the driver's runs use RCCL, one rank per GPU.
     backend = os.environ.get("ACINO_DIST_BACKEND", "nccl")
+    if args.dry_run and not torch.cuda.is_available():
+        backend = "gloo"
     dev_index = int(os.environ.get("ACINO_FORCE_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
     import torch.distributed as dist
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        return _dry_run(rank, world, backend, dev_index)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
+            assert dev_index < torch.cuda.device_count(), f"rank {rank}: device {dev_index} of {torch.cuda.device_count()}"
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
@@ -606,8 +727,40 @@ def main():
         return dict(ms_per_step=1e3 * dt_ / args.steps, value=world * args.frames * args.steps / dt_, unit="frames/s", scaling="weak",
                     what=f"{world} independent {args.frames}-frame sequences, one per GPU, single-GPU solver, no data-path collective")
 
-    other = time_other_driver("windows") if (world > 1 and args.shard == "both") else None
-    replicas = time_replicas() if (world > 1 and args.shard == "both") else None
+    # N > 1, --shard both: BOTH sharded drivers are timed the same way first; the faster one becomes the headline (and is the
+    # one profiled below), the other one, the replicas (weak scaling) and the one-GPU model stand beside it
+    pre = {}
+    replicas = None
+    if world > 1 and args.shard == "both":
+        for kind in ("separators", "windows"):
+            if rank == 0:
+                _log(f"driver {kind}")
+            pre[kind] = time_other_driver(kind)
+        windows = pre["windows"]["value"] > pre["separators"]["value"]
+    if world > 1 and args.shard in ("both", "replicas"):
+        if rank == 0:
+            _log("replicas")
+        replicas = time_replicas()
+    dev_seen = dict(rank=rank, device=dev_index, name=torch.cuda.get_device_name(dev_index),
+                    uuid=str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", "")))
+    devices_seen = [dev_seen]
+    if world > 1:
+        devices_seen = [None] * world
+        dist.all_gather_object(devices_seen, dev_seen)
+    if world > 1 and args.shard == "replicas":
+        if rank == 0:
+            _emit({"metric": "FTE frames/sec (residual+Jac+LM step), 6-cam x 20-joint", "value": replicas["value"], "unit": "frames/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": replicas["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": f"FTE LM iteration, {N_CAMS} cam x 20 markers x {args.frames} frames PER GPU (replicas), loop "
+                                          "trajectory, seed 20210313", "frames": args.frames, "cams": N_CAMS, "markers": 20, "states": 25,
+                              "parallelism": f"{world} replicas, no data-path collective"},
+                   "world": world, "backend": backend, "devices_seen": devices_seen,
+                   "every_rank_its_own_device": len({d["device"] for d in devices_seen}) == world,
+                   "drivers": {"headline": "replicas", "replicas": replicas}, "roofline": None, "cpu_baseline": None})
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     common = dict(ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,                           # never stops: every step is full work
                   shared_gpu="ACINO_FORCE_DEVICE" in os.environ)                             # (ranks sharing one GPU: functional runs only)
     solver_kw = {}
@@ -772,7 +925,11 @@ def main():
             "lm_state": {k: st[k] for k in ("cost", "iter", "accepted", "lam", "status_name", "trunc_eps")},
         }
         if world > 1:
-            out["drivers"] = {"headline": "windows" if windows else "separators", "windows": other if not windows else None,
+            out["world"], out["backend"], out["devices_seen"] = world, backend, devices_seen
+            out["every_rank_its_own_device"] = len({d["device"] for d in devices_seen}) == world
+            out["drivers"] = {"headline": "windows" if windows else "separators",
+                              "chosen": "the faster of the two sharded drivers in their own timed runs" if pre else f"--shard {args.shard}",
+                              "separators": pre.get("separators"), "windows": pre.get("windows"),
                               "replicas": replicas, "modelled_on_one_gpu": _shard_model_figures(world, args.halo)}
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
@@ -793,7 +950,9 @@ def main():
             _log("done")
         elif world > 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        if world == 1:
+            out["world"], out["backend"], out["devices_seen"] = 1, None, devices_seen
+        _emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

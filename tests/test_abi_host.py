@@ -189,3 +189,35 @@ def test_chunk_plan_of_sharded_ranks():
         assert 1 <= last <= plan["m"] + 1 and (not pr or last >= 2 or plan["n_chunks"] == 1), (n, plan, last)
     whole = fte.solver_plan(fte.make_params(999, 6, 1 / 120, n_global=5000, n_offset=999, pin_left=True, pin_right=True, chunk_nodes=-1))
     assert whole["n_chunks"] == 0
+
+
+def test_bench_launches_its_own_ranks_and_prints_one_json_line():
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (how the driver starts N = 1) must launch its own N ranks and
+    leave exactly one JSON line on stdout - Gloo / c10d banners and progress belong to stderr.  --dry-run stops before the GPU work:
+    launch, rendezvous on 127.0.0.1, one all-reduce, one all-gather of the ranks' devices, the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, pr.stdout
+    obj = json.loads(lines[0])
+    assert obj["n_gpus"] == 2 and obj["world"] == 2 and obj["self_launched"] and obj["all_reduce_check"]
+    assert obj["devices_seen"] == [0, 1]                   # every rank reports the device its LOCAL_RANK names
+    assert "self-launch" in pr.stderr
+    # a launcher's ranks with the wrong --gpus are refused with a message, not silently run
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    pr2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env=env2, cwd=root)
+    assert pr2.returncode != 0 and "WORLD_SIZE" in pr2.stderr
+
+
+def test_bench_json_line_filter():
+    import bench
+    line, rest = bench._json_line_of('[Gloo] Rank 0 is connected\n{"not": "it"}\n{"metric": "m", "value": 1}\ntrailing')
+    assert line == '{"metric": "m", "value": 1}' and rest == ['[Gloo] Rank 0 is connected', '{"not": "it"}', 'trailing']
+    assert bench._json_line_of("nothing here")[0] is None
