@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libacinoset_hip.so")
 BUILD_ID_SOURCE = "camera_kernels.hip"      # defines acino_build_id()
-SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "chunk.hip", "fte_api.hip", "sba.hip", "ekf.hip", "skel_fte.hip"]
-HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "bcr_dev.hpp", "chunk.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
+SOURCES = ["camera_kernels.hip", "fte_assemble.hip", "bcr.hip", "seplevel.hip", "chunk.hip", "fte_api.hip", "sba.hip", "ekf.hip", "skel_fte.hip"]
+HEADERS = ["common.hpp", "fte_kernels.hpp", "bcr.hpp", "bcr_dev.hpp", "seplevel.hpp", "chunk.hpp", "trio80.hpp", "dense80.hpp", "cheetah_fk.hpp", os.path.join("..", "..", "include", "acinoset_hip.h")]
 
 ABI_VERSION = 3          # ACINO_ABI_VERSION of include/acinoset_hip.h
 N_ACTIVE = 25

@@ -19,6 +19,7 @@
 #include "bcr.hpp"
 #include "dense80.hpp"
 #include "bcr_dev.hpp"
+#include "seplevel.hpp"
 
 namespace acino {
 
@@ -189,7 +190,7 @@ k_bcr_elim(BcrChain ch, const int* __restrict__ elim, const FteConst* __restrict
   ACINO_STAMP(4);
   store_mat(ch.U + i * MB, Lm, tid);
   __syncthreads();
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+  if (tid < BS) ybuf(ch)[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
   ACINO_STAMP(5);
 }
 
@@ -300,7 +301,7 @@ k_bcr_elim_deep(BcrChain ch, const int* __restrict__ elim, int* numeric_err, con
     //  concurrently; alone, all siblings start together and the in-place store went unnoticed.)
     store_mat(ch.U + i * MB, Lm, tid);
     __syncthreads();
-    if (tid < BS) ch.b[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
+    if (tid < BS) ybuf(ch)[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
   }
 }
 
@@ -406,8 +407,8 @@ k_bcr_update(BcrChain ch, const int* __restrict__ remain, const FteConst* __rest
     double* yb = ya + BS;
     double* ysc = yb + BS;
     if (tid < BS) {
-      ya[tid] = im >= 0 ? ch.b[(size_t)im * BS + tid] : 0.0;
-      yb[tid] = ip >= 0 ? ch.b[(size_t)ip * BS + tid] : 0.0;
+      ya[tid] = im >= 0 ? ybuf(ch)[(size_t)im * BS + tid] : 0.0;
+      yb[tid] = ip >= 0 ? ybuf(ch)[(size_t)ip * BS + tid] : 0.0;
     }
     const int col = tid % BS, part = tid / BS, k0 = 27 * part, nk = part < 2 ? 27 : 26;
     double wa[27], wc[27];
@@ -523,8 +524,8 @@ k_bcr_update_deep(BcrChain ch, const int* __restrict__ remain, const int* __rest
                      // lanes along a row of W (coalesced); keeps this mat-vec off the tile workgroups' critical path
     if (im < 0 && ip < 0 && !AL) return;
     if (tid < BS) {
-      yv[tid] = im >= 0 ? ch.b[(size_t)im * BS + tid] : 0.0;
-      yv2[tid] = ip >= 0 ? ch.b[(size_t)ip * BS + tid] : 0.0;
+      yv[tid] = im >= 0 ? ybuf(ch)[(size_t)im * BS + tid] : 0.0;
+      yv2[tid] = ip >= 0 ? ybuf(ch)[(size_t)ip * BS + tid] : 0.0;
     }
     const int col = tid % BS, part = tid / BS, k0 = 27 * part, nk = part < 2 ? 27 : 26;
     double wa[27], wc[27];
@@ -656,7 +657,7 @@ k_bcr_backsub(BcrChain ch, const int* __restrict__ elim, const int* __restrict__
   if (l >= 0) fetch_mat<NTH>(vl, ch.Wl + i * MB, tid);
   if (r >= 0) fetch_mat<NTH>(vr, ch.Wr + i * MB, tid);
   fetch_mat<NTH>(vu, ch.U + i * MB, tid);
-  double t = (tid < BS) ? ch.b[(size_t)i * BS + tid] : 0.0;
+  double t = (tid < BS) ? ybuf(ch)[(size_t)i * BS + tid] : 0.0;
   if (tid < BS) {
     xv[tid] = l >= 0 ? ch.b[(size_t)l * BS + tid] : 0.0;
     xv[BS + tid] = r >= 0 ? ch.b[(size_t)r * BS + tid] : 0.0;
@@ -747,7 +748,7 @@ k_bcr_backsub_tail(BcrChain ch, const int* __restrict__ status, int* __restrict_
       }
     }
   }
-  const double yi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;     // y_i: written by the reduction, long ago
+  const double yi = tid < BS ? ybuf(ch)[(size_t)i * BS + tid] : 0.0;     // y_i: written by the reduction, long ago
   if (tid == 0) {   // cheap relaxed polls, ONE acquire (cache invalidation) once the deeper levels are done
     // BOUNDED: a workgroup only waits for lower block indices, which the dispatcher starts first in practice but HIP does
     // not promise; if the wait outlives ~0.5 s of polling (a step is < 1 ms) the kernel gives up, flags the step
@@ -1202,6 +1203,10 @@ struct SepTailArgs {
   int* done;             // [n_nodes]
   double* xbuf;          // [2][n_iso][80]
   double* norms;         // [4][n_iso]: |update|, |x| of the last sweep; the same of the sweep before it
+  // chains with fused narrow levels: the isolated nodes are FACTORED HERE (no elimination launch for them, no round trip of
+  // the factor): D + AL + SL + SR is formed in LDS; iso_loc = per entry (flags, location of block(next isolated node, this one))
+  const int* iso_loc;
+  int fused;
 };
 __device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_err) {
   long long polls = 0;
@@ -1279,10 +1284,57 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     // ---------------- isolated node: truncated solve + refinement sweeps ----------------
     const int p = blockIdx.x, n_iso = a.n_iso;
     const int j = a.iso[3 * p], l = p > 0 ? a.iso[3 * (p - 1)] : -1, r = p + 1 < n_iso ? a.iso[3 * (p + 1)] : -1;
-    load3(l >= 0 ? ch.Cpl + (size_t)l * MB : nullptr, r >= 0 ? ch.Cpl + (size_t)j * MB : nullptr, ch.U + (size_t)j * MB);
-    if (tid < BS) tv[tid] = ch.b[(size_t)j * BS + tid];         // y_j = U^T b_j (written by the reduction)
+#define ST_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[65] == 100) ch.dbg[k] = (long long)wall_clock64(); } while (0)
+    ST_STAMP(0);
+    if (a.fused) {
+      const int fl = a.iso_loc[2 * p];
+      const double2* s0 = reinterpret_cast<const double2*>(ch.Cpl + (size_t)(l >= 0 ? a.iso_loc[2 * (p - 1) + 1] : 0) * MB);
+      const double2* s1 = reinterpret_cast<const double2*>(ch.Cpl + (size_t)(r >= 0 ? a.iso_loc[2 * p + 1] : 0) * MB);
+      double2 v0[ST_V], v1[ST_V];
+#pragma unroll
+      for (int k = 0; k < ST_V; ++k) {
+        const int idx = tid + ST_T * k;
+        if (idx < BS * BS / 2) {
+          v0[k] = l >= 0 ? s0[idx] : make_double2(0.0, 0.0);
+          v1[k] = r >= 0 ? s1[idx] : make_double2(0.0, 0.0);
+        }
+      }
+      load_node_sum<ST_T>(Mu, tv, ch, j, fl, tid);               // D_j with everything the levels below left for it; b_j -> tv
+#pragma unroll
+      for (int k = 0; k < ST_V; ++k) {
+        const int idx = tid + ST_T * k;
+        if (idx < BS * BS / 2) {
+          const int e = 2 * idx, rr = e / BS, c = e % BS;
+          Ml[rr * LD + c] = v0[k].x;  Ml[rr * LD + c + 1] = v0[k].y;
+          Mr[rr * LD + c] = v1[k].x;  Mr[rr * LD + c + 1] = v1[k].y;
+        }
+      }
+      __syncthreads();
+      ST_STAMP(1);
+      chol80<ST_T / 64>(Mu, tid, numeric_err);
+      ST_STAMP(2);
+      if (tid < ST_P * BS) {         // y = U^T b  (rows <= column)
+        double sm = 0.0;
+        const int c1 = min(k1, row + 1);
+#pragma unroll
+        for (int q = 0; q < ST_W; ++q) {
+          const bool on = k0 + q < c1;
+          const int k = k0 + (on ? q : 0);
+          sm += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+        }
+        part[tid] = sm;
+      }
+      __syncthreads();
+      const double yj = tid < BS ? row_sum(tid) : 0.0;
+      __syncthreads();
+      if (tid < BS) tv[tid] = yj;
+    } else {
+      load3(l >= 0 ? ch.Cpl + (size_t)l * MB : nullptr, r >= 0 ? ch.Cpl + (size_t)j * MB : nullptr, ch.U + (size_t)j * MB);
+      if (tid < BS) tv[tid] = ybuf(ch)[(size_t)j * BS + tid];     // y_j = U^T b_j (written by the reduction)
+    }
     __syncthreads();
     const double x0 = upper_matvec();                            // truncated solve
+    ST_STAMP(3);
     double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0;
     double* xb0 = a.xbuf;
     double* xb1 = a.xbuf + (size_t)n_iso * BS;
@@ -1353,6 +1405,7 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     if (tid < BS) ch.b[(size_t)j * BS + tid] = xcur;
     __syncthreads();
     if (tid == 0) __hip_atomic_store(a.done + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    ST_STAMP(4);
     if (a.norms && a.refine > 0) {            // (waves 0 and 1 hold the 80 rows)
       for (int off = 32; off > 0; off >>= 1) {
         dabs = fmax(dabs, __shfl_down(dabs, off, 64));
@@ -1386,7 +1439,7 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   const int* en = ch.d_elim + 3 * (a.lv_off[lvl] + q);
   const int i = en[0], l = en[1], r = en[2];
   load3(l >= 0 ? ch.Wl + (size_t)i * MB : nullptr, r >= 0 ? ch.Wr + (size_t)i * MB : nullptr, ch.U + (size_t)i * MB);
-  const double yi = tid < BS ? ch.b[(size_t)i * BS + tid] : 0.0;
+  const double yi = tid < BS ? ybuf(ch)[(size_t)i * BS + tid] : 0.0;
   if (tid == 0) {
     if (l >= 0) st_wait(a.done + l, 1, numeric_err);
     if (r >= 0) st_wait(a.done + r, 1, numeric_err);
@@ -1418,15 +1471,28 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   if (tid < BS) ch.b[(size_t)i * BS + tid] = x;
   __syncthreads();
   if (tid == 0) __hip_atomic_store(a.done + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  ST_STAMP(5);
+#undef ST_STAMP
 }
 
 // ---- host side ------------------------------------------------------------------------------
-void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, int refine_sweeps) {
+void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, int refine_sweeps, bool fused) {
   refine = 0;
   levels.clear();
   elim.clear();
   remain.clear();
   pairs.clear();
+  elim6.clear();
+  iso_loc.clear();
+  fold.clear();
+  n_fold_pins = 0;
+  fused_levels = fused;
+  // fused narrow levels: which running sums of a node hold something, and where the block that couples a live node to the
+  // next live node on its right is (slot `node` of the coupling array, or n + i once the elimination of i has created it)
+  std::vector<char> has_sl(n, 0), has_sr(n, 0);
+  std::vector<int> rloc(n);
+  for (int i = 0; i < n; ++i) rloc[i] = i;
+  std::vector<int> fold_iso;
   std::vector<int> act(n);
   for (int i = 0; i < n; ++i) act[i] = i;
   auto pinned = [&](int node) { return (pin_left && node == 0) || (pin_right && node == n - 1); };
@@ -1449,8 +1515,17 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, in
           pairs.push_back(act[p]);
           pairs.push_back(act[p + 1]);
         }
+        if (fused) {
+          const int fl = (has_sl[act[p]] ? 1 : 0) | (has_sr[act[p]] ? 2 : 0), loc = p + 1 < R ? rloc[act[p]] : -1;
+          iso_loc.push_back(fl);
+          iso_loc.push_back(loc);
+          fold_iso.push_back(act[p]);
+          fold_iso.push_back(fl);
+          fold_iso.push_back(loc);
+        }
       }
       levels.push_back(lv);
+      act.clear();
       break;
     }
     std::vector<char> pick(R, 0);
@@ -1491,9 +1566,40 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, in
       ++n_rem;
     }
     lv.n_remain = n_rem;
+    if (fused && n_pick <= 128) {          // narrow level: one launch, elimination and Schur products (seplevel.hip)
+      lv.fused = true;
+      lv.T = slv_workgroups_per_node(n_pick);
+      lv.e6_off = (int)elim6.size() / 6;
+      for (int p = 0; p < R; ++p) {
+        if (!pick[p]) continue;
+        const int i = act[p], l = p > 0 ? act[p - 1] : -1, r = p + 1 < R ? act[p + 1] : -1;
+        elim6.push_back(i);
+        elim6.push_back(l);
+        elim6.push_back(r);
+        elim6.push_back((has_sl[i] ? 1 : 0) | (has_sr[i] ? 2 : 0) | ((l >= 0 && has_sr[l]) ? 4 : 0) | ((r >= 0 && has_sl[r]) ? 8 : 0));
+        elim6.push_back(l >= 0 ? rloc[l] : 0);
+        elim6.push_back(r >= 0 ? rloc[i] : 0);
+      }
+      for (int p = 0; p < R; ++p) {
+        if (!pick[p]) continue;
+        const int i = act[p], l = p > 0 ? act[p - 1] : -1, r = p + 1 < R ? act[p + 1] : -1;
+        if (l >= 0) has_sr[l] = 1;
+        if (r >= 0) has_sl[r] = 1;
+        if (l >= 0) rloc[l] = r >= 0 ? n + i : -1;
+      }
+    }
     levels.push_back(lv);
     act.swap(next);
     if (act.empty()) break;
+  }
+  if (fused) {             // what is left are the pins: their sums are materialised for the export (k_sep_fold)
+    for (size_t p = 0; p < act.size(); ++p) {
+      fold.push_back(act[p]);
+      fold.push_back((has_sl[act[p]] ? 1 : 0) | (has_sr[act[p]] ? 2 : 0));
+      fold.push_back(p + 1 < act.size() ? rloc[act[p]] : -1);
+    }
+    n_fold_pins = (int)act.size();
+    fold.insert(fold.end(), fold_iso.begin(), fold_iso.end());
   }
   tail.clear();
   tail_levels = 0;
@@ -1554,7 +1660,7 @@ int bcr_set_func_attributes() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
   ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep_tail),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBacksubTailLds));
-  return ACINO_OK;
+  return slv_set_func_attributes();
 }
 
 // k_sep_tail's isolated workgroups spin-wait on each other's flags, the levels above them on lower block indices: the launch
@@ -1609,18 +1715,50 @@ static bool dbg_check(const char* what, int level, const BcrChain& ch, const int
 
 bool bcr_level0_adds_al(const BcrSchedule& sch) {
   if (sch.levels.empty() || getenv("ACINO_SEP_COMBINE")) return false;
+  if (sch.fused_levels) {      // every node is consumed by a kernel that forms D + AL + SL + SR itself
+    for (const BcrLevel& lv : sch.levels)
+      if (!lv.fused && !lv.isolated) return false;
+    return true;
+  }
   const BcrLevel& lv = sch.levels[0];
   // (every node of the chain must pass through exactly one of the two narrow-level kernels at level 0)
   return !lv.isolated && lv.n_elim <= 128 && lv.n_remain <= 128;
 }
 
-int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
+// true when k_sep_tail runs the back-substitution of this chain (truncated solve, sweeps and every level above in one launch)
+static bool sep_tail_applies(const BcrChain& ch, const BcrSchedule& sch) {
+  const int top = (int)sch.levels.size() - 1;
+  return sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf && ch.st_flags && top <= 12 &&
+         sch.levels[top].n_elim <= 128;
+}
+
+int bcr_reduce(const BcrChain& ch_in, const BcrSchedule& sch, const FteConst* d_c, int* d_numeric_err,
                const int* d_status, hipStream_t s, Profiler* prof) {
   static const bool dbg = getenv("ACINO_DEBUG_SYNC") != nullptr;
   bool dbg_hit = false;
   int level = 0;
-  const bool add_al = ch.AL0 != nullptr && bcr_level0_adds_al(sch);
+  const bool fz = sch.fused_levels && ch_in.SL != nullptr;      // chain with fused narrow levels
+  BcrChain ch = ch_in;
+  const bool add_al = !fz && ch.AL0 != nullptr && bcr_level0_adds_al(sch);
   for (const BcrLevel& lv : sch.levels) {
+    if (fz && lv.fused) {
+      {
+        ProfSpan sp(prof, PC_ELIM_DEEP, s, lv.n_elim);
+        if (int rc = slv_launch_level(ch, lv, d_numeric_err, d_status, s)) return rc;
+      }
+      if (dbg && !dbg_hit) dbg_hit = dbg_check("level (fused)", level, ch, ch.d_elim + 3 * lv.elim_off, lv.n_elim, 3, d_numeric_err, s);
+      ++level;
+      continue;
+    }
+    if (fz && lv.isolated) {
+      if (sep_tail_applies(ch, sch)) break;              // k_sep_tail factors the isolated nodes itself
+      // per-level kernels: materialise D + AL + SL + SR (and the couplings' home slots) for them
+      {
+        ProfSpan sp(prof, PC_SEP_COMBINE, s, lv.n_elim);
+        if (int rc = slv_launch_fold(ch, ch.d_fold + 3 * (size_t)sch.n_fold_pins, lv.n_elim, d_status, s)) return rc;
+      }
+      ch.AL0 = nullptr;
+    }
     {
       const bool fused0 = level == 0 && ch.st != nullptr;
       const bool explicit_c = !fused0 && !(ch.implicit_couplings && lv.adjacent);
@@ -1675,6 +1813,10 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
     }
     ++level;
   }
+  if (fz && sch.n_fold_pins > 0) {       // the pins' Schur complements, for the export
+    ProfSpan sp(prof, PC_SEP_COMBINE, s, sch.n_fold_pins);
+    if (int rc = slv_launch_fold(ch_in, ch_in.d_fold, sch.n_fold_pins, d_status, s)) return rc;
+  }
   if (!sch.pairs.empty() && ch.d_pairs && ch.trunc_eps2 && sch.refine == 0) {
     ProfSpan sp(prof, PC_TRUNC_CHECK, s, (long long)sch.pairs.size() / 2);
     hipLaunchKernelGGL(k_bcr_trunc_check, dim3((unsigned)(sch.pairs.size() / 2)), dim3(256), kTruncCheckLds, s, ch,
@@ -1687,8 +1829,7 @@ int bcr_reduce(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, 
 int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c, const int* d_status, hipStream_t s,
                 Profiler* prof, int* d_numeric_err) {
   int top = (int)sch.levels.size() - 1;
-  if (sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf && ch.st_flags && top <= 12 &&
-      sch.levels[top].n_elim <= 128) {
+  if (sep_tail_applies(ch, sch)) {
     // one launch for the truncated solve, the sweeps and every level above them (k_sep_tail)
     const BcrLevel& iso = sch.levels[top];
     SepTailArgs a;
@@ -1706,6 +1847,8 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     a.done = ch.st_flags + iso.n_elim;
     a.xbuf = ch.refine_buf + (size_t)iso.n_elim * BS;
     a.norms = ch.trunc_eps2;
+    a.fused = (sch.fused_levels && ch.SL != nullptr) ? 1 : 0;
+    a.iso_loc = ch.d_iso_loc;
     {
       ProfSpan sp(prof, PC_REFINE, s, blocks);
       hipLaunchKernelGGL(k_sep_tail, dim3(blocks), dim3(ST_T), kBacksubTailLds, s, ch, a, d_status, d_numeric_err);

@@ -11,6 +11,10 @@ struct BcrLevel {
   int elim_off, remain_off;  // offsets (in entries) into the device schedule arrays
   bool adjacent;             // some eliminated node still has a neighbour at original distance 1 (implicit coupling)
   bool isolated = false;     // last level of an INCOMPLETE reduction: every remaining node solved on its own
+  // fused level (k_sep_level, seplevel.hip): elimination AND the Schur products of a narrow level in one launch of T
+  // workgroups per node; entries of 6 ints at elim6[6 * e6_off ..]
+  bool fused = false;
+  int T = 0, e6_off = 0;
 };
 
 // Host-side elimination schedule for a chain of n nodes; pinned ends are never eliminated.
@@ -26,11 +30,25 @@ struct BcrSchedule {
   // DROPPED and every remaining node is factorised on its own.  pairs = (left node, right node) of every dropped
   // coupling block (stored at Cpl[left]); their normalised size is measured on the device (k_bcr_trunc_check).
   std::vector<int> pairs;
-  size_t ints() const { return elim.size() + remain.size() + tail.size() + pairs.size() + 4; }   // (+ the tail's progress counter)
+  size_t ints() const { return elim.size() + remain.size() + tail.size() + pairs.size() + 4 + fused_ints(); }   // (+ the tail's progress counter)
   // refine > 0 (incomplete reductions only): block-Jacobi sweeps over the isolated nodes that re-introduce the dropped
   // couplings after the truncated solve (k_bcr_refine); the isolated level then stays out of the fused tail.
   int refine = 0;
-  void build(int n, bool pin_left, bool pin_right, int max_levels = 0, int refine_sweeps = 0);
+  // ---- fused narrow levels (chains that carry the S / Y / second coupling arrays: BcrChain::SL != nullptr) ----
+  // A fused level never touches the diagonal block of a REMAINING node: the Schur products of an eliminated node i go to
+  // running sums SR[l] (what l receives from its right side) and SL[r], the new coupling block(r, l) to slot n + i of the
+  // coupling array.  Whoever consumes a node later (its own elimination, the isolated level, the fold of a pin) forms
+  // D + AL + SL + SR.  elim6 entry: node, left, right, flags, location of block(node, left), location of block(right, node)
+  //   flags: 1 SL[node] valid, 2 SR[node] valid, 4 SR[left] holds earlier contributions (add to them), 8 the same for SL[right]
+  bool fused_levels = false;
+  std::vector<int> elim6;
+  std::vector<int> iso_loc;   // isolated level, 2 ints per entry: flags, location of block(next isolated node, this node)
+  // nodes whose sums must be materialised for kernels that know nothing of them (pins: read by the export; the isolated level
+  // when k_sep_tail does not apply): 3 ints per entry - node, flags, location of its right coupling (copied to slot `node`; -1: none)
+  std::vector<int> fold;
+  int n_fold_pins = 0;        // the first n_fold_pins entries of fold are the pins, the rest the isolated level
+  size_t fused_ints() const { return elim6.size() + iso_loc.size() + fold.size(); }
+  void build(int n, bool pin_left, bool pin_right, int max_levels = 0, int refine_sweeps = 0, bool fused = false);
 };
 
 // Device views of one chain.
@@ -54,6 +72,15 @@ struct BcrChain {
   const double* AL0 = nullptr;    // separator chain of the chunked solver: [n][80][80] left-run contributions (lower tiles; row 79:
                                   // the update of b), added to D / b by the LEVEL-0 kernels of the reduction when set
   int* st_flags = nullptr;        // k_sep_tail: [n_isolated] iterate versions, then [n_nodes] done flags (null: per-level kernels)
+  // fused narrow levels (seplevel.hip; all null: the per-phase kernels of bcr.hip only).  With them Cpl holds 2 n blocks:
+  // slot n + i = the coupling created by the elimination of node i.
+  double* SL = nullptr;           // [n][80][80] running sum of the Schur contributions a node received from its LEFT side (lower
+  double* SR = nullptr;           //             tiles; row 79: the update of b) / from its RIGHT side
+  double* Y = nullptr;            // [n][80] y = U^T b of eliminated nodes (b itself stays intact until the back-substitution:
+                                  //         the sibling workgroups of a node all read it)
+  const int* d_elim6 = nullptr;
+  const int* d_iso_loc = nullptr;
+  const int* d_fold = nullptr;
   int implicit_couplings;    // 1: level-0 couplings are the analytic smoothness blocks (never stored)
   long long* dbg;            // optional [32] phase timestamps of workgroup 0 (gpu_stamps.py)
   // Fused system build (FTE chains only; all null for the separator chain): the level-0 kernels build

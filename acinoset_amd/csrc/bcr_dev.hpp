@@ -217,4 +217,70 @@ static __device__ __forceinline__ void right_table_interior(double* coefR, int t
   }
 }
 
+// Chains with fused narrow levels (seplevel.hip) keep y = U^T b of eliminated nodes in an array of its own.
+__device__ __forceinline__ double* ybuf(const BcrChain& ch) { return ch.Y ? ch.Y : ch.b; }
+
+// (fused narrow levels, seplevel.hip; the isolated level inside k_sep_tail)
+// D_i + AL_i + SL_i + SR_i (lower tiles; the sums only inside the 75 x 75 live part) -> Lm, b_i + their rows 79 -> yv.
+// Absent terms are read from D itself and masked afterwards (a conditional load compiles to a masked load with a full wait per
+// element: bcr.hip, k_bcr_update_deep).  All loads of the thread are in flight before the first LDS write.
+template <int NTH>
+__device__ __forceinline__ void load_node_sum(double* Lm, double* yv, const BcrChain& ch, int i, int fl, int tid) {
+  constexpr int NQ = (LOWER_ITEMS + NTH - 1) / NTH;
+  const size_t MB = (size_t)BS * BS;
+  const double* Dg = ch.D + i * MB;
+  const bool hal = ch.AL0 != nullptr, hsl = (fl & 1) != 0, hsr = (fl & 2) != 0;
+  const double* Ag = hal ? ch.AL0 + i * MB : Dg;
+  const double* Lg = hsl ? ch.SL + i * MB : Dg;
+  const double* Rg = hsr ? ch.SR + i * MB : Dg;
+  double2 dv[NQ], av[NQ], lv[NQ], rv[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int idx = tid + NTH * k;
+    if (idx < LOWER_ITEMS) {
+      int rr, cc;
+      lower_item(idx, rr, cc);
+      dv[k] = *reinterpret_cast<const double2*>(Dg + rr * BS + cc);
+      av[k] = *reinterpret_cast<const double2*>(Ag + rr * BS + cc);
+      lv[k] = *reinterpret_cast<const double2*>(Lg + rr * BS + cc);
+      rv[k] = *reinterpret_cast<const double2*>(Rg + rr * BS + cc);
+    }
+  }
+  double bb = 0.0, ab = 0.0, lb = 0.0, rb = 0.0;
+  if (tid < BS) {
+    bb = ch.b[(size_t)i * BS + tid];
+    const int c = tid < 3 * NP ? tid : 0;
+    ab = Ag[(size_t)(BS - 1) * BS + c];
+    lb = Lg[(size_t)(BS - 1) * BS + c];
+    rb = Rg[(size_t)(BS - 1) * BS + c];
+  }
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int idx = tid + NTH * k;
+    if (idx < LOWER_ITEMS) {
+      int rr, cc;
+      lower_item(idx, rr, cc);
+      const bool in0 = rr < 3 * NP && cc < 3 * NP, in1 = rr < 3 * NP && cc + 1 < 3 * NP;
+      double x = dv[k].x, y = dv[k].y;
+      x += (hal && in0) ? av[k].x : 0.0;
+      y += (hal && in1) ? av[k].y : 0.0;
+      x += (hsl && in0) ? lv[k].x : 0.0;
+      y += (hsl && in1) ? lv[k].y : 0.0;
+      x += (hsr && in0) ? rv[k].x : 0.0;
+      y += (hsr && in1) ? rv[k].y : 0.0;
+      Lm[rr * LD + cc] = x;
+      Lm[rr * LD + cc + 1] = y;
+    }
+  }
+  if (tid < BS) {
+    const bool live = tid < 3 * NP;
+    double v = bb;
+    v += (hal && live) ? ab : 0.0;
+    v += (hsl && live) ? lb : 0.0;
+    v += (hsr && live) ? rb : 0.0;
+    yv[tid] = v;
+  }
+}
+
+
 }  // namespace acino

@@ -201,13 +201,15 @@ __device__ __forceinline__ int panel_tile(int kb, int q) {
   return (v >> (4 * q)) & 15;
 }
 
+// NW: waves of the workgroup (4, or 8 in the 512-thread kernels: the extra waves share the trailing tiles)
+template <int NW = 4>
 __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   if (wave == 0) chol16_inv(Lm, lane, err);
   __syncthreads();
   for (int kb = 0; kb < NT; ++kb) {
     const double* Ukk = Lm + (kb * 16) * LD + kb * 16;
-    {  // panel: tile(t,kb) <- tile(t,kb) * U_kk   (L(ib,kb) = A(ib,kb) L_kk^-T below, U(j,kb) above the diagonal)
+    if (NW == 4 || wave < 4) {  // panel: tile(t,kb) <- tile(t,kb) * U_kk   (L(ib,kb) = A(ib,kb) L_kk^-T below, U(j,kb) above the diagonal)
       double* A = Lm + (panel_tile(kb, wave) * 16) * LD + kb * 16;
       double av[4], bv[4];
 #pragma unroll
@@ -239,7 +241,7 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
       if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
     } else {
       const int ntask = trail_n(kb);
-      for (int t = wave - 1; t < ntask; t += 3) {
+      for (int t = wave - 1; t < ntask; t += NW - 1) {
         const int code = trail_code(kb, t), ti = code >> 4, tj = code & 15;
         double* Cc = Lm + (ti * 16) * LD + tj * 16;
         const double* A = Lm + (ti * 16) * LD + kb * 16;

@@ -6,6 +6,7 @@
 
 #include "bcr.hpp"
 #include "chunk.hpp"
+#include "seplevel.hpp"
 
 namespace acino {
 
@@ -78,13 +79,17 @@ struct Carver {
 // (sharded ranks - pinned separators - take the chunked solver too since round 4: the pins join the separator chain)
 static bool use_chunks(const acino_fte_params* p) { return p->chunk_nodes >= 0; }
 
+static bool fused_levels_enabled() { return getenv("ACINO_NO_FUSED_LEVELS") == nullptr; }
+
 // Host-side layout of a context: the chunk plan and the reduction schedule (of the separator chain when chunked).
 struct Layout {
   ChunkPlan plan;
   BcrSchedule sched;
   void build(const acino_fte_params* p) {
     plan.build(chain_nodes(p), use_chunks(p) ? p->chunk_nodes : -1, p->pin_left != 0, p->pin_right != 0);
-    if (plan.active()) sched.build(plan.n_sep, p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps);
+    // (separator chains take the fused narrow levels of seplevel.hip; ACINO_NO_FUSED_LEVELS=1: the per-phase kernels of bcr.hip)
+    if (plan.active()) sched.build(plan.n_sep, p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps,
+                                   fused_levels_enabled());
     else sched.build(chain_nodes(p), p->pin_left != 0, p->pin_right != 0, p->bcr_levels, p->refine_sweeps);
   }
 };
@@ -147,10 +152,16 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
     sc.n_nodes = lay.plan.n_sep;
     sc.D = c.take<double>(S * BS * BS);
     sc.U = c.take<double>(S * BS * BS);
-    sc.Cpl = c.take<double>(S * BS * BS);
+    const bool fz = lay.sched.fused_levels;
+    sc.Cpl = c.take<double>((fz ? 2 : 1) * S * BS * BS);     // fused levels: slot S + i = the coupling the elimination of i created
     sc.Wl = c.take<double>(S * BS * BS);
     sc.Wr = c.take<double>(S * BS * BS);
     sc.b = c.take<double>(S * BS);
+    if (fz) {
+      sc.SL = c.take<double>(S * BS * BS);
+      sc.SR = c.take<double>(S * BS * BS);
+      sc.Y = c.take<double>(S * BS);
+    }
     sc.AL0 = c.take<double>(S * BS * BS);   // (the sweep's left-run contributions; handed to the reduction by chunk_reduce)
     sc.implicit_couplings = 0;      // dense couplings, plain (non-fused) kernels
     sc.st = nullptr;
@@ -718,6 +729,18 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
   if (e == hipSuccess && !ctx->sched.pairs.empty())
     e = hipMemcpyAsync(ctx->b.sched + ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size(),
                        ctx->sched.pairs.data(), sizeof(int) * ctx->sched.pairs.size(), hipMemcpyHostToDevice, s);
+  // (fused narrow levels: their entry tables follow the tail's progress counter)
+  const size_t fused_off = ctx->sched.elim.size() + ctx->sched.remain.size() + ctx->sched.tail.size() + ctx->sched.pairs.size() + 4;
+  {
+    std::vector<int> fz;
+    fz.insert(fz.end(), ctx->sched.elim6.begin(), ctx->sched.elim6.end());
+    fz.insert(fz.end(), ctx->sched.iso_loc.begin(), ctx->sched.iso_loc.end());
+    fz.insert(fz.end(), ctx->sched.fold.begin(), ctx->sched.fold.end());
+    if (e == hipSuccess && !fz.empty()) {
+      e = hipMemcpyAsync(ctx->b.sched + fused_off, fz.data(), sizeof(int) * fz.size(), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);       // (fz is a local)
+    }
+  }
   if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
   if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s);
   // (the runs write the contribution AL of every separator that has a run on its right: a right pin has none - zero once)
@@ -744,6 +767,11 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     }
     ctx->n_trunc = red.n_pairs;
     red.refine_buf = ctx->b.refine_buf;
+    if (ctx->sched.fused_levels) {
+      red.d_elim6 = ctx->b.sched + fused_off;
+      red.d_iso_loc = red.d_elim6 + ctx->sched.elim6.size();
+      red.d_fold = red.d_iso_loc + ctx->sched.iso_loc.size();
+    }
     // one persistent launch for the separator chain's back-substitution: its isolated workgroups wait for each other, so it
     // is kept off GPUs that other spin-waiting kernels may share (shared_gpu: batched clips, several ranks on one device)
     // - and off devices that cannot hold all of its workgroups at once (occupancy x compute units of THIS device: a CU mask, a
@@ -947,8 +975,10 @@ int acino_fte_export_separators(acino_fte_ctx* ctx, double* d_sep, int rank, int
 size_t acino_sep_scratch_bytes(int n_sep) {
   if (n_sep < 1) return 0;
   BcrSchedule sch;
+  // (GENERAL 80 x 80 blocks: the fused narrow levels of seplevel.hip need the identity padding of FTE nodes - their right-hand
+  //  side rides in the padding column - so this entry point keeps the per-phase kernels)
   sch.build(n_sep, false, false);
-  size_t ints = sch.elim.size() + sch.remain.size() + 8;
+  size_t ints = sch.elim.size() + sch.remain.size() + sch.fused_ints() + 8;
   return 6 * align_up((size_t)n_sep * BS * BS * sizeof(double)) + align_up(ints * sizeof(int)) + 1024;   // D U Cpl Wl Wr, b
 }
 
@@ -969,13 +999,23 @@ static BcrChain sep_chain(void* d_scratch, int n_sep, const BcrSchedule& sch) {
   ch.n_nodes = n_sep;
   ch.D = c.take<double>((size_t)n_sep * BS * BS);
   ch.U = c.take<double>((size_t)n_sep * BS * BS);
-  ch.Cpl = c.take<double>((size_t)n_sep * BS * BS);
+  ch.Cpl = c.take<double>((sch.fused_levels ? 2 : 1) * (size_t)n_sep * BS * BS);
   ch.Wl = c.take<double>((size_t)n_sep * BS * BS);
   ch.Wr = c.take<double>((size_t)n_sep * BS * BS);
   ch.b = c.take<double>((size_t)n_sep * BS);
-  int* d_sched = c.take<int>(sch.elim.size() + sch.remain.size() + 8);
+  if (sch.fused_levels) {
+    ch.SL = c.take<double>((size_t)n_sep * BS * BS);
+    ch.SR = c.take<double>((size_t)n_sep * BS * BS);
+    ch.Y = c.take<double>((size_t)n_sep * BS);
+  }
+  int* d_sched = c.take<int>(sch.elim.size() + sch.remain.size() + sch.fused_ints() + 8);
   ch.d_elim = d_sched;
   ch.d_remain = d_sched + sch.elim.size();
+  if (sch.fused_levels) {
+    ch.d_elim6 = ch.d_remain + sch.remain.size();
+    ch.d_iso_loc = ch.d_elim6 + sch.elim6.size();
+    ch.d_fold = ch.d_iso_loc + sch.iso_loc.size();
+  }
   ch.d_tail = nullptr;            // (the separator chain keeps the per-level kernels)
   ch.d_done = nullptr;
   ch.implicit_couplings = 0;
@@ -995,22 +1035,28 @@ struct SchedArg {
 __global__ void k_write_schedule(SchedArg a, int* __restrict__ dst) {
   for (int i = threadIdx.x; i < a.n; i += blockDim.x) dst[i] = a.v[i];
 }
-static bool sep_schedule_fits_arg(const BcrSchedule& sch) { return sch.elim.size() + sch.remain.size() <= 960; }
+static bool sep_schedule_fits_arg(const BcrSchedule& sch) { return sch.elim.size() + sch.remain.size() + sch.fused_ints() <= 960; }
+static std::vector<int> sep_schedule_ints(const BcrSchedule& sch) {      // in the order sep_chain lays them out
+  std::vector<int> v(sch.elim);
+  v.insert(v.end(), sch.remain.begin(), sch.remain.end());
+  v.insert(v.end(), sch.elim6.begin(), sch.elim6.end());
+  v.insert(v.end(), sch.iso_loc.begin(), sch.iso_loc.end());
+  v.insert(v.end(), sch.fold.begin(), sch.fold.end());
+  return v;
+}
 static int sep_upload_schedule(const BcrChain& ch, const BcrSchedule& sch, hipStream_t s) {
   int* d_sched = const_cast<int*>(ch.d_elim);
+  const std::vector<int> v = sep_schedule_ints(sch);
   if (sep_schedule_fits_arg(sch)) {
     SchedArg a;
-    a.n = (int)(sch.elim.size() + sch.remain.size());
-    std::copy(sch.elim.begin(), sch.elim.end(), a.v);
-    std::copy(sch.remain.begin(), sch.remain.end(), a.v + sch.elim.size());
+    a.n = (int)v.size();
+    std::copy(v.begin(), v.end(), a.v);
     hipLaunchKernelGGL(k_write_schedule, dim3(1), dim3(256), 0, s, a, d_sched);
     ACINO_LAUNCH_CHECK();
     return ACINO_OK;
   }
-  ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, sch.elim.data(), sizeof(int) * sch.elim.size(), hipMemcpyHostToDevice, s));
-  if (!sch.remain.empty())
-    ACINO_HIP_CHECK(hipMemcpyAsync(d_sched + sch.elim.size(), sch.remain.data(), sizeof(int) * sch.remain.size(),
-                                   hipMemcpyHostToDevice, s));
+  ACINO_HIP_CHECK(hipMemcpyAsync(d_sched, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice, s));
+  ACINO_HIP_CHECK(hipStreamSynchronize(s));       // (v is a local; chains this long are not graph-captured)
   return ACINO_OK;
 }
 static int sep_launch(const BcrChain& ch, const BcrSchedule& sch, const double* d_sep, int n_sep, double* d_sep_x,
@@ -1348,6 +1394,7 @@ int acino_fte_get_result(acino_fte_ctx* ctx, double ts, double* d_x, double* d_p
 int acino_fte_debug_stamps(acino_fte_ctx* ctx, long long* d_dbg) {
   ACINO_REQUIRE(ctx, "null");
   ctx->chain.dbg = d_dbg;
+  ctx->sepchain.dbg = d_dbg;       // (k_sep_level, k_sep_tail: selectors in their own comments)
   return ACINO_OK;
 }
 
