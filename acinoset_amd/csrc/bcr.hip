@@ -1208,6 +1208,16 @@ struct SepTailArgs {
   const int* iso_loc;
   int fused;
 };
+// Hand-off of an 80-double vector between workgroups of one launch: the values travel as agent-scope RELAXED atomics (written
+// through to / read from the point where the XCDs' L2s are coherent), the workgroup barrier after the stores waits for every
+// wave's stores to be acknowledged (vmcnt(0)), then one lane raises the flag.  No release / acquire fences: those write back /
+// invalidate a whole L2 (~1.3 us + ~0.5 us per hand-off, measured with the stamps of scripts/sep_stamps.py; a sweep has two).
+__device__ __forceinline__ void st_put(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double st_get(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_err) {
   long long polls = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
@@ -1231,6 +1241,9 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   double* part = tv + BS;         // [ST_P][80]
   const int tid = threadIdx.x;
   const size_t MB = (size_t)BS * BS;
+#define ST_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[65] == 100) ch.dbg[k] = (long long)wall_clock64(); } while (0)
+  ST_STAMP(6);
+  if (ch.dbg && tid == 0 && blockIdx.x == 0 && ch.dbg[65] == 100) ch.dbg[7] = (long long)wall_clock64();    // (workgroup 0's start: the common time base)
   const int row = tid % BS, pr = tid / BS, k0 = ST_W * pr, k1 = min(k0 + ST_W, BS);
   auto row_sum = [&](int r) {     // the ST_P partial sums of row r, fixed order
     double v = part[r];
@@ -1280,11 +1293,26 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     __syncthreads();
     return v;
   };
+  // x = G t for a FULL symmetric G in Mu (fused isolated level: G = D^-1 replaces the factor, one product instead of two)
+  auto full_matvec = [&]() {
+    if (tid < ST_P * BS) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < ST_W; ++q) {
+        const int k = k0 + (k0 + q < k1 ? q : 0);
+        s += (k0 + q < k1 ? 1.0 : 0.0) * Mu[row * LD + k] * tv[k];
+      }
+      part[tid] = s;
+    }
+    __syncthreads();
+    const double v = tid < BS ? row_sum(tid) : 0.0;
+    __syncthreads();
+    return v;
+  };
   if ((int)blockIdx.x < a.n_iso) {
     // ---------------- isolated node: truncated solve + refinement sweeps ----------------
     const int p = blockIdx.x, n_iso = a.n_iso;
     const int j = a.iso[3 * p], l = p > 0 ? a.iso[3 * (p - 1)] : -1, r = p + 1 < n_iso ? a.iso[3 * (p + 1)] : -1;
-#define ST_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[65] == 100) ch.dbg[k] = (long long)wall_clock64(); } while (0)
     ST_STAMP(0);
     if (a.fused) {
       const int fl = a.iso_loc[2 * p];
@@ -1313,50 +1341,74 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
       ST_STAMP(1);
       chol80<ST_T / 64>(Mu, tid, numeric_err);
       ST_STAMP(2);
-      if (tid < ST_P * BS) {         // y = U^T b  (rows <= column)
-        double sm = 0.0;
-        const int c1 = min(k1, row + 1);
+      // G = D^-1 = U U^T over the factor (nobody else needs the factor of an isolated node): every later solve with D is ONE
+      // 80 x 80 product instead of two triangular ones - the truncated solve and each of the sweeps lose a dependent stage
+      {
+        const int wv = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
+        d4 gacc[2];
 #pragma unroll
-        for (int q = 0; q < ST_W; ++q) {
-          const bool on = k0 + q < c1;
-          const int k = k0 + (on ? q : 0);
-          sm += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+        for (int u = 0; u < 2; ++u) {
+          const int t = wv + 8 * u;
+          gacc[u] = d4{0, 0, 0, 0};
+          if (t < 15) {
+            const int ib = tri_i(t), jb = tri_j(t);
+            const double* pa = Mu + (ib * 16 + li) * LD + ib * 16 + lk;   // U(ib, k >= ib)[i][kk]
+            const double* pb = Mu + (jb * 16 + li) * LD + ib * 16 + lk;   // U(jb, k >= ib)[j][kk]
+            switch (ib) {
+              case 0: gacc[u] = mma_seq<20, false>(gacc[u], pa, 4, pb, 4); break;
+              case 1: gacc[u] = mma_seq<16, false>(gacc[u], pa, 4, pb, 4); break;
+              case 2: gacc[u] = mma_seq<12, false>(gacc[u], pa, 4, pb, 4); break;
+              case 3: gacc[u] = mma_seq<8, false>(gacc[u], pa, 4, pb, 4); break;
+              default: gacc[u] = mma_seq<4, false>(gacc[u], pa, 4, pb, 4); break;
+            }
+          }
         }
-        part[tid] = sm;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = wv + 8 * u;
+          if (t < 15) {
+            const int ib = tri_i(t), jb = tri_j(t);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              Mu[(ib * 16 + lk + 4 * rr) * LD + jb * 16 + li] = gacc[u][rr];
+              if (ib != jb) Mu[(jb * 16 + li) * LD + ib * 16 + lk + 4 * rr] = gacc[u][rr];
+            }
+          }
+        }
       }
-      __syncthreads();
-      const double yj = tid < BS ? row_sum(tid) : 0.0;
-      __syncthreads();
-      if (tid < BS) tv[tid] = yj;
     } else {
       load3(l >= 0 ? ch.Cpl + (size_t)l * MB : nullptr, r >= 0 ? ch.Cpl + (size_t)j * MB : nullptr, ch.U + (size_t)j * MB);
       if (tid < BS) tv[tid] = ybuf(ch)[(size_t)j * BS + tid];     // y_j = U^T b_j (written by the reduction)
     }
     __syncthreads();
-    const double x0 = upper_matvec();                            // truncated solve
+    const bool use_g = a.fused != 0;
+    const double x0 = use_g ? full_matvec() : upper_matvec();    // truncated solve (fused: G b; else U y)
     ST_STAMP(3);
     double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0;
     double* xb0 = a.xbuf;
     double* xb1 = a.xbuf + (size_t)n_iso * BS;
     if (a.refine > 0) {
-      if (tid < BS) xb0[(size_t)p * BS + tid] = x0;
+      if (tid < BS) st_put(xb0 + (size_t)p * BS + tid, x0);
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(a.ver + p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(a.ver + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int s = 1; s <= a.refine; ++s) {
       const double* src = (s - 1) & 1 ? xb1 : xb0;
       double* dst = s & 1 ? xb1 : xb0;
+      if (s == 2) ST_STAMP(8);
       if (tid == 0) {
         if (l >= 0) st_wait(a.ver + p - 1, s, numeric_err);
         if (r >= 0) st_wait(a.ver + p + 1, s, numeric_err);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (s == 2) ST_STAMP(9);
       }
       __syncthreads();
       if (tid < BS) {
-        xl[tid] = l >= 0 ? __builtin_nontemporal_load(src + (size_t)(p - 1) * BS + tid) : 0.0;
-        xr[tid] = r >= 0 ? __builtin_nontemporal_load(src + (size_t)(p + 1) * BS + tid) : 0.0;
+        xl[tid] = l >= 0 ? st_get(src + (size_t)(p - 1) * BS + tid) : 0.0;
+        xr[tid] = r >= 0 ? st_get(src + (size_t)(p + 1) * BS + tid) : 0.0;
       }
       __syncthreads();
+      if (s == 2) ST_STAMP(11);
       if (tid < ST_P * BS) {         // t = block(j, l) x_l + block(j, r) x_r ;  block(j, r) = Cpl[j]^T
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -1371,23 +1423,28 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
       __syncthreads();
       if (tid < BS) tv[tid] = row_sum(tid);
       __syncthreads();
-      if (tid < ST_P * BS) {         // w = U^T t  (rows <= column)
-        double sm = 0.0;
-        const int c1 = min(k1, row + 1);
+      double d;
+      if (use_g) {
+        d = full_matvec();                                       // d = G t
+      } else {
+        if (tid < ST_P * BS) {       // w = U^T t  (rows <= column)
+          double sm = 0.0;
+          const int c1 = min(k1, row + 1);
 #pragma unroll
-        for (int q = 0; q < ST_W; ++q) {
-          const bool on = k0 + q < c1;
-          const int k = k0 + (on ? q : 0);
-          sm += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+          for (int q = 0; q < ST_W; ++q) {
+            const bool on = k0 + q < c1;
+            const int k = k0 + (on ? q : 0);
+            sm += (on ? 1.0 : 0.0) * Mu[k * LD + row] * tv[k];
+          }
+          part[tid] = sm;
         }
-        part[tid] = sm;
+        __syncthreads();
+        const double w = tid < BS ? row_sum(tid) : 0.0;
+        __syncthreads();
+        if (tid < BS) tv[tid] = w;
+        __syncthreads();
+        d = upper_matvec();                                      // d = U w
       }
-      __syncthreads();
-      const double w = tid < BS ? row_sum(tid) : 0.0;
-      __syncthreads();
-      if (tid < BS) tv[tid] = w;
-      __syncthreads();
-      const double d = upper_matvec();                           // d = U w
       if (tid < BS) {
         const double x = x0 - d;
         dabs_prev = dabs;
@@ -1395,16 +1452,18 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
         dabs = fabs(x - xcur);
         xabs = fabs(x);
         xcur = x;
-        if (s < a.refine) dst[(size_t)p * BS + tid] = x;
+        if (s < a.refine) st_put(dst + (size_t)p * BS + tid, x);
       }
+      if (s == 2) ST_STAMP(12);
       if (s < a.refine) {
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.ver + p, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(a.ver + p, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (s == 2) ST_STAMP(13);
     }
-    if (tid < BS) ch.b[(size_t)j * BS + tid] = xcur;
+    if (tid < BS) st_put(ch.b + (size_t)j * BS + tid, xcur);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.done + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(a.done + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ST_STAMP(4);
     if (a.norms && a.refine > 0) {            // (waves 0 and 1 hold the 80 rows)
       for (int off = 32; off > 0; off >>= 1) {
@@ -1438,17 +1497,24 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   if (lvl >= a.n_lv) return;
   const int* en = ch.d_elim + 3 * (a.lv_off[lvl] + q);
   const int i = en[0], l = en[1], r = en[2];
+  if (a.fused && a.refine > 0) {
+    // The isolated workgroups of this launch are the critical path and start with ~200 KB of loads each; the 3 x 51 KB of every
+    // level node are not needed before the sweeps are over.  Hold them back until the first isolated node has published its
+    // truncated solve (its factorisation is done by then), so the two sets of loads do not share the memory system.
+    if (tid == 0) st_wait(a.ver, 1, nullptr);
+    __syncthreads();
+  }
   load3(l >= 0 ? ch.Wl + (size_t)i * MB : nullptr, r >= 0 ? ch.Wr + (size_t)i * MB : nullptr, ch.U + (size_t)i * MB);
   const double yi = tid < BS ? ybuf(ch)[(size_t)i * BS + tid] : 0.0;
   if (tid == 0) {
     if (l >= 0) st_wait(a.done + l, 1, numeric_err);
     if (r >= 0) st_wait(a.done + r, 1, numeric_err);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  ST_STAMP(1);                  // (level node: both neighbours solved)
   if (tid < BS) {
-    xl[tid] = l >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)l * BS + tid) : 0.0;
-    xr[tid] = r >= 0 ? __builtin_nontemporal_load(ch.b + (size_t)r * BS + tid) : 0.0;
+    xl[tid] = l >= 0 ? st_get(ch.b + (size_t)l * BS + tid) : 0.0;
+    xr[tid] = r >= 0 ? st_get(ch.b + (size_t)r * BS + tid) : 0.0;
   }
   __syncthreads();
   if (tid < ST_P * BS) {
@@ -1468,9 +1534,9 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   if (tid < BS) tv[tid] = t;
   __syncthreads();
   const double x = upper_matvec();
-  if (tid < BS) ch.b[(size_t)i * BS + tid] = x;
+  if (tid < BS) st_put(ch.b + (size_t)i * BS + tid, x);
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(a.done + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(a.done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ST_STAMP(5);
 #undef ST_STAMP
 }
@@ -1568,7 +1634,7 @@ void BcrSchedule::build(int n, bool pin_left, bool pin_right, int max_levels, in
     lv.n_remain = n_rem;
     if (fused && n_pick <= 128) {          // narrow level: one launch, elimination and Schur products (seplevel.hip)
       lv.fused = true;
-      lv.T = slv_workgroups_per_node(n_pick);
+      lv.T = std::max(2, slv_workgroups_per_node(n_pick));      // (>= 2: a workgroup's tile share must fit its registers)
       lv.e6_off = (int)elim6.size() / 6;
       for (int p = 0; p < R; ++p) {
         if (!pick[p]) continue;

@@ -32,9 +32,10 @@ namespace acino {
 // tile codes: 0 .. 24 P_l(a, b) = 5 a + b (a >= b only), 25 .. 49 P_r, 50 .. 74 X(a, b) (rows: right neighbour, cols: left)
 // strips: bit s < 5: columns 16 s .. of W_l; bit 5 + s: of W_r
 static int slv_cost(unsigned strips, int n_tiles, bool first) {
+  // matrix instructions on the busiest SIMD after the factorisation: a whole strip (60) per wave, the strips dealt to eight
+  // waves = four SIMDs; 20 per product tile, tiles dealt the same way
   const int ns = __builtin_popcount(strips);
-  const int cs = ns <= 2 ? 20 * ns : 60 * ((ns + 3) / 4);        // matrix instructions on the busiest wave
-  return cs + 20 * ((n_tiles + 3) / 4) + (first ? 40 : 0);        // (workgroup 0 also stores the factor and y)
+  return 60 * ((ns + 3) / 4) + 20 * ((n_tiles + 3) / 4) + (first ? 30 : 0);        // (workgroup 0 also stores the factor)
 }
 static unsigned slv_strips_of(int code) {
   const int kind = code / 25, a = (code % 25) / 5, b = code % 5;
@@ -49,52 +50,155 @@ void slv_plan_build(int T, int* out /* [T][SLV_STRIDE] */) {
       for (int b = 0; b <= a; ++b) order.push_back(25 * kind + 5 * a + b);
   for (int a = 0; a < 5; ++a)
     for (int b = 0; b < 5; ++b) order.push_back(50 + 5 * a + b);
-  std::vector<std::vector<int>> bin(T);
-  // start: contiguous chunks in an order that keeps tiles sharing strips together (P_l by rows, P_r by rows, X by rows)
-  for (size_t k = 0; k < order.size(); ++k) bin[std::min<size_t>(T - 1, k * T / order.size())].push_back(order[k]);
   auto strips = [&](const std::vector<int>& v) {
     unsigned m = 0;
     for (int c : v) m |= slv_strips_of(c);
     return m;
   };
-  auto cost = [&](int g) { return slv_cost(strips(bin[g]), (int)bin[g].size(), g == 0); };
-  // local search: move one tile out of the most expensive workgroup while that lowers the maximum (then the sum)
-  for (int it = 0; it < 400; ++it) {
-    int worst = 0;
-    for (int g = 1; g < T; ++g)
-      if (cost(g) > cost(worst)) worst = g;
-    const int cw = cost(worst);
-    int best_gain = 0, best_k = -1, best_to = -1;
-    for (size_t k = 0; k < bin[worst].size(); ++k) {
-      const int code = bin[worst][k];
-      std::vector<int> rest = bin[worst];
-      rest.erase(rest.begin() + k);
-      const int c_rest = slv_cost(strips(rest), (int)rest.size(), worst == 0);
-      for (int g = 0; g < T; ++g) {
-        if (g == worst) continue;
-        std::vector<int> more = bin[g];
-        more.push_back(code);
-        const int c_more = slv_cost(strips(more), (int)more.size(), g == 0);
-        const int gain = cw - std::max(c_rest, c_more);
-        if (gain > best_gain) {
-          best_gain = gain;
-          best_k = (int)k;
-          best_to = g;
+  auto bins_objective = [&](const std::vector<std::vector<int>>& b, long long& mx, long long& sq) {
+    mx = 0;
+    sq = 0;
+    for (int g = 0; g < (int)b.size(); ++g) {
+      const long long c = slv_cost(strips(b[g]), (int)b[g].size(), g == 0);
+      mx = std::max(mx, c);
+      sq += c * c;
+    }
+  };
+  // rows 0 .. 4 into n contiguous groups of nearly equal weight (w: tiles per row); returns the first row of each group + 5
+  auto row_groups = [](int n, const int (&w)[5]) {
+    std::vector<int> cut(1, 0);
+    int tot = 0, acc = 0;
+    for (int a = 0; a < 5; ++a) tot += w[a];
+    for (int a = 0; a < 5; ++a) {
+      acc += w[a];
+      while ((int)cut.size() < n && acc * n >= tot * (int)cut.size() && a + 1 < 5 && 5 - (a + 1) >= n - (int)cut.size()) cut.push_back(a + 1);
+    }
+    while ((int)cut.size() < n) cut.push_back(std::min(4, cut.back() + 1));
+    cut.push_back(5);
+    return cut;
+  };
+  // start: contiguous chunks in an order that keeps tiles sharing strips together (P_l by rows, P_r by rows, X by rows) ...
+  std::vector<std::vector<int>> bin(T);
+  for (size_t k = 0; k < order.size(); ++k) bin[std::min<size_t>(T - 1, k * T / order.size())].push_back(order[k]);
+  // ... or the best STRUCTURED split: npl workgroups share P_l by row ranges, npr share P_r, and R x C share X as a grid of row
+  // and column ranges (a rectangle of X needs |rows| strips of W_r and |cols| strips of W_l)
+  {
+    long long best_mx, best_sq;
+    bins_objective(bin, best_mx, best_sq);
+    const int wp[5] = {1, 2, 3, 4, 5}, wx[5] = {5, 5, 5, 5, 5};
+    for (int npl = 1; npl <= 5 && T >= 3; ++npl)
+      for (int npr = 1; npr <= 5; ++npr)
+        for (int R = 1; R <= 5; ++R)
+          for (int C = 1; C <= 5; ++C) {
+            if (npl + npr + R * C != T) continue;
+            std::vector<std::vector<int>> b(T);
+            int g = 0;
+            const std::vector<int> cl = row_groups(npl, wp), cr = row_groups(npr, wp), xr = row_groups(R, wx), xc = row_groups(C, wx);
+            for (int q = 0; q < npl; ++q, ++g)
+              for (int a = cl[q]; a < cl[q + 1]; ++a)
+                for (int c = 0; c <= a; ++c) b[g].push_back(5 * a + c);
+            for (int q = 0; q < npr; ++q, ++g)
+              for (int a = cr[q]; a < cr[q + 1]; ++a)
+                for (int c = 0; c <= a; ++c) b[g].push_back(25 + 5 * a + c);
+            for (int q = 0; q < R; ++q)
+              for (int u = 0; u < C; ++u, ++g)
+                for (int a = xr[q]; a < xr[q + 1]; ++a)
+                  for (int c = xc[u]; c < xc[u + 1]; ++c) b[g].push_back(50 + 5 * a + c);
+            long long mx, sq;
+            bins_objective(b, mx, sq);
+            if (mx < best_mx || (mx == best_mx && sq < best_sq)) {
+              best_mx = mx;
+              best_sq = sq;
+              bin = b;
+            }
+          }
+    if (T == 2)                       // P_l + the first n rows of X | P_r + the other rows
+      for (int n = 0; n <= 5; ++n) {
+        std::vector<std::vector<int>> b(2);
+        for (int a = 0; a < 5; ++a)
+          for (int c = 0; c <= a; ++c) {
+            b[0].push_back(5 * a + c);
+            b[1].push_back(25 + 5 * a + c);
+          }
+        for (int a = 0; a < 5; ++a)
+          for (int c = 0; c < 5; ++c) b[a < n ? 0 : 1].push_back(50 + 5 * a + c);
+        long long mx, sq;
+        bins_objective(b, mx, sq);
+        if (mx < best_mx || (mx == best_mx && sq < best_sq)) {
+          best_mx = mx;
+          best_sq = sq;
+          bin = b;
         }
       }
-    }
-    if (best_k < 0) break;
-    bin[best_to].push_back(bin[worst][best_k]);
-    bin[worst].erase(bin[worst].begin() + best_k);
   }
-  // who stores a strip of W_l / W_r to HBM (the back-substitution reads them): the first workgroup that computes it
-  unsigned stored = 0;
+  auto cost = [&](int g) { return slv_cost(strips(bin[g]), (int)bin[g].size(), g == 0); };
+  // local search on (largest cost, sum of squared costs): the best single move or swap of tiles between two workgroups, until
+  // none improves.  (The first term is what the level waits for; the second keeps the search moving across plateaus of it.)
+  auto objective = [&](long long& mx, long long& sq) {
+    mx = 0;
+    sq = 0;
+    for (int g = 0; g < T; ++g) {
+      const long long c = cost(g);
+      mx = std::max(mx, c);
+      sq += c * c;
+    }
+  };
+  for (int it = 0; it < 2000; ++it) {
+    long long mx0, sq0;
+    objective(mx0, sq0);
+    long long best_mx = mx0, best_sq = sq0;
+    int bg = -1, bk = -1, bh = -1, bj = -1;          // move tile k of g to h (bj < 0) or swap it with tile j of h
+    for (int g = 0; g < T; ++g)
+      for (size_t k = 0; k < bin[g].size(); ++k)
+        for (int h = 0; h < T; ++h) {
+          if (h == g) continue;
+          for (int j = -1; j < (int)bin[h].size(); ++j) {
+            if (j >= 0 && h < g) continue;            // (each swap once)
+            const int a = bin[g][k];
+            if (j < 0) {
+              bin[g].erase(bin[g].begin() + k);
+              bin[h].push_back(a);
+            } else {
+              std::swap(bin[g][k], bin[h][j]);
+            }
+            long long mx, sq;
+            objective(mx, sq);
+            if (mx < best_mx || (mx == best_mx && sq < best_sq)) {
+              best_mx = mx;
+              best_sq = sq;
+              bg = g; bk = (int)k; bh = h; bj = j;
+            }
+            if (j < 0) {
+              bin[h].pop_back();
+              bin[g].insert(bin[g].begin() + k, a);
+            } else {
+              std::swap(bin[g][k], bin[h][j]);
+            }
+          }
+        }
+    if (bg < 0) break;
+    if (bj < 0) {
+      const int a = bin[bg][bk];
+      bin[bg].erase(bin[bg].begin() + bk);
+      bin[bh].push_back(a);
+    } else {
+      std::swap(bin[bg][bk], bin[bh][bj]);
+    }
+  }
+  // who stores a strip of W_l / W_r to HBM (the back-substitution reads them): of the workgroups that compute it, the one
+  // with the fewest strips to store so far
+  std::vector<unsigned> own(T, 0u);
+  for (int st = 0; st < 10; ++st) {
+    int best = -1;
+    for (int g = 0; g < T; ++g)
+      if ((strips(bin[g]) >> st) & 1u)
+        if (best < 0 || __builtin_popcount(own[g]) < __builtin_popcount(own[best])) best = g;
+    if (best >= 0) own[best] |= 1u << st;
+  }
   for (int g = 0; g < T; ++g) {
     int* row = out + (size_t)g * SLV_STRIDE;
-    const unsigned m = strips(bin[g]);
-    row[0] = (int)m;
-    row[1] = (int)(m & ~stored);
-    stored |= m;
+    row[0] = (int)strips(bin[g]);
+    row[1] = (int)own[g];
     row[2] = (int)bin[g].size();
     std::sort(bin[g].begin(), bin[g].end());
     for (size_t k = 0; k < bin[g].size(); ++k) row[3 + k] = bin[g][k];
@@ -122,10 +226,9 @@ int slv_upload_plans() {
 // ---- device side ---------------------------------------------------------------------------------------------------------
 // (load_node_sum: bcr_dev.hpp)
 // one row tile IB of the strip W(:, cc .. cc+15) = U^T B: acc = sum_{k <= IB} U(k, IB)^T B(k, strip); result into the strip's own
-// place in LDS (in place: the wave holds the whole strip of B in bv) and, when asked, to HBM (column 79 - the rider y - as 0)
+// place in LDS (in place: the wave holds the whole strip of B in bv)
 template <int IB>
-__device__ __forceinline__ void slv_row_tile(const double* Lm, const double (&bv)[20], double* Wb, double* __restrict__ Wg, int cc,
-                                             int li, int lk) {
+__device__ __forceinline__ void slv_row_tile(const double* Lm, const double (&bv)[20], double* Wb, int cc, int li, int lk) {
   constexpr int NS = 4 * (IB + 1);
   double av[NS];
 #pragma unroll
@@ -135,19 +238,32 @@ __device__ __forceinline__ void slv_row_tile(const double* Lm, const double (&bv
   for (int t = 0; t < NS; ++t) acc = mfma(av[t], bv[t], acc);
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) Wb[(IB * 16 + lk + 4 * rr) * LD + cc + li] = acc[rr];
-  if (Wg) {
-    const bool rider = cc + li == BS - 1;
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store in flight (vmcnt(0)) -
+// between the rounds of the strip phase that was a round trip to HBM per round
+__device__ __forceinline__ void slv_lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// the first 4 NK rows of the strip Wb(:, cc .. cc + 15) as the B operand (what row tiles <= NK - 1 need); column 79 carries the
+// node's right-hand side (the rider): a masked fix-up of the four lanes that hold it, only in the strip that has it
+template <int NK>
+__device__ __forceinline__ void slv_strip_operand(const double* Wb, const double* yv, double (&bv)[20], int cc, int li, int lk) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Wg[(IB * 16 + lk + 4 * rr) * BS + cc + li] = rider ? 0.0 : acc[rr];
+  for (int t = 0; t < 4 * NK; ++t) bv[t] = Wb[(4 * t + lk) * LD + cc + li];
+  if (cc == BS - 16) {
+    if (li == 15) {
+#pragma unroll
+      for (int t = 0; t < 4 * NK; ++t) bv[t] = yv[4 * t + lk];
+    }
   }
 }
-__device__ __forceinline__ void slv_strip_operand(const double* Wb, const double* yv, double (&bv)[20], int cc, int li, int lk) {
-  const bool rider = cc + li == BS - 1;           // column 79 carries the node's right-hand side
-#pragma unroll
-  for (int t = 0; t < 20; ++t) bv[t] = rider ? yv[4 * t + lk] : Wb[(4 * t + lk) * LD + cc + li];
-}
+constexpr int SLV_T = 512;       // threads: two waves per SIMD hide each other's LDS latencies in the strip / product phases
+constexpr int SLV_V = (BS * BS / 2 + SLV_T - 1) / SLV_T;
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SLV_T)
 k_sep_level(BcrChain ch, SepLevelArgs a, int* __restrict__ numeric_err, const int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (status && *status != 0) return;
@@ -174,15 +290,15 @@ k_sep_level(BcrChain ch, SepLevelArgs a, int* __restrict__ numeric_err, const in
 #define SLV_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)bx == ch.dbg[64] && (long long)a.T == ch.dbg[65]) ch.dbg[k] = (long long)wall_clock64(); } while (0)
   SLV_STAMP(0);
   // ---- everything this workgroup reads from HBM, requested at once --------------------------------------------------
-  double2 cl[13], cr[13];
-  if (strips & 0x1Fu) fetch_mat(cl, ch.Cpl + (size_t)loc_l * MB, tid);       // block(i, l): rows i, cols l
-  if (strips & 0x3E0u) fetch_mat(cr, ch.Cpl + (size_t)loc_r * MB, tid);      // block(r, i): rows r, cols i  (used transposed)
-  load_node_sum<256>(Lm, yv, ch, i, fl, tid);
-  if (strips & 0x1Fu) stage_mat(WL, cl, tid);
+  double2 cl[SLV_V], cr[SLV_V];
+  if (strips & 0x1Fu) fetch_mat<SLV_T>(cl, ch.Cpl + (size_t)loc_l * MB, tid);       // block(i, l): rows i, cols l
+  if (strips & 0x3E0u) fetch_mat<SLV_T>(cr, ch.Cpl + (size_t)loc_r * MB, tid);      // block(r, i): rows r, cols i  (used transposed)
+  load_node_sum<SLV_T>(Lm, yv, ch, i, fl, tid);
+  if (strips & 0x1Fu) stage_mat<SLV_T>(WL, cl, tid);
   if (strips & 0x3E0u) {
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const int idx = tid + 256 * k;
+    for (int k = 0; k < SLV_V; ++k) {
+      const int idx = tid + SLV_T * k;
       if (idx < BS * BS / 2) {
         const int e = 2 * idx, rr = e / BS, c = e % BS;
         WR[c * LD + rr] = cr[k].x;
@@ -192,83 +308,77 @@ k_sep_level(BcrChain ch, SepLevelArgs a, int* __restrict__ numeric_err, const in
   }
   __syncthreads();
   SLV_STAMP(1);
-  chol80(Lm, tid, g == 0 ? numeric_err : nullptr);
+  chol80<SLV_T / 64>(Lm, tid, g == 0 ? numeric_err : nullptr);
   SLV_STAMP(2);
-  if (g == 0) {                  // y = U^T b -> Y, the factor -> U (what the back-substitution of this node reads)
-    if (tid < 3 * BS) {
-      const int row = tid % BS, part = tid / BS;
-      double yy = 0.0;
-      const int c1 = min(27 * part + 27, row + 1);
-      for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
-      ysc[tid] = yy;
+  if (g == 0 && tid < 256) store_mat(ch.U + i * MB, Lm, tid);      // the factor (what the back-substitution of this node reads)
+  // ---- strips of W = U^T [C_l | C_r], in place, a WHOLE strip per wave: a wave holds its strip's operand in registers before it
+  //      writes the first result and no other wave touches those columns, so the phase has no barrier - the two waves of a SIMD
+  //      hide each other's LDS latencies.  (Measured, scripts/bench/strip_phase.hip: the row tiles of a strip over four waves,
+  //      two strips per round with a barrier each, is 7.3 us for ten strips - 3.8 us of it LDS traffic and barriers that do not
+  //      overlap with the matrix instructions; without barriers the same work is 4.9 us.)
+  {
+    const int ns = __popc(strips);
+    for (int q = wave; q < ns; q += SLV_T / 64) {
+      unsigned m = strips;
+      for (int k = 0; k < q; ++k) m &= m - 1;
+      const int s = __ffs(m) - 1, side = s >= 5, cc = 16 * (side ? s - 5 : s);
+      double* Wb = side ? WR : WL;
+      double bv[20];
+      slv_strip_operand<5>(Wb, yv, bv, cc, li, lk);
+      slv_row_tile<4>(Lm, bv, Wb, cc, li, lk);
+      slv_row_tile<3>(Lm, bv, Wb, cc, li, lk);
+      slv_row_tile<2>(Lm, bv, Wb, cc, li, lk);
+      slv_row_tile<1>(Lm, bv, Wb, cc, li, lk);
+      slv_row_tile<0>(Lm, bv, Wb, cc, li, lk);
     }
-    __syncthreads();
-    if (tid < BS) ch.Y[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
-    store_mat(ch.U + i * MB, Lm, tid);
   }
+  slv_lds_barrier();
   SLV_STAMP(3);
-  // ---- strips of W = U^T [C_l | C_r], in place --------------------------------------------------------------------------
-  const int ns = __popc(strips);
-  auto nth_strip = [&](int q) {
-    unsigned m = strips;
-    for (int k = 0; k < q; ++k) m &= m - 1;
-    return __ffs(m) - 1;
-  };
-  if (ns >= 3) {                 // a whole strip per wave: no hazards between waves, no barriers
-    for (int q = wave; q < ns; q += 4) {
-      const int s = nth_strip(q), side = s >= 5, cc = 16 * (side ? s - 5 : s);
-      double* Wb = side ? WR : WL;
-      double* Wg = ((stores >> s) & 1u) ? (side ? ch.Wr : ch.Wl) + i * MB : nullptr;
-      double bv[20];
-      slv_strip_operand(Wb, yv, bv, cc, li, lk);
-      slv_row_tile<4>(Lm, bv, Wb, Wg, cc, li, lk);
-      slv_row_tile<3>(Lm, bv, Wb, Wg, cc, li, lk);
-      slv_row_tile<2>(Lm, bv, Wb, Wg, cc, li, lk);
-      slv_row_tile<1>(Lm, bv, Wb, Wg, cc, li, lk);
-      slv_row_tile<0>(Lm, bv, Wb, Wg, cc, li, lk);
+  // W_l, W_r for the back-substitution, each strip by one of the workgroups that hold it (the rider's column as 0): requested
+  // now, they drain under the products
+  for (unsigned m = strips & stores; m; m &= m - 1) {
+    const int s = __ffs(m) - 1, side = s >= 5, cc = 16 * (side ? s - 5 : s);
+    const double* Wb = side ? WR : WL;
+    double* Wg = (side ? ch.Wr : ch.Wl) + i * MB;
+    double v[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int e = tid + SLV_T * it, k = e >> 4, j = e & 15;
+      v[it] = e < BS * 16 ? Wb[k * LD + cc + j] : 0.0;
     }
-  } else {                       // one or two strips: the row tiles of a strip over the waves {4}, {3}, {2, 0}, {1}
-    for (int q = 0; q < ns; ++q) {
-      const int s = nth_strip(q), side = s >= 5, cc = 16 * (side ? s - 5 : s);
-      double* Wb = side ? WR : WL;
-      double* Wg = ((stores >> s) & 1u) ? (side ? ch.Wr : ch.Wl) + i * MB : nullptr;
-      double bv[20];
-      slv_strip_operand(Wb, yv, bv, cc, li, lk);
-      __syncthreads();           // every wave holds the strip before any wave overwrites a part of it
-      if (wave == 0) slv_row_tile<4>(Lm, bv, Wb, Wg, cc, li, lk);
-      else if (wave == 1) slv_row_tile<3>(Lm, bv, Wb, Wg, cc, li, lk);
-      else if (wave == 2) {
-        slv_row_tile<2>(Lm, bv, Wb, Wg, cc, li, lk);
-        slv_row_tile<0>(Lm, bv, Wb, Wg, cc, li, lk);
-      } else slv_row_tile<1>(Lm, bv, Wb, Wg, cc, li, lk);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int e = tid + SLV_T * it, k = e >> 4, j = e & 15;
+      if (e < BS * 16) Wg[k * BS + cc + j] = (cc + j == BS - 1) ? 0.0 : v[it];
     }
   }
-  __syncthreads();
-  SLV_STAMP(4);
-  // ---- products: this workgroup's tiles, four per wave and batch (the old sums requested before the matrix instructions) ---
+  // ---- products: this workgroup's tiles, two per wave and batch (the old sums requested before the matrix instructions) ---
   for (int q0 = 0; q0 < nt; q0 += 16) {
-    d4 old[4];
-    int code[4];
+    d4 old[2];
+    int code[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = q0 + wave + 4 * u;
-      code[u] = q < nt ? pl[3 + q] : -1;
+    for (int u = 0; u < 2; ++u) {
+      const int q = q0 + wave + 8 * u;
+      int c = q < nt ? pl[3 + q] : -1;
+      if (c >= 0) {
+        const int kind = c / 25;
+        if ((kind != 1 && l < 0) || (kind != 0 && r < 0)) c = -1;             // (an end node has no such neighbour)
+      }
+      code[u] = c;
       old[u] = d4{0, 0, 0, 0};
-      if (code[u] >= 0 && code[u] < 50) {
-        const int kind = code[u] / 25, ta = (code[u] % 25) / 5, tb = code[u] % 5;
-        const int nb = kind == 0 ? l : r;
-        if (nb >= 0 && (fl & (kind == 0 ? 4 : 8))) {
-          const double* Sg = (kind == 0 ? ch.SR : ch.SL) + (size_t)nb * MB;
+      if (c >= 0 && c < 50) {              // running sums: start from what earlier levels left there
+        const int kind = c / 25, ta = (c % 25) / 5, tb = c % 5;
+        if (fl & (kind == 0 ? 4 : 8)) {
+          const double* Sg = (kind == 0 ? ch.SR + (size_t)l * MB : ch.SL + (size_t)r * MB);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) old[u][rr] = Sg[(ta * 16 + lk + 4 * rr) * BS + tb * 16 + li];
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       if (code[u] < 0) continue;
       const int kind = code[u] / 25, ta = (code[u] % 25) / 5, tb = code[u] % 5;
-      if ((kind != 1 && l < 0) || (kind != 0 && r < 0)) continue;
       const double* A = kind == 0 ? WL : WR;          // rows of the result: columns of A
       const double* B = kind == 1 ? WR : WL;
       d4 acc = mma_seq<BS / 4, true>(old[u], A + lk * LD + ta * 16 + li, 4 * LD, B + lk * LD + tb * 16 + li, 4 * LD);
@@ -284,6 +394,23 @@ k_sep_level(BcrChain ch, SepLevelArgs a, int* __restrict__ numeric_err, const in
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Sg[(ta * 16 + lk + 4 * rr) * BS + tb * 16 + li] = acc[rr];
       }
+    }
+  }
+  SLV_STAMP(4);
+  if (g == 0) {                  // y = U^T b -> Y
+    const bool from_l = (strips >> 4) & 1u, from_r = (strips >> 9) & 1u;
+    if (from_l || from_r) {
+      if (tid < BS) ch.Y[(size_t)i * BS + tid] = (from_l ? WL : WR)[tid * LD + BS - 1];
+    } else {
+      if (tid < 3 * BS) {
+        const int row = tid % BS, part = tid / BS;
+        double yy = 0.0;
+        const int c1 = min(27 * part + 27, row + 1);
+        for (int c = 27 * part; c < c1; ++c) yy += Lm[c * LD + row] * yv[c];
+        ysc[tid] = yy;
+      }
+      __syncthreads();
+      if (tid < BS) ch.Y[(size_t)i * BS + tid] = ysc[tid] + ysc[BS + tid] + ysc[2 * BS + tid];
     }
   }
   SLV_STAMP(5);
@@ -357,7 +484,7 @@ int slv_launch_level(const BcrChain& ch, const BcrLevel& lv, int* d_numeric_err,
   a.total = lv.n_elim * lv.T;
   a.nx = std::min(8, (a.total + 31) / 32);
   a.per = (a.total + a.nx - 1) / a.nx;
-  hipLaunchKernelGGL(k_sep_level, dim3(8 * a.per), dim3(256), kSepLevelLds, s, ch, a, d_numeric_err, d_status);
+  hipLaunchKernelGGL(k_sep_level, dim3(8 * a.per), dim3(SLV_T), kSepLevelLds, s, ch, a, d_numeric_err, d_status);
   ACINO_LAUNCH_CHECK();
   return ACINO_OK;
 }

@@ -18,7 +18,7 @@ for _ in range(3):
 print("plan", fte.solver_plan(c.params), "bcr_levels", c.params.bcr_levels)
 dbg = torch.zeros(72, dtype=torch.int64, device="cuda")
 check(lib().acino_fte_debug_stamps(c._h, ptr(dbg)))
-lv_names = ["start", "operands staged", "chol80 done", "y / U stored (g = 0)", "strips done", "products stored"]
+lv_names = ["start", "operands staged", "chol80 done", "strips done", "products stored", "y / U stored (g = 0)"]
 tl_names = ["start", "operands staged", "chol80 done", "x0 done", "sweeps done, x stored", "level node done"]
 for T in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
     for wg in (0, 1, 2, 3, 57, 118, 200):
@@ -28,12 +28,18 @@ for T in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
         if d[5] == 0:
             continue
         print(f"k_sep_level T={T} wg {wg}: " + ", ".join(f"{lv_names[k]} {(d[k] - d[0]) / 100.0:.2f}" for k in range(1, 6) if d[k]))
-for wg in (0, 1, 30, 58, 59, 60, 100, 150, 200):
+for wg in (0, 1, 30, 58, 59, 60, 100, 118, 119, 150, 200, 237):
     dbg.zero_(); dbg[64] = wg; dbg[65] = 100
     c.step(); torch.cuda.synchronize()
     d = dbg.cpu().numpy()
-    if d[0] == 0 and d[5] == 0:
+    if d[6] == 0:
         continue
-    base = d[0] if d[0] else d[5]
-    print(f"k_sep_tail wg {wg}: " + ", ".join(f"{tl_names[k]} {(d[k] - base) / 100.0:.2f}" for k in range(1, 6) if d[k]))
+    base = d[7]
+    if d[0]:
+        if d[8]:
+            print(f"   sweep 2 of wg {wg}: starts {(d[8] - base) / 100.0:.2f}, flags seen {(d[9] - base) / 100.0:.2f}, acquired {(d[10] - base) / 100.0:.2f}, "
+                  f"neighbours' iterates in LDS {(d[11] - base) / 100.0:.2f}, new iterate {(d[12] - base) / 100.0:.2f}, published {(d[13] - base) / 100.0:.2f}")
+        print(f"k_sep_tail wg {wg} (isolated): enters {(d[6] - base) / 100.0:.2f}, " + ", ".join(f"{tl_names[k]} {(d[k] - base) / 100.0:.2f}" for k in range(1, 5) if d[k]))
+    else:
+        print(f"k_sep_tail wg {wg} (level node): enters {(d[6] - base) / 100.0:.2f}, neighbours solved {(d[1] - base) / 100.0:.2f}, done {(d[5] - base) / 100.0:.2f}")
 c.close()
