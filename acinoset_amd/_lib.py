@@ -185,6 +185,7 @@ SIGNATURES = {
                                         _P, _P, _P, _Z, C.POINTER(SkelFteInfo), _P]),
     "acino_selftest_mfma": (_I, [_P, _P, _I, _P, _P]),
     "acino_debug_poison_lds": (_I, [_I, _I, _P]),
+    "acino_debug_level_split": (_I, [_I, _P]),
 }
 
 _lib = None

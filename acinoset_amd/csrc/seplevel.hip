@@ -497,3 +497,10 @@ int slv_launch_fold(const BcrChain& ch, const int* d_entries, int n, const int* 
 }
 
 }  // namespace acino
+
+extern "C" int acino_debug_level_split(int T, int32_t* out) {
+  using namespace acino;
+  ACINO_REQUIRE(T >= 1 && T <= SLV_MAXT && out, "T in 1 .. 16");
+  slv_plan_build(T, out);
+  return ACINO_OK;
+}

@@ -490,6 +490,11 @@ int acino_fte_shard_control(acino_fte_ctx* ctx, const double* d_all_partials, in
  * any kernel that reads LDS it has not written itself then produces NaN). */
 int acino_debug_poison_lds(int n_blocks, int spin, void* stream);
 int acino_selftest_mfma(const double* d_a, const double* d_b, int k, double* d_c, void* stream);
+/* Host only (tests): the table by which the fused narrow levels of the separator reduction (csrc/seplevel.hip) split an
+ * eliminated node's work over T workgroups, 1 <= T <= 16.  out[T][64] ints per workgroup: bit mask of the strips of
+ * [W_l | W_r] it computes (bit s < 5: columns 16 s .. of W_l, bit 5 + s: of W_r), bit mask of the strips it stores, number
+ * of product tiles, then the tile codes (0 .. 24 P_l(a, b) = 5 a + b with a >= b; 25 .. 49 P_r; 50 .. 74 X(a, b)). */
+int acino_debug_level_split(int T, int32_t* out);
 
 #ifdef __cplusplus
 }

@@ -221,3 +221,33 @@ def test_bench_json_line_filter():
     line, rest = bench._json_line_of('[Gloo] Rank 0 is connected\n{"not": "it"}\n{"metric": "m", "value": 1}\ntrailing')
     assert line == '{"metric": "m", "value": 1}' and rest == ['[Gloo] Rank 0 is connected', '{"not": "it"}', 'trailing']
     assert bench._json_line_of("nothing here")[0] is None
+
+
+def test_level_split_tables_cover_every_tile_once():
+    """Fused narrow levels of the separator reduction (csrc/seplevel.hip): for every T the T workgroups of a node together
+    compute each of the 55 output tiles (15 lower tiles of P_l, 15 of P_r, 25 of X) exactly once, every workgroup computes the
+    strips of W its tiles read, every strip of W_l / W_r has exactly one workgroup that stores it, and the shares are balanced."""
+    import ctypes as C
+    want = {5 * a + b for a in range(5) for b in range(a + 1)}
+    want |= {25 + t for t in want} | {50 + t for t in range(25)}
+    for T in range(1, 17):
+        buf = (C.c_int32 * (T * 64))()
+        assert _lib.lib().acino_debug_level_split(T, buf) == 0
+        rows = np.frombuffer(buf, dtype=np.int32).reshape(T, 64)
+        seen, stored, counts = [], 0, []
+        for g in range(T):
+            strips, stores, nt = int(rows[g, 0]), int(rows[g, 1]), int(rows[g, 2])
+            tiles = [int(c) for c in rows[g, 3:3 + nt]]
+            assert all(c == -1 for c in rows[g, 3 + nt:]) and tiles == sorted(tiles)
+            need = 0
+            for c in tiles:
+                kind, a, b = c // 25, (c % 25) // 5, c % 5
+                need |= ((1 << a) | (1 << b)) if kind == 0 else (((32 << a) | (32 << b)) if kind == 1 else ((32 << a) | (1 << b)))
+            assert strips == need and stores & ~strips == 0 and stored & stores == 0, (T, g)
+            stored |= stores
+            seen += tiles
+            counts.append(nt)
+        assert sorted(seen) == sorted(want), T
+        assert stored == 0x3FF, T
+        assert max(counts) <= -(-55 // T) + 8, (T, counts)          # no workgroup left with most of the node
+    assert _lib.lib().acino_debug_level_split(17, (C.c_int32 * 64)()) != 0

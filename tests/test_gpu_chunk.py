@@ -233,3 +233,28 @@ def test_separator_tail_falls_back_to_the_per_level_kernels_on_a_device_that_can
         assert g[3] == 0 and r[3] == 0 and g[1] == r[1], (it, g[3], r[3])
         assert abs(g[0] - r[0]) <= 1e-11 * abs(r[0]), (it, g[0], r[0])
         assert np.abs(g[4] - r[4]).max() < 1e-10, (it, float(np.abs(g[4] - r[4]).max()))
+
+
+@pytest.mark.parametrize("n,kw", [(999, {}), (999, dict(bcr_levels=0)), (3331, {}), (400, dict(shared_gpu=True)), (190, {}),
+                                   (2500, dict(chunk_nodes=4))])
+def test_fused_narrow_levels_equal_the_per_phase_kernels(mods, monkeypatch, n, kw):
+    """Round 6: a narrow level of the separator reduction is ONE launch (csrc/seplevel.hip: elimination and Schur products, the
+    products kept as per-side running sums, the isolated level factored inside k_sep_tail).  ACINO_NO_FUSED_LEVELS=1 selects the
+    per-phase kernels of csrc/bcr.hip for the same chain: both are exact eliminations of the same system, so the LM walk - trial
+    cost, accept / reject, predicted reduction, trial iterate - must agree to rounding.  Cases: truncated + refined (tail kernel),
+    complete reduction, a shared GPU (per-level back-substitution: the sums are folded for it), a chain too short to truncate,
+    many short runs (wide first level on the old kernels, narrow ones fused)."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(n, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    xa = _start(fte, seq, n, 7 * n)
+    monkeypatch.setenv("ACINO_NO_FUSED_LEVELS", "1")
+    ref = _walk(fte, seq["det"], rig, seq["Ts"], xa, 6, **kw)
+    monkeypatch.delenv("ACINO_NO_FUSED_LEVELS")
+    got = _walk(fte, seq["det"], rig, seq["Ts"], xa, 6, **kw)
+    for it, (r, g) in enumerate(zip(ref, got)):
+        assert r[3] == g[3] == 0, (it, r[3], g[3])
+        assert r[1] == g[1], it
+        assert abs(r[0] - g[0]) <= 1e-9 * abs(r[0]), (it, r[0], g[0])
+        assert abs(r[2] - g[2]) <= 1e-7 * abs(r[2]) + 1e-12, (it, r[2], g[2])
+        assert np.abs(r[4] - g[4]).max() < 1e-8, (it, np.abs(r[4] - g[4]).max())
