@@ -88,6 +88,35 @@ class SkeletonModel:
         return 3 + 3 * self.prog["n_angles"]
 
 
+def _rows_by_frame_value(idx, want):
+    """Rows of a detection table (frame index ``idx``, one distinct value per row) that hold the frames ``want`` - looked up by
+    VALUE, as the reference does (utils.py:105-120 -> ``frame == n - 1``).  A wanted frame that the table does not hold is an
+    error, never the next frame's row."""
+    idx = np.asarray(idx, dtype=np.int64)
+    want = np.asarray(want, dtype=np.int64)
+    order = np.argsort(idx)
+    pos = np.searchsorted(idx[order], want)
+    if idx.size == 0 or (pos >= idx.size).any() or (idx[order][np.minimum(pos, idx.size - 1)] != want).any():
+        raise ValueError("frame window outside the detection tables")
+    return order[pos]
+
+
+def _forehead_union(tabs, lik_thresh, k_arr, d_arr, r_arr, t_arr):
+    """The triangulated forehead over every frame that AT LEAST TWO cameras hold (the reference's pairwise triangulation uses
+    every frame a camera pair shares, calib.py:394-423) - frames, points [F, 3] (NaN where no pair sees it).  A camera without
+    the frame contributes a row of likelihood 0."""
+    frames = np.unique(np.concatenate([idx for _p, _v, idx in tabs]))
+    held = np.stack([np.isin(frames, idx) for _p, _v, idx in tabs], axis=1)
+    frames, held = frames[held.sum(1) >= 2], held[held.sum(1) >= 2]
+    cols = []
+    for c, (parts, vals, idx) in enumerate(tabs):
+        col = np.zeros((frames.size, 1, 3))
+        col[held[:, c], 0] = vals[_rows_by_frame_value(idx, frames[held[:, c]]), parts.index("forehead")]
+        cols.append(col)
+    tri = calib.triangulate_pairs_dense(np.stack(cols, axis=1), lik_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
+    return frames, np.asarray(tri.cpu().numpy() if isinstance(tri, torch.Tensor) else tri)[:, 0]
+
+
 def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_frames=N_FRAMES, start_frame=START_FRAME,
                 h=H_STEP, pairing="reference", lik_thresh=LIK_THRESH, r_meas=R_MEAS, model_weight=MODEL_WEIGHT, initial_line=True):
     """build.py:28-304.  ``project_dir`` is the reference's: ``data/4_cam_scene_static_sba.json`` and ``data/*.h5`` are read
@@ -116,13 +145,7 @@ def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_f
             raise ValueError("a detection table needs one distinct frame index per row")
         tabs.append((parts, vals, idx))
     want = np.arange(start_frame, start_frame + n_frames, dtype=np.int64)
-    rows = []
-    for parts, vals, idx in tabs:
-        order = np.argsort(idx)
-        pos = np.searchsorted(idx[order], want)
-        if (pos >= idx.size).any() or (idx[order][np.minimum(pos, idx.size - 1)] != want).any():
-            raise ValueError("frame window outside the detection tables")
-        rows.append(order[pos])
+    rows = [_rows_by_frame_value(idx, want) for _parts, _vals, idx in tabs]
     # ---- measurements and weights per pose slot (:113-128, :184-206)
     pair = marker_pairing(skel_dict, names, pairing)
     Lp = len(names)
@@ -135,20 +158,11 @@ def build_model(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, n_f
             sl = vals[rows[c], parts.index(mk)]
             meas[:, c, l] = sl[:, :2]
             w[:, c, l] = np.where(sl[:, 2] > lik_thresh, 1.0 / r_meas, 0.0)
-    # ---- initial point: line through the triangulated "forehead" over ALL frames the cameras share (:143-166), a regression
-    #      against the frame VALUE, evaluated at 0 .. N-1 (:157)
+    # ---- initial point: line through the triangulated "forehead" over ALL frames that a camera pair shares (:143-166), a
+    #      regression against the frame VALUE, evaluated at 0 .. N-1 (:157)
     init_x = np.zeros((n_frames, 3 + 3 * prog["n_angles"]))
     if initial_line and all("forehead" in parts for parts, _v, _i in tabs) and C_ >= 2:   # (initial_line=False: the caller brings x0)
-        common = tabs[0][2]
-        for _p, _v, idx in tabs[1:]:
-            common = np.intersect1d(common, idx)
-        cols = []
-        for parts, vals, idx in tabs:
-            order = np.argsort(idx)
-            cols.append(vals[order[np.searchsorted(idx[order], common)], parts.index("forehead")][:, None, :])
-        det = np.stack(cols, axis=1)                                                                            # [F, C, 1, 3]
-        tri = calib.triangulate_pairs_dense(det, lik_thresh, k_arr, d_arr, r_arr, t_arr, return_masks=False)
-        tri = np.asarray(tri.cpu().numpy() if isinstance(tri, torch.Tensor) else tri)[:, 0]
+        common, tri = _forehead_union(tabs, lik_thresh, k_arr, d_arr, r_arr, t_arr)
         ok = np.isfinite(tri).all(1)
         if ok.sum() >= 2:
             f = common.astype(np.float64)[ok]
@@ -190,7 +204,9 @@ def _finite_diff_states(x_full, hh):
 def solve_models(models, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-10, gtol=1e-8, l1_eps=1e-2, lam_max=1e16):
     """The GPU solve of SEVERAL ``SkeletonModel`` s of the same skeleton, cameras and length in one call
     (acino_skel_fte_solve_batch: one workgroup per clip in the banded factorisation, a Levenberg-Marquardt controller per clip
-    on the device).  ``x0``: None or one [N, P] array per model.  Returns ``[(results, info), ...]`` in the order of ``models``."""
+    on the device).  ``x0``: None or one [N, P] array per model.  Returns ``[(results, info), ...]`` in the order of ``models``.
+    In a batch a clip that fails numerically does not fail the call: its ``info["status_name"]`` is "numeric" (its results are
+    the last accepted iterate) and the other clips' results stand."""
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     m0 = models[0]
@@ -241,11 +257,13 @@ def solve_models(models, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-1
     return out
 
 
-def solve_model(model, x0=None, **solver_kw):
+def solve_model(model, x0=None, max_iter=200, lam0=1e-3, ftol=1e-10, xtol=1e-10, gtol=1e-8, l1_eps=1e-2, lam_max=1e16):
     """The GPU solve of a ``SkeletonModel`` (acino_skel_fte_solve).  Returns (results, info): ``results`` has the layout of
     ``convert_to_dict`` (positions [N, n_pose, 3], x / dx / ddx [N, P]); states outside ``model.active`` keep their initial
-    values - which must be 0, as in the reference's initialisation (:215-222)."""
-    return solve_models([model], None if x0 is None else [x0], **solver_kw)[0]
+    values - which must be 0, as in the reference's initialisation (:215-222).  A numeric failure raises (one clip: the
+    failure is the call's)."""
+    return solve_models([model], None if x0 is None else [x0], max_iter=max_iter, lam0=lam0, ftol=ftol, xtol=xtol, gtol=gtol,
+                        l1_eps=l1_eps, lam_max=lam_max)[0]
 
 
 def solve_model_parallel(model, x0=None, window=N_FRAMES, outer_max=40, xtol_outer=1e-7, first_max_iter=30, later_max_iter=30,
@@ -267,6 +285,8 @@ def solve_model_parallel(model, x0=None, window=N_FRAMES, outer_max=40, xtol_out
     reach ``xtol_outer`` in 40 outer iterations (9 s; the cost still falls by ~0.4 % per outer iteration): where a stretch of
     the video has no detections the trajectory is held by the smoothness term alone (weight 0.002 / h^4 = 4e5) and
     information crosses it half a window per outer iteration - ``solve_video`` (free windows) is the practical entry for that."""
+    if "max_iter" in solver_kw:
+        raise TypeError("solve_model_parallel: the inner iteration budget is first_max_iter / later_max_iter (and outer_max), not max_iter")
     N, P = model.N, model.P
     act = np.asarray(model.active, dtype=np.int64)
     if N < 2 * window:
@@ -321,16 +341,35 @@ def video_windows(first_frame, last_frame, window, overlap):
     return starts
 
 
+def window_residual_px(model, info):
+    """Mean absolute reprojection residual (px) at the end state of a solved window: the L1 objective is sum w |e| with w = 1 / R
+    on every detection above the threshold (x and y are two rows each), plus a smoothness term that is small beside it."""
+    n_rows = 2 * int((np.asarray(model.weights) > 0).sum())
+    return float(info["cost_final"]) * R_MEAS / max(n_rows, 1)
+
+
 def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, first_frame=None, last_frame=None, window=N_FRAMES,
-                overlap=20, **kw):
+                overlap=20, warm_px=15.0, warm_passes=3, **kw):
     """A whole video as the reference would have to do it - windows of ``window`` frames (build.py:131-133: N = 100), here
     ALL of them in one batched GPU solve: consecutive windows overlap by ``overlap`` frames and every frame is taken from
     the window in which it lies deepest.  An extension (the reference solves one window per run): the initial point of a
     window is the triangulated forehead of its OWN frames, gaps interpolated (the reference fits one straight line through the
     forehead of the whole video and evaluates it at 0 .. N-1 whatever ``start_frame`` is, :143-166 - fine for its one window
-    near the start, metres away for a window later in a video in which the subject turns round).  ``kw``: build_model's (``pairing``, ``h``,
-    ...) and solve_models' (``max_iter``, ...) keywords.  Returns ``(results, infos, starts)``: ``results`` as convert_to_dict
-    over frames first_frame .. last_frame, one info per window."""
+    near the start, metres away for a window later in a video in which the subject turns round).
+
+    Warm starts: a window that starts with all joint angles 0 can settle in a wrong local minimum of the L1 objective (the
+    body facing the other way: mean residuals of 20 .. 140 px where its neighbours end at 2 .. 6).  After the first batched solve
+    every window whose mean absolute residual exceeds ``warm_px`` is solved AGAIN from its better neighbour's end state - the
+    shared ``overlap`` frames copied, the neighbour's joint angles at the nearest shared frame held over the rest, positions
+    from the triangulated forehead - and the better of the two end states is kept; up to ``warm_passes`` passes, each one
+    batched call over the windows concerned (a repaired window can repair its other neighbour in the next pass).
+
+    ``dx`` / ``ddx`` are taken per window and selected with the same depth rule as ``x``: at a seam between two windows the
+    stitched ``x`` jumps between two independently converged solutions, and differences ACROSS a seam would read as spikes of
+    jump / h and jump / h^2.  ``kw``: build_model's (``pairing``, ``h``, ...) and solve_models' (``max_iter``, ...) keywords.
+    Returns ``(results, infos, starts)``: ``results`` as convert_to_dict over frames first_frame .. last_frame (plus
+    ``start_frame`` and ``seams``: the first frame, relative to first_frame, of every stretch taken from a new window), one
+    info per window (with ``mean_abs_residual_px`` and ``warm_started_from``)."""
     build_kw = {k: kw.pop(k) for k in ("h", "pairing", "lik_thresh", "r_meas", "model_weight") if k in kw}
     if dlc_tables is None:
         paths = sorted(glob.glob(os.path.join(project_dir, "data", "*.h5")))
@@ -345,15 +384,13 @@ def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, fir
     # the forehead of every frame, triangulated once (the reference's initial point uses the same marker, build.py:143-166)
     head = None
     tabs3 = [(list(tb[0]), np.asarray(tb[1], dtype=np.float64), ix) for tb, ix in zip(dlc_tables, idx)]
+    want = np.arange(f0, f1 + 1)
+    rows3 = [_rows_by_frame_value(ix, want) for _parts, _vals, ix in tabs3]       # (every table must hold f0 .. f1: ValueError)
     if all("forehead" in parts for parts, _v, _i in tabs3) and len(tabs3) >= 2:
         if scene is None:
             scene = io.load_scene(os.path.join(project_dir, "data", "4_cam_scene_static_sba.json"))[:4]
         k_arr, d_arr, r_arr, t_arr = (np.asarray(a, dtype=np.float64) for a in scene)
-        want = np.arange(f0, f1 + 1)
-        cols = []
-        for parts, vals, ix in tabs3:
-            order = np.argsort(ix)
-            cols.append(vals[order[np.searchsorted(ix[order], want)], parts.index("forehead")][:, None, :])
+        cols = [vals[rw, parts.index("forehead")][:, None, :] for (parts, vals, _ix), rw in zip(tabs3, rows3)]
         tri = calib.triangulate_pairs_dense(np.stack(cols, axis=1), build_kw.get("lik_thresh", LIK_THRESH), k_arr,
                                             d_arr.reshape((-1, 4)), r_arr, t_arr, return_masks=False)
         tri = np.asarray(tri.cpu().numpy() if isinstance(tri, torch.Tensor) else tri)[:, 0]
@@ -371,17 +408,58 @@ def solve_video(skel_dict, project_dir=None, *, scene=None, dlc_tables=None, fir
         models.append(m)
         x0s.append(x0)
     solved = solve_models(models, x0s, **kw)
+    px = [window_residual_px(m, i) for m, (_r, i) in zip(models, solved)]
+    warm_from = [None] * len(starts)
+    act = np.asarray(models[0].active, dtype=np.int64)
+    for _pass in range(int(warm_passes)):
+        redo, x0r = [], []
+        for i, st in enumerate(starts):
+            if not (px[i] > warm_px):
+                continue
+            cand = [j for j in (i - 1, i + 1) if 0 <= j < len(starts) and px[j] < px[i] and px[j] <= warm_px]
+            if not cand:
+                continue
+            j = min(cand, key=lambda q: px[q])
+            xj, sj = solved[j][0]["x"], starts[j]
+            lo_g, hi_g = max(st, sj), min(st, sj) + window            # shared frames [lo_g, hi_g) (global numbering)
+            if hi_g <= lo_g:
+                continue
+            x0 = x0s[i].copy()
+            edge = xj[(hi_g - 1 if sj < st else lo_g) - sj]           # the neighbour's state at the shared frame nearest to the rest
+            x0[:, act[act >= 3]] = edge[act[act >= 3]][None, :]        # its joint angles held over the window ...
+            x0[lo_g - st:hi_g - st] = xj[lo_g - sj:hi_g - sj]          # ... and the shared frames as the neighbour left them
+            x0[:, act] = np.clip(x0[:, act], models[i].lo[:, act], models[i].hi[:, act])
+            redo.append((i, j))
+            x0r.append(x0)
+        if not redo:
+            break
+        again = solve_models([models[i] for i, _j in redo], x0r, **kw)
+        improved = False
+        for (i, j), (res, info) in zip(redo, again):
+            p_new = window_residual_px(models[i], info)
+            if info["status_name"] != "numeric" and p_new < px[i]:
+                solved[i], px[i], warm_from[i], improved = (res, info), p_new, j, True
+        if not improved:
+            break
     Lp, P = len(models[0].names), models[0].P
-    pos, x = np.zeros((total, Lp, 3)), np.zeros((total, P))
+    pos, x, dx, ddx = np.zeros((total, Lp, 3)), np.zeros((total, P)), np.zeros((total, P)), np.zeros((total, P))
     depth = np.full(total, -1.0)
-    for st, (res, _info) in zip(starts, solved):
+    owner = np.full(total, -1)
+    for w_i, (st, (res, _info)) in enumerate(zip(starts, solved)):
         d = np.minimum(np.arange(window), window - 1 - np.arange(window)).astype(np.float64)
         sl = slice(st - f0, st - f0 + window)
         take = d > depth[sl]
         pos[sl][take], x[sl][take] = res["positions"][take], res["x"][take]
+        dx[sl][take], ddx[sl][take] = res["dx"][take], res["ddx"][take]
+        owner[sl][take] = w_i
         depth[sl] = np.maximum(depth[sl], d)
-    dx, ddx = _finite_diff_states(x, float(models[0].h))
-    return dict(positions=pos, x=x, dx=dx, ddx=ddx, start_frame=f0), [i for _r, i in solved], starts
+    infos = []
+    for i, (_r, info) in enumerate(solved):
+        info = dict(info)
+        info["mean_abs_residual_px"], info["warm_started_from"] = px[i], warm_from[i]
+        infos.append(info)
+    seams = [int(n) for n in np.nonzero(np.diff(owner) != 0)[0] + 1]
+    return dict(positions=pos, x=x, dx=dx, ddx=ddx, start_frame=f0, seams=seams), infos, starts
 
 
 def convert_to_dict(m, poses=None):

@@ -1223,7 +1223,7 @@ __device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
     __builtin_amdgcn_s_sleep(1);
     if (++polls > (1ll << 22)) {
-      if (numeric_err) atomicOr(numeric_err, 2);
+      if (numeric_err) atomicOr(numeric_err, 2 | 8);      // (bit 3: it was THIS kernel - the host may fall back to the per-level kernels)
       break;
     }
   }

@@ -1291,6 +1291,13 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
   ACINO_REQUIRE(ctx, "null");
   ACINO_REQUIRE(max_iter >= 0, "max_iter");
   acino_fte_state st;
+  // (a context continues where its last solve stopped: the device's iteration counter is cumulative.  What the fall-back below
+  //  has left of THIS call's budget is counted from the value at entry - only read where the fall-back can happen.)
+  int iter_at_entry = 0;
+  if (ctx->sepchain.st_flags && max_iter > 0) {
+    if (int rc = acino_fte_get_state(ctx, &st, stream)) return rc;
+    iter_at_entry = st.iter;
+  }
   for (int it = 0; it < max_iter; ++it) {
     int rc = acino_fte_step(ctx, stream);
     if (rc) return rc;
@@ -1304,10 +1311,16 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
   }
   int rc = acino_fte_get_state(ctx, &st, stream);
   if (rc) return rc;
-  if (st.status == 6 && ctx->sepchain.st_flags && max_iter > 0) {
-    // the single-launch back-substitution of the separator chain waited in vain for a lower workgroup (something else holds
-    // the compute units it counted on): the refused step changed nothing but the counters - fall back to the per-level
-    // kernels for the rest of this context's life and go on from the same iterate
+  int ne = 0;
+  if (st.status == 6) {
+    ACINO_HIP_CHECK(hipMemcpyAsync(&ne, ctx->b.numeric_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ACINO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  }
+  if (st.status == 6 && (ne & 8) && ctx->sepchain.st_flags && max_iter > 0) {
+    // the single-launch back-substitution of the separator chain (k_sep_tail: numeric_err bit 3) waited in vain for another
+    // workgroup (something else holds the compute units it counted on): the refused step changed nothing but the counters -
+    // fall back to the per-level kernels for the rest of this context's life and go on from the same iterate.  (The other
+    // bounded wait - the d_done tail of bcr.hip - has no such alternative: status 6 is returned.)
     ctx->sepchain.st_flags = nullptr;
     ctx->sep.flags = nullptr;
     ctx->sep.n_flags = 0;
@@ -1322,7 +1335,8 @@ int acino_fte_solve(acino_fte_ctx* ctx, int max_iter, acino_fte_state* out, void
     ACINO_HIP_CHECK(hipMemsetAsync(ctx->b.numeric_err, 0, sizeof(int), s));
     ACINO_HIP_CHECK(hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s));
     ACINO_HIP_CHECK(hipStreamSynchronize(s));
-    return acino_fte_solve(ctx, max_iter > st.iter ? max_iter - st.iter : 1, out, stream);
+    const int done = st.iter - iter_at_entry;          // steps of this call that were applied before the refused one
+    return acino_fte_solve(ctx, max_iter > done ? max_iter - done : 1, out, stream);
   }
   if (out) *out = st;
   if (st.status == 5) {

@@ -927,7 +927,10 @@ int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, cons
       infos[b].pad0 = 0;
     }
   }
-  if (numeric) {
+  // One clip: the failure is the call's.  A batch: every clip's outcome is in infos[b].status (5 = numeric) and the results of
+  // the other clips stand - one degenerate window must not cost the caller the whole video; without infos there is nowhere to
+  // report it per clip, so the call fails as before.
+  if (numeric && (B == 1 || !infos)) {
     set_error("non-positive pivot in the banded factorisation at every damping up to lam_max (system not positive definite)");
     return ACINO_ERR_NUMERIC;
   }

@@ -436,7 +436,9 @@ int acino_skel_fte_solve(const acino_skel_fte_params* p, const acino_skel_op* h_
  * solves windows of N = 100 frames, build.py:131-133 - a video is many of them): every array gains a leading clip index
  * (d_meas[n_clips][N][C][n_pose][2], d_x[n_clips][N][n_active], ..., infos[n_clips]); no coupling across clips; one
  * workgroup per clip walks its banded factorisation, every clip has its own Levenberg-Marquardt controller on the device
- * and stops on its own criteria. */
+ * and stops on its own criteria.  With n_clips > 1 and infos given, a clip that fails numerically (infos[b].status = 5) does
+ * NOT fail the call: the other clips' results stand and the return value is ACINO_OK; the caller reads the status per clip.
+ * (n_clips = 1, or no infos: ACINO_ERR_NUMERIC as acino_skel_fte_solve.) */
 size_t acino_skel_fte_workspace_bytes_batch(const acino_skel_fte_params* p, int n_clips);
 int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, const acino_skel_op* h_ops, const int32_t* h_active,
                                const double* d_meas, const double* d_w, const double* d_cams24, const double* d_lo,
