@@ -46,7 +46,7 @@ ALG_FLOPS_STEP = 4.7e5              # SURVEY 8d total
 ALG_BYTES_STEP = 3600.0             # compulsory bytes / frame / iteration (detections 2880 + x in/out 720)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector = matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0
-PROFILE_DIR = "round5"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
+PROFILE_DIR = "round6"        # profiles/<dir>/pmc_*.json: quoted only when their build_id matches the loaded library
 
 
 def _log(msg):
@@ -460,21 +460,23 @@ def secondary_metrics(det, rig, Ts):
     return out
 
 
-def _shard_model_figures(world, halo):
+def _shard_model_figures(world, halo, frames=N_FRAMES):
     """What profiles/<PROFILE_DIR>/shard_model.txt (scripts/shard_model.py: real pinned / windowed contexts of every rank stepped
-    in lock step on ONE GPU, collectives emulated and not timed) predicts for this rank count: the per-rank ms of both drivers
-    before collectives, to hold the measured line against."""
+    in lock step on ONE GPU, collectives emulated and not timed) predicts for this rank count and sequence length: the per-rank
+    ms of both drivers before collectives, to hold the measured line against."""
     import re
-    out = dict(source=f"profiles/{PROFILE_DIR}/shard_model.txt", note="per-rank ms per iteration on one GPU, collectives not included")
+    out = dict(source=f"profiles/{PROFILE_DIR}/shard_model.txt", frames=int(frames),
+               note="per-rank ms per iteration on one GPU, collectives not included")
+    pre = rf"frames {int(frames)} \| "
     try:
         for line in open(os.path.join(ROOT, "profiles", PROFILE_DIR, "shard_model.txt")):
-            m = re.match(r"world 1: .* single-GPU step ([0-9.]+) ms", line)
+            m = re.match(pre + r"world 1: .* single-GPU step ([0-9.]+) ms", line)
             if m:
                 out["single_gpu_ms"] = float(m.group(1))
-            m = re.match(rf"world {world}: .*chunked sweep.* = ([0-9.]+) ms per iteration", line)
+            m = re.match(pre + rf"world {world}: .*chunked sweep.* = ([0-9.]+) ms per iteration", line)
             if m:
                 out["separators_ms"] = float(m.group(1))
-            m = re.match(rf"windows: world {world}, halo (\d+): .*default.*: step ([0-9.]+) ms", line)
+            m = re.match(pre + rf"windows: world {world}, halo (\d+): .*default.*: step ([0-9.]+) ms", line)
             if m and (int(m.group(1)) == int(halo) or "windows_ms" not in out):
                 out["windows_ms"], out["windows_halo"] = float(m.group(2)), int(m.group(1))
     except OSError as exc:
@@ -930,7 +932,7 @@ def main():
             out["drivers"] = {"headline": "windows" if windows else "separators",
                               "chosen": "the faster of the two sharded drivers in their own timed runs" if pre else f"--shard {args.shard}",
                               "separators": pre.get("separators"), "windows": pre.get("windows"),
-                              "replicas": replicas, "modelled_on_one_gpu": _shard_model_figures(world, args.halo)}
+                              "replicas": replicas, "modelled_on_one_gpu": _shard_model_figures(world, args.halo, args.frames)}
             out["collectives"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                                   "per_step": coll,
                                   "payload_bytes": ({"all_gather_edge_slabs": world * 2 * (args.halo + 3) * 25 * 8, "all_gather_scalars": world * 8 * 8}

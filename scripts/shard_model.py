@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""One rank's work in the sharded solves, measured on ONE GPU at 10 000 frames for world = 2, 4, 8.  Separator-system driver
+"""One rank's work in the sharded solves, measured on ONE GPU for world = 2, 4, 8 at 10 000 frames (the north star's size: a
+latency-bound iteration) and at 40 000 / 80 000 frames (where one GPU is throughput-bound and sharding pays).
+usage: shard_model.py [frames ...]   (default 10000 40000 80000; every line is prefixed "frames F | ").  Separator-system driver
 (ShardedFTE): all ranks as real pinned contexts stepped in lock step, collectives emulated on the device and not timed, the
 four phases of an interior rank timed with HIP events - with the whole-chain reduction (what pinned ranks ran until round 3)
 and with the chunked sweep (round 4).  Overlapping windows (WindowedFTE): an interior rank's window as a single context."""
@@ -9,9 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acinoset_amd import fte, synth
 from acinoset_amd._lib import lib, ptr, check, stream_ptr, SEP_DOUBLES, BS
 
-N = 10000
-seq = synth.make_sequence(N, "loop"); rig = (seq["K"], seq["D"], seq["R"], seq["t"])
-x0 = fte.triangulation_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
+SIZES = [int(a) for a in sys.argv[1:]] or [10000, 40000, 80000]
+N = seq = rig = x0 = None
+def load(n):
+    global N, seq, rig, x0
+    N = n
+    seq = synth.make_sequence(N, "loop"); rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    x0 = fte.triangulation_init(seq["det"], *rig, 0.5)[:, fte.ACTIVE]
 def single_gpu_step():
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -97,37 +103,43 @@ def sharded_rank_step(world, chunk_nodes, steps=30):
 
 
 from acinoset_amd import dist as adist
-t1 = single_gpu_step()
-print(f"world 1: {N} frames, single-GPU step {t1:.3f} ms (hipGraph replay)")
-for world in (2, 4, 8):
-    for tag, cn in (("whole-chain reduction (rounds 1-3)", -1), ("chunked sweep, pins in the separator chain (round 4)", 0)):
-        n_mid, ph, pl, cost = sharded_rank_step(world, cn)
-        tot = sum(ph)
-        print(f"world {world}: interior rank with {n_mid} frames, {tag} [runs of {pl['m']} nodes, {pl['n_sep']} separators]: "
-              f"reduce {ph[0]:.3f} + separator solve / back-substitution / trial {ph[1]:.3f} + halo / assembly / sums {ph[2]:.3f} + control "
-              f"{ph[3]:.3f} = {tot:.3f} ms per iteration (cost of rank {cost:.6f}) -> speed-up over 1 GPU without collectives "
-              f"{t1 / tot:.2f}x, with 3 x 25 us of collectives {t1 / (tot + 0.075):.2f}x")
-
-# ---- overlapping windows (dist.WindowedFTE): an interior rank's work is the complete step on N/world + 2*halo frames;
-#      no separator solve; two small all-gathers (not included).  Also with the incomplete reduction on top.
-print()
-for halo in (96, 192):
+for size in SIZES:
+    load(size)
+    P = f"frames {N} | "
+    t1 = single_gpu_step()
+    print(f"{P}world 1: {N} frames, single-GPU step {t1:.3f} ms (hipGraph replay) = {N / t1 / 1e3:.1f} M frames/s", flush=True)
     for world in (2, 4, 8):
-        n = min(N, N // world + 2 * halo)
-        for tag, kw in (("complete reduction", dict(bcr_levels=0)), ("default (truncated + refined, verified)", {})):
-            s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                ctx = fte.FTEContext(seq["det"][1000:1000 + n], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,
-                                     n_global=N, n_offset=1000, own_first=halo, own_count=n - 2 * halo, **kw)
-                ctx.enable_graph(True); ctx.set_x(x0[1000:1000 + n])
-                for _ in range(5): ctx.step()
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(50): ctx.step()
-                torch.cuda.synchronize(); tw = 1e3 * (time.perf_counter() - t0) / 50
-                stw = ctx.state()
-                assert stw["status"] == 0 and stw["accepted"] >= 15, stw
-                plan, K, r = fte.solver_plan(ctx.params), int(ctx.params.bcr_levels), int(ctx.params.refine_sweeps)
-                ctx.close()
-            print(f"windows: world {world}, halo {halo}: {n} frames/rank, {tag} (runs of {plan['m']} nodes, {plan['n_sep']} separators, "
-                  f"levels {K}, sweeps {r}, bound {stw['trunc_eps']:.1e}): step {tw:.3f} ms -> speed-up over 1 GPU without collectives "
-                  f"{t1 / tw:.2f}x, with 2 x 25 us of collectives {t1 / (tw + 0.05):.2f}x")
+        variants = (("whole-chain reduction (rounds 1-3)", -1), ("chunked sweep, pins in the separator chain (round 4)", 0))
+        for tag, cn in (variants if N <= 10000 else variants[1:]):
+            n_mid, ph, pl, cost = sharded_rank_step(world, cn)
+            tot = sum(ph)
+            print(f"{P}world {world}: interior rank with {n_mid} frames, {tag} [runs of {pl['m']} nodes, {pl['n_sep']} separators]: "
+                  f"reduce {ph[0]:.3f} + separator solve / back-substitution / trial {ph[1]:.3f} + halo / assembly / sums {ph[2]:.3f} + control "
+                  f"{ph[3]:.3f} = {tot:.3f} ms per iteration (cost of rank {cost:.6f}) -> speed-up over 1 GPU without collectives "
+                  f"{t1 / tot:.2f}x, with 3 x 25 us of collectives {t1 / (tot + 0.075):.2f}x", flush=True)
+
+    # ---- overlapping windows (dist.WindowedFTE): an interior rank's work is the complete step on N/world + 2*halo frames;
+    #      no separator solve; two small all-gathers (not included).  Also with the incomplete reduction on top.
+    print()
+    for halo in (96, 192):
+        for world in (2, 4, 8):
+            n = min(N, N // world + 2 * halo)
+            o = min(1000, N - n)
+            for tag, kw in (("complete reduction", dict(bcr_levels=0)), ("default (truncated + refined, verified)", {})):
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    ctx = fte.FTEContext(seq["det"][o:o + n], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True,
+                                         n_global=N, n_offset=o, own_first=halo, own_count=n - 2 * halo, **kw)
+                    ctx.enable_graph(True); ctx.set_x(x0[o:o + n])
+                    for _ in range(5): ctx.step()
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(50): ctx.step()
+                    torch.cuda.synchronize(); tw = 1e3 * (time.perf_counter() - t0) / 50
+                    stw = ctx.state()
+                    assert stw["status"] == 0 and stw["accepted"] >= 15, stw
+                    plan, K, r = fte.solver_plan(ctx.params), int(ctx.params.bcr_levels), int(ctx.params.refine_sweeps)
+                    ctx.close()
+                print(f"{P}windows: world {world}, halo {halo}: {n} frames/rank, {tag} (runs of {plan['m']} nodes, {plan['n_sep']} separators, "
+                      f"levels {K}, sweeps {r}, bound {stw['trunc_eps']:.1e}): step {tw:.3f} ms -> speed-up over 1 GPU without collectives "
+                      f"{t1 / tw:.2f}x, with 2 x 25 us of collectives {t1 / (tw + 0.05):.2f}x", flush=True)
+    print()
