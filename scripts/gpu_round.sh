@@ -16,7 +16,7 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64
 cd $R
 python scripts/summarize_pmc.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 # the bench line LAST: it quotes the PMC summary of this very binary (bench.py reads profiles/<PROFILE_DIR>, build-id checked)
-mkdir -p $R/profiles/round5 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round5/ 2>/dev/null
+mkdir -p $R/profiles/round6 && cp $OUT/summary/pmc_traffic.json $OUT/summary/pmc_mfma_lds.json $R/profiles/round6/ 2>/dev/null
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_stats -o stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err)
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 find $OUT/rocprof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/rocprofv3_kernel_stats.csv
@@ -29,7 +29,7 @@ find $OUT/rocprof_all -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OU
 rm -rf $OUT/rocprof_all
 timeout 600 python scripts/extras_report.py $OUT/summary > $OUT/extras.log 2>&1
 timeout 900 bash scripts/pmc_waits.sh > /dev/null 2>&1; cp $R/gpurun_out/waits/waits.txt $OUT/summary/pmc_wait_states.txt 2>/dev/null
-timeout 600 python scripts/shard_model.py > $OUT/summary/shard_model.txt 2>&1
+timeout 900 python scripts/shard_model.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/shard_model.txt
 # config 5's SBA half at full size: kernel stats and wait states of the fused kernels
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_sba -o sba -- python $R/scripts/sba_config5.py f64 10 > /dev/null 2> $OUT/rocprof_sba.err)
 find $OUT/rocprof_sba -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/summary/sba_config5_kernel_stats.csv; rm -rf $OUT/rocprof_sba
@@ -40,6 +40,13 @@ timeout 1500 bash scripts/pmc_waits_any.sh extras python $R/scripts/extras_workl
 cp $R/gpurun_out/waits_extras/waits.txt $OUT/summary/pmc_wait_states_extras.txt 2>/dev/null; cp $R/gpurun_out/waits_extras/kernel_stats.csv $OUT/summary/extras_kernel_stats.csv 2>/dev/null
 timeout 120 python scripts/backsub_stamps.py 100 2>&1 | grep -v amdgpu.ids > $OUT/summary/backsub_step_stamps.txt
 timeout 120 python scripts/sweep_stamps.py 100 3 2>&1 | grep -v amdgpu.ids > $OUT/summary/sweep_node_stamps.txt
+# round 6: the separator chain's kernels from the inside, short chains, the soak table, the skeleton probes
+timeout 120 python scripts/sep_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/separator_chain_stamps.txt
+timeout 300 python scripts/short_chain_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/short_chain_probe.txt
+(timeout 600 python scripts/soak.py; timeout 600 python scripts/chunk_stress.py) 2>&1 | grep -v amdgpu.ids > $OUT/summary/soak_and_stress_final_binary.txt
+timeout 300 python scripts/schwarz_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_schwarz_fixed_point.txt
+timeout 300 python scripts/video_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_whole_video_windows.txt
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acinoset_amd/csrc -I include scripts/bench/strip_phase.hip -o /tmp/strip_phase 2>/dev/null && /tmp/strip_phase) > $OUT/summary/strip_phase_microbenchmark.txt 2>&1
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
 # keep the merge-back small: the raw counter dumps are not needed once summarised
