@@ -1207,16 +1207,26 @@ struct SepTailArgs {
   // the factor): D + AL + SL + SR is formed in LDS; iso_loc = per entry (flags, location of block(next isolated node, this one))
   const int* iso_loc;
   int fused;
+  int fences;            // debug (ACINO_TAIL_FENCES=1): release / acquire fences around the hand-offs as well
 };
 // Hand-off of an 80-double vector between workgroups of one launch: the values travel as agent-scope RELAXED atomics (written
 // through to / read from the point where the XCDs' L2s are coherent), the workgroup barrier after the stores waits for every
-// wave's stores to be acknowledged (vmcnt(0)), then one lane raises the flag.  No release / acquire fences: those write back /
+// wave's stores to be acknowledged (st_put_done: vmcnt(0)), then one lane raises the flag.  No release / acquire fences: those write back /
 // invalidate a whole L2 (~1.3 us + ~0.5 us per hand-off, measured with the stamps of scripts/sep_stamps.py; a sweep has two).
 __device__ __forceinline__ void st_put(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... and every wave that stored waits for ITS OWN stores to be acknowledged before it goes to the workgroup barrier behind which
+// one lane raises the flag: on gfx942 / gfx950 __syncthreads() does not wait for vector-memory stores (not in threadgroup-split
+// mode a workgroup shares one L1, so a workgroup-scope release needs no vmcnt(0)) - without this wait the flag, written through
+// a different channel, can overtake the values (seen once in ~500 000 steps as a run-to-run difference of the soak test)
+__device__ __forceinline__ void st_put_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0)
 __device__ __forceinline__ double st_get(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_raise(int* flag, int v, int fences) {
+  if (fences) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_err) {
   long long polls = 0;
@@ -1390,8 +1400,9 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     double* xb1 = a.xbuf + (size_t)n_iso * BS;
     if (a.refine > 0) {
       if (tid < BS) st_put(xb0 + (size_t)p * BS + tid, x0);
+      st_put_done();
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(a.ver + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) st_raise(a.ver + p, 1, a.fences);
     }
     for (int s = 1; s <= a.refine; ++s) {
       const double* src = (s - 1) & 1 ? xb1 : xb0;
@@ -1400,6 +1411,7 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
       if (tid == 0) {
         if (l >= 0) st_wait(a.ver + p - 1, s, numeric_err);
         if (r >= 0) st_wait(a.ver + p + 1, s, numeric_err);
+        if (a.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (s == 2) ST_STAMP(9);
       }
       __syncthreads();
@@ -1456,14 +1468,16 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
       }
       if (s == 2) ST_STAMP(12);
       if (s < a.refine) {
+        st_put_done();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.ver + p, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) st_raise(a.ver + p, s + 1, a.fences);
       }
       if (s == 2) ST_STAMP(13);
     }
     if (tid < BS) st_put(ch.b + (size_t)j * BS + tid, xcur);
+    st_put_done();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.done + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) st_raise(a.done + j, 1, a.fences);
     ST_STAMP(4);
     if (a.norms && a.refine > 0) {            // (waves 0 and 1 hold the 80 rows)
       for (int off = 32; off > 0; off >>= 1) {
@@ -1509,6 +1523,7 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   if (tid == 0) {
     if (l >= 0) st_wait(a.done + l, 1, numeric_err);
     if (r >= 0) st_wait(a.done + r, 1, numeric_err);
+    if (a.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   ST_STAMP(1);                  // (level node: both neighbours solved)
@@ -1535,8 +1550,9 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   __syncthreads();
   const double x = upper_matvec();
   if (tid < BS) st_put(ch.b + (size_t)i * BS + tid, x);
+  st_put_done();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(a.done + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) st_raise(a.done + i, 1, a.fences);
   ST_STAMP(5);
 #undef ST_STAMP
 }
@@ -1914,6 +1930,7 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     a.xbuf = ch.refine_buf + (size_t)iso.n_elim * BS;
     a.norms = ch.trunc_eps2;
     a.fused = (sch.fused_levels && ch.SL != nullptr) ? 1 : 0;
+    a.fences = getenv("ACINO_TAIL_FENCES") ? 1 : 0;
     a.iso_loc = ch.d_iso_loc;
     {
       ProfSpan sp(prof, PC_REFINE, s, blocks);
