@@ -173,21 +173,25 @@ def cpu_baseline(det, rig, Ts, x0_full, sample_frames=10000, iters=3):
             np.savez(path, det=det[:n], K=K, D=D, R=R, t=t, Ts=Ts, xa=xa)
             bounds = np.linspace(0, n, procs + 1).astype(int)
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
-            t1 = time.perf_counter()
-            ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", path, str(a), str(b), str(iters)],
-                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT, text=True)
-                  for a, b in zip(bounds[:-1], bounds[1:])]
-            each = []
-            for pr in ps:       # plain numpy processes (no torch, no GPU); bounded: a stuck host never hangs the bench
-                o, _ = pr.communicate(timeout=max(60.0, 6.0 * dt))
-                each.append(float(o.strip().splitlines()[-1]))
-            wall = time.perf_counter() - t1
-        slow = max(each)
+            passes = []
+            for _pass in range(3):          # three passes, the MEDIAN is reported (a ~1 s measurement on a busy host wanders by +-15 %)
+                t1 = time.perf_counter()
+                ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", path, str(a), str(b), str(iters)],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT, text=True)
+                      for a, b in zip(bounds[:-1], bounds[1:])]
+                each = []
+                for pr in ps:   # plain numpy processes (no torch, no GPU); bounded: a stuck host never hangs the bench
+                    o, _ = pr.communicate(timeout=max(60.0, 6.0 * dt))
+                    each.append(float(o.strip().splitlines()[-1]))
+                passes.append((max(each), time.perf_counter() - t1, each))
+        passes.sort(key=lambda v: v[0])
+        slow, wall, each = passes[len(passes) // 2]
         out["all_cores"] = dict(value=n / (slow / (iters + 0.5)), unit="frames/s", cores=procs, nproc=ncpu, each_seconds=each,
+                                slowest_block_seconds_of_the_three_passes=[v[0] for v in passes],
                                 sample=f"the same {n} frames cut into {procs} contiguous blocks, one single-threaded "
                                        f"oracle process per block (python -m oracle.cpu_baseline), {iters} LM iterations "
-                                       f"each, run together: slowest block {slow:.1f} s (wall incl. interpreter start "
-                                       f"{wall:.1f} s); blocks are solved independently (no coupling across block "
+                                       f"each, run together, three passes: median slowest block {slow:.2f} s (wall incl. interpreter "
+                                       f"start {wall:.1f} s); blocks are solved independently (no coupling across block "
                                        "boundaries), i.e. an upper bound for a frame-sharded CPU port")
     except Exception as exc:                           # pragma: no cover
         for pr in locals().get("ps", []):
