@@ -527,6 +527,287 @@ k_skel_solve(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doubl
   }
 }
 
+// ---- the same solve with the window in REGISTERS (round 6) ---------------------------------------------------------------
+// k_skel_solve walks the band through memory: every frame reloads its 4 PT x PT panel (73 KB at PT = 48), reads, updates and
+// writes back the six window blocks, and writes the panel again - three dependent HBM round trips per frame - and its
+// substitutions are loops of one thread per row.  Here the six window blocks (n + i, n + j), 1 <= j <= i <= 3, stay in the
+// accumulator registers of the four waves (tile (rt, ct) of every block on wave (rt NTP + ct) % 4: the shift from one frame to
+// the next then never leaves a wave), the next frame's panel is written from them into LDS, the four blocks of row n + 4 that
+// enter the window are requested a frame ahead, and only the factored panel goes to memory (for the backward pass, whose panels
+// are requested a frame ahead as well).  The substitutions: the 16 x 16 products with the inverted diagonal tiles on 256
+// threads + a shuffle tree, the updates of the rows below one thread per row.  Same arithmetic per entry, other summation order.
+constexpr int SK2_T = 256, SK2_W = SK2_T / 64;     // four waves: 512 registers per lane hold the window (eight waves spill it)
+static_assert(SK2_T == 256, "the 16 x 16 products of the substitutions are laid out on 256 threads");
+template <int PT>
+__global__ void __launch_bounds__(SK2_T)
+k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, double gtol, double* __restrict__ band_all,
+              const double* __restrict__ rhs_all, double* __restrict__ yv_all, double* __restrict__ delta_all,
+              const double* __restrict__ gn_part) {
+  constexpr int LDP = PT + 1, NTP = PT / 16, RT = 4 * NTP, NT2 = NTP * NTP, NS = (NT2 + SK2_W - 1) / SK2_W;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  SkelClip& cs = clip[blockIdx.x];
+  if (cs.status != 0) return;
+  {
+    __shared__ double gred[SK2_T / 64];
+    __shared__ int stop;
+    const int nfr = dev->n_frames;
+    double gm = 0.0;
+    for (int i = threadIdx.x; i < nfr; i += SK2_T) gm = fmax(gm, gn_part[(size_t)blockIdx.x * nfr + i]);
+    for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+    if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SK2_T / 64; ++w) gm = fmax(gm, gred[w]);
+      cs.gnorm = gm;
+      cs.it += 1;
+      cs.pivot_err = 0;
+      stop = gm <= gtol;
+      if (stop) cs.status = 3;
+    }
+    __syncthreads();
+    if (stop) return;
+  }
+  int* const numeric_err = &cs.pivot_err;
+  const size_t fr0 = (size_t)blockIdx.x * dev->n_frames;
+  double* const band = band_all + fr0 * 4 * PT * PT;
+  const double* const rhs = rhs_all + fr0 * PT;
+  double* const yv = yv_all + fr0 * PT;
+  double* const delta = delta_all + fr0 * PT;
+  double* Pn = reinterpret_cast<double*>(smem_raw);       // [4 PT][LDP]
+  double* ring = Pn + 4 * PT * LDP;                        // [4][PT] right-hand sides / solutions of frames n .. n + 3
+  double* tv = ring + 4 * PT;                              // [PT]
+  double* part = tv + PT;                                  // [10][PT] partial sums of the backward pass
+  const int N = dev->n_frames;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  // block (row frame a, column frame b) of the band, b <= a <= b + 3 (nullptr beyond the clip: zeros)
+  auto blockp = [&](int a, int b) -> const double* { return (a < N && b < N) ? band + ((size_t)b * 4 + (a - b)) * PT * PT : nullptr; };
+  // this wave's tile of slot sl: rem = wave + 8 sl -> (rt, ct); a tile as 4 doubles per lane in the accumulator layout
+  auto tile_load = [&](const double* B, int sl) {
+    const int rem = wave + SK2_W * sl;
+    d4 v = {0, 0, 0, 0};
+    if (B && rem < NT2) {
+      const int rt = rem / NTP, ct = rem % NTP;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v[rr] = B[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li];
+    }
+    return v;
+  };
+  auto tile_to_panel = [&](int row_block, int sl, const d4& v) {
+    const int rem = wave + SK2_W * sl;
+    if (rem < NT2) {
+      const int rt = rem / NTP, ct = rem % NTP;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Pn[(row_block * PT + rt * 16 + lk + 4 * rr) * LDP + ct * 16 + li] = v[rr];
+    }
+  };
+  // window blocks in registers: 0 (1,1)  1 (2,1)  2 (2,2)  3 (3,1)  4 (3,2)  5 (3,3); fresh: row n + 4, columns n + 1 .. n + 4
+  d4 win[6][NS], fresh[4][NS];
+  {
+    const int wi[6] = {1, 2, 2, 3, 3, 3}, wj[6] = {1, 1, 2, 1, 2, 3};
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) win[b][sl] = tile_load(blockp(wi[b], wj[b]), sl);
+  }
+  for (int e = tid; e < 4 * PT * PT; e += SK2_T) {          // the panel of frame 0
+    const int j = e / (PT * PT), rem = e % (PT * PT);
+    Pn[(j * PT + rem / PT) * LDP + rem % PT] = (j < N) ? band[(size_t)j * PT * PT + rem] : 0.0;
+  }
+  for (int e = tid; e < 3 * PT; e += SK2_T) ring[e] = (e / PT < N) ? rhs[e] : 0.0;      // frames 0, 1, 2
+  __syncthreads();
+  for (int n = 0; n < N; ++n) {
+    // the four blocks of row n + 4 (untouched so far: nothing reaches further than three frames), a frame ahead of their use
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) fresh[j][sl] = tile_load(blockp(n + 4, n + 1 + j), sl);
+    if (tid < PT) ring[((n + 3) & 3) * PT + tid] = (n + 3 < N) ? rhs[(size_t)(n + 3) * PT + tid] : 0.0;
+    // ---- factor the panel (as k_skel_solve)
+#pragma unroll 1
+    for (int kb = 0; kb < NTP; ++kb) {
+      double* Tkk = Pn + (kb * 16) * LDP + kb * 16;
+      if (wave == 0) {
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Tkk[(lk + 4 * r) * LDP + li];
+        chol16_inv_acc<LDP>(Tkk, acc, lane, numeric_err);
+      }
+      __syncthreads();
+      for (int t = kb + 1 + wave; t < RT; t += SK2_W) {          // panel: tile(t, kb) <- tile(t, kb) U_kk
+        double* At = Pn + (t * 16) * LDP + kb * 16;
+        double av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          av[s] = At[li * LDP + 4 * s + lk];
+          bv[s] = Tkk[(4 * s + lk) * LDP + li];
+        }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(av[s], bv[s], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) At[(lk + 4 * rr) * LDP + li] = acc[rr];
+      }
+      __syncthreads();
+      int q = 0;                                             // trailing tiles inside the panel
+      for (int ct = kb + 1; ct < NTP; ++ct)
+        for (int rt = ct; rt < RT; ++rt, ++q) {
+          if (q % SK2_W != wave) continue;
+          double* Cc = Pn + (rt * 16) * LDP + ct * 16;
+          const double* Ar = Pn + (rt * 16) * LDP + kb * 16;
+          const double* Ac = Pn + (ct * 16) * LDP + kb * 16;
+          d4 a;
+          double av[4], bv[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LDP + li];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            av[s] = Ar[li * LDP + 4 * s + lk];
+            bv[s] = Ac[li * LDP + 4 * s + lk];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LDP + li] = a[rr];
+        }
+      if (kb + 1 < NTP) __syncthreads();
+    }
+    __syncthreads();
+    // ---- the factored panel to memory (the backward pass reads it): requested now, drains under what follows
+    for (int e = tid; e < 4 * PT * PT; e += SK2_T) {
+      const int j = e / (PT * PT), rem = e % (PT * PT);
+      if (n + j < N) band[((size_t)n * 4 + j) * PT * PT + rem] = Pn[(j * PT + rem / PT) * LDP + rem % PT];
+    }
+    // ---- forward substitution, block by block: y_kb = U_kk^T u_kb (a 16 x 16 product: threads (r, c) + a shuffle tree over c),
+    //      then every row below loses L[row][kb block] y_kb - the rows of this frame and the three frames' right-hand sides
+    double* rn = ring + (n & 3) * PT;
+    for (int kb = 0; kb < NTP; ++kb) {
+      {
+        const int r = tid >> 4, c = tid & 15;                // y[r] = sum_c U[c][r] u[c]   (U upper triangular: c <= r)
+        double v = c <= r ? Pn[(16 * kb + c) * LDP + 16 * kb + r] * rn[16 * kb + c] : 0.0;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (c == 0) tv[16 * kb + r] = v;
+      }
+      __syncthreads();
+      if (tid < 16) rn[16 * kb + tid] = tv[16 * kb + tid];
+      if (tid >= 16 * (kb + 1) && tid < 4 * PT) {              // row tid of the panel (rows >= PT: frames n + 1 .. n + 3)
+        const int row = tid;
+        double sub = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sub += Pn[row * LDP + 16 * kb + c] * tv[16 * kb + c];
+        if (row < PT) rn[row] -= sub;
+        else ring[((n + row / PT) & 3) * PT + row % PT] -= sub;
+      }
+      __syncthreads();
+    }
+    if (tid < PT) yv[(size_t)n * PT + tid] = rn[tid];
+    // ---- window update in registers: block (n + i, n + j) -= L_i L_j^T
+    {
+      const int wi[6] = {1, 2, 2, 3, 3, 3}, wj[6] = {1, 1, 2, 1, 2, 3};
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          const int rem = wave + SK2_W * sl;
+          if (rem < NT2) {
+            const int rt = rem / NTP, ct = rem % NTP;
+            const double* Ar = Pn + (wi[b] * PT + rt * 16 + li) * LDP + lk;
+            const double* Ac = Pn + (wj[b] * PT + ct * 16 + li) * LDP + lk;
+            win[b][sl] = mma_seq<PT / 4, true>(win[b][sl], Ar, 4, Ac, 4);
+          }
+        }
+    }
+    __syncthreads();                                         // every read of this frame's panel is done
+    // ---- the next frame's panel from the window; the window moves on by one frame
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+      tile_to_panel(0, sl, win[0][sl]);
+      tile_to_panel(1, sl, win[1][sl]);
+      tile_to_panel(2, sl, win[3][sl]);
+      tile_to_panel(3, sl, fresh[0][sl]);
+      win[0][sl] = win[2][sl];
+      win[1][sl] = win[4][sl];
+      win[2][sl] = win[5][sl];
+      win[3][sl] = fresh[1][sl];
+      win[4][sl] = fresh[2][sl];
+      win[5][sl] = fresh[3][sl];
+    }
+    __syncthreads();
+  }
+  // ---------------- backward: x_n = L_nn^-T (y_n - sum_j L_n+j,n^T x_n+j) ----------------
+  constexpr int PV = (4 * PT * PT + SK2_T - 1) / SK2_T;
+  double pre[PV];
+  auto request_panel = [&](int n) {
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int e = tid + SK2_T * k;
+      const int j = e / (PT * PT);
+      pre[k] = (e < 4 * PT * PT && n >= 0 && n + j < N) ? band[(size_t)n * 4 * PT * PT + e] : 0.0;
+    }
+  };
+  auto stage_panel = [&]() {
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int e = tid + SK2_T * k;
+      if (e < 4 * PT * PT) {
+        const int j = e / (PT * PT), rem = e % (PT * PT);
+        Pn[(j * PT + rem / PT) * LDP + rem % PT] = pre[k];
+      }
+    }
+  };
+  for (int e = tid; e < 4 * PT; e += SK2_T) ring[e] = 0.0;
+  request_panel(N - 1);
+  __syncthreads();
+  for (int n = N - 1; n >= 0; --n) {
+    stage_panel();
+    request_panel(n - 1);                                    // a frame ahead
+    const double yn = tid < PT ? yv[(size_t)n * PT + tid] : 0.0;
+    __syncthreads();
+    // t = y_n - sum_j L_j^T x_n+j: 9 partial sums per column (3 frames x 3 thirds of the rows), then one add per column
+    for (int t9 = tid; t9 < 9 * PT; t9 += SK2_T) {
+      const int col = t9 % PT, pj = t9 / PT, j = 1 + pj / 3, third = pj % 3;
+      constexpr int R3 = (PT + 2) / 3;
+      const double* xj = ring + ((n + j) & 3) * PT;
+      double sm = 0.0;
+      if (n + j < N)
+        for (int r = third * R3; r < min(PT, (third + 1) * R3); ++r) sm += Pn[(j * PT + r) * LDP + col] * xj[r];
+      part[pj * PT + col] = sm;
+    }
+    __syncthreads();
+    if (tid < PT) {
+      double t = yn;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) t -= part[q * PT + tid];
+      tv[tid] = t;
+    }
+    __syncthreads();
+    double* xn = ring + (n & 3) * PT;
+    for (int kb = NTP - 1; kb >= 0; --kb) {
+      {                                                       // x[r] = sum_c U[r][c] s[c]   (c >= r)
+        const int r = tid >> 4, c = tid & 15;
+        double v = c >= r ? Pn[(16 * kb + r) * LDP + 16 * kb + c] * tv[16 * kb + c] : 0.0;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (c == 0) xn[16 * kb + r] = v;
+      }
+      __syncthreads();
+      if (tid < 16 * kb) {                                    // the columns above lose L[kb block][col]^T x_kb
+        double sub = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sub += Pn[(16 * kb + r) * LDP + tid] * xn[16 * kb + r];
+        tv[tid] -= sub;
+      }
+      __syncthreads();
+    }
+    if (tid < PT) delta[(size_t)n * PT + tid] = xn[tid];
+    __syncthreads();
+  }
+}
+
 // ---- trial iterate and the controller's sums -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_skel_trial(const SkelDev* __restrict__ dev, const SkelClip* __restrict__ clip, double* __restrict__ xb0,
@@ -831,7 +1112,8 @@ int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, cons
   ACINO_HIP_CHECK(hipStreamSynchronize(s));                // (h lives on this frame)
   const size_t lds_asm = sizeof(double) * (SK_MAXP + ACINO_SKEL_MAX_OPS * 12 + (ACINO_SKEL_MAX_OPS + 1) * 3 + SK_MAXROWS * 5 + 8 +
                                            (size_t)h.n_rows * (P | 1));
-  const size_t lds_solve = sizeof(double) * ((size_t)4 * PT * (PT + 1) + 5 * PT);
+  const size_t lds_solve = sizeof(double) * ((size_t)4 * PT * (PT + 1) + 16 * PT);     // panel, ring, tv, the backward pass's partial sums
+  static const bool solve_in_registers = getenv("ACINO_SKEL_OLD_SOLVE") == nullptr;     // (A/B switch: the round-5 kernel walks the band through memory)
   {
     static PerDeviceOnce attr;
     if (attr.first()) {
@@ -847,6 +1129,14 @@ int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, cons
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<48>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
       ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve2<16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve2<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve2<48>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
+      ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel_solve2<64>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, big_solve));
     }
   }
@@ -882,11 +1172,20 @@ int acino_skel_fte_solve_batch(const acino_skel_fte_params* p, int n_clips, cons
   std::vector<SkelClip> hc(B);
   for (int it = 1; it <= p->max_iter; ++it) {
     if ((rc = build(0))) return rc;
-    switch (PT) {
-      case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
-      case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
-      case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
-      default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+    if (solve_in_registers && PT <= 48) {        // (PT = 64: window + operands exceed the 512 registers of a lane; the round-5 kernel)
+      switch (PT) {
+        case 16: hipLaunchKernelGGL(k_skel_solve2<16>, dim3(B), dim3(SK2_T), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        case 32: hipLaunchKernelGGL(k_skel_solve2<32>, dim3(B), dim3(SK2_T), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        case 48: hipLaunchKernelGGL(k_skel_solve2<48>, dim3(B), dim3(SK2_T), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        default: hipLaunchKernelGGL(k_skel_solve2<64>, dim3(B), dim3(SK2_T), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+      }
+    } else {
+      switch (PT) {
+        case 16: hipLaunchKernelGGL(k_skel_solve<16>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        case 32: hipLaunchKernelGGL(k_skel_solve<32>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        case 48: hipLaunchKernelGGL(k_skel_solve<48>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+        default: hipLaunchKernelGGL(k_skel_solve<64>, dim3(B), dim3(SK_ST), lds_solve, s, d_dev, d_clip, p->gtol, D(lay.band), D(lay.rhs), D(lay.yv), D(lay.delta), D(lay.gn)); break;
+      }
     }
     ACINO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_skel_trial, dim3(n_trial, B), dim3(256), 0, s, d_dev, d_clip, D(lay.x[0]), D(lay.x[1]), D(lay.g[0]),
