@@ -581,33 +581,50 @@ k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doub
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   // block (row frame a, column frame b) of the band, b <= a <= b + 3 (nullptr beyond the clip: zeros)
   auto blockp = [&](int a, int b) -> const double* { return (a < N && b < N) ? band + ((size_t)b * 4 + (a - b)) * PT * PT : nullptr; };
-  // this wave's tile of slot sl: rem = wave + 8 sl -> (rt, ct); a tile as 4 doubles per lane in the accumulator layout
-  auto tile_load = [&](const double* B, int sl) {
-    const int rem = wave + SK2_W * sl;
+  // Tiles to waves.  The six window blocks form three chains under the shift of a frame: A = (3,3) -> (2,2) -> (1,1) -> panel (the
+  // DIAGONAL blocks: lower tiles only), B = (3,2) -> (2,1) -> panel, C = (3,1) -> panel.  Tile t of a chain's block lives on wave
+  // (t + off) % 4, slot t / 4, with its own off per chain - the same for every block of the chain, so the shift never leaves a wave,
+  // and the waves that get the odd tile differ: 11 / 12 / 12 / 10 tiles per wave at PT = 48 instead of 18 on wave 0.
+  constexpr int NL = NTP * (NTP + 1) / 2;
+  constexpr int OFF_A = 1, OFF_B = 0, OFF_C = 3;
+  auto tile_rc = [&](int sl, int off, bool lower, int& rt, int& ct) {
+    const int t = 4 * sl + ((wave - off) & 3);
+    if (lower) {
+      rt = (t >= 1) + (t >= 3) + (t >= 6);
+      ct = t - rt * (rt + 1) / 2;
+      return t < NL;
+    }
+    rt = t / NTP;
+    ct = t % NTP;
+    return t < NT2;
+  };
+  auto tile_load = [&](const double* B, int sl, int off, bool lower) {
+    int rt, ct;
     d4 v = {0, 0, 0, 0};
-    if (B && rem < NT2) {
-      const int rt = rem / NTP, ct = rem % NTP;
+    if (tile_rc(sl, off, lower, rt, ct) && B) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) v[rr] = B[(rt * 16 + lk + 4 * rr) * PT + ct * 16 + li];
     }
     return v;
   };
-  auto tile_to_panel = [&](int row_block, int sl, const d4& v) {
-    const int rem = wave + SK2_W * sl;
-    if (rem < NT2) {
-      const int rt = rem / NTP, ct = rem % NTP;
+  auto tile_to_panel = [&](int row_block, int sl, int off, bool lower, const d4& v) {
+    int rt, ct;
+    if (tile_rc(sl, off, lower, rt, ct)) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) Pn[(row_block * PT + rt * 16 + lk + 4 * rr) * LDP + ct * 16 + li] = v[rr];
     }
   };
   // window blocks in registers: 0 (1,1)  1 (2,1)  2 (2,2)  3 (3,1)  4 (3,2)  5 (3,3); fresh: row n + 4, columns n + 1 .. n + 4
+  // (fresh[0] goes to the panel, [1] into chain C, [2] into chain B, [3] into chain A)
+  constexpr int woff[6] = {OFF_A, OFF_B, OFF_A, OFF_C, OFF_B, OFF_A}, foff[4] = {OFF_B, OFF_C, OFF_B, OFF_A};
+  constexpr bool wlow[6] = {true, false, true, false, false, true}, flow[4] = {false, false, false, true};
   d4 win[6][NS], fresh[4][NS];
   {
     const int wi[6] = {1, 2, 2, 3, 3, 3}, wj[6] = {1, 1, 2, 1, 2, 3};
 #pragma unroll
     for (int b = 0; b < 6; ++b)
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) win[b][sl] = tile_load(blockp(wi[b], wj[b]), sl);
+      for (int sl = 0; sl < NS; ++sl) win[b][sl] = tile_load(blockp(wi[b], wj[b]), sl, woff[b], wlow[b]);
   }
   for (int e = tid; e < 4 * PT * PT; e += SK2_T) {          // the panel of frame 0
     const int j = e / (PT * PT), rem = e % (PT * PT);
@@ -620,19 +637,22 @@ k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doub
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) fresh[j][sl] = tile_load(blockp(n + 4, n + 1 + j), sl);
+      for (int sl = 0; sl < NS; ++sl) fresh[j][sl] = tile_load(blockp(n + 4, n + 1 + j), sl, foff[j], flow[j]);
     if (tid < PT) ring[((n + 3) & 3) * PT + tid] = (n + 3 < N) ? rhs[(size_t)(n + 3) * PT + tid] : 0.0;
-    // ---- factor the panel (as k_skel_solve)
+    // ---- factor the panel (as k_skel_solve, with a LOOK-AHEAD: while waves 1 .. 3 do the trailing tiles of block column kb, wave
+    //      0 updates the next diagonal tile alone and goes straight into its 16-pivot chain - the chains but the first are off the
+    //      other waves' critical path)
+    if (wave == 0) {
+      double* T00 = Pn;
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = T00[(lk + 4 * r) * LDP + li];
+      chol16_inv_acc<LDP>(T00, acc, lane, numeric_err);
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int kb = 0; kb < NTP; ++kb) {
       double* Tkk = Pn + (kb * 16) * LDP + kb * 16;
-      if (wave == 0) {
-        d4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Tkk[(lk + 4 * r) * LDP + li];
-        chol16_inv_acc<LDP>(Tkk, acc, lane, numeric_err);
-      }
-      __syncthreads();
       for (int t = kb + 1 + wave; t < RT; t += SK2_W) {          // panel: tile(t, kb) <- tile(t, kb) U_kk
         double* At = Pn + (t * 16) * LDP + kb * 16;
         double av[4], bv[4];
@@ -648,30 +668,45 @@ k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doub
         for (int rr = 0; rr < 4; ++rr) At[(lk + 4 * rr) * LDP + li] = acc[rr];
       }
       __syncthreads();
-      int q = 0;                                             // trailing tiles inside the panel
-      for (int ct = kb + 1; ct < NTP; ++ct)
-        for (int rt = ct; rt < RT; ++rt, ++q) {
-          if (q % SK2_W != wave) continue;
-          double* Cc = Pn + (rt * 16) * LDP + ct * 16;
-          const double* Ar = Pn + (rt * 16) * LDP + kb * 16;
-          const double* Ac = Pn + (ct * 16) * LDP + kb * 16;
-          d4 a;
-          double av[4], bv[4];
+      if (kb + 1 == NTP) break;
+      if (wave == 0) {                                       // the next diagonal tile and its chain
+        double* Cc = Pn + ((kb + 1) * 16) * LDP + (kb + 1) * 16;
+        const double* A = Pn + ((kb + 1) * 16) * LDP + kb * 16;
+        d4 a;
+        double av[4];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LDP + li];
+        for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LDP + li];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            av[s] = Ar[li * LDP + 4 * s + lk];
-            bv[s] = Ac[li * LDP + 4 * s + lk];
+        for (int s = 0; s < 4; ++s) av[s] = A[li * LDP + 4 * s + lk];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma(-av[s], av[s], a);
+        chol16_inv_acc<LDP>(Cc, a, lane, numeric_err);
+      } else {
+        int q = 0;                                           // the other trailing tiles inside the panel: waves 1 .. 3
+        for (int ct = kb + 1; ct < NTP; ++ct)
+          for (int rt = ct; rt < RT; ++rt) {
+            if (rt == kb + 1 && ct == kb + 1) continue;      // (wave 0's)
+            if ((q++) % (SK2_W - 1) != wave - 1) continue;
+            double* Cc = Pn + (rt * 16) * LDP + ct * 16;
+            const double* Ar = Pn + (rt * 16) * LDP + kb * 16;
+            const double* Ac = Pn + (ct * 16) * LDP + kb * 16;
+            d4 a;
+            double av[4], bv[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) a[rr] = Cc[(lk + 4 * rr) * LDP + li];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              av[s] = Ar[li * LDP + 4 * s + lk];
+              bv[s] = Ac[li * LDP + 4 * s + lk];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LDP + li] = a[rr];
           }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) a = mfma(-av[s], bv[s], a);
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LDP + li] = a[rr];
-        }
-      if (kb + 1 < NTP) __syncthreads();
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // ---- the factored panel to memory (the backward pass reads it): requested now, drains under what follows
     for (int e = tid; e < 4 * PT * PT; e += SK2_T) {
       const int j = e / (PT * PT), rem = e % (PT * PT);
@@ -710,9 +745,8 @@ k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doub
       for (int b = 0; b < 6; ++b)
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-          const int rem = wave + SK2_W * sl;
-          if (rem < NT2) {
-            const int rt = rem / NTP, ct = rem % NTP;
+          int rt, ct;
+          if (tile_rc(sl, woff[b], wlow[b], rt, ct)) {
             const double* Ar = Pn + (wi[b] * PT + rt * 16 + li) * LDP + lk;
             const double* Ac = Pn + (wj[b] * PT + ct * 16 + li) * LDP + lk;
             win[b][sl] = mma_seq<PT / 4, true>(win[b][sl], Ar, 4, Ac, 4);
@@ -723,10 +757,10 @@ k_skel_solve2(const SkelDev* __restrict__ dev, SkelClip* __restrict__ clip, doub
     // ---- the next frame's panel from the window; the window moves on by one frame
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-      tile_to_panel(0, sl, win[0][sl]);
-      tile_to_panel(1, sl, win[1][sl]);
-      tile_to_panel(2, sl, win[3][sl]);
-      tile_to_panel(3, sl, fresh[0][sl]);
+      tile_to_panel(0, sl, OFF_A, true, win[0][sl]);         // (the diagonal block: lower tiles - nothing reads the others)
+      tile_to_panel(1, sl, OFF_B, false, win[1][sl]);
+      tile_to_panel(2, sl, OFF_C, false, win[3][sl]);
+      tile_to_panel(3, sl, OFF_B, false, fresh[0][sl]);
       win[0][sl] = win[2][sl];
       win[1][sl] = win[4][sl];
       win[2][sl] = win[5][sl];
