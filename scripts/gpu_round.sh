@@ -46,6 +46,7 @@ timeout 300 python scripts/short_chain_probe.py 2>&1 | grep -v amdgpu.ids > $OUT
 (timeout 600 python scripts/soak.py; timeout 600 python scripts/chunk_stress.py) 2>&1 | grep -v amdgpu.ids > $OUT/summary/soak_and_stress_final_binary.txt
 timeout 300 python scripts/schwarz_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_schwarz_fixed_point.txt
 timeout 300 python scripts/video_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_whole_video_windows.txt
+(timeout 200 python scripts/skel_solve_probe.py; echo "--- the round-5 kernel (ACINO_SKEL_OLD_SOLVE=1):"; ACINO_SKEL_OLD_SOLVE=1 timeout 200 python scripts/skel_solve_probe.py) 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_solve_per_frame.txt
 (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acinoset_amd/csrc -I include scripts/bench/strip_phase.hip -o /tmp/strip_phase 2>/dev/null && /tmp/strip_phase) > $OUT/summary/strip_phase_microbenchmark.txt 2>&1
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
