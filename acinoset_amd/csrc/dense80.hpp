@@ -241,7 +241,10 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
       if (dbg && kb == 0 && tid == 0) dbg[17] = (long long)wall_clock64();
     } else {
       const int ntask = trail_n(kb);
-      for (int t = wave - 1; t < ntask; t += NW - 1) {
+      // (NW = 8: wave 4 shares the pivot chain's SIMD - an fp64 matrix instruction there holds the chain's issue port for 64
+      //  cycles - and stays out; the six waves of the other three SIMDs take the tiles)
+      const int helper = NW == 8 ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1, n_help = NW == 8 ? 6 : NW - 1;
+      for (int t = (NW == 8 && wave == 4) ? ntask : helper; t < ntask; t += n_help) {
         const int code = trail_code(kb, t), ti = code >> 4, tj = code & 15;
         double* Cc = Lm + (ti * 16) * LD + tj * 16;
         const double* A = Lm + (ti * 16) * LD + kb * 16;
