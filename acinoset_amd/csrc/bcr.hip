@@ -1184,14 +1184,16 @@ __global__ void k_bcr_refine_copy(BcrChain ch, const int* __restrict__ iso, cons
 // 51 KB matrices - is one workgroup per node that loads its matrices ONCE into LDS and then only trades 80-double vectors
 // with its neighbours through memory:
 //   isolated node p (blocks 0 .. n_iso-1):  x0 = U y;  sweep s = 1..r:  x(s) = x0 - U U^T (C_l x_l(s-1) + C_r x_r(s-1));
-//     version s of the node's iterate goes to xbuf[s & 1][p] and is announced by ver[p] = s + 1 (release, agent scope); a
-//     neighbour writes version s only after it has read this node's version s - 1, so two buffers suffice.
+//     version s of the node's iterate goes to buffer s & 1 of the node, every value in a pair of 64-bit words that carry the
+//     version's tag next to the data (ll_put / ll_get below: no flag, no fence); a neighbour writes version s only after it
+//     has read this node's version s - 1, so two buffers suffice.
 //   node i of level k < K (blocks after them, deepest level first):  x_i = U (y_i - W_l x_l - W_r x_r) once done[l], done[r].
 // Isolated workgroups wait for EACH OTHER, so all n_iso of them must be resident together: one per CU (156 KB of LDS), the
 // lowest block indices of the launch - the host only uses this kernel for n_iso <= 128 on a GPU that is not shared
 // (acino_fte_params::shared_gpu = 0); every other workgroup waits for lower block indices only.  Waits are bounded polls
 // (as in k_bcr_backsub_tail): a timeout flags the step (numeric_err bit 1 -> status 6) and lets the launch drain.
-// The flags are zeroed by the consumer that follows (k_chunk_backsub), i.e. before the next launch of this kernel.
+// The one flag left (ver[0], below) is zeroed and the epoch of the tags is advanced by the consumer that follows
+// (k_chunk_backsub), i.e. before the next launch of this kernel.
 constexpr int ST_T = 512, ST_P = ST_T / BS, ST_W = (BS + ST_P - 1) / ST_P, ST_V = (BS * BS / 2 + ST_T - 1) / ST_T;
 struct SepTailArgs {
   const int* iso;        // [n_iso][3] entries of the isolated level (node, -1, -1)
@@ -1199,34 +1201,52 @@ struct SepTailArgs {
   int n_lv;              // regular levels below the isolated one
   int lv_off[12];        // elim-entry offset of level K-1, K-2, ... 0
   int lv_cnt[12];
-  int* ver;              // [n_iso]
-  int* done;             // [n_nodes]
-  double* xbuf;          // [2][n_iso][80]
+  int* ver;              // ver[0]: isolated node 0 has published its truncated solve (the level nodes hold their loads back until then)
+  const int* epoch;      // the launch's number: part of every tag, so the slots never need cleaning
+  unsigned long long* ll;   // [2][n_iso][80][2] iterates of the sweeps, then [n_nodes][80][2] solutions - tagged pairs
   double* norms;         // [4][n_iso]: |update|, |x| of the last sweep; the same of the sweep before it
   // chains with fused narrow levels: the isolated nodes are FACTORED HERE (no elimination launch for them, no round trip of
   // the factor): D + AL + SL + SR is formed in LDS; iso_loc = per entry (flags, location of block(next isolated node, this one))
   const int* iso_loc;
   int fused;
-  int fences;            // debug (ACINO_TAIL_FENCES=1): release / acquire fences around the hand-offs as well
 };
-// Hand-off of an 80-double vector between workgroups of one launch: the values travel as agent-scope RELAXED atomics (written
-// through to / read from the point where the XCDs' L2s are coherent), the workgroup barrier after the stores waits for every
-// wave's stores to be acknowledged (st_put_done: vmcnt(0)), then one lane raises the flag.  No release / acquire fences: those write back /
-// invalidate a whole L2 (~1.3 us + ~0.5 us per hand-off, measured with the stamps of scripts/sep_stamps.py; a sweep has two).
-__device__ __forceinline__ void st_put(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Hand-off of an 80-double vector between workgroups of one launch.  Every double travels as two 64-bit words, each half of
+// the value next to a 32-bit tag (epoch of the launch, version of the vector), written and read as agent-scope RELAXED atomics
+// (written through to / read from the point where the XCDs' L2s are coherent).  A 64-bit access is single-copy atomic, so a
+// word's tag vouches for the half beside it: the reader polls the words themselves until both carry the tag it expects.  No
+// flag behind the data, hence nothing that has to be ordered: no wait for the stores' acknowledgement, no barrier, no second
+// round trip to read the values after the flag (the flag protocol this replaces: ~1.6 us to publish - vmcnt(0), barrier, flag -
+// and ~0.6 us between seeing the flag and having the values, per hand-off, by the stamps of scripts/sep_stamps.py; and no
+// release / acquire fences, which write back / invalidate a whole L2: ~1.3 us + ~0.5 us each).  Tags are compared for equality
+// and differ between consecutive launches and between the versions of one launch, so a stale slot can never pass and the slots
+// are never cleaned.
+__device__ __forceinline__ void ll_put(unsigned long long* slot, double v, unsigned tag) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+  __hip_atomic_store(slot, (u & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot + 1, (u >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// ... and every wave that stored waits for ITS OWN stores to be acknowledged before it goes to the workgroup barrier behind which
-// one lane raises the flag: on gfx942 / gfx950 __syncthreads() does not wait for vector-memory stores (not in threadgroup-split
-// mode a workgroup shares one L1, so a workgroup-scope release needs no vmcnt(0)) - without this wait the flag, written through
-// a different channel, can overtake the values (seen once in ~500 000 steps as a run-to-run difference of the soak test)
-__device__ __forceinline__ void st_put_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0)
-__device__ __forceinline__ double st_get(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ double ll_get(const unsigned long long* slot, unsigned tag, int* numeric_err) {
+  long long polls = 0;
+  for (;;) {
+    const unsigned long long w0 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag)
+      return __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+    __builtin_amdgcn_s_sleep(1);
+    if (++polls > (1ll << 22)) {      // (bit 3: it was THIS kernel - the host may fall back to the per-level kernels)
+      if (numeric_err) atomicOr(numeric_err, 2 | 8);
+      return 0.0;
+    }
+  }
 }
-__device__ __forceinline__ void st_raise(int* flag, int v, int fences) {
-  if (fences) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  else __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// both neighbours' vectors into LDS: waves 0-1 poll the left one's slots, waves 2-3 the right one's (null: zeros)
+__device__ __forceinline__ void ll_get_pair(double* xl, double* xr, const unsigned long long* sl, const unsigned long long* sr,
+                                            unsigned tag, int* numeric_err, int tid) {
+  if (tid < BS) xl[tid] = sl ? ll_get(sl + 2 * tid, tag, numeric_err) : 0.0;
+  else if (tid >= 128 && tid < 128 + BS) xr[tid - 128] = sr ? ll_get(sr + 2 * (tid - 128), tag, numeric_err) : 0.0;
+}
+__device__ __forceinline__ void st_raise(int* flag, int v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_wait(const int* flag, int need, int* numeric_err) {
   long long polls = 0;
@@ -1251,6 +1271,8 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   double* part = tv + BS;         // [ST_P][80]
   const int tid = threadIdx.x;
   const size_t MB = (size_t)BS * BS;
+  const unsigned tag0 = (unsigned)*a.epoch << 6;          // tags of this launch: + 1 + s iterate of sweep s, + 63 a node's solution
+  unsigned long long* const fin = a.ll + (size_t)2 * a.n_iso * BS * 2;
 #define ST_STAMP(k) do { if (ch.dbg && tid == 0 && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[65] == 100) ch.dbg[k] = (long long)wall_clock64(); } while (0)
   ST_STAMP(6);
   if (ch.dbg && tid == 0 && blockIdx.x == 0 && ch.dbg[65] == 100) ch.dbg[7] = (long long)wall_clock64();    // (workgroup 0's start: the common time base)
@@ -1353,6 +1375,8 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
       ST_STAMP(2);
       // G = D^-1 = U U^T over the factor (nobody else needs the factor of an isolated node): every later solve with D is ONE
       // 80 x 80 product instead of two triangular ones - the truncated solve and each of the sweeps lose a dependent stage
+      // (adding each column block's term under the factorisation, through chol80's hook, was tried: the factorisation grows by
+      //  what the product shrinks, 0.9 us each - the terms are few and the hooks' LDS traffic sits beside the pivot chain's)
       {
         const int wv = tid >> 6, ln = tid & 63, li = ln & 15, lk = ln >> 4;
         d4 gacc[2];
@@ -1396,29 +1420,18 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     const double x0 = use_g ? full_matvec() : upper_matvec();    // truncated solve (fused: G b; else U y)
     ST_STAMP(3);
     double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0;
-    double* xb0 = a.xbuf;
-    double* xb1 = a.xbuf + (size_t)n_iso * BS;
+    unsigned long long* xb0 = a.ll;
+    unsigned long long* xb1 = a.ll + (size_t)n_iso * BS * 2;
     if (a.refine > 0) {
-      if (tid < BS) st_put(xb0 + (size_t)p * BS + tid, x0);
-      st_put_done();
-      __syncthreads();
-      if (tid == 0) st_raise(a.ver + p, 1, a.fences);
+      if (tid < BS) ll_put(xb0 + ((size_t)p * BS + tid) * 2, x0, tag0 + 1);
+      if (p == 0 && tid == 0) st_raise(a.ver, 1);          // (a throttle, not a hand-off: nothing is read behind it)
     }
     for (int s = 1; s <= a.refine; ++s) {
-      const double* src = (s - 1) & 1 ? xb1 : xb0;
-      double* dst = s & 1 ? xb1 : xb0;
+      const unsigned long long* src = (s - 1) & 1 ? xb1 : xb0;
+      unsigned long long* dst = s & 1 ? xb1 : xb0;
       if (s == 2) ST_STAMP(8);
-      if (tid == 0) {
-        if (l >= 0) st_wait(a.ver + p - 1, s, numeric_err);
-        if (r >= 0) st_wait(a.ver + p + 1, s, numeric_err);
-        if (a.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (s == 2) ST_STAMP(9);
-      }
-      __syncthreads();
-      if (tid < BS) {
-        xl[tid] = l >= 0 ? st_get(src + (size_t)(p - 1) * BS + tid) : 0.0;
-        xr[tid] = r >= 0 ? st_get(src + (size_t)(p + 1) * BS + tid) : 0.0;
-      }
+      ll_get_pair(xl, xr, l >= 0 ? src + (size_t)(p - 1) * BS * 2 : nullptr, r >= 0 ? src + (size_t)(p + 1) * BS * 2 : nullptr,
+                  tag0 + (unsigned)s, numeric_err, tid);
       __syncthreads();
       if (s == 2) ST_STAMP(11);
       if (tid < ST_P * BS) {         // t = block(j, l) x_l + block(j, r) x_r ;  block(j, r) = Cpl[j]^T
@@ -1464,20 +1477,14 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
         dabs = fabs(x - xcur);
         xabs = fabs(x);
         xcur = x;
-        if (s < a.refine) st_put(dst + (size_t)p * BS + tid, x);
+        if (s < a.refine) ll_put(dst + ((size_t)p * BS + tid) * 2, x, tag0 + 1 + (unsigned)s);
       }
       if (s == 2) ST_STAMP(12);
-      if (s < a.refine) {
-        st_put_done();
-        __syncthreads();
-        if (tid == 0) st_raise(a.ver + p, s + 1, a.fences);
-      }
-      if (s == 2) ST_STAMP(13);
     }
-    if (tid < BS) st_put(ch.b + (size_t)j * BS + tid, xcur);
-    st_put_done();
-    __syncthreads();
-    if (tid == 0) st_raise(a.done + j, 1, a.fences);
+    if (tid < BS) {
+      ll_put(fin + ((size_t)j * BS + tid) * 2, xcur, tag0 + 63);
+      ch.b[(size_t)j * BS + tid] = xcur;
+    }
     ST_STAMP(4);
     if (a.norms && a.refine > 0) {            // (waves 0 and 1 hold the 80 rows)
       for (int off = 32; off > 0; off >>= 1) {
@@ -1520,18 +1527,10 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   }
   load3(l >= 0 ? ch.Wl + (size_t)i * MB : nullptr, r >= 0 ? ch.Wr + (size_t)i * MB : nullptr, ch.U + (size_t)i * MB);
   const double yi = tid < BS ? ybuf(ch)[(size_t)i * BS + tid] : 0.0;
-  if (tid == 0) {
-    if (l >= 0) st_wait(a.done + l, 1, numeric_err);
-    if (r >= 0) st_wait(a.done + r, 1, numeric_err);
-    if (a.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
+  ll_get_pair(xl, xr, l >= 0 ? fin + (size_t)l * BS * 2 : nullptr, r >= 0 ? fin + (size_t)r * BS * 2 : nullptr, tag0 + 63,
+              numeric_err, tid);
   __syncthreads();
-  ST_STAMP(1);                  // (level node: both neighbours solved)
-  if (tid < BS) {
-    xl[tid] = l >= 0 ? st_get(ch.b + (size_t)l * BS + tid) : 0.0;
-    xr[tid] = r >= 0 ? st_get(ch.b + (size_t)r * BS + tid) : 0.0;
-  }
-  __syncthreads();
+  ST_STAMP(1);                  // (level node: both neighbours' solutions in LDS)
   if (tid < ST_P * BS) {
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -1549,10 +1548,10 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
   if (tid < BS) tv[tid] = t;
   __syncthreads();
   const double x = upper_matvec();
-  if (tid < BS) st_put(ch.b + (size_t)i * BS + tid, x);
-  st_put_done();
-  __syncthreads();
-  if (tid == 0) st_raise(a.done + i, 1, a.fences);
+  if (tid < BS) {
+    ll_put(fin + ((size_t)i * BS + tid) * 2, x, tag0 + 63);
+    ch.b[(size_t)i * BS + tid] = x;
+  }
   ST_STAMP(5);
 #undef ST_STAMP
 }
@@ -1810,7 +1809,7 @@ bool bcr_level0_adds_al(const BcrSchedule& sch) {
 // true when k_sep_tail runs the back-substitution of this chain (truncated solve, sweeps and every level above in one launch)
 static bool sep_tail_applies(const BcrChain& ch, const BcrSchedule& sch) {
   const int top = (int)sch.levels.size() - 1;
-  return sch.refine > 0 && top >= 0 && sch.levels[top].isolated && ch.refine_buf && ch.st_flags && top <= 12 &&
+  return sch.refine > 0 && sch.refine <= 60 && top >= 0 && sch.levels[top].isolated && ch.refine_buf && ch.st_flags && ch.st_ll && top <= 12 &&
          sch.levels[top].n_elim <= 128;
 }
 
@@ -1926,11 +1925,10 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
       blocks += sch.levels[k].n_elim;
     }
     a.ver = ch.st_flags;
-    a.done = ch.st_flags + iso.n_elim;
-    a.xbuf = ch.refine_buf + (size_t)iso.n_elim * BS;
+    a.epoch = ch.st_flags + ch.n_st_flags;
+    a.ll = ch.st_ll;
     a.norms = ch.trunc_eps2;
     a.fused = (sch.fused_levels && ch.SL != nullptr) ? 1 : 0;
-    a.fences = getenv("ACINO_TAIL_FENCES") ? 1 : 0;
     a.iso_loc = ch.d_iso_loc;
     {
       ProfSpan sp(prof, PC_REFINE, s, blocks);

@@ -71,7 +71,9 @@ struct BcrChain {
   double* refine_buf = nullptr;   // [3][n_isolated][80] x0 and the two iterates of the refinement sweeps
   const double* AL0 = nullptr;    // separator chain of the chunked solver: [n][80][80] left-run contributions (lower tiles; row 79:
                                   // the update of b), added to D / b by the LEVEL-0 kernels of the reduction when set
-  int* st_flags = nullptr;        // k_sep_tail: [n_isolated] iterate versions, then [n_nodes] done flags (null: per-level kernels)
+  int* st_flags = nullptr;        // k_sep_tail: [n_st_flags] flags (zeroed by the consumer of the solution), then the epoch of its
+  int n_st_flags = 0;             //             hand-off tags (null: per-level kernels)
+  unsigned long long* st_ll = nullptr;   // k_sep_tail: tagged word pairs, [2][n_isolated][80][2] iterates + [n][80][2] solutions
   // fused narrow levels (seplevel.hip; all null: the per-phase kernels of bcr.hip only).  With them Cpl holds 2 n blocks:
   // slot n + i = the coupling created by the elimination of node i.
   double* SL = nullptr;           // [n][80][80] running sum of the Schur contributions a node received from its LEFT side (lower

@@ -828,8 +828,10 @@ k_chunk_backsub(BcrChain ch, SepView sp, const FteConst* __restrict__ cst, const
   const double* t_hd = t_cur ? trial.hd1 : trial.hd0;
   double* const fst = ch.Wl + (size_t)first * BS;           // f_k of this run's nodes
   if (ch.dbg && (long long)blockIdx.x == ch.dbg[64] && ch.dbg[66] == 1 && tid == 0) ch.dbg[61] = (long long)wall_clock64();
-  if (c == 0 && sp.flags)                                   // (k_sep_tail's hand-off flags: clean for the next iteration)
-    for (int e = tid; e < sp.n_flags; e += BK_T) sp.flags[e] = 0;
+  if (c == 0 && sp.flags) {                                 // (k_sep_tail's flags: clean for the next iteration; the int behind
+    for (int e = tid; e < sp.n_flags; e += BK_T) sp.flags[e] = 0;   // them is the epoch its hand-off tags are made of)
+    if (tid == 0) sp.flags[sp.n_flags] += 1;
+  }
   if (tid < 16) sync[tid] = 0;
   if (tid < 2 * BS) ub[tid] = 0.0;
   if (tid < NP) kq[tid] = K.q_w[tid];

@@ -28,7 +28,7 @@ struct SepView {
   double* AL;   // [80][80] -(sum over the run on its right of F^T G F), lower tiles; row 79: its update of b.  An array of its
                 // own: level 0 of the separator reduction reads it while sibling workgroups already write W_l / W_r
   double* b;    // [80]
-  int* flags = nullptr;   // the hand-off flags of k_sep_tail, zeroed again by k_chunk_backsub (n_flags ints; may be null)
+  int* flags = nullptr;   // the flags of k_sep_tail, zeroed again by k_chunk_backsub (n_flags ints, then the epoch counter it advances; may be null)
   int n_flags = 0;
 };
 

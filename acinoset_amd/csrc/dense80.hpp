@@ -202,8 +202,13 @@ __device__ __forceinline__ int panel_tile(int kb, int q) {
 }
 
 // NW: waves of the workgroup (4, or 8 in the 512-thread kernels: the extra waves share the trailing tiles)
-template <int NW = 4>
-__device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr) {
+struct Chol80NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// hook(kb): called by every wave but the pivot chain's once column block kb of U is final (after its trailing tiles of step kb;
+// for the last block after the last panel) - work that only needs the finished columns rides under the chain of block kb + 1
+template <int NW = 4, class Hook = Chol80NoHook>
+__device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long* dbg = nullptr, Hook&& hook = Hook()) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   if (wave == 0) chol16_inv(Lm, lane, err);
   __syncthreads();
@@ -224,7 +229,10 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
       for (int rr = 0; rr < 4; ++rr) A[(lk + 4 * rr) * LD + li] = acc[rr];
     }
     __syncthreads();
-    if (kb == NT - 1) break;
+    if (kb == NT - 1) {
+      if (wave != 0) hook(kb);
+      break;
+    }
     if (wave == 0) {
       double* Cc = Lm + ((kb + 1) * 16) * LD + (kb + 1) * 16;
       const double* A = Lm + ((kb + 1) * 16) * LD + kb * 16;
@@ -265,6 +273,7 @@ __device__ __forceinline__ void chol80(double* Lm, int tid, int* err, long long*
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Cc[(lk + 4 * rr) * LD + li] = a[rr];
       }
+      hook(kb);
     }
     __syncthreads();
   }

@@ -27,8 +27,10 @@ struct Buffers {
   int* sched;         // elim (3/entry), remain (4/entry), tail (4/entry), dropped-coupling pairs (2/entry), tail counter
   double* trunc_eps2; // [n_pairs + 1]
   double* refine_buf; // [3][n_isolated][80] (incomplete reduction with refinement sweeps)
-  int* st_flags;      // [n_isolated + n_sep] hand-off flags of k_sep_tail (chunked solver with refinement)
+  int* st_flags;      // [n_isolated + n_sep] flags of k_sep_tail (chunked solver with refinement), then the epoch counter
   int n_st_flags;
+  unsigned long long* st_ll;   // k_sep_tail's hand-off slots (BcrChain::st_ll)
+  size_t n_st_ll;
 };
 
 }  // namespace acino
@@ -120,9 +122,13 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
   b.st_flags = nullptr;
   b.n_st_flags = 0;
+  b.st_ll = nullptr;
+  b.n_st_ll = 0;
   if (lay.sched.refine > 0 && chunked) {
     b.n_st_flags = lay.sched.levels.back().n_elim + lay.plan.n_sep;
-    b.st_flags = c.take<int>((size_t)b.n_st_flags);
+    b.st_flags = c.take<int>((size_t)b.n_st_flags + 2);
+    b.n_st_ll = (2 * (size_t)lay.sched.levels.back().n_elim + (size_t)lay.plan.n_sep) * BS * 2;
+    b.st_ll = c.take<unsigned long long>(b.n_st_ll);
   }
   BcrChain chn;
   chn.n_nodes = (int)T;
@@ -742,7 +748,8 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
     }
   }
   if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
-  if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * (size_t)ctx->b.n_st_flags, s);
+  if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * ((size_t)ctx->b.n_st_flags + 2), s);
+  if (e == hipSuccess && ctx->b.st_ll) e = hipMemsetAsync(ctx->b.st_ll, 0, sizeof(unsigned long long) * ctx->b.n_st_ll, s);
   // (the runs write the contribution AL of every separator that has a run on its right: a right pin has none - zero once)
   if (e == hipSuccess && ctx->plan.active() && ctx->plan.n_sep > 0)
     e = hipMemsetAsync(const_cast<double*>(ctx->sepchain.AL0), 0, sizeof(double) * (size_t)ctx->plan.n_sep * BS * BS, s);
@@ -786,7 +793,11 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
         return rc;
       }
       if (const char* e = getenv("ACINO_SEP_TAIL_CAPACITY")) capacity = atoi(e);   // (tests: pretend a smaller device)
-      if (blocks > 0 && blocks <= capacity) red.st_flags = ctx->b.st_flags;
+      if (blocks > 0 && blocks <= capacity) {
+        red.st_flags = ctx->b.st_flags;
+        red.n_st_flags = ctx->b.n_st_flags;
+        red.st_ll = ctx->b.st_ll;
+      }
     }
   }
   if (ctx->plan.active()) {

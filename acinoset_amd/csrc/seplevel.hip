@@ -308,32 +308,60 @@ k_sep_level(BcrChain ch, SepLevelArgs a, int* __restrict__ numeric_err, const in
   }
   __syncthreads();
   SLV_STAMP(1);
-  chol80<SLV_T / 64>(Lm, tid, g == 0 ? numeric_err : nullptr);
-  SLV_STAMP(2);
-  if (g == 0 && tid < 256) store_mat(ch.U + i * MB, Lm, tid);      // the factor (what the back-substitution of this node reads)
-  // ---- strips of W = U^T [C_l | C_r], in place, a WHOLE strip per wave: a wave holds its strip's operand in registers before it
-  //      writes the first result and no other wave touches those columns, so the phase has no barrier - the two waves of a SIMD
-  //      hide each other's LDS latencies.  (Measured, scripts/bench/strip_phase.hip: the row tiles of a strip over four waves,
-  //      two strips per round with a barrier each, is 7.3 us for ten strips - 3.8 us of it LDS traffic and barriers that do not
-  //      overlap with the matrix instructions; without barriers the same work is 4.9 us.)
-  {
-    const int ns = __popc(strips);
-    for (int q = wave; q < ns; q += SLV_T / 64) {
-      unsigned m = strips;
-      for (int k = 0; k < q; ++k) m &= m - 1;
-      const int s = __ffs(m) - 1, side = s >= 5, cc = 16 * (side ? s - 5 : s);
-      double* Wb = side ? WR : WL;
-      double bv[20];
-      slv_strip_operand<5>(Wb, yv, bv, cc, li, lk);
-      slv_row_tile<4>(Lm, bv, Wb, cc, li, lk);
-      slv_row_tile<3>(Lm, bv, Wb, cc, li, lk);
-      slv_row_tile<2>(Lm, bv, Wb, cc, li, lk);
-      slv_row_tile<1>(Lm, bv, Wb, cc, li, lk);
-      slv_row_tile<0>(Lm, bv, Wb, cc, li, lk);
+  // ---- factorisation, with the strips of W = U^T [C_l | C_r] riding under it.  Row tile IB of a strip needs column block IB of U
+  //      and the strip's rows <= IB: a wave that owns a strip holds the strip's operand in registers from the start, and once
+  //      the panel of block IB is done it computes that row tile (in place: no other wave touches those columns) while wave 0
+  //      runs the pivots of block IB + 1.  Owners are the six waves of the three SIMDs the pivot chain does not live on; the
+  //      chain's SIMD mate (wave 4) takes a seventh strip whole, after the factorisation, when its SIMD is free.  What is left
+  //      after the last panel is row tile 4 of every strip.  (Before: all strips after the factorisation, 4.7-6.4 us.)
+  const int ns = __popc(strips);
+  const int helper = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  const int q0 = (helper >= 0 && helper < ns) ? helper : -1, q1 = (helper >= 0 && helper < 3 && 7 + helper < ns) ? 7 + helper : -1;
+  auto strip_at = [&](int q, double*& Wb, int& cc) {
+    unsigned m = strips;
+    for (int k = 0; k < q; ++k) m &= m - 1;
+    const int s = __ffs(m) - 1, side = s >= 5;
+    cc = 16 * (side ? s - 5 : s);
+    Wb = side ? WR : WL;
+  };
+  double bv0[20], bv1[20];
+  double *Wb0 = WL, *Wb1 = WL;
+  int cc0 = 0, cc1 = 0;
+  if (q0 >= 0) {
+    strip_at(q0, Wb0, cc0);
+    slv_strip_operand<5>(Wb0, yv, bv0, cc0, li, lk);
+  }
+  if (q1 >= 0) {
+    strip_at(q1, Wb1, cc1);
+    slv_strip_operand<5>(Wb1, yv, bv1, cc1, li, lk);
+  }
+  auto row_tiles = [&](int kb) {
+    if (q0 < 0) return;
+    switch (kb) {
+      case 0: slv_row_tile<0>(Lm, bv0, Wb0, cc0, li, lk); if (q1 >= 0) slv_row_tile<0>(Lm, bv1, Wb1, cc1, li, lk); break;
+      case 1: slv_row_tile<1>(Lm, bv0, Wb0, cc0, li, lk); if (q1 >= 0) slv_row_tile<1>(Lm, bv1, Wb1, cc1, li, lk); break;
+      case 2: slv_row_tile<2>(Lm, bv0, Wb0, cc0, li, lk); if (q1 >= 0) slv_row_tile<2>(Lm, bv1, Wb1, cc1, li, lk); break;
+      case 3: slv_row_tile<3>(Lm, bv0, Wb0, cc0, li, lk); if (q1 >= 0) slv_row_tile<3>(Lm, bv1, Wb1, cc1, li, lk); break;
+      default: slv_row_tile<4>(Lm, bv0, Wb0, cc0, li, lk); if (q1 >= 0) slv_row_tile<4>(Lm, bv1, Wb1, cc1, li, lk); break;
     }
+  };
+  chol80<SLV_T / 64>(Lm, tid, g == 0 ? numeric_err : nullptr, nullptr, row_tiles);
+  SLV_STAMP(2);
+  if (wave == 4 && ns > 6) {       // the seventh strip, whole
+    double* Wb;
+    int cc;
+    strip_at(6, Wb, cc);
+    double bv[20];
+    slv_strip_operand<5>(Wb, yv, bv, cc, li, lk);
+    slv_row_tile<4>(Lm, bv, Wb, cc, li, lk);
+    slv_row_tile<3>(Lm, bv, Wb, cc, li, lk);
+    slv_row_tile<2>(Lm, bv, Wb, cc, li, lk);
+    slv_row_tile<1>(Lm, bv, Wb, cc, li, lk);
+    slv_row_tile<0>(Lm, bv, Wb, cc, li, lk);
   }
   slv_lds_barrier();
   SLV_STAMP(3);
+  if (g == 0 && tid < 256) store_mat(ch.U + i * MB, Lm, tid);      // the factor (what the back-substitution of this node reads)
   // W_l, W_r for the back-substitution, each strip by one of the workgroups that hold it (the rider's column as 0): requested
   // now, they drain under the products
   for (unsigned m = strips & stores; m; m &= m - 1) {

@@ -37,8 +37,8 @@ for wg in (0, 1, 30, 58, 59, 60, 100, 118, 119, 150, 200, 237):
     base = d[7]
     if d[0]:
         if d[8]:
-            print(f"   sweep 2 of wg {wg}: starts {(d[8] - base) / 100.0:.2f}, flags seen {(d[9] - base) / 100.0:.2f}, acquired {(d[10] - base) / 100.0:.2f}, "
-                  f"neighbours' iterates in LDS {(d[11] - base) / 100.0:.2f}, new iterate {(d[12] - base) / 100.0:.2f}, published {(d[13] - base) / 100.0:.2f}")
+            print(f"   sweep 2 of wg {wg}: starts {(d[8] - base) / 100.0:.2f}, neighbours' iterates in LDS {(d[11] - base) / 100.0:.2f}, "
+                  f"new iterate stored {(d[12] - base) / 100.0:.2f}")
         print(f"k_sep_tail wg {wg} (isolated): enters {(d[6] - base) / 100.0:.2f}, " + ", ".join(f"{tl_names[k]} {(d[k] - base) / 100.0:.2f}" for k in range(1, 5) if d[k]))
     else:
         print(f"k_sep_tail wg {wg} (level node): enters {(d[6] - base) / 100.0:.2f}, neighbours solved {(d[1] - base) / 100.0:.2f}, done {(d[5] - base) / 100.0:.2f}")
