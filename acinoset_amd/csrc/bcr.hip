@@ -1419,7 +1419,7 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
     const bool use_g = a.fused != 0;
     const double x0 = use_g ? full_matvec() : upper_matvec();    // truncated solve (fused: G b; else U y)
     ST_STAMP(3);
-    double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0;
+    double xcur = x0, dabs = 0.0, dabs_prev = 0.0, xabs = fabs(x0), xabs_prev = 0.0, d_first = 0.0, d_second = 0.0;
     unsigned long long* xb0 = a.ll;
     unsigned long long* xb1 = a.ll + (size_t)n_iso * BS * 2;
     if (a.refine > 0) {
@@ -1477,6 +1477,8 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
         dabs = fabs(x - xcur);
         xabs = fabs(x);
         xcur = x;
+        if (s == 1) d_first = dabs;
+        if (s == 2) d_second = dabs;
         if (s < a.refine) ll_put(dst + ((size_t)p * BS + tid) * 2, x, tag0 + 1 + (unsigned)s);
       }
       if (s == 2) ST_STAMP(12);
@@ -1492,22 +1494,28 @@ k_sep_tail(BcrChain ch, SepTailArgs a, const int* __restrict__ status, int* __re
         xabs = fmax(xabs, __shfl_down(xabs, off, 64));
         dabs_prev = fmax(dabs_prev, __shfl_down(dabs_prev, off, 64));
         xabs_prev = fmax(xabs_prev, __shfl_down(xabs_prev, off, 64));
+        d_first = fmax(d_first, __shfl_down(d_first, off, 64));
+        d_second = fmax(d_second, __shfl_down(d_second, off, 64));
       }
       if ((tid & 63) == 0 && tid < 128) {
-        double* q4 = part + 4 * (tid >> 6);
-        q4[0] = dabs;
-        q4[1] = xabs;
-        q4[2] = dabs_prev;
-        q4[3] = xabs_prev;
+        double* q6 = part + 6 * (tid >> 6);
+        q6[0] = dabs;
+        q6[1] = xabs;
+        q6[2] = dabs_prev;
+        q6[3] = xabs_prev;
+        q6[4] = d_first;
+        q6[5] = d_second;
       }
       __syncthreads();
-      if (tid == 0) {
-        a.norms[p] = fmax(part[0], part[4]);
-        a.norms[n_iso + p] = fmax(part[1], part[5]);
+      if (tid == 0) {             // (layout: bcr_backsub, the per-sweep launches)
+        a.norms[p] = fmax(part[0], part[6]);
+        a.norms[n_iso + p] = fmax(part[1], part[7]);
         if (a.refine >= 2) {
-          a.norms[2 * n_iso + p] = fmax(part[2], part[6]);
-          a.norms[3 * n_iso + p] = fmax(part[3], part[7]);
+          a.norms[2 * n_iso + p] = fmax(part[2], part[8]);
+          a.norms[3 * n_iso + p] = fmax(part[3], part[9]);
         }
+        if (a.refine >= 3) a.norms[4 * n_iso + p] = fmax(part[4], part[10]);
+        if (a.refine >= 4) a.norms[5 * n_iso + p] = fmax(part[5], part[11]);
       }
     }
     return;
@@ -1951,10 +1959,15 @@ int bcr_backsub(const BcrChain& ch, const BcrSchedule& sch, const FteConst* d_c,
     for (int sw = 0; sw < sch.refine; ++sw) {
       const bool last = sw + 1 == sch.refine;
       ProfSpan sp(prof, PC_REFINE, s, lv.n_elim);
-      // the last two sweeps record max |update| (and max |x|) per node: k_totals turns them into the bound on the error
-      // trunc_eps2 layout with refinement, n = isolated nodes: [0, n) |update| and [n, 2n) |x| of the last sweep,
-      // [2n, 3n) |update| and [3n, 4n) |x| of the sweep before it
-      double* norms = last ? ch.trunc_eps2 : (sw + 2 == sch.refine ? ch.trunc_eps2 + 2 * (size_t)lv.n_elim : (double*)nullptr);
+      // the last two and the first two sweeps record max |update| (and max |x|) per node: k_totals turns them into the bound
+      // on the error.  trunc_eps2 layout with refinement, n = isolated nodes: [0, n) |update| and [n, 2n) |x| of the last
+      // sweep, [2n, 3n) |update| and [3n, 4n) |x| of the sweep before it; with >= 3 sweeps [4n, 5n) |update| of the first,
+      // with >= 4 [5n, 6n) |update| of the second (a sweep writes |x| behind its |update|: the first's is overwritten by the
+      // second's |update|, the second's lands in [6n, 7n) and is not used)
+      double* norms = last ? ch.trunc_eps2
+                           : (sw + 2 == sch.refine ? ch.trunc_eps2 + 2 * (size_t)lv.n_elim
+                                                   : (sw == 0 ? ch.trunc_eps2 + 4 * (size_t)lv.n_elim
+                                                              : (sw == 1 ? ch.trunc_eps2 + 5 * (size_t)lv.n_elim : (double*)nullptr)));
       hipLaunchKernelGGL(k_bcr_refine, dim3(lv.n_elim), dim3(RF_T), kBacksubTailLds, s, ch, iso, lv.n_elim,
                          sw == 0 ? (const double*)nullptr : it[(sw - 1) & 1], it[sw & 1], x0, (last && sw > 0) ? 1 : 0, norms,
                          d_status);

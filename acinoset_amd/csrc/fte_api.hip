@@ -117,7 +117,7 @@ static size_t carve(const acino_fte_params* p, char* base, Buffers* out, BcrChai
   b.nbehind = c.take<int>(4);
   b.numeric_err = b.nbehind + 1;
   b.sched = c.take<int>(sched_ints);
-  b.trunc_eps2 = c.take<double>(4 * (n_pairs + 1) + 1);   // (refinement: four [n_isolated] arrays of sweep norms)
+  b.trunc_eps2 = c.take<double>(7 * (n_pairs + 1) + 1);   // (refinement: seven [n_isolated] arrays of sweep norms, bcr_backsub)
   b.refine_buf = nullptr;
   if (lay.sched.refine > 0) b.refine_buf = c.take<double>(3 * (size_t)lay.sched.levels.back().n_elim * BS);
   b.st_flags = nullptr;
@@ -258,12 +258,12 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
   // combined in order - a fixed summation order, one barrier.  1024 threads: this single workgroup is a chain of
   // HBM round trips (one per stride), so the stride count is what it costs - 4 instead of 14 for 10 000 frames
   constexpr int NW = 16;
-  __shared__ double sh[NW][8];
+  __shared__ double sh[NW][10];
   // thread 0 will run the controller: its operands are requested now, beside the reductions
   acino_fte_state S;
   LmTol T{0, 0, 0, 0, 0};
   int ne = 0, nb = 0, n_ref = 0;
-  double e2 = 0.0, ttol = 0.0, r_d1 = 0.0, r_d0 = 0.0, r_x = 0.0;
+  double e2 = 0.0, ttol = 0.0, r_d1 = 0.0, r_d0 = 0.0, r_x = 0.0, r_f1 = 0.0, r_f2 = 0.0;
   if (threadIdx.x == 0) {
     S = *st;
     T = LmTol{cst->gtol, cst->ftol, cst->xtol, cst->lam_max, cst->clamp_lambda};
@@ -282,6 +282,8 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
         r_d1 = fmax(r_d1, trunc_eps2[i]);
         r_x = fmax(r_x, trunc_eps2[n_iso + i]);
         r_d0 = fmax(r_d0, trunc_eps2[2 * n_iso + i]);
+        r_f1 = fmax(r_f1, trunc_eps2[4 * n_iso + i]);      // (zero where the sweep count leaves them unwritten)
+        r_f2 = fmax(r_f2, trunc_eps2[5 * n_iso + i]);
       }
     } else {
       for (int i = threadIdx.x; i < n_trunc; i += 64 * NW) e2 = fmax(e2, trunc_eps2[i]);
@@ -305,6 +307,8 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     r_d1 = fmax(r_d1, __shfl_down(r_d1, off, 64));
     r_d0 = fmax(r_d0, __shfl_down(r_d0, off, 64));
     r_x = fmax(r_x, __shfl_down(r_x, off, 64));
+    r_f1 = fmax(r_f1, __shfl_down(r_f1, off, 64));
+    r_f2 = fmax(r_f2, __shfl_down(r_f2, off, 64));
   }
   if ((threadIdx.x & 63) == 0) {
     double* w = sh[threadIdx.x >> 6];
@@ -316,6 +320,8 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     w[5] = r_d1;
     w[6] = r_d0;
     w[7] = r_x;
+    w[8] = r_f1;
+    w[9] = r_f2;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -332,6 +338,8 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
       r_d1 = fmax(r_d1, sh[w][5]);
       r_d0 = fmax(r_d0, sh[w][6]);
       r_x = fmax(r_x, sh[w][7]);
+      r_f1 = fmax(r_f1, sh[w][8]);
+      r_f2 = fmax(r_f2, sh[w][9]);
     }
     double tot[8] = {c, p, s, g, (double)nb, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -340,12 +348,23 @@ k_totals(acino_fte_state* st, const double* cost_part, int n_cost, const double*
     if (with_step && n_trunc > 0) {
       // what the step's relative error is bounded by.  Plain truncation: eps, the measured size of the dropped couplings.
       // With r block-Jacobi sweeps over them (bcr.hip k_bcr_refine): the iteration contracts by rho <= 2 eps per sweep, so
-      // the error left after the last sweep is <= rho / (1 - rho) |last update|; rho is measured as the ratio of the last
-      // two updates (one sweep only: rho = 1/2 assumed), and a rho above 1/2 refuses the step.
+      // the error left after the last sweep is <= rho / (1 - rho) |last update|; rho is measured as a ratio of consecutive
+      // updates (one sweep only: rho = 1/2 assumed), and a rho above 1/2 refuses the step.
       double bound;
       if (n_ref > 0) {
-        // (an update after a sweep that changed nothing - r_d0 == 0 < r_d1 - is no contraction: rho = 1 refuses the step)
-        const double rho = n_ref >= 2 ? (r_d0 > 0.0 ? r_d1 / r_d0 : (r_d1 > 0.0 ? 1.0 : 0.0)) : 0.5;
+        // The contraction is measured where it can be: an update at the rounding level (below 2^-44 of the largest component)
+        // is noise, and so is a ratio it takes part in.  The first two sweeps give the clean measurement (the truncated solve
+        // is off by ~rho, their updates are ~rho and ~rho^2 of the solution); the last two confirm it as long as they are above
+        // the noise - with many sweeps they are not, and their ratio (noise over noise, ~1) must not refuse a converged
+        // solve.  Nothing measurable at all (the first update already at rounding): rho = 1/2 assumed, as with one sweep.
+        double rho = 0.5;
+        if (n_ref >= 2) {
+          const double noise = 0x1p-44 * r_x;
+          const double d1 = n_ref == 2 ? r_d0 : r_f1, d2 = n_ref == 2 ? r_d1 : (n_ref == 3 ? r_d0 : r_f2);
+          const double rho_first = d1 > noise ? d2 / d1 : 0.5;
+          const double rho_last = (r_d1 > noise && r_d0 > noise) ? r_d1 / r_d0 : 0.0;
+          rho = fmax(rho_first, rho_last);
+        }
         bound = (rho <= 0.5 && r_x > 0.0) ? rho / (1.0 - rho) * r_d1 / r_x : (r_d1 == 0.0 ? 0.0 : 1.0);
         S.trunc_eps = bound;
       } else {
@@ -747,7 +766,7 @@ int acino_fte_create(acino_fte_ctx** out, const acino_fte_params* p, const doubl
       if (e == hipSuccess) e = hipStreamSynchronize(s);       // (fz is a local)
     }
   }
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (4 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->b.trunc_eps2, 0, sizeof(double) * (7 * (ctx->sched.pairs.size() / 2 + 1) + 1), s);
   if (e == hipSuccess && ctx->b.st_flags) e = hipMemsetAsync(ctx->b.st_flags, 0, sizeof(int) * ((size_t)ctx->b.n_st_flags + 2), s);
   if (e == hipSuccess && ctx->b.st_ll) e = hipMemsetAsync(ctx->b.st_ll, 0, sizeof(unsigned long long) * ctx->b.n_st_ll, s);
   // (the runs write the contribution AL of every separator that has a run on its right: a right pin has none - zero once)

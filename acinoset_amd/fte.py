@@ -9,6 +9,7 @@ reject controller (fte_api.hip).  ``fte_solve`` returns the reference's ``fte.pi
 (:548-559): ``{positions [N,20,3], x [N,25], dx [N,25], ddx [N,25], start_frame}``.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -131,9 +132,12 @@ class FTEContext:
     # REFINE_SWEEPS block-Jacobi sweeps - verified on the device every iteration (state["trunc_eps"] <= trunc_tol, status 7
     # "truncation" otherwise, on which solve() continues with one more level).  bcr_levels = 0 asks for the complete
     # reduction, chunk_nodes = -1 for block cyclic reduction over the whole chain (the round-1/2 solver).
-    TRUNC_DISTANCE = 160
-    REFINE_SWEEPS = 3     # (2 sweeps: -7 us per iteration and a measured bound <= 1.2e-14 on every probe sequence - scripts/refine_probe.py -,
-                          #  i.e. above rounding: solves that must walk the exact path decision for decision keep the third, <= 1.5e-18)
+    # (a sweep costs ~2.5 us since the sweeps trade their vectors as tagged words, a reduction level ~27 us: one level less and
+    #  four sweeps more than rounds 4-6 had - 160 frames, 3 sweeps.  scripts/levels_probe.py: at 10 000 frames of the benchmark
+    #  sequence one level + 7 sweeps leave a verified bound <= 3.2e-16 in every iteration of the solve, 6 sweeps 3.5e-14; slow
+    #  gaits, whose smoothness prior couples further, are refused at this distance and escalate, as they did at 160.)
+    TRUNC_DISTANCE = 80
+    REFINE_SWEEPS = 7
     TRUNC_TOL = 1e-12
 
     @classmethod
@@ -171,20 +175,30 @@ class FTEContext:
         if self._graph:
             check(lib().acino_fte_enable_graph(self._h, 1))
 
-    def _escalate(self):
+    def _escalate(self, bound=None):
         """After status 7 (the truncated solve's verified error bound exceeded trunc_tol; the refused step was never
-        applied): the same problem with one more reduction level (the complete reduction once the chain is exhausted),
-        restarted from the current iterate."""
+        applied): the same problem with more reduction levels (the complete reduction once the chain is exhausted),
+        restarted from the current iterate.  ``bound``: the refused step's state["trunc_eps"], see _next_levels."""
         x = self.result()[0]
-        levels = self._next_levels()
+        levels = self._next_levels(bound)
         self.close()
         self._rebuild_with_levels(levels)
         check(lib().acino_fte_set_x(self._h, ptr(x), stream_ptr()))
         return levels
 
-    def _next_levels(self):
-        levels = int(self.params.bcr_levels) + 1
-        if int(self.params.bcr_levels) == 0 or levels >= solver_plan(self.params)["levels"]:
+    def _next_levels(self, bound=None):
+        """One level more - or, when the refused bound says how far off the truncation was, as many as it takes: the dropped
+        couplings square with every level, so a bound b (~rho^(sweeps + 1)) becomes ~b^(2^j) after j more levels; the
+        smallest j that brings it a decade under the tolerance.  (A bound of 1.0 means the sweeps did not contract by 1/2:
+        no size to extrapolate from.)"""
+        cur, jump = int(self.params.bcr_levels), 1
+        tol = float(self.params.trunc_tol)
+        if bound is not None and cur > 0 and 0.0 < bound < 1.0 and 0.0 < tol < 1.0:
+            need = math.log(0.1 * tol) / math.log(bound)
+            if need > 1.0:
+                jump = max(1, int(math.ceil(math.log2(need) - 1e-9)))
+        levels = cur + jump
+        if cur == 0 or levels >= solver_plan(self.params)["levels"]:
             levels = 0
         return levels
 
@@ -246,7 +260,7 @@ class FTEContext:
 
     def solve(self, max_iter):
         """Up to max_iter LM iterations IN TOTAL.  A step the truncated linear solve could not verify (status 7) is never
-        applied: the context is rebuilt with one more reduction level and the solve continues from the current iterate
+        applied: the context is rebuilt with more reduction levels (_next_levels) and the solve continues from the current iterate
         (the rebuilt controller starts from lam0 again); a refusal that uses up the last iteration is returned as status 7."""
         st = FteState()
         done = 0
@@ -258,7 +272,7 @@ class FTEContext:
             if info["status"] != 7 or info["iter"] >= int(max_iter):
                 return info
             done = info["iter"]
-            self._escalate()
+            self._escalate(info.get("trunc_eps"))
 
     def state(self):
         st = FteState()

@@ -136,6 +136,15 @@ def test_window_plan_and_params_host_logic():
     assert fte.auto_bcr_levels(mk(10000), 160) == 2 and fte.auto_bcr_levels(mk(10000), 384) == 4      # 42 * 2^K frames
     assert fte.auto_bcr_levels(mk(10000, chunk_nodes=-1), 384) == 7 and fte.auto_bcr_levels(mk(700, chunk_nodes=-1), 384) == 0
     assert fte.auto_bcr_levels(mk(300), 160) == 0                                        # chain too short to truncate
+    assert fte.auto_bcr_levels(mk(10000), fte.FTEContext.TRUNC_DISTANCE) == 1 and fte.FTEContext.REFINE_SWEEPS == 7
+    # escalation after a refused step: one level more, or as many as the refused bound calls for (couplings square per level)
+    import types
+    nxt = lambda levels, bound=None, tol=1e-12: fte.FTEContext._next_levels(
+        types.SimpleNamespace(params=mk(10000, bcr_levels=levels, trunc_tol=tol, refine_sweeps=7)), bound)
+    assert nxt(1) == 2 and nxt(1, 1.0) == 2 and nxt(1, 0.0) == 2            # no size to extrapolate from
+    assert nxt(1, 1.3e-8) == 2                                              # 1.3e-8 squared is under 1e-13
+    assert nxt(1, 3.3e-6) == 3 and nxt(2, 2e-7) == 3                        # needs the fourth power / the square
+    assert nxt(1, 0.05) == 5 and nxt(1, 0.3) == 6 and nxt(6) == 7 and nxt(7) == 0 and nxt(4, 0.3) == 0 and nxt(0, 1e-3) == 0    # (the chain has 8 levels: beyond 7, the complete reduction)
 
 
 def test_build_id_matches_sources_and_cpu_baseline_worker(tmp_path):

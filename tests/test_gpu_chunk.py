@@ -220,7 +220,7 @@ def test_separator_tail_falls_back_to_the_per_level_kernels_on_a_device_that_can
     ref = _walk(fte, seq["det"], rig, seq["Ts"], xa, 4)
     monkeypatch.setenv("ACINO_SEP_TAIL_CAPACITY", "1")
     got = _walk(fte, seq["det"], rig, seq["Ts"], xa, 4)
-    # ... and it IS the other set of kernels: per-level back-substitution launches, three refinement launches instead of one
+    # ... and it IS the other set of kernels: per-level back-substitution launches, one refinement launch per sweep instead of one
     ctx = fte.FTEContext(seq["det"], *rig, seq["Ts"], ftol=0.0, xtol=0.0, gtol=0.0, clamp_lambda=True)
     ctx.set_x(xa)
     ctx.step()
@@ -228,7 +228,7 @@ def test_separator_tail_falls_back_to_the_per_level_kernels_on_a_device_that_can
     ctx.step()
     launches = {k: v["launches"] for k, v in ctx.profile_end().items()}
     ctx.close()
-    assert launches["backsub"] >= 1 and launches["refine"] == 3, launches
+    assert launches["backsub"] >= 1 and launches["refine"] == fte.FTEContext.REFINE_SWEEPS, launches
     for it, (r, g) in enumerate(zip(ref, got)):
         assert g[3] == 0 and r[3] == 0 and g[1] == r[1], (it, g[3], r[3])
         assert abs(g[0] - r[0]) <= 1e-11 * abs(r[0]), (it, g[0], r[0])
