@@ -48,6 +48,9 @@ timeout 300 python scripts/schwarz_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/sum
 timeout 300 python scripts/video_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_whole_video_windows.txt
 (timeout 200 python scripts/skel_solve_probe.py; echo "--- the round-5 kernel (ACINO_SKEL_OLD_SOLVE=1):"; ACINO_SKEL_OLD_SOLVE=1 timeout 200 python scripts/skel_solve_probe.py) 2>&1 | grep -v amdgpu.ids > $OUT/summary/skeleton_solve_per_frame.txt
 (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acinoset_amd/csrc -I include scripts/bench/strip_phase.hip -o /tmp/strip_phase 2>/dev/null && /tmp/strip_phase) > $OUT/summary/strip_phase_microbenchmark.txt 2>&1
+(for a in "10000 loop 20210313 2:3,1:6,1:7,1:8,1:12" "3331 loop 5 4:3,3:7,2:10" "999 loop 4 4:3,3:7,2:12" "6000 walk 3 3:3,2:7,1:7" "4000 sprint 1 4:3,3:7,2:7" "400 sprint 4 4:3,3:7" "20000 trot 6 2:3,1:7"; do timeout 300 python scripts/levels_probe.py $a; done) 2>&1 | grep -v amdgpu.ids > $OUT/summary/levels_against_sweeps.txt
+(timeout 900 python scripts/tail_race_probe.py 3331 2000 40; timeout 600 python scripts/tail_race_probe.py 10000 1000 20) 2>&1 | grep -v amdgpu.ids > $OUT/summary/tail_handoff_repeatability.txt
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I acinoset_amd/csrc -I include scripts/bench/chain16.hip -o /tmp/chain16 2>/dev/null && /tmp/chain16) > $OUT/summary/pivot_chain_microbenchmark.txt 2>&1
 cp $OUT/bench.json $OUT/summary/bench_n1.json; cp $OUT/bench_under_rocprof.json $OUT/summary/bench_n1_under_rocprof.json
 cp $OUT/pytest_gpu.log $OUT/smoke.log $OUT/summary/
 # keep the merge-back small: the raw counter dumps are not needed once summarised
