@@ -189,9 +189,11 @@ typedef struct acino_fte_params {
                             * couplings after the truncated solve (0 = none).  In theory r sweeps leave a relative
                             * energy-norm error <= (2 eps)^(r+1) / (1 - 2 eps).  What the device CHECKS against trunc_tol with
                             * r > 0 is an a-posteriori estimate from the sweeps themselves (eps is not measured then):
-                            * rho / (1 - rho) * max|last update| / max|x| with rho = ratio of the max-norms of the last two
-                            * updates (r = 1: rho = 1/2 assumed); rho > 1/2, or an update after a sweep that changed nothing,
-                            * refuses the step (status 7).  The estimate is written to acino_fte_state::trunc_eps. */
+                            * rho / (1 - rho) * max|last update| / max|x| with rho = a ratio of the max-norms of consecutive
+                            * updates: of the first two sweeps and - while those are above the rounding level, 2^-44 max|x| -
+                            * of the last two, the larger of both (r = 1, or a first update already at rounding: rho = 1/2
+                            * assumed); rho > 1/2 refuses the step (status 7).  The estimate is written to
+                            * acino_fte_state::trunc_eps. */
 } acino_fte_params;
 #define ACINO_PREC_F64 0
 #define ACINO_PREC_BF16_ROWS 1
