@@ -67,8 +67,12 @@ __device__ __forceinline__ void redescending_f(const LossF& L, float err, float&
 // in fp64, projection / Jacobian / robust weights in fp32, the scaled residuals and the 2x3 Jacobian ROWS rounded to
 // bf16, M_l and v_l accumulated in fp32; from Lambda_l on (phases C-tail, D, E) fp64 as before.  The cost is summed in
 // fp64 from the UNROUNDED fp32 residuals (accept / reject decisions need more than 8 bits).
-template <bool JAC, int PREC>
-__global__ void __launch_bounds__(256)
+// SPLIT = 2 (short chains: fewer workgroups than the chip holds at once, so only the latency of ONE workgroup counts) deals the
+// cameras of a (frame, marker) to two lanes next to each other - contiguous halves of the camera list, summed left + right:
+// 8 frames x 20 markers x 2 = 320 threads, three cameras per lane instead of six.  (For long chains it loses: the kernel keeps
+// ~165 registers, five-wave workgroups fit twice on a CU where four-wave ones fit three times - NOTES_perf.md round 6.)
+template <bool JAC, int PREC, int SPLIT = 1>
+__global__ void __launch_bounds__(SPLIT == 2 ? 2 * FPB * NL : 256)
 k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restrict__ st, int which,
                const double* __restrict__ det, const double* __restrict__ x0, const double* __restrict__ x1,
                double* __restrict__ H0, double* __restrict__ H1, double* __restrict__ g0, double* __restrict__ g1,
@@ -114,10 +118,12 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     fk_columns(F[f], j);
   }
   __syncthreads();
-  // ---- C: projection (+ twists on the otherwise idle threads)
-  const int nproj = nf * NL;
+  // ---- C: projection (+ twists: on the otherwise idle threads; SPLIT = 2 has none - all threads, first; the twists go
+  //      over sin / cos, dead since the barrier)
+  const int nproj = SPLIT * nf * NL;
   if (JAC) {
-    for (int task = tid - nproj; task < nf * 22; task += (int)blockDim.x - nproj > 0 ? (int)blockDim.x - nproj : 1) {
+    const int t0 = SPLIT == 2 ? tid : tid - nproj, dt = SPLIT == 2 ? (int)blockDim.x : ((int)blockDim.x - nproj > 0 ? (int)blockDim.x - nproj : 1);
+    for (int task = t0; task < nf * 22; task += dt) {
       if (task < 0) break;
       int f = task / 22, a = task - f * 22;
       int g = c_state_grp[a + 3];
@@ -132,7 +138,8 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     }
   }
   if (tid < nproj) {
-    const int f = tid / NL, l = tid - f * NL;
+    const int half = SPLIT == 2 ? (tid & 1) : 0, fl = SPLIT == 2 ? (tid >> 1) : tid;
+    const int f = fl / NL, l = fl - f * NL;
     const int n = f0 + f;
     const bool owned = n >= K.own_lo && n < K.own_hi;      // window sharding: only owned frames enter the cost
     double cost_c = 0.0;
@@ -149,15 +156,22 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
     redescending<false>(K.loss, 0.0, rho0, dd, hh);
     int behind = 0;
     const int C = K.n_cams;
+    const int c_lo = (SPLIT == 2 && half) ? (C + 1) / 2 : 0, c_hi = (SPLIT == 2 && !half) ? (C + 1) / 2 : C;   // this lane's cameras
     // software-pipelined detection reads: camera ci+1's (x, y, likelihood) is requested before camera ci is
     // processed - the loop body branches (zero weight, behind camera), which would otherwise expose one HBM
     // latency per camera
     const double* dbase = det + ((int64_t)n * C * NL + l) * 3;
-    double nx = dbase[0], ny = dbase[1], nlik = dbase[2];
-    for (int ci = 0; ci < C; ++ci) {
+    double nx = 0.0, ny = 0.0, nlik = 0.0;
+    if (c_lo < c_hi) {
+      const double* d = dbase + (int64_t)c_lo * NL * 3;
+      nx = d[0];
+      ny = d[1];
+      nlik = d[2];
+    }
+    for (int ci = c_lo; ci < c_hi; ++ci) {
       const Cam& cam = K.cams[ci];
       const double um = nx, vm = ny, lik = nlik;
-      if (ci + 1 < C) {
+      if (ci + 1 < c_hi) {
         const double* d = dbase + (int64_t)(ci + 1) * NL * 3;
         nx = d[0];
         ny = d[1];
@@ -281,14 +295,31 @@ k_fte_assemble(const FteConst* __restrict__ cst, const acino_fte_state* __restri
       }
     }
     if (PREC != ACINO_PREC_F64) {
+      if (JAC && SPLIT == 2) {       // (the mixed-precision rows accumulate in fp32: so does the sum of the two halves)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Mf[k] += __shfl_xor(Mf[k], 1, 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vf[k] += __shfl_xor(vf[k], 1, 64);
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) M[k] = (double)Mf[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) v[k] = (double)vf[k];
+    } else if (JAC && SPLIT == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double o = __shfl_xor(M[k], 1, 64);
+        M[k] = half ? o + M[k] : M[k] + o;             // left half + right half, on both lanes
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double o = __shfl_xor(v[k], 1, 64);
+        v[k] = half ? o + v[k] : v[k] + o;
+      }
     }
     if (owned) my_cost += cost_c;
     if (behind && owned) atomicAdd(nbehind, behind);
-    if (JAC) {
+    if (JAC && half == 0) {
       // Lambda = [[M, -B], [-B^T, -P B]],  B = M P,  P = [p]x ;  f = [v, p x v]
       const double Mm[3][3] = {{M[0], M[1], M[2]}, {M[1], M[3], M[4]}, {M[2], M[4], M[5]}};
       const double P[3][3] = {{0, -pz, py}, {pz, 0, -px}, {-py, px, 0}};
@@ -465,25 +496,40 @@ int launch_assemble(const FteConst* d_c, const FteConst& h_c, const acino_fte_st
   if (nb == 0) return ACINO_OK;
   const size_t lds = sizeof(FrameLds) * FPB + 64;
   static PerDeviceOnce attr;
+  static int cus_of[64] = {};
+  int dev = 0;
+  ACINO_HIP_CHECK(hipGetDevice(&dev));
   if (attr.first()) {
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_F64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_F64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_BF16_ROWS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_BF16_ROWS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<true, ACINO_PREC_BF16_RES>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<false, ACINO_PREC_BF16_RES>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define ACINO_ASM_ATTR(J, P, S)                                                                                       \
+  ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fte_assemble<J, P, S>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    ACINO_ASM_ATTR(true, ACINO_PREC_F64, 1);        ACINO_ASM_ATTR(false, ACINO_PREC_F64, 1);
+    ACINO_ASM_ATTR(true, ACINO_PREC_BF16_ROWS, 1);  ACINO_ASM_ATTR(false, ACINO_PREC_BF16_ROWS, 1);
+    ACINO_ASM_ATTR(true, ACINO_PREC_BF16_RES, 1);   ACINO_ASM_ATTR(false, ACINO_PREC_BF16_RES, 1);
+    ACINO_ASM_ATTR(true, ACINO_PREC_F64, 2);        ACINO_ASM_ATTR(false, ACINO_PREC_F64, 2);
+    ACINO_ASM_ATTR(true, ACINO_PREC_BF16_ROWS, 2);  ACINO_ASM_ATTR(false, ACINO_PREC_BF16_ROWS, 2);
+    ACINO_ASM_ATTR(true, ACINO_PREC_BF16_RES, 2);   ACINO_ASM_ATTR(false, ACINO_PREC_BF16_RES, 2);
+#undef ACINO_ASM_ATTR
     ACINO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(FrameLds) * FPB)));
+    int cus = 0;
+    ACINO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cus_of[dev] = cus;
   }
-#define ACINO_LAUNCH_ASSEMBLE(J, P)                                                                                  \
-  hipLaunchKernelGGL((k_fte_assemble<J, P>), dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1], H[0], \
-                     H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0)
+  // short chains - a workgroup per CU at most - take the camera-split variant: what counts there is the latency of one
+  // workgroup, and its longest phase is the serial loop over the cameras (999 frames: 27.6 -> 23.9 us; with two workgroups on a
+  // CU it loses already - 3 331 frames: 30 -> 43 us)
+  int split = (dev >= 0 && dev < 64 && nb <= cus_of[dev]) ? 2 : 1;
+  if (const char* e = getenv("ACINO_ASM_SPLIT")) split = atoi(e) == 2 ? 2 : 1;
+#define ACINO_LAUNCH_ASSEMBLE(J, P)                                                                                   \
+  do {                                                                                                                \
+    if (split == 2)                                                                                                   \
+      hipLaunchKernelGGL((k_fte_assemble<J, P, 2>), dim3(nb), dim3(2 * FPB * NL), lds, s, d_c, d_st, which, d_det, x[0], x[1], \
+                         H[0], H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);     \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_fte_assemble<J, P, 1>), dim3(nb), dim3(256), lds, s, d_c, d_st, which, d_det, x[0], x[1],  \
+                         H[0], H[1], g[0], g[1], hd[0], hd[1], d_cost_partials, d_nbehind, respect_status ? 1 : 0);     \
+  } while (0)
   if (h_c.precision == ACINO_PREC_BF16_ROWS) {
     if (need_jac) ACINO_LAUNCH_ASSEMBLE(true, ACINO_PREC_BF16_ROWS);
     else ACINO_LAUNCH_ASSEMBLE(false, ACINO_PREC_BF16_ROWS);

@@ -292,7 +292,7 @@ class FTEContext:
                     "totals", "control", "backsub_tail", "trunc_check", "chunk_sweep", "sep_combine", "chunk_backsub", "refine")
     PROF_KERNELS = dict(elim="k_bcr_elim", elim_deep="k_sep_level", update0="k_bcr_update0", update="k_bcr_update",
                         update_deep="k_bcr_update_deep", backsub0="k_bcr_backsub0", backsub="k_bcr_backsub",
-                        backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true, 0>", totals="k_totals", control="k_control",
+                        backsub_tail="k_bcr_backsub_tail", trial="k_trial", assemble="k_fte_assemble<true, 0, 1>", totals="k_totals", control="k_control",
                         trunc_check="k_bcr_trunc_check", chunk_sweep="k_chunk_sweep", sep_combine="k_sep_combine",
                         chunk_backsub="k_chunk_backsub", refine="k_sep_tail")
 
