@@ -258,3 +258,34 @@ def test_fused_narrow_levels_equal_the_per_phase_kernels(mods, monkeypatch, n, k
         assert abs(r[0] - g[0]) <= 1e-9 * abs(r[0]), (it, r[0], g[0])
         assert abs(r[2] - g[2]) <= 1e-7 * abs(r[2]) + 1e-12, (it, r[2], g[2])
         assert np.abs(r[4] - g[4]).max() < 1e-8, (it, np.abs(r[4] - g[4]).max())
+
+
+@pytest.mark.parametrize("n,levels,sweeps", [(3331, 3, 7), (3331, 3, 12), (10000, 1, 7), (10000, 1, 12)])
+def test_truncation_bound_with_many_sweeps_and_the_tagged_handoffs(mods, n, levels, sweeps):
+    """Round 6, second half.  (i) The refinement sweeps of k_sep_tail trade their vectors as tagged 64-bit word pairs (no flag):
+    whole solves with few levels and many sweeps walk the path of the complete reduction - same iterations, same accepted steps,
+    cost to rounding.  (ii) The bound on what the truncation leaves is measured from the FIRST clean pair of sweeps: with >= 6
+    sweeps the last two updates are rounding noise, their ratio (~1) used to refuse converged solves; now every step verifies
+    and the reported bound sits at the rounding level, below the default tolerance."""
+    calib, fte, synth = mods
+    seq = synth.make_sequence(n, "loop")
+    rig = (seq["K"], seq["D"], seq["R"], seq["t"])
+    xa = _start(fte, seq, n, 3 * n)
+    ref = fte.FTEContext(seq["det"], *rig, seq["Ts"], bcr_levels=0)
+    ref.set_x(xa)
+    iref = ref.solve(80)
+    ref.close()
+    ctx = fte.FTEContext(seq["det"], *rig, seq["Ts"], bcr_levels=levels, refine_sweeps=sweeps, trunc_tol=fte.FTEContext.TRUNC_TOL)
+    ctx.set_x(xa)
+    worst = 0.0
+    for _ in range(80):
+        ctx.step()
+        st = ctx.state()
+        worst = max(worst, st["trunc_eps"])
+        if st["status"] != 0:
+            break
+    ctx.close()
+    assert st["status_name"] == iref["status_name"] and st["status"] in (1, 2, 3), (st["status_name"], iref["status_name"], worst)
+    assert st["iter"] == iref["iter"] and st["accepted"] == iref["accepted"]
+    assert abs(st["cost"] - iref["cost"]) <= 1e-12 * abs(iref["cost"])
+    assert 0.0 < worst <= fte.FTEContext.TRUNC_TOL, worst
